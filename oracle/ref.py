@@ -1,0 +1,228 @@
+"""ctypes wrapper over oracle/_ref/libwhisper_ref.so -- TEST INFRASTRUCTURE ONLY.
+
+libwhisper_ref.so is the reference's own CPU path (Whisper/source/whisper.cpp + ggml.c, compiled unmodified by
+oracle/Makefile) plus the flat C harness of oracle/ref_harness.cpp.  Only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py may import this module; the product path never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libwhisper_ref.so")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        L.ref_init.restype = C.c_void_p
+        L.ref_init.argtypes = [C.c_char_p]
+        L.ref_free.argtypes = [C.c_void_p]
+        L.ref_hparams.argtypes = [C.c_void_p, _i32p]
+        L.ref_pcm_to_mel.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
+        L.ref_set_mel.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
+        L.ref_mel_len.argtypes = [C.c_void_p]
+        L.ref_get_mel.argtypes = [C.c_void_p, _f32p]
+        L.ref_encode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_decode.argtypes = [C.c_void_p, _i32p, C.c_int, C.c_int, C.c_int]
+        L.ref_logits_size.restype = C.c_size_t
+        L.ref_logits_size.argtypes = [C.c_void_p]
+        L.ref_get_logits.argtypes = [C.c_void_p, _f32p]
+        L.ref_get_probs.argtypes = [C.c_void_p, _f32p]
+        L.ref_get_cross_kv.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
+        L.ref_get_self_kv.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p, _f32p]
+        L.ref_trace_enable.argtypes = [C.c_int]
+        L.ref_trace_name.argtypes = [C.c_int, C.c_char_p, C.c_int]
+        L.ref_trace_get.restype = C.c_long
+        L.ref_trace_get.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_long]
+        L.ref_sample_best.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.ref_sample_timestamp.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.ref_token_special.argtypes = [C.c_void_p, C.c_int]
+        L.ref_token_to_str.restype = C.c_char_p
+        L.ref_token_to_str.argtypes = [C.c_void_p, C.c_int]
+        L.ref_tokenize.argtypes = [C.c_void_p, C.c_char_p, _i32p, C.c_int]
+        L.ref_is_multilingual.argtypes = [C.c_void_p]
+        L.ref_full.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_int]
+        L.ref_full_n_segments.argtypes = [C.c_void_p]
+        for n in ("ref_full_segment_t0", "ref_full_segment_t1"):
+            getattr(L, n).restype = C.c_int64
+            getattr(L, n).argtypes = [C.c_void_p, C.c_int]
+        L.ref_full_segment_text.restype = C.c_char_p
+        L.ref_full_segment_text.argtypes = [C.c_void_p, C.c_int]
+        L.ref_full_n_tokens.argtypes = [C.c_void_p, C.c_int]
+        L.ref_full_token_id.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_full_token_p.restype = C.c_float
+        L.ref_full_token_p.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_timings.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
+        L.ref_reset_timings.argtypes = [C.c_void_p]
+        L.ref_system_info.restype = C.c_char_p
+        L.ref_lookup_tables.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint16, flags="C_CONTIGUOUS")] * 2
+        _lib = L
+    return _lib
+
+
+class RefWhisper:
+    """One whisper_context of the reference CPU implementation."""
+
+    def __init__(self, model_path: str, n_threads: int = 1, log_level: int = 1):
+        self.L = lib()
+        self.L.ref_set_log_level(log_level)
+        self.ctx = self.L.ref_init(model_path.encode())
+        if not self.ctx:
+            raise RuntimeError("reference whisper_init failed for " + model_path)
+        self.n_threads = n_threads
+        hp = np.zeros(11, np.int32)
+        self.L.ref_hparams(self.ctx, hp)
+        (self.n_vocab, self.n_audio_ctx, self.n_audio_state, self.n_audio_head, self.n_audio_layer,
+         self.n_text_ctx, self.n_text_state, self.n_text_head, self.n_text_layer, self.n_mels, self.f16) = map(int, hp)
+
+    def close(self):
+        if self.ctx:
+            self.L.ref_free(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- mel ----
+    def pcm_to_mel(self, pcm: np.ndarray) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        rc = self.L.ref_pcm_to_mel(self.ctx, pcm, len(pcm), self.n_threads)
+        assert rc == 0
+        return self.get_mel()
+
+    def set_mel(self, mel: np.ndarray):
+        """mel: [n_mel][n_len] float32 (row = mel bin), whisper.cpp:2332-2347."""
+        mel = np.ascontiguousarray(mel, np.float32)
+        assert mel.shape[0] == self.n_mels
+        rc = self.L.ref_set_mel(self.ctx, mel, mel.shape[1], mel.shape[0])
+        assert rc == 0
+
+    def get_mel(self) -> np.ndarray:
+        n = self.L.ref_mel_len(self.ctx)
+        out = np.zeros((self.n_mels, n), np.float32)
+        self.L.ref_get_mel(self.ctx, out)
+        return out
+
+    # ---- encoder / decoder ----
+    def encode(self, mel_offset: int = 0):
+        rc = self.L.ref_encode(self.ctx, mel_offset, self.n_threads)
+        assert rc == 0
+
+    def cross_kv(self, layer: int):
+        k = np.zeros((self.n_audio_ctx, self.n_audio_state), np.float32)
+        v = np.zeros_like(k)
+        self.L.ref_get_cross_kv(self.ctx, layer, k, v)
+        return k, v
+
+    def self_kv(self, layer: int, rows: int):
+        k = np.zeros((rows, self.n_text_state), np.float32)
+        v = np.zeros_like(k)
+        self.L.ref_get_self_kv(self.ctx, layer, rows, k, v)
+        return k, v
+
+    def decode(self, tokens: Sequence[int], n_past: int):
+        """Returns (logits, probs), each [n_tokens][n_vocab]."""
+        t = np.ascontiguousarray(tokens, np.int32)
+        rc = self.L.ref_decode(self.ctx, t, len(t), n_past, self.n_threads)
+        assert rc == 0
+        n = self.L.ref_logits_size(self.ctx)
+        logits = np.zeros(n, np.float32)
+        probs = np.zeros(n, np.float32)
+        self.L.ref_get_logits(self.ctx, logits)
+        self.L.ref_get_probs(self.ctx, probs)
+        return logits.reshape(len(t), -1), probs.reshape(len(t), -1)
+
+    def sample_best(self):
+        vals = [C.c_int32(), C.c_int32(), C.c_float(), C.c_float(), C.c_float()]
+        self.L.ref_sample_best(self.ctx, *[C.byref(v) for v in vals])
+        return dict(id=vals[0].value, tid=vals[1].value, p=vals[2].value, pt=vals[3].value, ptsum=vals[4].value)
+
+    def sample_timestamp(self, is_initial: bool):
+        vals = [C.c_int32(), C.c_int32(), C.c_float(), C.c_float(), C.c_float()]
+        self.L.ref_sample_timestamp(self.ctx, int(is_initial), *[C.byref(v) for v in vals])
+        return dict(id=vals[0].value, tid=vals[1].value, p=vals[2].value, pt=vals[3].value, ptsum=vals[4].value)
+
+    # ---- probe points ----
+    def trace(self, on: bool = True):
+        self.L.ref_trace_enable(int(on))
+
+    def traced(self) -> Dict[str, np.ndarray]:
+        out = {}
+        buf = C.create_string_buffer(128)
+        for i in range(self.L.ref_trace_count()):
+            self.L.ref_trace_name(i, buf, 128)
+            name = buf.value
+            ne = (C.c_int32 * 4)()
+            n = self.L.ref_trace_get(name, ne, None, 0)
+            a = np.zeros(n, np.float32)
+            self.L.ref_trace_get(name, ne, a.ctypes.data_as(C.c_void_p), n)
+            out[name.decode()] = a.reshape(ne[3], ne[2], ne[1], ne[0]).squeeze()
+        return out
+
+    # ---- whisper_full ----
+    def full(self, pcm: np.ndarray, lang: str = "en", no_context: bool = True, single_segment: bool = False,
+             translate: bool = False, max_tokens: int = 0, audio_ctx: int = 0, prompt: Optional[Sequence[int]] = None):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        flags = int(no_context) | (int(single_segment) << 1) | (int(translate) << 2)
+        pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        rc = self.L.ref_full(self.ctx, pcm, len(pcm), self.n_threads, lang.encode(), flags, max_tokens, audio_ctx,
+                             pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt))
+        if rc != 0:
+            raise RuntimeError("whisper_full rc=%d" % rc)
+        segs = []
+        for i in range(self.L.ref_full_n_segments(self.ctx)):
+            nt = self.L.ref_full_n_tokens(self.ctx, i)
+            segs.append(dict(
+                t0=self.L.ref_full_segment_t0(self.ctx, i), t1=self.L.ref_full_segment_t1(self.ctx, i),
+                text=self.L.ref_full_segment_text(self.ctx, i),
+                tokens=[self.L.ref_full_token_id(self.ctx, i, j) for j in range(nt)],
+                probs=[self.L.ref_full_token_p(self.ctx, i, j) for j in range(nt)]))
+        return segs
+
+    def timings_us(self):
+        out = np.zeros(5, np.int64)
+        self.L.ref_timings(self.ctx, out)
+        return dict(load=int(out[0]), mel=int(out[1]), sample=int(out[2]), encode=int(out[3]), decode=int(out[4]))
+
+    def reset_timings(self):
+        self.L.ref_reset_timings(self.ctx)
+
+
+def lookup_tables():
+    """(gelu, exp) uint16[65536] bit patterns of the FP16 tables ggml builds at init (ggml.c:1375-1385)."""
+    g = np.zeros(65536, np.uint16)
+    e = np.zeros(65536, np.uint16)
+    lib().ref_lookup_tables(g, e)
+    return g, e
+
+
+def read_wav_mono16(path: str) -> np.ndarray:
+    """PCM16 mono WAV -> float32 in [-1, 1) (the conversion the reference's examples use, /32768)."""
+    import wave
+    with wave.open(path, "rb") as w:
+        assert w.getsampwidth() == 2
+        n = w.getnframes()
+        a = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32)
+        if w.getnchannels() == 2:
+            a = a.reshape(-1, 2).mean(axis=1)
+    return a / 32768.0
