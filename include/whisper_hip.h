@@ -1,0 +1,154 @@
+/* whisper_hip.h -- C ABI of libwhisper_hip.so, the MI355X (gfx950) compute path.
+ *
+ * This is the drop-in boundary below the reference's host code: everything the reference implements in
+ * Whisper/Whisper/WhisperContext.{h,cpp} (encode/decode graphs), Whisper/ML/MlContext.{h,cpp} (one method per
+ * tensor op, each a D3D11 compute-shader dispatch) and ComputeShaders/*.hlsl is replaced by the entry points
+ * below.  Plain pointers and sizes only; no C++ types, no torch types.  All device pointers are HIP device
+ * pointers; `stream` is a hipStream_t passed as void* (0 = the null stream).  Every function returns 0 on
+ * success or a negative wh_status; wh_last_error() gives the text.  Nothing here ever falls back to the CPU.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference tree).
+ */
+#ifndef WHISPER_HIP_H
+#define WHISPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WH_API __attribute__( ( visibility( "default" ) ) )
+
+typedef enum wh_status
+{
+	WH_OK = 0,
+	WH_E_INVALIDARG = -1,	/* E_INVALIDARG in the reference's HRESULT vocabulary */
+	WH_E_OUTOFMEMORY = -2,
+	WH_E_HIP = -3,			/* a HIP runtime call failed; see wh_last_error() */
+	WH_E_NOT_READY = -4,	/* model not finalized / encode not run before decode */
+	WH_E_NO_DEVICE = -5,
+	WH_E_BOUNDS = -6
+} wh_status;
+
+WH_API const char* wh_last_error( void );
+
+/* ---- device (replaces Whisper/D3D/createDevice.cpp, listGPUs.cpp; Whisper/ML/Device.cpp:92-124) ---- */
+WH_API int wh_device_count( void );
+/* name: >= 256 bytes. Mirrors the adapter enumeration behind Whisper::listGPUs (Whisper/API/iContext.cl.h:62-70). */
+WH_API int wh_device_info( int device, char* name, size_t nameCap, uint64_t* totalMemBytes, int* computeUnits );
+WH_API int wh_device_set( int device );
+
+/* ---- model (replaces Whisper/Whisper/ModelBuffers.{h,cpp}, WhisperModel.cpp:257-340 "loadGpu") ----
+ * sModelParams of the reference (Whisper/Whisper/sModelParams.h:5-18), same field order as the ggml file. */
+typedef struct wh_hparams
+{
+	int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+	int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels, f16;
+} wh_hparams;
+
+typedef struct wh_model wh_model;
+
+/* Size in bytes of the packed device weight arena for these hparams (FP16 matrices, FP32 vectors, our layout). */
+WH_API int64_t wh_model_arena_bytes( const wh_hparams* hp );
+/* arenaDev == NULL: the library hipMallocs the arena.  Otherwise the caller owns device memory of at least
+ * wh_model_arena_bytes() bytes (e.g. a torch tensor that was just filled by an RCCL broadcast); pass
+ * alreadyFilled != 0 if it already holds a finalized arena image from another rank with the same hparams. */
+WH_API int wh_model_create( const wh_hparams* hp, void* arenaDev, int alreadyFilled, wh_model** out );
+WH_API void wh_model_destroy( wh_model* m );
+/* Upload one tensor of the ggml file by its file name ("encoder.blocks.3.attn.query.weight" ...;
+ * name map Whisper/Whisper/WhisperModel.cpp:63-162).  ne[] in ggml order (ne[0] contiguous), nDims 1..3,
+ * isF16 = the file's ftype != 0.  `data` is HOST memory, copied synchronously.  Unknown names, wrong shapes and
+ * duplicates are errors, like the reference loader (WhisperModel.cpp:292-297, 331-335). */
+WH_API int wh_model_set_tensor( wh_model* m, const char* name, int nDims, const int32_t* ne, int isF16, const void* data );
+/* Mel filterbank from the file header, [n_mel][n_fft] FP32 (WhisperModel.cpp:456-470). */
+WH_API int wh_model_set_filters( wh_model* m, int nMel, int nFft, const float* data );
+/* Verifies every expected tensor arrived exactly once (WhisperModel.cpp:331-335) and builds derived data. */
+WH_API int wh_model_finalize( wh_model* m );
+WH_API int wh_model_arena( wh_model* m, void** dev, int64_t* bytes );
+WH_API int wh_model_hparams( const wh_model* m, wh_hparams* out );
+
+/* ---- context (replaces DirectCompute::WhisperContext, Whisper/Whisper/WhisperContext.h:20-140) ----
+ * One context owns activations, the FP16 self- and cross-attention KV caches (KeyValueBuffers.h:7-53) for up to
+ * maxBatch independent 30 s windows that are processed in lock step, and its workspace.  Single-threaded use,
+ * like the reference (Whisper/ML/Device.cpp:163-177). */
+typedef struct wh_context wh_context;
+
+typedef enum wh_flags
+{
+	WH_FLAG_NONE = 0,
+	/* Emulate the reference CPU path's FP16, thread-partitioned accumulation of the decoder P.V product
+	 * (Whisper/source/ggml.c:4689-4735, 4615-4644) with `parityThreads` virtual threads. Slow; for parity runs. */
+	WH_FLAG_PARITY_PV = 1
+} wh_flags;
+
+WH_API int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out );
+WH_API void wh_context_destroy( wh_context* c );
+WH_API int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads );
+/* {RAM, VRAM} accounting like getMemoryUse() in the reference (WhisperContext.cpp:641-666) */
+WH_API int wh_context_memory( const wh_context* c, int64_t* vramBytes );
+
+/* PCM -> log-mel on the GPU. Replaces Spectrogram::pcmToMel (Whisper/Whisper/Spectrogram.cpp:64-122) ==
+ * log_mel_spectrogram (Whisper/source/whisper.cpp:2060-2180): hop 160, Hann 400, |DFT|^2 with the reference's
+ * p[j]+=p[400-j] fold, 80x201 filterbank, log10 clamp, (global max - 8) clamp, (x+4)/4.
+ * pcmDev: FP32 [nSamples] device; melDev: FP32 [n_mel][nLen] device with nLen = nSamples/160 (row = mel bin).
+ * The normalisation maximum is over the whole buffer, as in runFull. */
+WH_API int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, float* melDev, int64_t* nLenOut );
+
+/* Encoder. Replaces WhisperContext::encode (WhisperContext.cpp:310-399) == whisper_encode (whisper.cpp:1084-1496).
+ * melDev: FP32 device, `batch` spectrograms each [n_mel][melLen] (melStride floats apart); for each the window
+ * [melOffset, melOffset + 2*n_audio_ctx) is taken and zero-padded (MelInputTensor.cpp:8-63).  Fills the
+ * cross-attention caches of all decoder layers for batch slots 0..batch-1 and resets their self-attention state. */
+WH_API int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets );
+
+/* Decoder step. Replaces WhisperContext::decode (WhisperContext.cpp:578-639) == whisper_decode (whisper.cpp:1508-1872).
+ * tokens: HOST int32 [batch][nTokens]; every sequence advances from position nPast by nTokens.
+ * Outputs for the LAST token of each sequence (the only row the reference ever consumes, ContextImpl.cpp:159-169):
+ *   logitsHost / probsHost: HOST FP32 [batch][n_vocab], either may be NULL (skips that download).
+ * Synchronises the stream before returning when any host output is requested. */
+WH_API int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int nPast, float* logitsHost, float* probsHost );
+
+/* sTokenData of the reference (Whisper/Whisper/sTokenData.h): the result of ContextImpl::sampleBest. */
+typedef struct wh_token_data
+{
+	int32_t id, tid;
+	float p, pt, ptsum;
+} wh_token_data;
+
+/* Greedy sampling on the device, from the probabilities of the last wh_decode call. Replaces
+ * ContextImpl::sampleBest / sampleTimestamp (Whisper/Whisper/ContextImpl.cpp:71-169): timestamp-vs-text rule,
+ * initial-timestamp <= 1.00 s cap, first of the top-4 that is not sot/solm/not. forceTimestamp / isInitial are
+ * per call (same for all sequences). out: HOST [batch]. Exact ties resolve to the lower token id. */
+WH_API int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial, wh_token_data* out );
+
+/* Test / parity access to internal state (the reference reaches these through its Tracing probe points,
+ * Whisper/Whisper/WhisperContext.cpp:142-638). All outputs HOST FP32.
+ *   what = "encode-out"  [batch][n_ctx][d]           (only valid right after wh_encode)
+ *          "cross-k" / "cross-v"   layer, [batch][n_ctx][d] token-major like the reference's kvCross
+ *          "self-k" / "self-v"     layer, [batch][rows][d]
+ */
+WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* dstHost, int64_t dstCapFloats );
+
+/* ---- op-level entry points (replace the MlContext methods, Whisper/ML/MlContext.h:13-113). Device pointers. ---- */
+
+/* MlContext::mulMat with an FP16 weight (ComputeShaders/mulMatTiled.hlsl, mulMatByRowTiled.hlsl):
+ * out[m][n] = sum_k fp16(a[m][k]) * w[n][k] (+ bias[n]) (+ residual[m][n]); a: FP16 [M][K] (already rounded, which is
+ * what ggml does at ggml.c:4588-4611), w: FP16 [N][K], out FP32 [M][N]. bias/residual may be NULL. */
+WH_API int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float* bias, const float* residual,
+	float* out, int M, int N, int K );
+/* mulMat + addRepeatGelu (ComputeShaders/addRepeatGelu.hlsl): out FP16 [M][N] = gelu16( acc + bias ) */
+WH_API int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16, const float* bias, void* outF16, int M, int N, int K );
+/* MlContext::norm + fmaRepeat (norm.hlsl, fmaRepeat1.hlsl): out FP16 [rows][d] = fp16( norm(x) * w + b ) */
+WH_API int wh_op_layer_norm( void* stream, const float* x, const float* w, const float* b, void* outF16, int rows, int d );
+/* MlContext::flashAttention, unmasked (flashAttention.hlsl:76-169 == ggml.c:5912-6097).
+ * q, k: FP16 [batch*heads][nCtx][64]; vT: FP16 [batch*heads][64][nCtxPad] with nCtxPad = roundup(nCtx, 64) ... see DESIGN.md;
+ * out: FP16 [batch][nCtx][heads*64]. */
+WH_API int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vT, void* out, int batch, int heads, int nCtx );
+/* softMax over rows with the reference's FP16 exp table semantics (softMax.hlsl / ggml.c:5030-5090): in place, FP32 */
+WH_API int wh_op_soft_max( void* stream, float* x, int rows, int cols );
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,54 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/whisper_hip.h declares.
+No compute is called here (there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from whisper_amd import binding, ggml_format as gf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "whisper_hip.h")).read()
+    return sorted(set(re.findall(r"WH_API\s+[\w\s\*]+?\b(wh_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(binding.LIB_PATH):
+        from whisper_amd import build
+        build.build_hip()
+    lib = ctypes.CDLL(binding.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(binding.EXPORTS) == names
+
+
+def test_arena_layout_is_pure_function_of_hparams():
+    """Ranks that only receive the RCCL broadcast rely on this: same hparams -> same byte count (no GPU needed)."""
+    hp = gf.hparams_for("medium")
+    n1 = binding.arena_bytes(hp)
+    n2 = binding.arena_bytes(gf.hparams_for("medium"))
+    assert n1 == n2
+    # FP16 matrices dominate: ~ the size of the real ggml-medium.bin (1.53 GB) minus FP32 leftovers
+    assert 1.4e9 < n1 < 1.7e9
+    assert binding.arena_bytes(gf.hparams_for("large-v2")) > 2.9e9
+
+
+def test_invalid_hparams_are_rejected():
+    hp = gf.hparams_for("tiny")
+    hp.n_audio_head = 5                     # 384 / 5 != 64
+    with pytest.raises(binding.WhisperHipError):
+        binding.arena_bytes(hp)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU, creating a model must fail loudly (WH_E_NO_DEVICE), never compute on the host."""
+    if binding.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(binding.WhisperHipError):
+        binding.HipModel(gf.hparams_for("test-d128"))

@@ -1,0 +1,257 @@
+"""GPU parity tests, graph level: wh_mel_spectrogram / wh_encode / wh_decode / wh_sample_best through the C ABI against
+(a) the committed outputs of the reference's CPU path (tests/golden, produced by oracle/_ref), (b) the numpy
+restatement on the same inputs, (c) oracle/_ref run live when it travelled with the snapshot, and -- at full model
+sizes, where the oracle would take minutes -- size-independent properties (batch invariance, probability mass,
+KV-cache consistency between a prompt step and token-by-token steps).
+
+End-to-end tolerance (see tests/test_oracle.py): two faithful implementations of the reference's FP16-table numerics
+that differ only in FP32 summation order sit ~2e-3 (max) / 4e-4 (mean) apart on the logits of this model; the bounds
+here are 2.5x that measured floor. north_star asks for 1e-3 on real weights; stage-level tests (test_gpu_ops.py) hold
+each kernel to FP32 round-off.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import whisper_np as wn  # noqa: E402
+from whisper_amd import binding, ggml_format as gf  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+E2E_MAX, E2E_MEAN = 6e-3, 1e-3
+
+
+def report(name, got, want):
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    print("%-34s max|want|=%9.4f maxdiff=%.3e meandiff=%.3e" % (name, np.abs(want).max(), d.max(), d.mean()))
+    return d
+
+
+@pytest.fixture(scope="module")
+def hip_tiny(tiny_model):
+    m = binding.HipModel.from_ggml(tiny_model)
+    yield m
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def np_tiny(tiny_model, golden):
+    n = wn.WhisperNP(tiny_model)
+    n.encode(golden["mel"], 0)
+    return n
+
+
+def test_device_is_mi355x():
+    info = binding.device_info(0)
+    print(info)
+    assert binding.device_count() >= 1 and "gfx950" in info["name"]
+
+
+def test_mel_spectrogram(hip_tiny, golden, tiny_model):
+    ctx = binding.HipContext(hip_tiny, 1)
+    pcm = golden["pcm16"].astype(np.float32) / 32768.0
+    mel = ctx.mel_spectrogram(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    assert mel.shape == (80, 1100)
+    d = report("mel vs reference", mel, golden["mel"])
+    assert d.max() < 5e-4 and d.mean() < 5e-6           # the reference's own FP32-FFT noise on near-silent bins
+    d = report("mel vs float64 restatement", mel, wn.log_mel_spectrogram(pcm, tiny_model.filters))
+    assert d.max() < 2e-5
+    # ragged / edge lengths: shorter than one frame, not a multiple of the hop, zeros
+    for n in (0, 159, 160, 401, 16000 + 77):
+        x = np.zeros(max(n, 1), np.float32)[:n] if n < 400 else pcm[:n]
+        if n == 0:
+            continue
+        got = ctx.mel_spectrogram(torch.from_numpy(np.ascontiguousarray(x)).cuda()).cpu().numpy()
+        assert got.shape == (80, n // 160)
+        if n >= 160:
+            want = wn.log_mel_spectrogram(x, tiny_model.filters)
+            assert np.abs(got - want).max() < 2e-5, n
+    ctx.close()
+
+
+def test_encoder(hip_tiny, golden, np_tiny):
+    ctx = binding.HipContext(hip_tiny, 2)
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    ctx.encode(mel)
+    out = ctx.debug_read("encode-out")[0]
+    d = report("encode-out vs reference", out, golden["encode_out"])
+    assert d.max() < E2E_MAX + 2e-3 and d.mean() < E2E_MEAN      # + FP16 rounding of the read-back
+    for il in (0, 3):
+        for nm in ("k", "v"):
+            got = ctx.debug_read("cross-" + nm, il)[0]
+            want = golden["cross_%s%d" % (nm, il)].astype(np.float32)
+            d = report("cross-%s[%d] vs reference" % (nm, il), got, want)
+            assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+            mine = np_tiny.kv.cross_k[il] if nm == "k" else np_tiny.kv.cross_v[il]
+            d = report("cross-%s[%d] vs restatement" % (nm, il), got, mine)
+            assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+    ctx.close()
+
+
+def test_encoder_batch_and_offsets(hip_tiny, golden):
+    """Windows in one batch are independent: same window at different batch slots / offsets gives identical caches."""
+    ctx = binding.HipContext(hip_tiny, 3)
+    mel = golden["mel"]
+    shifted = np.zeros((80, 1100 + 40), np.float32)
+    shifted[:, 40:] = mel
+    pad = np.zeros((80, 1140), np.float32)
+    pad[:, :1100] = mel
+    batch = torch.from_numpy(np.stack([pad, shifted, pad])).cuda()
+    ctx.encode(batch, offsets=[0, 40, 0])
+    k = ctx.debug_read("cross-k", 3)
+    assert np.array_equal(k[0], k[2])
+    assert np.array_equal(k[0], k[1])          # offset slicing reproduces the same window
+    ctx1 = binding.HipContext(hip_tiny, 1)
+    ctx1.encode(torch.from_numpy(mel).cuda())
+    assert np.array_equal(ctx1.debug_read("cross-k", 3)[0], k[0])      # batch size does not change results
+    ctx.close()
+    ctx1.close()
+
+
+def run_steps(ctx, golden, batch=1):
+    outs = []
+    pos, n_past = 0, 0
+    for i, ln in enumerate(golden["step_lens"]):
+        toks = golden["steps"][pos:pos + ln]
+        logits, probs = ctx.decode(np.tile(toks, (batch, 1)), n_past)
+        outs.append((logits, probs))
+        pos += ln
+        n_past += ln
+    return outs
+
+
+def test_decoder_parity_mode(hip_tiny, golden, np_tiny, tiny_model):
+    """Forced-token steps with the reference's FP16 thread-partitioned P.V emulated (n_threads = 1, as the fixture)."""
+    ctx = binding.HipContext(hip_tiny, 1)
+    ctx.encode(torch.from_numpy(golden["mel"]).cuda())
+    ctx.set_parity(1)
+    sp = gf.special_tokens(tiny_model.hparams)
+    outs = run_steps(ctx, golden)
+    pos, n_past = 0, 0
+    for i, (logits, probs) in enumerate(outs):
+        ln = int(golden["step_lens"][i])
+        d = report("logits step %d vs reference" % i, logits[0], golden["logits%d" % i])
+        assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
+        nl, npr = np_tiny.decode(golden["steps"][pos:pos + ln], n_past, n_threads=1)
+        d = report("logits step %d vs restatement" % i, logits[0], nl[-1])
+        assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
+        assert abs(float(probs[0].astype(np.float64).sum()) - 1.0) < 1e-4
+        # token ids: identical to the reference unless its own top-2 are within the implementation noise
+        ref_ids = golden["sample%d" % i]
+        sb = ctx.sample_best(1)[0]
+        st = ctx.sample_best(1, True, i == 0)[0]
+        print("step", i, "sample", sb, "timestamp", st, "reference", ref_ids, golden["samplep%d" % i])
+        for mine, ref_id in ((sb, ref_ids[0]), (st, ref_ids[2])):
+            if mine["id"] != ref_id:
+                assert abs(probs[0][mine["id"]] - probs[0][ref_id]) < 2e-6
+        # the device sampler against the host restatement on the SAME probabilities: exact
+        hb = wn.sample_best(probs[0], sp["beg"], sp["sot"], sp["solm"], sp["not_"])
+        ht = wn.sample_best(probs[0], sp["beg"], sp["sot"], sp["solm"], sp["not_"], True, i == 0)
+        assert (sb["id"], sb["tid"]) == (hb["id"], hb["tid"]) and (st["id"], st["tid"]) == (ht["id"], ht["tid"])
+        assert abs(sb["p"] - hb["p"]) < 1e-9 and abs(sb["ptsum"] - hb["ptsum"]) < 1e-7 and abs(st["pt"] - ht["pt"]) < 1e-6
+        pos += ln
+        n_past += ln
+    rows = int(golden["step_lens"].sum())
+    for nm in ("k", "v"):
+        got = ctx.debug_read("self-" + nm, 0, rows)[0]
+        d = report("self-%s[0] vs reference" % nm, got, golden["self_%s0" % nm].astype(np.float32))
+        assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+    ctx.close()
+
+
+def test_decoder_fast_path(hip_tiny, golden, np_tiny):
+    """FP32 P.V (what the reference's own GPU shaders do) against the restatement with the same choice."""
+    ctx = binding.HipContext(hip_tiny, 1)
+    ctx.encode(torch.from_numpy(golden["mel"]).cuda())
+    ctx.set_parity(0)
+    outs = run_steps(ctx, golden)
+    pos, n_past = 0, 0
+    for i, (logits, _) in enumerate(outs):
+        ln = int(golden["step_lens"][i])
+        nl, _ = np_tiny.decode(golden["steps"][pos:pos + ln], n_past, exact_pv=False)
+        d = report("fast logits step %d vs restatement(fp32 PV)" % i, logits[0], nl[-1])
+        assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
+        d = report("fast logits step %d vs reference (1 thread)" % i, logits[0], golden["logits%d" % i])
+        pos += ln
+        n_past += ln
+    ctx.close()
+
+
+def test_decoder_batch_invariance_and_kv_consistency(hip_tiny, golden):
+    """(1) every sequence of a lock-step batch gets the result of a batch of one; (2) feeding the prompt token by token
+    through the KV cache gives the same last-row logits as one multi-token step (same kernels, same order)."""
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    ctx1 = binding.HipContext(hip_tiny, 1)
+    ctx1.encode(mel)
+    single = run_steps(ctx1, golden)
+    ctx3 = binding.HipContext(hip_tiny, 3)
+    ctx3.encode(torch.stack([mel, mel, mel]))
+    triple = run_steps(ctx3, golden, batch=3)
+    for (l1, p1), (l3, p3) in zip(single, triple):
+        for b in range(3):
+            assert np.array_equal(l1[0], l3[b]) and np.array_equal(p1[0], p3[b])
+    # prompt in one step vs token by token
+    prompt = golden["steps"][:int(golden["step_lens"][0])]
+    ctx1.encode(mel)
+    la, _ = ctx1.decode(prompt[None, :], 0)
+    ctx1.encode(mel)
+    for j, t in enumerate(prompt):
+        lb, _ = ctx1.decode(np.array([[t]], np.int32), j)
+    d = report("prompt step vs token-by-token", la[0], lb[0])
+    assert d.max() < 2e-4            # skinny kernels both ways; only the accumulation grouping of the attention differs
+    ctx1.close()
+    ctx3.close()
+
+
+def test_live_reference_if_present(hip_tiny, tiny_model, golden, ref_lib_available, tmp_path):
+    """When oracle/_ref travelled with the snapshot, run the reference on the GPU box's CPU and compare a fresh input."""
+    if not ref_lib_available:
+        pytest.skip("oracle/_ref/libwhisper_ref.so not present")
+    from oracle import ref
+    path = str(tmp_path / "m.bin")
+    gf.write_model(path, tiny_model)
+    w = ref.RefWhisper(path, n_threads=1, log_level=0)
+    rng = np.random.default_rng(99)
+    mel = rng.uniform(-1, 1, (80, 3000)).astype(np.float32)          # config-3 style synthetic mel
+    w.set_mel(mel)
+    w.encode(0)
+    sp = gf.special_tokens(tiny_model.hparams)
+    rl, _ = w.decode([sp["sot"], sp["not_"]], 0)
+    ctx = binding.HipContext(hip_tiny, 1)
+    ctx.encode(torch.from_numpy(mel).cuda())
+    ctx.set_parity(1)
+    gl, _ = ctx.decode(np.array([[sp["sot"], sp["not_"]]], np.int32), 0)
+    d = report("live reference logits (uniform mel)", gl[0], rl[-1])
+    assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
+    k, v = w.cross_kv(2)
+    d = report("live reference cross-k[2]", ctx.debug_read("cross-k", 2)[0], k)
+    assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+    ctx.close()
+
+
+def test_full_size_properties():
+    """ggml-medium shape (random weights; the oracle needs ~10 s per window on the host): properties that do not need it.
+    batch invariance across 2 windows, probabilities sum to one, no NaN, decode determinism."""
+    model = gf.synth_model("medium", seed=1)
+    m = binding.HipModel.from_ggml(model)
+    ctx = binding.HipContext(m, 2)
+    rng = np.random.default_rng(2)
+    mel = rng.uniform(-1, 1, (2, 80, 3000)).astype(np.float32)
+    mel[1] = mel[0]
+    ctx.encode(torch.from_numpy(mel).cuda())
+    k = ctx.debug_read("cross-k", 23)
+    assert np.isfinite(k).all() and np.array_equal(k[0], k[1])
+    sp = gf.special_tokens(model.hparams)
+    toks = np.array([[sp["sot"], sp["sot"] + 1, sp["transcribe"]]] * 2, np.int32)
+    logits, probs = ctx.decode(toks, 0)
+    assert np.isfinite(logits).all() and np.array_equal(logits[0], logits[1])
+    assert abs(float(probs[0].astype(np.float64).sum()) - 1.0) < 1e-4
+    l2, _ = ctx.decode(np.array([[123], [123]], np.int32), 3)
+    ctx.encode(torch.from_numpy(mel).cuda())
+    ctx.decode(toks, 0)
+    l3, _ = ctx.decode(np.array([[123], [123]], np.int32), 3)
+    assert np.array_equal(l2, l3)
+    print("medium-shape context VRAM: %.1f MB" % (ctx.vram_bytes() / 1e6))
+    ctx.close()
+    m.close()

@@ -1,0 +1,113 @@
+"""CPU tests: pin the numpy restatement (oracle/whisper_np.py) against the reference's own outputs.
+
+Two pins: (a) tests/golden/ref_test_d128.npz -- produced by the reference CPU path compiled unmodified (oracle/_ref),
+always available; (b) oracle/_ref run live when the .so is present. The reference tree holds no golden vectors of its
+own for this path.
+
+Tolerances. A single stage fed with the reference's own input matches to FP32 round-off (~1e-6). End to end, ANY
+implementation whose FP32 summation order differs from ggml's accumulates FP16 rounding flips (activations, GELU/exp
+table arguments); measured restatement-vs-reference noise on this model: encoder output max 2e-3 / mean 3e-4, logits
+max 2e-3 / mean 4e-4 (|logit| <= 2.5). The end-to-end bounds below are 2.5x that floor.
+"""
+import numpy as np
+import pytest
+
+from oracle import whisper_np as wn
+from whisper_amd import ggml_format as gf
+
+E2E_MAX, E2E_MEAN = 6e-3, 1e-3
+
+
+def test_lookup_tables_match_reference(golden):
+    """gelu16 / exp16 restate table_gelu_f16 / table_exp_f16 (ggml.c:1375-1385) for every one of the 65536 inputs."""
+    bits = np.arange(65536, dtype=np.uint16)
+    x = bits.view(np.float16).astype(np.float32)
+    finite = np.isfinite(x)
+    g = wn.gelu16(x).astype(np.float16).view(np.uint16)
+    e = wn.exp16(x).astype(np.float16).view(np.uint16)
+    # numpy's tanh/exp vs glibc's: allow at most a handful of 1-ulp differences
+    gd = np.abs(g[finite].astype(np.int32) - golden["table_gelu"][finite].astype(np.int32))
+    neg = finite & (x <= 0)
+    ed = np.abs(e[neg].astype(np.int32) - golden["table_exp"][neg].astype(np.int32))
+    assert gd.max() <= 1 and (gd > 0).mean() < 1e-3
+    assert ed.max() <= 1 and (ed > 0).mean() < 1e-3
+
+
+def test_mel_restatement(golden, tiny_model):
+    pcm = golden["pcm16"].astype(np.float32) / 32768.0
+    mel = wn.log_mel_spectrogram(pcm, tiny_model.filters)
+    assert mel.shape == golden["mel"].shape == (80, 1100)
+    d = np.abs(mel - golden["mel"])
+    # the reference's FP32 recursive FFT carries its own noise on near-silent bins
+    assert d.max() < 5e-4 and d.mean() < 5e-6
+
+
+def test_encoder_restatement(golden, tiny_model):
+    n = wn.WhisperNP(tiny_model)
+    tr = {}
+    out = n.encode(golden["mel"], 0, trace=tr)
+    d = np.abs(out - golden["encode_out"])
+    assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
+    d = np.abs(tr["enc-KQV"] - golden["enc_kqv0"].astype(np.float32))
+    assert d.max() < 4e-3 and d.mean() < 1e-4        # first layer only: few flips yet
+    for il in (0, 3):
+        for nm, mine in (("k", n.kv.cross_k[il]), ("v", n.kv.cross_v[il])):
+            d = np.abs(mine - golden["cross_%s%d" % (nm, il)].astype(np.float32))
+            assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+
+
+def test_decoder_restatement(golden, tiny_model):
+    """Teacher-forced token steps with the FP16 thread-partitioned P.V emulation at the fixture's n_threads = 1."""
+    n = wn.WhisperNP(tiny_model)
+    n.encode(golden["mel"], 0)
+    pos, n_past = 0, 0
+    sp = gf.special_tokens(tiny_model.hparams)
+    for i, ln in enumerate(golden["step_lens"]):
+        toks = golden["steps"][pos:pos + ln]
+        logits, probs = n.decode(toks, n_past, n_threads=1)
+        d = np.abs(logits[-1] - golden["logits%d" % i])
+        assert d.max() < E2E_MAX and d.mean() < E2E_MEAN, (i, d.max(), d.mean())
+        assert abs(float(probs[-1].astype(np.float64).sum()) - 1.0) < 1e-4
+        sb = wn.sample_best(probs[-1], sp["beg"], sp["sot"], sp["solm"], sp["not_"])
+        st = wn.sample_best(probs[-1], sp["beg"], sp["sot"], sp["solm"], sp["not_"], True, i == 0)
+        # token choice can only differ where the reference's own top-2 probabilities are within the noise
+        ref_ids = golden["sample%d" % i]
+        if sb["id"] != ref_ids[0]:
+            assert abs(probs[-1][sb["id"]] - probs[-1][ref_ids[0]]) < 2e-6
+        if st["id"] != ref_ids[2]:
+            assert abs(probs[-1][st["id"]] - probs[-1][ref_ids[2]]) < 2e-6
+        pos += ln
+        n_past += ln
+
+
+def test_pv_thread_partition_semantics():
+    """The FP16 accumulate emulation: 1 thread == sequential, n threads == per-range partials summed in FP32."""
+    rng = np.random.default_rng(0)
+    P = rng.random((2, 37)).astype(np.float32)
+    P /= P.sum(axis=1, keepdims=True)
+    V = rng.standard_normal((37, 64)).astype(np.float16).astype(np.float32)
+    a1 = wn.WhisperNP.pv_f16_accumulate(P, V, 1)
+    a4 = wn.WhisperNP.pv_f16_accumulate(P, V, 4)
+    exact = (P.astype(np.float64) @ V.astype(np.float64))
+    assert np.abs(a1 - exact).max() < 5e-3 and np.abs(a4 - exact).max() < 5e-3
+    # results are FP16-representable sums of <= 4 FP16 partials
+    assert np.all(a1 == a1.astype(np.float16).astype(np.float32))
+    parts = [wn.WhisperNP.pv_f16_accumulate(P[:, 10 * i:10 * (i + 1)], V[10 * i:10 * (i + 1)], 1) for i in range(4)]
+    assert np.array_equal(a4, ((parts[0] + parts[1]) + parts[2]) + parts[3])
+
+
+def test_live_reference_matches_golden(golden, tiny_model, ref_lib_available, tmp_path):
+    """When oracle/_ref is built, re-run the reference and require bit-identical results to the committed fixture."""
+    if not ref_lib_available:
+        pytest.skip("oracle/_ref/libwhisper_ref.so not built (needs /root/reference)")
+    from oracle import ref
+    path = str(tmp_path / "m.bin")
+    gf.write_model(path, tiny_model)
+    w = ref.RefWhisper(path, n_threads=1, log_level=0)
+    w.set_mel(golden["mel"])
+    w.encode(0)
+    k, _ = w.cross_kv(0)
+    assert np.array_equal(k.astype(np.float16), golden["cross_k0"])
+    ln = int(golden["step_lens"][0])
+    logits, _ = w.decode(golden["steps"][:ln], 0)
+    assert np.array_equal(logits[-1], golden["logits0"])

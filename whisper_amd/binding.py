@@ -1,0 +1,239 @@
+"""ctypes binding of include/whisper_hip.h (libwhisper_hip.so) -- the only way Python reaches the GPU path.
+
+There is no CPU fallback here by design: if the shared library is missing or no HIP device is visible every entry point
+raises. torch is used only as plumbing (device buffers for inputs, streams, torch.distributed for the weight broadcast).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import ggml_format as gf
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwhisper_hip.so")
+
+WH_FLAG_PARITY_PV = 1
+
+# every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "wh_last_error", "wh_device_count", "wh_device_info", "wh_device_set",
+    "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
+    "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
+    "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_memory",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_debug_read",
+    "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
+]
+
+
+class HParamsC(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in gf.HPARAM_FIELDS]
+
+
+class TokenDataC(C.Structure):
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float)]
+
+
+class WhisperHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libwhisper_hip.so; raises if it has not been built (python -m whisper_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WhisperHipError("libwhisper_hip.so is missing (%s): run `python -m whisper_amd.build`; "
+                                  "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float)
+        L.wh_last_error.restype = C.c_char_p
+        L.wh_device_info.argtypes = [i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        L.wh_model_arena_bytes.restype = i64
+        L.wh_model_arena_bytes.argtypes = [C.POINTER(HParamsC)]
+        L.wh_model_create.argtypes = [C.POINTER(HParamsC), vp, i32, C.POINTER(vp)]
+        L.wh_model_destroy.argtypes = [vp]
+        L.wh_model_destroy.restype = None
+        L.wh_model_set_tensor.argtypes = [vp, C.c_char_p, i32, C.POINTER(C.c_int32), i32, vp]
+        L.wh_model_set_filters.argtypes = [vp, i32, i32, vp]
+        L.wh_model_finalize.argtypes = [vp]
+        L.wh_model_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.wh_model_hparams.argtypes = [vp, C.POINTER(HParamsC)]
+        L.wh_context_create.argtypes = [vp, i32, vp, C.POINTER(vp)]
+        L.wh_context_destroy.argtypes = [vp]
+        L.wh_context_destroy.restype = None
+        L.wh_context_set_flags.argtypes = [vp, C.c_uint32, i32]
+        L.wh_context_memory.argtypes = [vp, C.POINTER(i64)]
+        L.wh_mel_spectrogram.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
+        L.wh_encode.argtypes = [vp, vp, i32, i64, i64, vp]
+        L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.wh_sample_best.argtypes = [vp, i32, i32, i32, C.POINTER(TokenDataC)]
+        L.wh_debug_read.argtypes = [vp, C.c_char_p, i32, i32, vp, i64]
+        L.wh_op_mul_mat.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
+        L.wh_op_mul_mat_gelu.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
+        L.wh_op_layer_norm.argtypes = [vp, vp, vp, vp, vp, i32, i32]
+        L.wh_op_flash_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
+        L.wh_op_soft_max.argtypes = [vp, vp, i32, i32]
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise WhisperHipError("libwhisper_hip rc=%d: %s" % (rc, lib().wh_last_error().decode(errors="replace")))
+
+
+def device_count() -> int:
+    return lib().wh_device_count()
+
+
+def device_info(device: int = 0):
+    name = C.create_string_buffer(256)
+    mem = C.c_uint64()
+    cus = C.c_int()
+    check(lib().wh_device_info(device, name, 256, C.byref(mem), C.byref(cus)))
+    return dict(name=name.value.decode(), total_mem=mem.value, compute_units=cus.value)
+
+
+def _hp_c(hp: gf.HParams) -> HParamsC:
+    return HParamsC(*hp.as_list())
+
+
+def arena_bytes(hp: gf.HParams) -> int:
+    n = lib().wh_model_arena_bytes(C.byref(_hp_c(hp)))
+    if n < 0:
+        check(-1)
+    return int(n)
+
+
+class HipModel:
+    """Weights resident in one packed device arena (ModelBuffers of the reference)."""
+
+    def __init__(self, hp: gf.HParams, arena_ptr: int = 0, already_filled: bool = False, keepalive=None):
+        self.hp = hp
+        self.handle = C.c_void_p()
+        self._keepalive = keepalive
+        check(lib().wh_model_create(C.byref(_hp_c(hp)), C.c_void_p(arena_ptr) if arena_ptr else None, int(already_filled),
+                                    C.byref(self.handle)))
+
+    @classmethod
+    def from_ggml(cls, model: gf.GgmlModel, arena_ptr: int = 0, keepalive=None) -> "HipModel":
+        m = cls(model.hparams, arena_ptr, False, keepalive)
+        L = lib()
+        filt = np.ascontiguousarray(model.filters, np.float32)
+        check(L.wh_model_set_filters(m.handle, filt.shape[0], filt.shape[1], filt.ctypes.data_as(C.c_void_p)))
+        for name, a in model.tensors.items():
+            a = np.ascontiguousarray(a)
+            ne = (C.c_int32 * a.ndim)(*reversed(a.shape))
+            check(L.wh_model_set_tensor(m.handle, name.encode(), a.ndim, ne, int(a.dtype == np.float16), a.ctypes.data_as(C.c_void_p)))
+        check(L.wh_model_finalize(m.handle))
+        return m
+
+    @classmethod
+    def from_file(cls, path: str) -> "HipModel":
+        return cls.from_ggml(gf.read_model(path))
+
+    def arena(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        check(lib().wh_model_arena(self.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def close(self):
+        if self.handle:
+            lib().wh_model_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipContext:
+    """Activations + KV caches for up to max_batch 30 s windows processed in lock step (WhisperContext of the reference)."""
+
+    def __init__(self, model: HipModel, max_batch: int = 1, stream: int = 0):
+        self.model = model
+        self.hp = model.hp
+        self.max_batch = max_batch
+        self.handle = C.c_void_p()
+        check(lib().wh_context_create(model.handle, max_batch, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
+        self.batch = 0
+
+    def close(self):
+        if self.handle:
+            lib().wh_context_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_parity(self, n_threads: int):
+        """n_threads > 0: emulate the CPU reference's FP16 thread-partitioned P.V accumulation; 0: FP32 fast path."""
+        check(lib().wh_context_set_flags(self.handle, WH_FLAG_PARITY_PV if n_threads > 0 else 0, max(n_threads, 1)))
+
+    def vram_bytes(self) -> int:
+        n = C.c_int64()
+        check(lib().wh_context_memory(self.handle, C.byref(n)))
+        return n.value
+
+    def mel_spectrogram(self, pcm_dev, out_dev=None):
+        """pcm_dev: torch float32 CUDA tensor [n]. Returns torch float32 [n_mel][n//160] on the device."""
+        import torch
+        n = pcm_dev.numel()
+        n_len = n // 160
+        if out_dev is None:
+            out_dev = torch.empty((self.hp.n_mels, n_len), dtype=torch.float32, device=pcm_dev.device)
+        got = C.c_int64()
+        check(lib().wh_mel_spectrogram(self.handle, C.c_void_p(pcm_dev.data_ptr()), n, C.c_void_p(out_dev.data_ptr()), C.byref(got)))
+        return out_dev
+
+    def encode(self, mel_dev, offsets: Optional[Sequence[int]] = None):
+        """mel_dev: torch float32 CUDA tensor [batch][n_mel][mel_len] (or [n_mel][mel_len])."""
+        if mel_dev.dim() == 2:
+            mel_dev = mel_dev.unsqueeze(0)
+        assert mel_dev.is_contiguous() and mel_dev.shape[1] == self.hp.n_mels
+        b, _, ln = mel_dev.shape
+        offs = (C.c_int32 * b)(*(offsets if offsets is not None else [0] * b))
+        check(lib().wh_encode(self.handle, C.c_void_p(mel_dev.data_ptr()), b, ln, self.hp.n_mels * ln, offs))
+        self.batch = b
+
+    def decode(self, tokens, n_past: int, want_logits: bool = True, want_probs: bool = True):
+        """tokens: int array [batch][n_tokens]. Returns (logits, probs) of the LAST token, each [batch][n_vocab] or None."""
+        t = np.ascontiguousarray(tokens, np.int32)
+        if t.ndim == 1:
+            t = t[None, :]
+        b, n = t.shape
+        logits = np.empty((b, self.hp.n_vocab), np.float32) if want_logits else None
+        probs = np.empty((b, self.hp.n_vocab), np.float32) if want_probs else None
+        check(lib().wh_decode(self.handle, t.ctypes.data_as(C.c_void_p), b, n, n_past,
+                              logits.ctypes.data_as(C.c_void_p) if want_logits else None,
+                              probs.ctypes.data_as(C.c_void_p) if want_probs else None))
+        return logits, probs
+
+    def sample_best(self, batch: int, force_timestamp: bool = False, is_initial: bool = False):
+        out = (TokenDataC * batch)()
+        check(lib().wh_sample_best(self.handle, batch, int(force_timestamp), int(is_initial), out))
+        return [dict(id=o.id, tid=o.tid, p=o.p, pt=o.pt, ptsum=o.ptsum) for o in out]
+
+    def debug_read(self, what: str, layer: int = 0, rows: int = 0) -> np.ndarray:
+        d = self.hp.n_audio_state
+        b = self.batch
+        if what == "encode-out" or what.startswith("cross"):
+            shape = (b, self.hp.n_audio_ctx, d)
+        else:
+            shape = (b, rows, d)
+        out = np.empty(shape, np.float32)
+        check(lib().wh_debug_read(self.handle, what.encode(), layer, rows, out.ctypes.data_as(C.c_void_p), out.size))
+        return out

@@ -1,0 +1,84 @@
+"""Builds the native libraries in-tree (hipcc cross-compiles gfx950 without a GPU).
+
+    python -m whisper_amd.build            # libwhisper_hip.so (+ libWhisper.so host API when its sources exist)
+
+The .so files land in whisper_amd/lib/ so they travel with the source snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HOST = os.path.join(HERE, "host")
+LIB_DIR = os.path.join(HERE, "lib")
+HIP_LIB = os.path.join(LIB_DIR, "libwhisper_hip.so")
+HOST_LIB = os.path.join(LIB_DIR, "libWhisper.so")
+
+HIP_SOURCES = ["gemm.hip", "attn_enc.hip", "attn_dec.hip", "elementwise.hip", "mel.hip", "runtime.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build step failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_hip(force: bool = False) -> str:
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs = []
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + [os.path.join(ROOT, "include", "whisper_hip.h")]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    for s in HIP_SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
+        if force or _newer(obj, [src] + headers):
+            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
+                  "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+        objs.append(obj)
+    if force or _newer(HIP_LIB, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    return HIP_LIB
+
+
+def build_host(force: bool = False):
+    """libWhisper.so: the COM-style iModel/iContext host API (plain C++, no HIP headers)."""
+    if not os.path.isdir(HOST):
+        return None
+    srcs = sorted(os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".cpp"))
+    if not srcs:
+        return None
+    hdrs = [os.path.join(HOST, f) for f in os.listdir(HOST) if f.endswith(".h")]
+    hdrs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if force or _newer(HOST_LIB, srcs + hdrs + [HIP_LIB]):
+        _run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+              "-o", HOST_LIB] + srcs + ["-L" + LIB_DIR, "-lwhisper_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+    return HOST_LIB
+
+
+def build_all(force: bool = False):
+    t = time.time()
+    build_hip(force)
+    build_host(force)
+    print("native build ok in %.1fs" % (time.time() - t), flush=True)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

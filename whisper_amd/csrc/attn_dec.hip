@@ -1,0 +1,147 @@
+// Decoder attention (self with causal mask, cross over the encoder keys) for a handful of query rows per sequence.
+//
+// Replaces the decoder's mulMat(K,Q) -> diagMaskInf -> softMax -> mulMat(V,.) chain of the reference
+// (Whisper/Whisper/WhisperContext.cpp:455-470, 505-519; mulMatByRowTiled.hlsl, diagMaskInf.hlsl, softMax*.hlsl).
+// Numerics of the reference CPU path (Whisper/source/whisper.cpp:1618-1660, 1715-1748):
+//   S = K.fp16(Q) (FP32 accumulate, ggml.c:4588-4611, Q and K both pre-scaled by (d/H)^-0.25), causal -inf mask
+//   (ggml.c:4967-5020), table softmax with a double sum (ggml.c:5030-5090), then P.V:
+//     fast path    FP32 accumulation (what the reference's own GPU shaders do),
+//     parity path  the CPU path's FP16, key-by-key, thread-partitioned accumulation (ggml.c:4689-4735 + :4615-4644)
+//                  emulated exactly for `parityThreads` virtual threads.
+// One 256-thread workgroup per (head, sequence, query row). HBM-bound: each K/V row is read once per query row.
+#include "kernels.h"
+
+namespace wh
+{
+	namespace
+	{
+		constexpr int MAX_KEYS = 1536;
+		constexpr int MAX_VTHREADS = 16;
+
+		__global__ void __launch_bounds__( 256 ) attentionDec( const DecAttnArgs a )
+		{
+			__shared__ float sc[ MAX_KEYS ];
+			__shared__ float qs[ HEAD_DIM ];
+			__shared__ float red[ 32 ][ HEAD_DIM ];
+			__shared__ float shf[ 4 ];
+			__shared__ double shd[ 4 ];
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int h = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+			const int d = a.H * HEAD_DIM;
+			const long long rowQ = (long long)b * a.nTok + i;
+			const f16* const K = a.kc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
+			const f16* const V = a.vc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
+			// keys visible to this query row
+			const int nk = a.causal ? min( a.nPast + i + 1, a.nKeys ) : a.nKeys;
+
+			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
+			__syncthreads();
+
+			// ---- scores ----
+			float mx = -INFINITY;
+			for( int key = tid; key < nk; key += 256 )
+			{
+				const f16* kr = K + (long long)key * HEAD_DIM;
+				float s = 0.0f;
+#pragma unroll
+				for( int c8 = 0; c8 < 8; c8++ )
+				{
+					const f16x8 kv = *(const f16x8*)( kr + c8 * 8 );
+#pragma unroll
+					for( int j = 0; j < 8; j++ ) s = fmaf( (float)kv[ j ], qs[ c8 * 8 + j ], s );
+				}
+				sc[ key ] = s;
+				mx = fmaxf( mx, s );
+			}
+			mx = waveReduceMax( mx );
+			if( lane == 0 ) shf[ wave ] = mx;
+			__syncthreads();
+			mx = fmaxf( fmaxf( shf[ 0 ], shf[ 1 ] ), fmaxf( shf[ 2 ], shf[ 3 ] ) );
+
+			// ---- table softmax ----
+			double sum = 0.0;
+			for( int key = tid; key < nk; key += 256 )
+			{
+				const float e = exp16( sc[ key ] - mx );
+				sc[ key ] = e;
+				sum += (double)e;
+			}
+			sum = waveReduceSumD( sum );
+			if( lane == 0 ) shd[ wave ] = sum;
+			__syncthreads();
+			const float inv = (float)( 1.0 / ( ( shd[ 0 ] + shd[ 1 ] ) + ( shd[ 2 ] + shd[ 3 ] ) ) );
+			for( int key = tid; key < nk; key += 256 ) sc[ key ] *= inv;
+			__syncthreads();
+
+			float result = 0.0f;
+			if( a.parityThreads <= 0 )
+			{
+				// ---- P.V, FP32: 32 key slots x 8 lanes of 8 dims ----
+				const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
+				float acc[ 8 ];
+#pragma unroll
+				for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
+				for( int key = g; key < nk; key += 32 )
+				{
+					const f16x8 vv = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
+					const float p = sc[ key ];
+#pragma unroll
+					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ j ], p, acc[ j ] );
+				}
+#pragma unroll
+				for( int j = 0; j < 8; j++ ) red[ g ][ j8 + j ] = acc[ j ];
+				__syncthreads();
+				if( tid < HEAD_DIM )
+				{
+					float t = 0.0f;
+#pragma unroll
+					for( int s = 0; s < 32; s++ ) t += red[ s ][ tid ];
+					result = t;
+				}
+			}
+			else
+			{
+				// ---- P.V exactly as ggml's transposed-src0 branch: per virtual thread, y = fp16( fma( v, p, y ) ) key by key
+				const int nth = min( a.parityThreads, MAX_VTHREADS );
+				const int nc = a.nKeys;	   // the partition is over ALL key columns, masked ones contribute p = 0
+				const int dc = ( nc + nth - 1 ) / nth;
+				for( int vt = wave; vt < nth; vt += 4 )
+				{
+					float y = 0.0f;
+					const int k1 = min( dc * ( vt + 1 ), nc );
+					for( int key = dc * vt; key < k1; key++ )
+					{
+						const float p = key < nk ? sc[ key ] : 0.0f;
+						const float v = (float)V[ (long long)key * HEAD_DIM + lane ];
+						y = round16( fmaf( v, p, y ) );
+					}
+					red[ vt ][ lane ] = y;
+				}
+				__syncthreads();
+				if( tid < HEAD_DIM )
+				{
+					float t = red[ 0 ][ tid ];
+					for( int vt = 1; vt < nth; vt++ ) t += red[ vt ][ tid ];
+					result = t;
+				}
+			}
+			if( tid < HEAD_DIM )
+				a.out[ rowQ * d + h * HEAD_DIM + tid ] = (f16)result;
+		}
+	}	// namespace
+
+	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream )
+	{
+		if( a.nKeys <= 0 || a.nKeys > MAX_KEYS || a.nTok <= 0 || a.batch <= 0 )
+		{
+			setError( "attentionDec: key count out of range" );
+			return -1;
+		}
+		hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( 256 ), 0, stream, a );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+}

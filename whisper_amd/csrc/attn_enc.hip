@@ -1,0 +1,290 @@
+// Encoder self-attention for gfx950, exact ggml_flash_attn_f16 semantics with the scores kept in registers.
+//
+// Replaces the encoder's mulMat(K,Q) -> softMax(1/8) -> mulMat(V,.) chain (Whisper/ML/Context.ops.cpp:199-213) and
+// flashAttention.hlsl:76-169 of the reference. Numerics follow the reference CPU path
+// (Whisper/source/ggml.c:5912-6097): S = K.Q with FP16 operands and FP32 accumulation, * 1/sqrt(64); row maximum
+// over ALL keys; e = exp16(S - max) (the FP16 table semantics); sum in double; P = fp16(e * float(1/sum)); O = V.P
+// with FP32 accumulation. Because P must be rounded to FP16 AFTER normalising by the full row sum, an online
+// (running-max) softmax cannot reproduce it; instead one workgroup owns 64 query rows x ALL keys:
+//
+//   * 512 threads = 8 waves; wave w owns keys [w*32*KT, (w+1)*32*KT) (KT = 6 for n_ctx = 1500 -> 1536 padded keys).
+//   * S^T tiles (32 keys x 32 queries) come from v_mfma_f32_32x32x16_f16 with K as the A operand straight from
+//     global/L2 (each K row is read by exactly one wave, so LDS staging would be pure overhead) and the Q tile as the
+//     B operand from LDS. The accumulators (KT*2 tiles x 16 registers) never leave the register file.
+//   * In the 32x32 accumulator layout a lane holds one query column and 16 keys per tile, so row max / row sum are
+//     in-lane loops + one xor-32 shuffle + an 8-entry LDS exchange between waves.
+//   * P is packed to FP16 in registers directly in the B-operand layout of the P.V MFMA: the accumulator's key order
+//     (r&3) + 8*(r>>2) + 4*(lane>>5) is matched by permuting the K-slots of the V^T operand (two 8-byte loads per
+//     lane from the transposed V the QKV GEMM epilogue wrote), so no cross-lane movement is needed.
+//   * the 8 partial O^T tiles are tree-reduced through LDS in a fixed order (deterministic).
+#include "kernels.h"
+
+namespace wh
+{
+	namespace
+	{
+		constexpr int AQ = 64;				   // query rows per workgroup
+		constexpr int AWAVES = 8;
+		constexpr int QSTRIDE = 72;			   // halfs per LDS row of the Q tile
+		constexpr int OSTRIDE = 65;			   // floats per LDS row of an O buffer
+		constexpr int ATT_LDS_BYTES = AQ * QSTRIDE * 2 + 2 * AWAVES * AQ * 4 + AWAVES * AQ * 8 + 4 * AQ * OSTRIDE * 4;
+
+		template<int KT>
+		__global__ void __launch_bounds__( 512, 2 ) attentionEnc( const f16* __restrict__ q, const f16* __restrict__ k,
+			const f16* __restrict__ vT, f16* __restrict__ out, int heads, int T, int Tpad )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[];
+			f16* const ldsQ = (f16*)smem;
+			float* const redMax = (float*)( smem + AQ * QSTRIDE * 2 );
+			float* const redInv = redMax + AWAVES * AQ;
+			double* const redSum = (double*)( redInv + AWAVES * AQ );
+			float* const obuf = (float*)( redSum + AWAVES * AQ );
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int hi = lane >> 5;
+			const int c = lane & 31;
+			const int bh = blockIdx.y;
+			const int q0 = blockIdx.x * AQ;
+			const f16* const Q = q + (long long)bh * T * HEAD_DIM;
+			const f16* const K = k + (long long)bh * T * HEAD_DIM;
+			const f16* const VT = vT + (long long)bh * HEAD_DIM * Tpad;
+			const int keyBase = wave * 32 * KT;
+
+			// Q tile -> LDS (one 16-byte chunk per thread)
+			{
+				const int row = tid >> 3;
+				const int kc = ( tid & 7 ) * 8;
+				int qr = q0 + row;
+				qr = qr < T ? qr : T - 1;
+				*(u32x4*)( ldsQ + row * QSTRIDE + kc ) = *(const u32x4*)( Q + (long long)qr * HEAD_DIM + kc );
+			}
+			__syncthreads();
+
+			// ---- S^T = K . Q^T ----
+			f32x16 S[ KT ][ 2 ];
+#pragma unroll
+			for( int kt = 0; kt < KT; kt++ )
+			{
+				int key = keyBase + kt * 32 + c;
+				key = key < T ? key : T - 1;
+				f16x8 kf[ 4 ];
+#pragma unroll
+				for( int kk = 0; kk < 4; kk++ )
+					kf[ kk ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + kk * 16 + hi * 8 );
+#pragma unroll
+				for( int qt = 0; qt < 2; qt++ )
+				{
+					f32x16 acc;
+#pragma unroll
+					for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
+#pragma unroll
+					for( int kk = 0; kk < 4; kk++ )
+					{
+						const f16x8 qf = *(const f16x8*)( ldsQ + ( qt * 32 + c ) * QSTRIDE + kk * 16 + hi * 8 );
+						acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( kf[ kk ], qf, acc, 0, 0, 0 );
+					}
+					S[ kt ][ qt ] = acc;
+				}
+			}
+
+			// ---- scale, mask the padded keys, row maximum ----
+			const float scale = 0.125f;	   // 1 / sqrt(64)
+			float mx[ 2 ] = { -INFINITY, -INFINITY };
+#pragma unroll
+			for( int kt = 0; kt < KT; kt++ )
+#pragma unroll
+				for( int qt = 0; qt < 2; qt++ )
+#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const int key = keyBase + kt * 32 + ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+						float s = S[ kt ][ qt ][ r ] * scale;
+						s = key < T ? s : -INFINITY;
+						S[ kt ][ qt ][ r ] = s;
+						mx[ qt ] = fmaxf( mx[ qt ], s );
+					}
+#pragma unroll
+			for( int qt = 0; qt < 2; qt++ )
+			{
+				mx[ qt ] = fmaxf( mx[ qt ], __shfl_xor( mx[ qt ], 32, 64 ) );
+				if( hi == 0 ) redMax[ wave * AQ + qt * 32 + c ] = mx[ qt ];
+			}
+			__syncthreads();
+#pragma unroll
+			for( int qt = 0; qt < 2; qt++ )
+			{
+				float m = redMax[ qt * 32 + c ];
+#pragma unroll
+				for( int w = 1; w < AWAVES; w++ ) m = fmaxf( m, redMax[ w * AQ + qt * 32 + c ] );
+				mx[ qt ] = m;
+			}
+
+			// ---- e = exp16(S - max), row sums in double ----
+			double sum[ 2 ] = { 0.0, 0.0 };
+#pragma unroll
+			for( int kt = 0; kt < KT; kt++ )
+#pragma unroll
+				for( int qt = 0; qt < 2; qt++ )
+#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const float s = S[ kt ][ qt ][ r ];
+						const float e = ( s == -INFINITY ) ? 0.0f : exp16( s - mx[ qt ] );
+						S[ kt ][ qt ][ r ] = e;
+						sum[ qt ] += (double)e;
+					}
+#pragma unroll
+			for( int qt = 0; qt < 2; qt++ )
+			{
+				sum[ qt ] += __shfl_xor( sum[ qt ], 32, 64 );
+				if( hi == 0 ) redSum[ wave * AQ + qt * 32 + c ] = sum[ qt ];
+			}
+			__syncthreads();
+			float inv[ 2 ];
+#pragma unroll
+			for( int qt = 0; qt < 2; qt++ )
+			{
+				double t = redSum[ qt * 32 + c ];
+#pragma unroll
+				for( int w = 1; w < AWAVES; w++ ) t += redSum[ w * AQ + qt * 32 + c ];
+				inv[ qt ] = (float)( 1.0 / t );
+			}
+
+			// ---- P = fp16(e * inv), packed in the B-operand layout of the P.V product ----
+			f16x8 P[ KT ][ 2 ][ 2 ];	// [key tile][16-key step][query tile]
+#pragma unroll
+			for( int kt = 0; kt < KT; kt++ )
+#pragma unroll
+				for( int st = 0; st < 2; st++ )
+#pragma unroll
+					for( int qt = 0; qt < 2; qt++ )
+#pragma unroll
+						for( int j = 0; j < 8; j++ )
+							P[ kt ][ st ][ qt ][ j ] = (f16)( S[ kt ][ qt ][ 8 * st + j ] * inv[ qt ] );
+
+			// ---- O^T = V^T . P^T over this wave's keys ----
+			f32x16 O[ 2 ][ 2 ];	   // [dd tile][query tile]
+#pragma unroll
+			for( int a = 0; a < 2; a++ )
+#pragma unroll
+				for( int b = 0; b < 2; b++ )
+#pragma unroll
+					for( int r = 0; r < 16; r++ ) O[ a ][ b ][ r ] = 0.0f;
+#pragma unroll
+			for( int kt = 0; kt < KT; kt++ )
+#pragma unroll
+				for( int st = 0; st < 2; st++ )
+				{
+					const int kb = keyBase + kt * 32 + 16 * st + 4 * hi;
+					f16x8 vf[ 2 ];
+#pragma unroll
+					for( int ddt = 0; ddt < 2; ddt++ )
+					{
+						const f16* pv = VT + (long long)( ddt * 32 + c ) * Tpad + kb;
+						const f16x4 lo = *(const f16x4*)( pv );
+						const f16x4 hi4 = *(const f16x4*)( pv + 8 );
+						vf[ ddt ] = __builtin_shufflevector( lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7 );
+					}
+#pragma unroll
+					for( int ddt = 0; ddt < 2; ddt++ )
+#pragma unroll
+						for( int qt = 0; qt < 2; qt++ )
+							O[ ddt ][ qt ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( vf[ ddt ], P[ kt ][ st ][ qt ], O[ ddt ][ qt ], 0, 0, 0 );
+				}
+
+			// ---- deterministic tree reduction of the 8 partial tiles through LDS: (0+4) (1+5) (2+6) (3+7) -> (0+2) (1+3) -> 0+1
+			// O^T layout: dd = ddt*32 + (r&3) + 8*(r>>2) + 4*hi (row), query = qt*32 + c (column); LDS image is [query][dd]
+#pragma unroll
+			for( int level = 4; level >= 1; level >>= 1 )
+			{
+				if( wave >= level && wave < 2 * level )
+				{
+					float* const dst = obuf + ( wave - level ) * AQ * OSTRIDE;
+#pragma unroll
+					for( int ddt = 0; ddt < 2; ddt++ )
+#pragma unroll
+						for( int qt = 0; qt < 2; qt++ )
+#pragma unroll
+							for( int r = 0; r < 16; r++ )
+								dst[ ( qt * 32 + c ) * OSTRIDE + ddt * 32 + ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi ] = O[ ddt ][ qt ][ r ];
+				}
+				__syncthreads();
+				if( wave < level )
+				{
+					const float* const src = obuf + wave * AQ * OSTRIDE;
+#pragma unroll
+					for( int ddt = 0; ddt < 2; ddt++ )
+#pragma unroll
+						for( int qt = 0; qt < 2; qt++ )
+#pragma unroll
+							for( int r = 0; r < 16; r++ )
+								O[ ddt ][ qt ][ r ] += src[ ( qt * 32 + c ) * OSTRIDE + ddt * 32 + ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi ];
+				}
+				__syncthreads();
+			}
+			if( wave == 0 )
+			{
+#pragma unroll
+				for( int ddt = 0; ddt < 2; ddt++ )
+#pragma unroll
+					for( int qt = 0; qt < 2; qt++ )
+#pragma unroll
+						for( int r = 0; r < 16; r++ )
+							obuf[ ( qt * 32 + c ) * OSTRIDE + ddt * 32 + ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi ] = O[ ddt ][ qt ][ r ];
+			}
+			__syncthreads();
+
+			// ---- store: out[b][t][h*64 + dd] FP16 (KQV_merged, whisper.cpp:1317-1321; the next product rounds it anyway)
+			{
+				const int row = tid >> 3;
+				const int d0 = ( tid & 7 ) * 8;
+				const int t = q0 + row;
+				if( t < T )
+				{
+					const int b = bh / heads, h = bh - b * heads;
+					f16x8 pk;
+#pragma unroll
+					for( int j = 0; j < 8; j++ ) pk[ j ] = (f16)obuf[ row * OSTRIDE + d0 + j ];
+					*(f16x8*)( out + ( (long long)b * T + t ) * ( heads * HEAD_DIM ) + h * HEAD_DIM + d0 ) = pk;
+				}
+			}
+		}
+
+		template<int KT>
+		int launchEncT( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
+		{
+			static bool attrSet = false;
+			if( !attrSet )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEnc<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES ) );
+				attrSet = true;
+			}
+			dim3 grid( ( T + AQ - 1 ) / AQ, batch * heads );
+			hipLaunchKernelGGL( attentionEnc<KT>, grid, dim3( 512 ), ATT_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+	}	// namespace
+
+	int attentionInit() { return 0; }
+
+	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
+	{
+		if( T <= 0 || T > 1536 || Tpad < ( ( T + 255 ) / 256 ) * 256 || ( Tpad & 7 ) != 0 )
+		{
+			setError( "attentionEnc: need 0 < T <= 1536 and Tpad >= roundup(T, 256)" );
+			return -1;
+		}
+		switch( ( T + 255 ) / 256 )
+		{
+		case 1: return launchEncT<1>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		case 2: return launchEncT<2>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		case 3: return launchEncT<3>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		case 4: return launchEncT<4>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		case 5: return launchEncT<5>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		default: return launchEncT<6>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		}
+	}
+}

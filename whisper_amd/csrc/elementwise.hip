@@ -1,0 +1,290 @@
+// Normalisation, embedding, layout and softmax/sampling kernels (HBM-bound; one wave per row, shuffle reductions).
+#include "kernels.h"
+
+namespace wh
+{
+	namespace
+	{
+		// ---- LayerNorm + affine -> FP16 -----------------------------------------------------------------------------
+		// norm.hlsl / normFixed.hlsl + fmaRepeat1.hlsl of the reference; numerics of ggml_compute_forward_norm_f32
+		// (Whisper/source/ggml.c:4098-4156): mean, centred sum of squares, 1/sqrt(var + 1e-5), then w*y + b as two
+		// separate FP32 operations (whisper.cpp:1195-1199), then the FP16 rounding the next weight product applies.
+		// The reference sums in double; FP32 two-pass with a wavefront shuffle tree differs by ~1e-7 relative.
+		constexpr int LN_MAX_PER_LANE = 32;
+
+		__global__ void __launch_bounds__( 256 ) layerNormKernel( const float* __restrict__ x, const float* __restrict__ w,
+			const float* __restrict__ b, f16* __restrict__ out, int rows, int d )
+		{
+			const int lane = threadIdx.x & 63;
+			const int row = blockIdx.x * 4 + ( threadIdx.x >> 6 );
+			if( row >= rows ) return;
+			const float* xr = x + (long long)row * d;
+			const int per = d >> 6;
+			float v[ LN_MAX_PER_LANE ];
+			float s = 0.0f;
+#pragma unroll
+			for( int i = 0; i < LN_MAX_PER_LANE; i++ )
+				if( i < per )
+				{
+					v[ i ] = xr[ lane + 64 * i ];
+					s += v[ i ];
+				}
+			const float mean = waveReduceSum( s ) / (float)d;
+			float s2 = 0.0f;
+#pragma unroll
+			for( int i = 0; i < LN_MAX_PER_LANE; i++ )
+				if( i < per )
+				{
+					v[ i ] -= mean;
+					s2 += v[ i ] * v[ i ];
+				}
+			const float var = waveReduceSum( s2 ) / (float)d;
+			const float scale = 1.0f / sqrtf( var + 1e-5f );
+			f16* o = out + (long long)row * d;
+#pragma unroll
+			for( int i = 0; i < LN_MAX_PER_LANE; i++ )
+				if( i < per )
+				{
+					const int c = lane + 64 * i;
+					const float y = __fmul_rn( v[ i ], scale );
+					o[ c ] = (f16)__fadd_rn( __fmul_rn( y, w[ c ] ), b[ c ] );
+				}
+		}
+
+		// ---- mel window -> padded FP16 conv input -----------------------------------------------------------------
+		// MelInputTensor::create (Whisper/Whisper/MelInputTensor.cpp:8-63) + convolutionPrep1.hlsl: slice
+		// [offset, offset + T) of each spectrogram, zero beyond its end, transposed to time-major and rounded to FP16
+		// (the convolution rounds its input, ggml.c:5252-5287). Row 0 and row T+1 stay zero: the conv's zero padding.
+		__global__ void __launch_bounds__( 256 ) melToConvInput( const float* __restrict__ mel, long long melStride, long long melLen,
+			const int* __restrict__ melOffsets, f16* __restrict__ x16, long long xBatchStride, int nMels, int T )
+		{
+			__shared__ float tile[ 64 ][ 65 ];
+			const int b = blockIdx.z;
+			const int t0 = blockIdx.x * 64;
+			const int c0 = blockIdx.y * 64;
+			const int off = melOffsets ? melOffsets[ b ] : 0;
+			const float* src = mel + (long long)b * melStride;
+			const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+			for( int r = ty; r < 64; r += 4 )
+			{
+				const int c = c0 + r;
+				const long long t = (long long)off + t0 + tx;
+				float v = 0.0f;
+				if( c < nMels && t0 + tx < T && t < melLen )
+					v = src[ (long long)c * melLen + t ];
+				tile[ r ][ tx ] = v;
+			}
+			__syncthreads();
+			for( int r = ty; r < 64; r += 4 )
+			{
+				const int t = t0 + r;
+				const int c = c0 + tx;
+				if( t < T && c < nMels )
+					x16[ (long long)b * xBatchStride + (long long)( t + 1 ) * nMels + c ] = (f16)tile[ tx ][ r ];
+			}
+		}
+
+		// ---- token + position embedding (addRows.hlsl; whisper.cpp:1544-1548) ---------------------------------------
+		__global__ void __launch_bounds__( 256 ) embedKernel( const int* __restrict__ tokens, const f16* __restrict__ te,
+			const float* __restrict__ pe, float* __restrict__ x, int rows, int nTok, int nPast, int d )
+		{
+			const int row = blockIdx.x;
+			const int tok = tokens[ row ];
+			const int pos = nPast + row % nTok;
+			for( int c = threadIdx.x; c < d; c += 256 )
+				x[ (long long)row * d + c ] = (float)te[ (long long)tok * d + c ] + pe[ (long long)pos * d + c ];
+		}
+
+		// ---- block reductions ------------------------------------------------------------------------------------
+		template<int NW>
+		__device__ __forceinline__ float blockMax( float v, float* sh )
+		{
+			v = waveReduceMax( v );
+			const int w = threadIdx.x >> 6;
+			if( ( threadIdx.x & 63 ) == 0 ) sh[ w ] = v;
+			__syncthreads();
+			float r = sh[ 0 ];
+#pragma unroll
+			for( int i = 1; i < NW; i++ ) r = fmaxf( r, sh[ i ] );
+			__syncthreads();
+			return r;
+		}
+		template<int NW>
+		__device__ __forceinline__ double blockSumD( double v, double* sh )
+		{
+			v = waveReduceSumD( v );
+			const int w = threadIdx.x >> 6;
+			if( ( threadIdx.x & 63 ) == 0 ) sh[ w ] = v;
+			__syncthreads();
+			double r = sh[ 0 ];
+#pragma unroll
+			for( int i = 1; i < NW; i++ ) r += sh[ i ];
+			__syncthreads();
+			return r;
+		}
+
+		// ---- table softmax over rows (softMax.hlsl / softMaxLong.hlsl; ggml.c:5030-5090) ---------------------------
+		// p = exp16( x - max ) / sum, sum in double like the reference, -inf -> 0. One 1024-thread block per row.
+		__global__ void __launch_bounds__( 1024 ) softMaxRows( const float* in, float* out, int cols )
+		{
+			__shared__ float shf[ 16 ];
+			__shared__ double shd[ 16 ];
+			const float* x = in + (long long)blockIdx.x * cols;
+			float* y = out + (long long)blockIdx.x * cols;
+			float m = -INFINITY;
+			for( int c = threadIdx.x; c < cols; c += 1024 ) m = fmaxf( m, x[ c ] );
+			m = blockMax<16>( m, shf );
+			double s = 0.0;
+			for( int c = threadIdx.x; c < cols; c += 1024 )
+			{
+				const float v = x[ c ];
+				const float e = ( v == -INFINITY ) ? 0.0f : exp16( v - m );
+				y[ c ] = e;
+				s += (double)e;
+			}
+			s = blockSumD<16>( s, shd );
+			const float inv = (float)( 1.0 / s );
+			for( int c = threadIdx.x; c < cols; c += 1024 ) y[ c ] = y[ c ] * inv;
+		}
+
+		// ---- ContextImpl::sampleBest on the device (Whisper/Whisper/ContextImpl.cpp:71-157) -------------------------
+		struct ArgMax
+		{
+			float v;
+			int i;
+		};
+		__device__ __forceinline__ ArgMax better( ArgMax a, ArgMax b )
+		{
+			// larger value wins; equal values resolve to the lower index (the reference's partial_sort leaves ties unspecified)
+			if( b.v > a.v || ( b.v == a.v && b.i < a.i ) ) return b;
+			return a;
+		}
+		__device__ __forceinline__ ArgMax blockArgMax( ArgMax a, ArgMax* sh )
+		{
+#pragma unroll
+			for( int o = 32; o > 0; o >>= 1 )
+			{
+				ArgMax b;
+				b.v = __shfl_xor( a.v, o, 64 );
+				b.i = __shfl_xor( a.i, o, 64 );
+				a = better( a, b );
+			}
+			const int w = threadIdx.x >> 6;
+			if( ( threadIdx.x & 63 ) == 0 ) sh[ w ] = a;
+			__syncthreads();
+			ArgMax r = sh[ 0 ];
+			for( int i = 1; i < 16; i++ ) r = better( r, sh[ i ] );
+			__syncthreads();
+			return r;
+		}
+
+		__global__ void __launch_bounds__( 1024 ) sampleBestKernel( const float* __restrict__ probs, int nVocab, int tokenBeg,
+			int tokenSot, int tokenSolm, int tokenNot, int forceTimestamp, int isInitial, TokenData* __restrict__ out )
+		{
+			__shared__ ArgMax sha[ 16 ];
+			__shared__ double shd[ 16 ];
+			const float* p = probs + (long long)blockIdx.x * nVocab;
+			const int tsEnd = isInitial ? min( tokenBeg + 101, nVocab ) : nVocab;
+
+			// best text token and the timestamp statistics
+			ArgMax tx = { -1.0f, 0x7fffffff }, ts = { -1.0f, 0x7fffffff };
+			double sumTs = 0.0;
+			for( int c = threadIdx.x; c < nVocab; c += 1024 )
+			{
+				const float v = p[ c ];
+				if( c < tokenBeg )
+					tx = better( tx, ArgMax{ v, c } );
+				else if( c < tsEnd )
+				{
+					ts = better( ts, ArgMax{ v, c } );
+					sumTs += (double)v;
+				}
+			}
+			tx = blockArgMax( tx, sha );
+			ts = blockArgMax( ts, sha );
+			sumTs = blockSumD<16>( sumTs, shd );
+			const bool onlyTs = ( sumTs > (double)fmaxf( tx.v, -1.0f ) ) || forceTimestamp;
+
+			// top-4 over the surviving tokens, first one that is not sot / solm / not
+			const int lo = onlyTs ? tokenBeg : 0;
+			int taken[ 4 ];
+			ArgMax pick = { -INFINITY, 0 };
+			for( int round = 0; round < 4; round++ )
+			{
+				ArgMax best = { -INFINITY, 0x7fffffff };
+				for( int c = lo + threadIdx.x; c < nVocab; c += 1024 )
+				{
+					bool skip = c >= tsEnd && c >= tokenBeg;	  // masked by the initial-timestamp cap
+					for( int k = 0; k < round; k++ ) skip = skip || ( taken[ k ] == c );
+					if( !skip ) best = better( best, ArgMax{ p[ c ], c } );
+				}
+				best = blockArgMax( best, sha );
+				taken[ round ] = best.i;
+				pick = best;
+				const bool special = best.i == tokenSot || best.i == tokenSolm || best.i == tokenNot;
+				if( !special ) break;
+			}
+			if( threadIdx.x == 0 )
+			{
+				TokenData r;
+				r.id = pick.i;
+				r.tid = ts.v > -1.0f ? ts.i : 0;
+				r.p = pick.v;
+				r.pt = (float)( (double)ts.v / ( sumTs + 1e-10 ) );
+				r.ptsum = (float)sumTs;
+				out[ blockIdx.x ] = r;
+			}
+		}
+	}	// namespace
+
+	int launchLayerNorm( const float* x, const float* w, const float* b, f16* out, int rows, int d, hipStream_t stream )
+	{
+		if( ( d & 63 ) != 0 || d > 64 * LN_MAX_PER_LANE || rows <= 0 )
+		{
+			setError( "layerNorm: d must be a multiple of 64, at most 2048" );
+			return -1;
+		}
+		hipLaunchKernelGGL( layerNormKernel, dim3( ( rows + 3 ) / 4 ), dim3( 256 ), 0, stream, x, w, b, out, rows, d );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets, f16* x16,
+		long long xBatchStride, int nMels, int T, int batch, hipStream_t stream )
+	{
+		dim3 grid( ( T + 63 ) / 64, ( nMels + 63 ) / 64, batch );
+		hipLaunchKernelGGL( melToConvInput, grid, dim3( 256 ), 0, stream, mel, melStride, melLen, melOffsets, x16, xBatchStride, nMels, T );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, int d, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( embedKernel, dim3( rows ), dim3( 256 ), 0, stream, tokens, te, pe, x, rows, nTok, nPast, d );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchSoftMaxRows( float* x, int rows, int cols, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( softMaxRows, dim3( rows ), dim3( 1024 ), 0, stream, x, x, cols );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchVocabSoftMax( const float* logits, float* probs, int rows, int nVocab, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( softMaxRows, dim3( rows ), dim3( 1024 ), 0, stream, logits, probs, nVocab );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchSampleBest( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
+		int forceTimestamp, int isInitial, TokenData* out, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( sampleBestKernel, dim3( rows ), dim3( 1024 ), 0, stream, probs, nVocab, tokenBeg, tokenSot, tokenSolm,
+			tokenNot, forceTimestamp, isInitial, out );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+}

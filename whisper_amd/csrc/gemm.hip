@@ -1,0 +1,435 @@
+// NT GEMM kernels for gfx950: FP16 x FP16 -> FP32 on v_mfma_f32_32x32x16_f16, fused epilogues.
+//
+// Replaces ComputeShaders/mulMatTiled.hlsl (32x32 LDS tiles, FP32 FMA) and mulMatByRowTiled.hlsl (GEMV) of the
+// reference, with the numerics of the reference's CPU path: activations are FP16 (rounded by the producer, which is
+// what ggml does before every weight product, Whisper/source/ggml.c:4588-4611), weights FP16, accumulation FP32.
+//
+// gemmTiled: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles), BK = 64,
+//   register-staged global->LDS double buffering, one barrier per K step. LDS rows are padded to 72 halfs (144 B):
+//   with the 32x32x16 operand layout (lane l reads row l&31, halfs (l>>5)*8..+8) every ds_read_b128 lane group then
+//   hits 16 distinct 16-byte slots of the 256-byte bank row, i.e. conflict free.
+//   Block ids are remapped so that each XCD (block id % 8) owns a contiguous band of M tiles: the band's A rows are
+//   fetched from HBM once per XCD and stay in that XCD's 4 MiB L2 while the (small) weight matrix is re-read from L2.
+// gemmSkinny: M <= 32 rows (decode steps). The weight matrix is the MFMA A operand (32 rows per workgroup), the few
+//   activation rows are the B operand; 4 waves split K and reduce through LDS. Weights are streamed exactly once.
+#include "kernels.h"
+
+namespace wh
+{
+	namespace
+	{
+		constexpr int BM = 128, BN = 128, BK = 64;
+		constexpr int LDS_STRIDE = BK + 8;						  // halfs per LDS row (144 bytes)
+		constexpr int TILE_HALFS = BM * LDS_STRIDE;				  // one operand tile
+		constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_HALFS * 2;	  // [buffer][A|W]
+
+		__device__ __forceinline__ long long rowOffset( int m, int Mb, int ld, long long batchStride )
+		{
+			if( Mb <= 0 ) return (long long)m * ld;
+			const int b = m / Mb;
+			const int t = m - b * Mb;
+			return (long long)b * batchStride + (long long)t * ld;
+		}
+
+		// One output element. m = global row, n = global column, v = FP32 accumulator.
+		template<int EPI>
+		__device__ __forceinline__ void epilogueOne( const GemmArgs& a, int m, int n, float v )
+		{
+			switch( EPI )
+			{
+			case EPI_F32:
+			{
+				if( a.bias ) v += a.bias[ n ];
+				const long long o = rowOffset( m, a.Mb, a.ldc, a.cBatchStride ) + n;
+				if( a.res ) v += a.res[ o ];
+				a.out32[ o ] = v;
+				break;
+			}
+			case EPI_F16_GELU:
+			{
+				const long long o = rowOffset( m, a.Mb, a.ldc, a.cBatchStride ) + n;
+				a.out16[ o ] = gelu16( v + a.bias[ n ] );
+				break;
+			}
+			case EPI_CONV2:
+			{
+				const int b = m / a.Mb;
+				const int t = m - b * a.Mb;
+				const float g = (float)gelu16( v + a.bias[ n ] );
+				a.out32[ (long long)m * a.ldc + n ] = a.pe[ (long long)t * a.N + n ] + g;
+				break;
+			}
+			case EPI_QKV_ENC:
+			{
+				const int d = a.H * HEAD_DIM;
+				const int sel = n / d;
+				const int c = n - sel * d;
+				const int h = c >> 6, dd = c & 63;
+				const int b = m / a.T;
+				const int t = m - b * a.T;
+				const float x = v + a.bias[ n ];
+				const long long bh = (long long)b * a.H + h;
+				if( sel == 0 )
+					a.q[ ( bh * a.T + t ) * HEAD_DIM + dd ] = (f16)x;
+				else if( sel == 1 )
+					a.k[ ( bh * a.T + t ) * HEAD_DIM + dd ] = (f16)x;
+				else
+					a.v[ ( bh * HEAD_DIM + dd ) * a.Tpad + t ] = (f16)x;
+				break;
+			}
+			case EPI_CROSS_KV:
+			{
+				const int d = a.H * HEAD_DIM;
+				const int layer = n / ( 2 * d );
+				const int c2 = n - layer * 2 * d;
+				const int isV = c2 >= d;
+				const int c = isV ? c2 - d : c2;
+				const int h = c >> 6, dd = c & 63;
+				const int b = m / a.T;
+				const int t = m - b * a.T;
+				const long long o = ( ( ( (long long)layer * a.B + b ) * a.H + h ) * a.T + t ) * HEAD_DIM + dd;
+				if( isV )
+					a.v[ o ] = (f16)( v + a.bias[ n ] );
+				else
+					a.k[ o ] = (f16)( v * a.scale );
+				break;
+			}
+			case EPI_QKV_DEC:
+			{
+				const int d = a.H * HEAD_DIM;
+				const int sel = n / d;
+				const int c = n - sel * d;
+				if( sel == 0 )
+				{
+					a.q[ (long long)m * d + c ] = (f16)( ( v + a.bias[ n ] ) * a.scale );
+					break;
+				}
+				const int h = c >> 6, dd = c & 63;
+				const int b = m / a.nTok;
+				const int pos = a.nPast + ( m - b * a.nTok );
+				const long long o = ( ( (long long)b * a.H + h ) * a.textCtx + pos ) * HEAD_DIM + dd;
+				if( sel == 1 )
+					a.k[ o ] = (f16)( v * a.scale );
+				else
+					a.v[ o ] = (f16)( v + a.bias[ n ] );
+				break;
+			}
+			case EPI_Q_DEC:
+				a.q[ (long long)m * a.N + n ] = (f16)( ( v + a.bias[ n ] ) * a.scale );
+				break;
+			}
+		}
+
+		template<int EPI>
+		__global__ void __launch_bounds__( 256, 2 ) gemmTiled( const GemmArgs a )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[];
+			f16* const lds = (f16*)smem;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int wm = wave >> 1, wn = wave & 1;
+
+			const int tilesN = ( a.N + BN - 1 ) / BN;
+			// XCD-aware, bijective block remap (each XCD gets a contiguous range of linear tile ids)
+			int lin;
+			{
+				const int nb = gridDim.x, bid = blockIdx.x;
+				const int q = nb >> 3, r = nb & 7;
+				const int xcd = bid & 7, idx = bid >> 3;
+				lin = ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + idx;
+			}
+			const int tm = lin / tilesN;
+			const int tn = lin - tm * tilesN;
+
+			// global -> register staging: 4 chunks of 16 bytes per thread per operand
+			const f16* gA[ 4 ];
+			const f16* gW[ 4 ];
+			int ldsOff[ 4 ];
+#pragma unroll
+			for( int i = 0; i < 4; i++ )
+			{
+				const int c = tid + i * 256;
+				const int row = c >> 3;
+				const int kc = ( c & 7 ) * 8;
+				int m = tm * BM + row;
+				m = m < a.M ? m : a.M - 1;
+				int n = tn * BN + row;
+				n = n < a.N ? n : a.N - 1;
+				gA[ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kc;
+				gW[ i ] = a.W + (long long)n * a.K + kc;
+				ldsOff[ i ] = row * LDS_STRIDE + kc;
+			}
+
+			f32x16 acc[ 2 ][ 2 ];
+#pragma unroll
+			for( int i = 0; i < 2; i++ )
+#pragma unroll
+				for( int j = 0; j < 2; j++ )
+#pragma unroll
+					for( int r = 0; r < 16; r++ )
+						acc[ i ][ j ][ r ] = 0.0f;
+
+			u32x4 ra[ 4 ], rw[ 4 ];
+			const int nk = a.K / BK;
+
+#pragma unroll
+			for( int i = 0; i < 4; i++ )
+			{
+				ra[ i ] = *(const u32x4*)( gA[ i ] );
+				rw[ i ] = *(const u32x4*)( gW[ i ] );
+			}
+#pragma unroll
+			for( int i = 0; i < 4; i++ )
+			{
+				*(u32x4*)( lds + ldsOff[ i ] ) = ra[ i ];
+				*(u32x4*)( lds + TILE_HALFS + ldsOff[ i ] ) = rw[ i ];
+			}
+			__syncthreads();
+
+			const int fragRow = lane & 31;
+			const int fragK = ( lane >> 5 ) * 8;
+
+			for( int kt = 0; kt < nk; kt++ )
+			{
+				const int cur = kt & 1;
+				const f16* const ldsA = lds + cur * 2 * TILE_HALFS;
+				const f16* const ldsW = ldsA + TILE_HALFS;
+				const bool more = kt + 1 < nk;
+				if( more )
+				{
+					const int ko = ( kt + 1 ) * BK;
+#pragma unroll
+					for( int i = 0; i < 4; i++ )
+					{
+						ra[ i ] = *(const u32x4*)( gA[ i ] + ko );
+						rw[ i ] = *(const u32x4*)( gW[ i ] + ko );
+					}
+				}
+#pragma unroll
+				for( int ks = 0; ks < BK / 16; ks++ )
+				{
+					f16x8 fa[ 2 ], fb[ 2 ];
+#pragma unroll
+					for( int i = 0; i < 2; i++ )
+					{
+						fa[ i ] = *(const f16x8*)( ldsA + ( wm * 64 + i * 32 + fragRow ) * LDS_STRIDE + ks * 16 + fragK );
+						fb[ i ] = *(const f16x8*)( ldsW + ( wn * 64 + i * 32 + fragRow ) * LDS_STRIDE + ks * 16 + fragK );
+					}
+#pragma unroll
+					for( int i = 0; i < 2; i++ )
+#pragma unroll
+						for( int j = 0; j < 2; j++ )
+							acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ], fb[ j ], acc[ i ][ j ], 0, 0, 0 );
+				}
+				if( more )
+				{
+					f16* const nxt = lds + ( cur ^ 1 ) * 2 * TILE_HALFS;
+#pragma unroll
+					for( int i = 0; i < 4; i++ )
+					{
+						*(u32x4*)( nxt + ldsOff[ i ] ) = ra[ i ];
+						*(u32x4*)( nxt + TILE_HALFS + ldsOff[ i ] ) = rw[ i ];
+					}
+				}
+				__syncthreads();
+			}
+
+			// epilogue: D[row][col], col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+			const int hi = lane >> 5;
+#pragma unroll
+			for( int i = 0; i < 2; i++ )
+			{
+#pragma unroll
+				for( int j = 0; j < 2; j++ )
+				{
+					const int n = tn * BN + wn * 64 + j * 32 + ( lane & 31 );
+					const int mBase = tm * BM + wm * 64 + i * 32 + 4 * hi;
+					const bool nOk = n < a.N;
+					bool packedV = false;
+					if constexpr( EPI == EPI_QKV_ENC )
+						packedV = nOk && n >= 2 * a.H * HEAD_DIM && ( a.T & 3 ) == 0;
+					if( packedV )
+					{
+						// transposed V: the 4 rows (r & 3) are 4 consecutive time steps of one (b, h, dd) row of vT
+						const int c = n - 2 * a.H * HEAD_DIM;
+						const int h = c >> 6, dd = c & 63;
+						const float bias = a.bias[ n ];
+#pragma unroll
+						for( int g = 0; g < 4; g++ )
+						{
+							const int m0 = mBase + 8 * g;
+							if( m0 < a.M )
+							{
+								const int b = m0 / a.T;
+								const int t = m0 - b * a.T;
+								f16x4 pk;
+								pk[ 0 ] = (f16)( acc[ i ][ j ][ 4 * g + 0 ] + bias );
+								pk[ 1 ] = (f16)( acc[ i ][ j ][ 4 * g + 1 ] + bias );
+								pk[ 2 ] = (f16)( acc[ i ][ j ][ 4 * g + 2 ] + bias );
+								pk[ 3 ] = (f16)( acc[ i ][ j ][ 4 * g + 3 ] + bias );
+								*(f16x4*)( a.v + ( ( (long long)b * a.H + h ) * HEAD_DIM + dd ) * a.Tpad + t ) = pk;
+							}
+						}
+					}
+					else if( nOk )
+					{
+#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							const int m = mBase + ( r & 3 ) + 8 * ( r >> 2 );
+							if( m < a.M )
+								epilogueOne<EPI>( a, m, n, acc[ i ][ j ][ r ] );
+						}
+					}
+				}
+			}
+		}
+
+		// ---- skinny: M <= 32 ----
+		constexpr int SK_WAVES = 4;
+
+		template<int EPI>
+		__global__ void __launch_bounds__( 256 ) gemmSkinny( const GemmArgs a )
+		{
+			__shared__ float red[ SK_WAVES - 1 ][ 16 ][ 64 ];
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int n0 = blockIdx.x * 32;
+
+			int n = n0 + ( lane & 31 );
+			n = n < a.N ? n : a.N - 1;
+			int m = lane & 31;
+			m = m < a.M ? m : a.M - 1;
+			const int kPer = a.K / SK_WAVES;
+			const int kBeg = wave * kPer + ( lane >> 5 ) * 8;
+			const f16* pw = a.W + (long long)n * a.K + kBeg;
+			const f16* px = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
+
+			f32x16 acc;
+#pragma unroll
+			for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
+
+			const int steps = kPer / 16;
+			int s = 0;
+			for( ; s + 4 <= steps; s += 4 )
+			{
+				f16x8 fw[ 4 ], fx[ 4 ];
+#pragma unroll
+				for( int u = 0; u < 4; u++ )
+				{
+					fw[ u ] = __builtin_nontemporal_load( (const f16x8*)( pw + ( s + u ) * 16 ) );
+					fx[ u ] = *(const f16x8*)( px + ( s + u ) * 16 );
+				}
+#pragma unroll
+				for( int u = 0; u < 4; u++ )
+					acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( fw[ u ], fx[ u ], acc, 0, 0, 0 );
+			}
+			for( ; s < steps; s++ )
+			{
+				const f16x8 fw = *(const f16x8*)( pw + s * 16 );
+				const f16x8 fx = *(const f16x8*)( px + s * 16 );
+				acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( fw, fx, acc, 0, 0, 0 );
+			}
+
+			if( wave > 0 )
+			{
+#pragma unroll
+				for( int r = 0; r < 16; r++ ) red[ wave - 1 ][ r ][ lane ] = acc[ r ];
+			}
+			__syncthreads();
+			if( wave != 0 ) return;
+#pragma unroll
+			for( int w = 0; w < SK_WAVES - 1; w++ )
+#pragma unroll
+				for( int r = 0; r < 16; r++ ) acc[ r ] += red[ w ][ r ][ lane ];
+
+			// D[row][col]: row = weight row (n), col = activation row (m)
+			const int mm = lane & 31;
+			if( mm >= a.M ) return;
+			const int hi = lane >> 5;
+#pragma unroll
+			for( int r = 0; r < 16; r++ )
+			{
+				const int nn = n0 + ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+				if( nn < a.N )
+					epilogueOne<EPI>( a, mm, nn, acc[ r ] );
+			}
+		}
+	}	// namespace
+
+	template<int EPI>
+	static int launchTiledT( const GemmArgs& a, hipStream_t stream )
+	{
+		static bool attrSet = false;
+		if( !attrSet )
+		{
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES ) );
+			attrSet = true;
+		}
+		const int tilesM = ( a.M + BM - 1 ) / BM, tilesN = ( a.N + BN - 1 ) / BN;
+		hipLaunchKernelGGL( gemmTiled<EPI>, dim3( tilesM * tilesN ), dim3( 256 ), GEMM_LDS_BYTES, stream, a );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+	template<int EPI>
+	static int launchSkinnyT( const GemmArgs& a, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( gemmSkinny<EPI>, dim3( ( a.N + 31 ) / 32 ), dim3( 256 ), 0, stream, a );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int gemmInit() { return 0; }
+
+	static int checkArgs( const GemmArgs& a )
+	{
+		if( a.M <= 0 || a.N <= 0 || a.K <= 0 || ( a.K % 64 ) != 0 )
+		{
+			setError( "gemm: M, N must be positive and K a positive multiple of 64" );
+			return -1;
+		}
+		if( ( a.lda % 8 ) != 0 || ( a.aBatchStride % 8 ) != 0 )
+		{
+			setError( "gemm: A rows must be 16-byte aligned" );
+			return -1;
+		}
+		return 0;
+	}
+
+	int launchGemm( const GemmArgs& a, hipStream_t stream )
+	{
+		WH_CHECK( checkArgs( a ) );
+		switch( a.epi )
+		{
+		case EPI_F32: return launchTiledT<EPI_F32>( a, stream );
+		case EPI_F16_GELU: return launchTiledT<EPI_F16_GELU>( a, stream );
+		case EPI_CONV2: return launchTiledT<EPI_CONV2>( a, stream );
+		case EPI_QKV_ENC: return launchTiledT<EPI_QKV_ENC>( a, stream );
+		case EPI_CROSS_KV: return launchTiledT<EPI_CROSS_KV>( a, stream );
+		case EPI_QKV_DEC: return launchTiledT<EPI_QKV_DEC>( a, stream );
+		case EPI_Q_DEC: return launchTiledT<EPI_Q_DEC>( a, stream );
+		}
+		setError( "gemm: unknown epilogue" );
+		return -1;
+	}
+
+	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream )
+	{
+		if( a.M > 32 )
+			return launchGemm( a, stream );
+		WH_CHECK( checkArgs( a ) );
+		switch( a.epi )
+		{
+		case EPI_F32: return launchSkinnyT<EPI_F32>( a, stream );
+		case EPI_F16_GELU: return launchSkinnyT<EPI_F16_GELU>( a, stream );
+		case EPI_QKV_DEC: return launchSkinnyT<EPI_QKV_DEC>( a, stream );
+		case EPI_Q_DEC: return launchSkinnyT<EPI_Q_DEC>( a, stream );
+		}
+		setError( "gemm: epilogue not available in the skinny kernel" );
+		return -1;
+	}
+}

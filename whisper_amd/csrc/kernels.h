@@ -1,0 +1,109 @@
+// Kernel launch interface shared by the .hip translation units and the model/context code.
+#pragma once
+#include "common.h"
+
+namespace wh
+{
+	// ---------------------------------------------------------------------------------------------------------------
+	// NT GEMM: acc[m][n] = sum_k A[m][k] * W[n][k], FP16 operands, FP32 accumulate on MFMA (32x32x16).
+	// Replaces mulMatTiled.hlsl / mulMatByRowTiled.hlsl and, through the row mapping below, the five convolution*.hlsl
+	// shaders. Every elementwise shader of the reference that follows a product (addRepeat*, addRepeatGelu,
+	// scaleInPlace, copyConvert, copyTranspose, addInPlace) is an epilogue here.
+	// ---------------------------------------------------------------------------------------------------------------
+	enum eEpilogue : int
+	{
+		EPI_F32 = 0,	  // out32 = acc (+bias[n]) (+res)                       mulMat + addRepeat(+Ex)
+		EPI_F16_GELU,	  // out16 = gelu16( acc + bias[n] )                     mulMat + addRepeatGelu
+		EPI_CONV2,		  // out32 = float( gelu16( acc + bias[n] ) ) + pe[t][n]  conv_1d_2s + gelu + positional embedding
+		EPI_QKV_ENC,	  // head-split FP16 Q, K and transposed V               encoder Q/K/V + copyConvert/copyTranspose
+		EPI_CROSS_KV,	  // cross-attention caches of all decoder layers        WhisperContext.cpp:345-389
+		EPI_QKV_DEC,	  // decoder: scaled Q, append scaled K and V to self-KV WhisperContext.cpp:424-452
+		EPI_Q_DEC,		  // decoder cross-attention query: fp16( (acc+bias)*scale )
+	};
+
+	struct GemmArgs
+	{
+		const f16* A;
+		const f16* W;
+		int M, N, K;
+		// A row m lives at A + (m / Mb) * aBatchStride + (m % Mb) * lda   (Mb >= M means one segment)
+		int lda, Mb;
+		long long aBatchStride;
+		int epi;
+		const float* bias;	  // [N] or null
+		const float* res;	  // same addressing as out32, or null
+		float* out32;
+		f16* out16;
+		// output row m lives at (m / Mb) * cBatchStride + (m % Mb) * ldc
+		int ldc;
+		long long cBatchStride;
+		const float* pe;	  // EPI_CONV2: [Mb][N]
+		float scale;
+		// head-split outputs
+		f16* q;				  // ENC: [b][h][T][64]   DEC: [m][d]
+		f16* k;				  // ENC: [b][h][T][64]   CROSS: [layer][b][h][T][64]   DEC: self-K [b][h][textCtx][64] (layer applied)
+		f16* v;				  // ENC: [b][h][64][Tpad] CROSS: like k                 DEC: self-V like k
+		int T, Tpad, H, B;
+		int nTok, nPast, textCtx;
+	};
+
+	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
+	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream );	// M <= 32 rows (decode steps): weights streamed once
+	int gemmInit();													// one-time function attributes
+
+	// ---------------------------------------------------------------------------------------------------------------
+	// elementwise / normalisation
+	// ---------------------------------------------------------------------------------------------------------------
+	// out16[row] = fp16( norm(x[row]) * w + b ); rows of length d (multiple of 64, <= 2048). norm.hlsl + fmaRepeat1.hlsl
+	int launchLayerNorm( const float* x, const float* w, const float* b, f16* out, int rows, int d, hipStream_t stream );
+	// x16[b][t+1][c] = fp16( mel[b][c][off_b + t] ), zero outside the spectrogram; rows 0 and T+1 are the conv padding
+	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets,
+		f16* x16, long long xBatchStride, int nMels, int T, int batch, hipStream_t stream );
+	// x[m] = float(te[token[m]]) + pe[nPast + m % nTok]   (addRows.hlsl)
+	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, int d, hipStream_t stream );
+	// in-place table softmax of FP32 rows (softMax*.hlsl with the CPU path's FP16 exp table semantics)
+	int launchSoftMaxRows( float* x, int rows, int cols, hipStream_t stream );
+
+	// ---------------------------------------------------------------------------------------------------------------
+	// attention
+	// ---------------------------------------------------------------------------------------------------------------
+	// encoder (unmasked) attention, all keys; q,k [bh][T][64], vT [bh][64][Tpad], out [b][T][H*64] FP16
+	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream );
+	int attentionInit();
+
+	struct DecAttnArgs
+	{
+		const f16* q;		   // [batch*nTok][d], already scaled
+		const f16* kc;		   // [batch][H][keyStride][64]
+		const f16* vc;
+		f16* out;			   // [batch*nTok][d]
+		int batch, H, nTok;
+		int nKeys;			   // keys visible to the LAST query (self: nPast+nTok; cross: n_audio_ctx)
+		int keyStride;		   // rows allocated per (b,h)
+		int causal;			   // 1: query i sees keys <= nPast + i
+		int nPast;
+		int parityThreads;	   // 0 = FP32 P.V; >0 = emulate ggml's FP16 thread-partitioned accumulation
+	};
+	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream );
+
+	// ---------------------------------------------------------------------------------------------------------------
+	// logits -> probabilities -> greedy token, on the device
+	// ---------------------------------------------------------------------------------------------------------------
+	struct TokenData
+	{
+		int id, tid;
+		float p, pt, ptsum;
+	};
+	// probs[row] = table softmax( logits[row] ) (ggml.c:5030-5090)
+	int launchVocabSoftMax( const float* logits, float* probs, int rows, int nVocab, hipStream_t stream );
+	// ContextImpl::sampleBest on the device
+	int launchSampleBest( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
+		int forceTimestamp, int isInitial, TokenData* out, hipStream_t stream );
+
+	// ---------------------------------------------------------------------------------------------------------------
+	// mel spectrogram
+	// ---------------------------------------------------------------------------------------------------------------
+	// raw log-mel (before clamp/normalise) [nMel][nLen] + running maximum; then normalise in place
+	int launchMel( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
+		int nMel, float* maxScratch, hipStream_t stream );
+}

@@ -1,0 +1,127 @@
+// PCM -> log-mel spectrogram on the GPU.
+//
+// Replaces Spectrogram::pcmToMel / SpectrogramContext::fft (Whisper/Whisper/Spectrogram.cpp:64-122,
+// melSpectrogram.cpp:318-391) == log_mel_spectrogram (Whisper/source/whisper.cpp:2060-2180):
+//   frames at hop 160 without centre padding (n_len = n_samples / 160), zero beyond the end; periodic Hann(400)
+//   applied in FP32 like the reference; 400-point real DFT; power; the reference's fold p[j] += p[400-j], j = 1..199
+//   (for a real signal p[400-j] == p[j], so the fold doubles those bins); 80x201 filterbank with a double sum;
+//   log10(max(., 1e-10)) stored as float; then, over the WHOLE buffer, clamp to (max - 8) and (x + 4) / 4.
+// The reference evaluates the DFT with a recursive FP32 FFT (radix-2 down to 25-point DFTs) whose own rounding noise
+// is ~1e-6 of the frame energy; here the DFT is evaluated directly in FP64 against a host-built twiddle table, i.e. it
+// is the exact value the reference approximates. HBM traffic is negligible (1.9 MB in, 1 MB out per 30 s); the kernel
+// is LDS/FP64-issue bound and takes well under 1 % of a window's time.
+#include "kernels.h"
+
+namespace wh
+{
+	namespace
+	{
+		constexpr int N_FFT = 400, N_BINS = 201, HOP = 160;
+		constexpr int FR = 8;	 // frames per workgroup
+
+		__device__ __forceinline__ int orderedInt( float f )
+		{
+			const int i = __float_as_int( f );
+			return i >= 0 ? i : i ^ 0x7fffffff;
+		}
+		__device__ __forceinline__ float fromOrderedInt( int i ) { return __int_as_float( i >= 0 ? i : i ^ 0x7fffffff ); }
+
+		__global__ void __launch_bounds__( 256 ) melKernel( const float* __restrict__ pcm, long long nSamples,
+			const float* __restrict__ filters, const double* __restrict__ dft, float* __restrict__ mel, long long nLen, int nMel,
+			int* __restrict__ maxOrdered )
+		{
+			__shared__ double tw[ 2 ][ N_FFT ];		  // cos, sin of 2 pi n / 400
+			__shared__ double fr[ FR ][ N_FFT ];		  // windowed frames
+			__shared__ double pw[ FR ][ N_BINS + 7 ];  // folded power spectrum
+			__shared__ int shMax;
+
+			const int tid = threadIdx.x;
+			const long long f0 = (long long)blockIdx.x * FR;
+			for( int i = tid; i < 2 * N_FFT; i += 256 ) ( &tw[ 0 ][ 0 ] )[ i ] = dft[ i ];
+			if( tid == 0 ) shMax = (int)0x80000000;
+			for( int i = tid; i < FR * N_FFT; i += 256 )
+			{
+				const int f = i / N_FFT, n = i - f * N_FFT;
+				const long long s = ( f0 + f ) * HOP + n;
+				// hann[n] = 0.5 * (1 - cos(2 pi n / 400)) evaluated in double and rounded to float, product in float (whisper.cpp:2073-2077, :2104)
+				const float hann = (float)( 0.5 * ( 1.0 - dft[ n ] ) );
+				const float x = ( s < nSamples && f0 + f < nLen ) ? pcm[ s ] : 0.0f;
+				fr[ f ][ n ] = (double)( hann * x );
+			}
+			__syncthreads();
+
+			// ---- DFT bins 0..200, FP64 ----
+			if( tid < N_BINS )
+			{
+				double re[ FR ], im[ FR ];
+#pragma unroll
+				for( int f = 0; f < FR; f++ ) re[ f ] = im[ f ] = 0.0;
+				int idx = 0;
+				for( int n = 0; n < N_FFT; n++ )
+				{
+					const double c = tw[ 0 ][ idx ], s = tw[ 1 ][ idx ];
+#pragma unroll
+					for( int f = 0; f < FR; f++ )
+					{
+						const double x = fr[ f ][ n ];
+						re[ f ] = fma( x, c, re[ f ] );
+						im[ f ] = fma( -x, s, im[ f ] );
+					}
+					idx += tid;
+					if( idx >= N_FFT ) idx -= N_FFT;
+				}
+				const double fold = ( tid >= 1 && tid < N_FFT / 2 ) ? 2.0 : 1.0;
+#pragma unroll
+				for( int f = 0; f < FR; f++ ) pw[ f ][ tid ] = fold * ( re[ f ] * re[ f ] + im[ f ] * im[ f ] );
+			}
+			__syncthreads();
+
+			// ---- filterbank + log10 ----
+			float localMax = -INFINITY;
+			for( int o = tid; o < FR * nMel; o += 256 )
+			{
+				const int j = o / FR, f = o - j * FR;
+				if( f0 + f >= nLen ) continue;
+				const float* w = filters + (long long)j * N_BINS;
+				double sum = 0.0;
+				for( int kk = 0; kk < N_BINS; kk++ ) sum = fma( pw[ f ][ kk ], (double)w[ kk ], sum );
+				sum = sum < 1e-10 ? 1e-10 : sum;
+				const float v = (float)log10( sum );
+				mel[ (long long)j * nLen + f0 + f ] = v;
+				localMax = fmaxf( localMax, v );
+			}
+			localMax = waveReduceMax( localMax );
+			if( ( tid & 63 ) == 0 && localMax > -INFINITY ) atomicMax( &shMax, orderedInt( localMax ) );
+			__syncthreads();
+			if( tid == 0 && shMax != (int)0x80000000 ) atomicMax( maxOrdered, shMax );
+		}
+
+		__global__ void __launch_bounds__( 256 ) melNormalize( float* __restrict__ mel, long long count, const int* __restrict__ maxOrdered )
+		{
+			const double mmax = (double)fromOrderedInt( *maxOrdered ) - 8.0;
+			for( long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256 )
+			{
+				double v = (double)mel[ i ];
+				v = v < mmax ? mmax : v;
+				mel[ i ] = (float)( ( v + 4.0 ) / 4.0 );
+			}
+		}
+
+		__global__ void melInitMax( int* maxOrdered ) { *maxOrdered = (int)0x80000000; }
+	}	// namespace
+
+	int launchMel( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
+		int nMel, float* maxScratch, hipStream_t stream )
+	{
+		if( nLen <= 0 ) return 0;
+		int* const mx = (int*)maxScratch;
+		hipLaunchKernelGGL( melInitMax, dim3( 1 ), dim3( 1 ), 0, stream, mx );
+		const int blocks = (int)( ( nLen + FR - 1 ) / FR );
+		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx );
+		const long long count = nLen * nMel;
+		const int nb = (int)( ( count + 255 ) / 256 < 2048 ? ( count + 255 ) / 256 : 2048 );
+		hipLaunchKernelGGL( melNormalize, dim3( nb ), dim3( 256 ), 0, stream, mel, count, mx );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+}

@@ -1,0 +1,898 @@
+// Model arena, context and the encode / decode graphs behind the C ABI of include/whisper_hip.h.
+//
+// This file is the MI355X counterpart of the reference's DirectCompute::WhisperContext
+// (Whisper/Whisper/WhisperContext.cpp: encode :310-399, encodeLayer :158-289, decode :578-639, decodeLayer :407-576),
+// ModelBuffers (Whisper/Whisper/ModelBuffers.h:8-112) and KeyValueBuffers (KeyValueBuffers.h:7-53). It is host code
+// only: every arithmetic step is a kernel from gemm.hip / attn_enc.hip / attn_dec.hip / elementwise.hip / mel.hip.
+//
+// Memory model (sized for 288 GB of HBM3E, no allocation in steady state):
+//   * ONE packed weight arena per model, layout a pure function of the hparams, so a rank that did not read the file
+//     can receive it with a single RCCL broadcast. Q/K/V weights of a layer are concatenated to one [3d][d] matrix, the
+//     cross-attention K/V weights of ALL decoder layers to one [2*L*d][d] matrix (one big GEMM per window).
+//   * per context: activations for maxBatch windows in lock step + FP16 KV caches
+//       cross  [layer][batch][head][n_audio_ctx][64]   (K pre-scaled by (d/H)^-0.25, whisper.cpp:1465)
+//       self   [layer][batch][head][n_text_ctx][64]
+#include "kernels.h"
+#include "../../include/whisper_hip.h"
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace wh
+{
+	static thread_local std::string g_lastError;
+	void setError( const std::string& s ) { g_lastError = s; }
+	int hipFail( hipError_t e, const char* what, const char* file, int line )
+	{
+		char buf[ 512 ];
+		snprintf( buf, sizeof( buf ), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString( e ), file, line, what );
+		g_lastError = buf;
+		return WH_E_HIP;
+	}
+}
+using namespace wh;
+
+namespace
+{
+	constexpr int CONV1_KPAD = 256;	   // 3 * 80 = 240 taps*channels, zero-padded to a multiple of 64
+	inline int64_t align256( int64_t x ) { return ( x + 255 ) & ~(int64_t)255; }
+	inline int roundUp( int x, int m ) { return ( x + m - 1 ) / m * m; }
+
+	struct EncLayer
+	{
+		int64_t ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2;
+	};
+	struct DecLayer
+	{
+		int64_t ln1w, ln1b, wqkv, bqkv, wo, bo, lncw, lncb, wcq, bcq, wco, bco, ln2w, ln2b, w1, b1, w2, b2;
+	};
+	struct Layout
+	{
+		int64_t filters, dft, encPe, conv1w, conv1b, conv2w, conv2b, lnPostW, lnPostB;
+		int64_t decPe, te, decLnW, decLnB, wcross, bcross;
+		std::vector<EncLayer> enc;
+		std::vector<DecLayer> dec;
+		int64_t total;
+	};
+
+	Layout makeLayout( const wh_hparams& hp )
+	{
+		Layout L;
+		int64_t o = 0;
+		auto take = [ & ]( int64_t bytes ) { const int64_t r = o; o = align256( o + bytes ); return r; };
+		const int64_t d = hp.n_audio_state, V = hp.n_vocab;
+		L.filters = take( 4ll * hp.n_mels * 201 );
+		L.dft = take( 8ll * 800 );
+		L.encPe = take( 4ll * hp.n_audio_ctx * d );
+		L.conv1w = take( 2ll * d * CONV1_KPAD );
+		L.conv1b = take( 4 * d );
+		L.conv2w = take( 2ll * d * 3 * d );
+		L.conv2b = take( 4 * d );
+		L.lnPostW = take( 4 * d );
+		L.lnPostB = take( 4 * d );
+		L.enc.resize( hp.n_audio_layer );
+		for( auto& e : L.enc )
+		{
+			e.ln1w = take( 4 * d ); e.ln1b = take( 4 * d );
+			e.wqkv = take( 2ll * 3 * d * d ); e.bqkv = take( 4 * 3 * d );
+			e.wo = take( 2ll * d * d ); e.bo = take( 4 * d );
+			e.ln2w = take( 4 * d ); e.ln2b = take( 4 * d );
+			e.w1 = take( 2ll * 4 * d * d ); e.b1 = take( 4 * 4 * d );
+			e.w2 = take( 2ll * 4 * d * d ); e.b2 = take( 4 * d );
+		}
+		L.decPe = take( 4ll * hp.n_text_ctx * d );
+		L.te = take( 2ll * V * d );
+		L.decLnW = take( 4 * d ); L.decLnB = take( 4 * d );
+		L.wcross = take( 2ll * 2 * hp.n_text_layer * d * d );
+		L.bcross = take( 4ll * 2 * hp.n_text_layer * d );
+		L.dec.resize( hp.n_text_layer );
+		for( auto& e : L.dec )
+		{
+			e.ln1w = take( 4 * d ); e.ln1b = take( 4 * d );
+			e.wqkv = take( 2ll * 3 * d * d ); e.bqkv = take( 4 * 3 * d );
+			e.wo = take( 2ll * d * d ); e.bo = take( 4 * d );
+			e.lncw = take( 4 * d ); e.lncb = take( 4 * d );
+			e.wcq = take( 2ll * d * d ); e.bcq = take( 4 * d );
+			e.wco = take( 2ll * d * d ); e.bco = take( 4 * d );
+			e.ln2w = take( 4 * d ); e.ln2b = take( 4 * d );
+			e.w1 = take( 2ll * 4 * d * d ); e.b1 = take( 4 * 4 * d );
+			e.w2 = take( 2ll * 4 * d * d ); e.b2 = take( 4 * d );
+		}
+		L.total = o;
+		return L;
+	}
+
+	int checkHparams( const wh_hparams* hp )
+	{
+		if( !hp ) { setError( "hparams is null" ); return WH_E_INVALIDARG; }
+		const int d = hp->n_audio_state;
+		if( d <= 0 || d != hp->n_text_state || ( d % 64 ) != 0 || hp->n_audio_head * HEAD_DIM != d || hp->n_text_head * HEAD_DIM != d )
+		{
+			setError( "unsupported model: need n_audio_state == n_text_state == 64 * heads" );
+			return WH_E_INVALIDARG;
+		}
+		if( hp->n_audio_ctx <= 0 || hp->n_audio_ctx > 1536 || hp->n_text_ctx <= 0 || hp->n_text_ctx > 1536 || hp->n_mels <= 0 ||
+			3 * hp->n_mels > CONV1_KPAD || ( hp->n_mels % 8 ) != 0 || hp->n_vocab <= 0 || hp->n_audio_layer <= 0 || hp->n_text_layer <= 0 )
+		{
+			setError( "unsupported model dimensions" );
+			return WH_E_INVALIDARG;
+		}
+		return 0;
+	}
+}	// namespace
+
+struct wh_model
+{
+	wh_hparams hp;
+	Layout L;
+	uint8_t* arena = nullptr;
+	bool ownsArena = false;
+	bool finalized = false;
+	std::set<std::string> loaded;
+	bool filtersSet = false;
+	template<class T> T* at( int64_t off ) const { return (T*)( arena + off ); }
+	size_t expectedTensors() const { return 11 + 15 * (size_t)hp.n_audio_layer + 24 * (size_t)hp.n_text_layer; }
+};
+
+struct wh_context
+{
+	wh_model* m = nullptr;
+	int maxBatch = 0;
+	hipStream_t stream = nullptr;
+	uint32_t flags = 0;
+	int parityThreads = 1;
+	int T = 0, Tpad = 0, maxRows = 0;
+	int64_t vram = 0;
+	bool encoded = false;
+	int lastBatch = 0;
+	// encoder activations
+	f16 *convIn = nullptr, *conv1Out = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *attn = nullptr, *h = nullptr;
+	float *x = nullptr, *encOut = nullptr;
+	int64_t convInStride = 0, conv1Stride = 0;
+	// caches
+	f16 *crossK = nullptr, *crossV = nullptr, *selfK = nullptr, *selfV = nullptr;
+	// decoder activations
+	float *dx = nullptr, *logits = nullptr, *probs = nullptr;
+	f16 *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr;
+	int* tokensDev = nullptr;
+	int* melOffsetsDev = nullptr;
+	TokenData* tokDataDev = nullptr;
+	float* melScratch = nullptr;
+	std::vector<void*> allocations;
+
+	template<class T> int alloc( T*& p, int64_t count, bool zero = false )
+	{
+		void* v = nullptr;
+		const int64_t bytes = count * (int64_t)sizeof( T );
+		WH_HIP( hipMalloc( &v, (size_t)bytes ) );
+		if( zero ) WH_HIP( hipMemsetAsync( v, 0, (size_t)bytes, stream ) );
+		allocations.push_back( v );
+		vram += bytes;
+		p = (T*)v;
+		return 0;
+	}
+};
+
+// ==================================================================================================================
+// device
+// ==================================================================================================================
+extern "C" {
+
+const char* wh_last_error( void ) { return g_lastError.c_str(); }
+
+int wh_device_count( void )
+{
+	int n = 0;
+	if( hipGetDeviceCount( &n ) != hipSuccess ) return 0;
+	return n;
+}
+
+int wh_device_info( int device, char* name, size_t nameCap, uint64_t* totalMemBytes, int* computeUnits )
+{
+	hipDeviceProp_t p;
+	WH_HIP( hipGetDeviceProperties( &p, device ) );
+	if( name && nameCap ) snprintf( name, nameCap, "%s (%s)", p.name, p.gcnArchName );
+	if( totalMemBytes ) *totalMemBytes = p.totalGlobalMem;
+	if( computeUnits ) *computeUnits = p.multiProcessorCount;
+	return 0;
+}
+
+int wh_device_set( int device )
+{
+	WH_HIP( hipSetDevice( device ) );
+	return 0;
+}
+
+// ==================================================================================================================
+// model
+// ==================================================================================================================
+int64_t wh_model_arena_bytes( const wh_hparams* hp )
+{
+	if( checkHparams( hp ) ) return -1;
+	return makeLayout( *hp ).total;
+}
+
+int wh_model_create( const wh_hparams* hp, void* arenaDev, int alreadyFilled, wh_model** out )
+{
+	if( !out ) { setError( "out is null" ); return WH_E_INVALIDARG; }
+	WH_CHECK( checkHparams( hp ) );
+	int nDev = 0;
+	if( hipGetDeviceCount( &nDev ) != hipSuccess || nDev <= 0 )
+	{
+		setError( "no HIP device: libwhisper_hip has no CPU fallback" );
+		return WH_E_NO_DEVICE;
+	}
+	wh_model* m = new wh_model();
+	m->hp = *hp;
+	m->L = makeLayout( *hp );
+	if( arenaDev )
+	{
+		m->arena = (uint8_t*)arenaDev;
+		m->ownsArena = false;
+	}
+	else
+	{
+		void* p = nullptr;
+		const hipError_t e = hipMalloc( &p, (size_t)m->L.total );
+		if( e != hipSuccess ) { delete m; return hipFail( e, "hipMalloc(arena)", __FILE__, __LINE__ ); }
+		m->arena = (uint8_t*)p;
+		m->ownsArena = true;
+	}
+	if( alreadyFilled )
+		m->finalized = true;
+	else
+	{
+		const hipError_t e = hipMemset( m->arena, 0, (size_t)m->L.total );
+		if( e != hipSuccess ) { wh_model_destroy( m ); return hipFail( e, "hipMemset(arena)", __FILE__, __LINE__ ); }
+	}
+	*out = m;
+	return 0;
+}
+
+void wh_model_destroy( wh_model* m )
+{
+	if( !m ) return;
+	if( m->ownsArena && m->arena ) (void)hipFree( m->arena );
+	delete m;
+}
+
+static int upload( wh_model* m, int64_t off, const void* src, int64_t bytes )
+{
+	WH_HIP( hipMemcpy( m->arena + off, src, (size_t)bytes, hipMemcpyHostToDevice ) );
+	return 0;
+}
+
+// Destination of one file tensor. kind: 0 = plain copy, 1 = conv weight (re-ordered), rows x cols is the expected shape.
+struct Slot
+{
+	int64_t off = -1;
+	int64_t rows = 0, cols = 0;	   // expected numpy shape (rows, cols); vectors have rows = 1
+	bool f16 = false;
+	int kind = 0;
+	int convIc = 0;
+};
+
+static bool parseBlock( const std::string& name, const char* prefix, int& idx, std::string& rest )
+{
+	const size_t pl = strlen( prefix );
+	if( name.compare( 0, pl, prefix ) != 0 ) return false;
+	size_t p = pl;
+	if( p >= name.size() || !isdigit( (unsigned char)name[ p ] ) ) return false;
+	int v = 0;
+	while( p < name.size() && isdigit( (unsigned char)name[ p ] ) ) v = v * 10 + ( name[ p++ ] - '0' );
+	if( p >= name.size() || name[ p ] != '.' ) return false;
+	idx = v;
+	rest = name.substr( p + 1 );
+	return true;
+}
+
+// Tensor name map: Whisper/Whisper/WhisperModel.cpp:63-162 == Whisper/source/whisper.cpp:774-940
+static bool resolve( const wh_model* m, const std::string& name, Slot& s )
+{
+	const wh_hparams& hp = m->hp;
+	const Layout& L = m->L;
+	const int64_t d = hp.n_audio_state;
+	auto mat = [ & ]( int64_t off, int64_t rows, int64_t cols ) { s.off = off; s.rows = rows; s.cols = cols; s.f16 = true; return true; };
+	auto vec = [ & ]( int64_t off, int64_t n ) { s.off = off; s.rows = 1; s.cols = n; s.f16 = false; return true; };
+	if( name == "encoder.positional_embedding" ) { s.off = L.encPe; s.rows = hp.n_audio_ctx; s.cols = d; s.f16 = false; return true; }
+	if( name == "encoder.conv1.weight" ) { s.kind = 1; s.convIc = hp.n_mels; return mat( L.conv1w, d, 3ll * hp.n_mels ); }
+	if( name == "encoder.conv1.bias" ) return vec( L.conv1b, d );
+	if( name == "encoder.conv2.weight" ) { s.kind = 1; s.convIc = (int)d; return mat( L.conv2w, d, 3 * d ); }
+	if( name == "encoder.conv2.bias" ) return vec( L.conv2b, d );
+	if( name == "encoder.ln_post.weight" ) return vec( L.lnPostW, d );
+	if( name == "encoder.ln_post.bias" ) return vec( L.lnPostB, d );
+	if( name == "decoder.positional_embedding" ) { s.off = L.decPe; s.rows = hp.n_text_ctx; s.cols = d; s.f16 = false; return true; }
+	if( name == "decoder.token_embedding.weight" ) return mat( L.te, hp.n_vocab, d );
+	if( name == "decoder.ln.weight" ) return vec( L.decLnW, d );
+	if( name == "decoder.ln.bias" ) return vec( L.decLnB, d );
+	int il = 0;
+	std::string r;
+	if( parseBlock( name, "encoder.blocks.", il, r ) )
+	{
+		if( il >= hp.n_audio_layer ) return false;
+		const EncLayer& e = L.enc[ il ];
+		if( r == "attn_ln.weight" ) return vec( e.ln1w, d );
+		if( r == "attn_ln.bias" ) return vec( e.ln1b, d );
+		if( r == "attn.query.weight" ) return mat( e.wqkv, d, d );
+		if( r == "attn.query.bias" ) return vec( e.bqkv, d );
+		if( r == "attn.key.weight" ) return mat( e.wqkv + 2 * d * d, d, d );
+		if( r == "attn.value.weight" ) return mat( e.wqkv + 4 * d * d, d, d );
+		if( r == "attn.value.bias" ) return vec( e.bqkv + 8 * d, d );
+		if( r == "attn.out.weight" ) return mat( e.wo, d, d );
+		if( r == "attn.out.bias" ) return vec( e.bo, d );
+		if( r == "mlp_ln.weight" ) return vec( e.ln2w, d );
+		if( r == "mlp_ln.bias" ) return vec( e.ln2b, d );
+		if( r == "mlp.0.weight" ) return mat( e.w1, 4 * d, d );
+		if( r == "mlp.0.bias" ) return vec( e.b1, 4 * d );
+		if( r == "mlp.2.weight" ) return mat( e.w2, d, 4 * d );
+		if( r == "mlp.2.bias" ) return vec( e.b2, d );
+		return false;
+	}
+	if( parseBlock( name, "decoder.blocks.", il, r ) )
+	{
+		if( il >= hp.n_text_layer ) return false;
+		const DecLayer& e = L.dec[ il ];
+		if( r == "attn_ln.weight" ) return vec( e.ln1w, d );
+		if( r == "attn_ln.bias" ) return vec( e.ln1b, d );
+		if( r == "attn.query.weight" ) return mat( e.wqkv, d, d );
+		if( r == "attn.query.bias" ) return vec( e.bqkv, d );
+		if( r == "attn.key.weight" ) return mat( e.wqkv + 2 * d * d, d, d );
+		if( r == "attn.value.weight" ) return mat( e.wqkv + 4 * d * d, d, d );
+		if( r == "attn.value.bias" ) return vec( e.bqkv + 8 * d, d );
+		if( r == "attn.out.weight" ) return mat( e.wo, d, d );
+		if( r == "attn.out.bias" ) return vec( e.bo, d );
+		if( r == "cross_attn_ln.weight" ) return vec( e.lncw, d );
+		if( r == "cross_attn_ln.bias" ) return vec( e.lncb, d );
+		if( r == "cross_attn.query.weight" ) return mat( e.wcq, d, d );
+		if( r == "cross_attn.query.bias" ) return vec( e.bcq, d );
+		if( r == "cross_attn.key.weight" ) return mat( L.wcross + 2 * ( 2ll * il ) * d * d, d, d );
+		if( r == "cross_attn.value.weight" ) return mat( L.wcross + 2 * ( 2ll * il + 1 ) * d * d, d, d );
+		if( r == "cross_attn.value.bias" ) return vec( L.bcross + 4 * ( 2ll * il + 1 ) * d, d );
+		if( r == "cross_attn.out.weight" ) return mat( e.wco, d, d );
+		if( r == "cross_attn.out.bias" ) return vec( e.bco, d );
+		if( r == "mlp_ln.weight" ) return vec( e.ln2w, d );
+		if( r == "mlp_ln.bias" ) return vec( e.ln2b, d );
+		if( r == "mlp.0.weight" ) return mat( e.w1, 4 * d, d );
+		if( r == "mlp.0.bias" ) return vec( e.b1, 4 * d );
+		if( r == "mlp.2.weight" ) return mat( e.w2, d, 4 * d );
+		if( r == "mlp.2.bias" ) return vec( e.b2, d );
+		return false;
+	}
+	return false;
+}
+
+static inline uint16_t f32ToF16Bits( float f )
+{
+	const _Float16 h = (_Float16)f;
+	uint16_t u;
+	memcpy( &u, &h, 2 );
+	return u;
+}
+static inline float f16BitsToF32( uint16_t u )
+{
+	_Float16 h;
+	memcpy( &h, &u, 2 );
+	return (float)h;
+}
+
+int wh_model_set_tensor( wh_model* m, const char* name, int nDims, const int32_t* ne, int isF16, const void* data )
+{
+	if( !m || !name || !ne || !data || nDims < 1 || nDims > 3 ) { setError( "set_tensor: bad argument" ); return WH_E_INVALIDARG; }
+	if( m->finalized ) { setError( "set_tensor: model already finalized" ); return WH_E_INVALIDARG; }
+	Slot s;
+	if( !resolve( m, name, s ) )
+	{
+		setError( std::string( "unknown tensor '" ) + name + "' in model file" );
+		return WH_E_INVALIDARG;
+	}
+	if( m->loaded.count( name ) )
+	{
+		setError( std::string( "tensor '" ) + name + "' appears twice" );
+		return WH_E_INVALIDARG;
+	}
+	int64_t count = 1;
+	for( int i = 0; i < nDims; i++ ) count *= ne[ i ];
+	if( count != s.rows * s.cols )
+	{
+		setError( std::string( "tensor '" ) + name + "' has wrong size in model file" );
+		return WH_E_INVALIDARG;
+	}
+	// shape check: ne[0] is the contiguous dimension
+	bool shapeOk;
+	if( s.kind == 1 )
+		shapeOk = nDims == 3 && ne[ 0 ] == 3 && ne[ 1 ] == s.convIc && ne[ 2 ] == s.rows;
+	else if( s.rows == 1 )
+		shapeOk = ne[ nDims - 1 ] == s.cols || ( nDims >= 1 && ne[ 0 ] == s.cols ) || ( nDims == 2 && ne[ 0 ] == 1 && ne[ 1 ] == s.cols );
+	else
+		shapeOk = nDims == 2 && ne[ 0 ] == s.cols && ne[ 1 ] == s.rows;
+	if( !shapeOk )
+	{
+		setError( std::string( "tensor '" ) + name + "' has wrong shape in model file" );
+		return WH_E_INVALIDARG;
+	}
+
+	if( s.kind == 1 )
+	{
+		// file: [out][in][3] (tap contiguous) -> ours: [out][tap * in + c], row padded with zeros (conv as an implicit GEMM)
+		const int64_t ic = s.convIc, oc = s.rows;
+		const int64_t kpad = ( s.off == m->L.conv1w ) ? CONV1_KPAD : 3 * ic;
+		std::vector<uint16_t> tmp( (size_t)( oc * kpad ), 0 );
+		for( int64_t o = 0; o < oc; o++ )
+			for( int64_t c = 0; c < ic; c++ )
+				for( int t = 0; t < 3; t++ )
+				{
+					const int64_t si = ( o * ic + c ) * 3 + t;
+					const uint16_t v = isF16 ? ( (const uint16_t*)data )[ si ] : f32ToF16Bits( ( (const float*)data )[ si ] );
+					tmp[ (size_t)( o * kpad + t * ic + c ) ] = v;
+				}
+		WH_CHECK( upload( m, s.off, tmp.data(), (int64_t)tmp.size() * 2 ) );
+	}
+	else if( s.f16 )
+	{
+		if( isF16 )
+			WH_CHECK( upload( m, s.off, data, count * 2 ) );
+		else
+		{
+			std::vector<uint16_t> tmp( (size_t)count );
+			for( int64_t i = 0; i < count; i++ ) tmp[ (size_t)i ] = f32ToF16Bits( ( (const float*)data )[ i ] );
+			WH_CHECK( upload( m, s.off, tmp.data(), count * 2 ) );
+		}
+	}
+	else
+	{
+		if( !isF16 )
+			WH_CHECK( upload( m, s.off, data, count * 4 ) );
+		else
+		{
+			std::vector<float> tmp( (size_t)count );
+			for( int64_t i = 0; i < count; i++ ) tmp[ (size_t)i ] = f16BitsToF32( ( (const uint16_t*)data )[ i ] );
+			WH_CHECK( upload( m, s.off, tmp.data(), count * 4 ) );
+		}
+	}
+	m->loaded.insert( name );
+	return 0;
+}
+
+int wh_model_set_filters( wh_model* m, int nMel, int nFft, const float* data )
+{
+	if( !m || !data ) { setError( "set_filters: bad argument" ); return WH_E_INVALIDARG; }
+	if( nMel != m->hp.n_mels || nFft != 201 ) { setError( "mel filterbank must be [n_mels][201]" ); return WH_E_INVALIDARG; }
+	WH_CHECK( upload( m, m->L.filters, data, 4ll * nMel * nFft ) );
+	m->filtersSet = true;
+	return 0;
+}
+
+int wh_model_finalize( wh_model* m )
+{
+	if( !m ) return WH_E_INVALIDARG;
+	if( m->finalized ) return 0;
+	if( m->loaded.size() != m->expectedTensors() )
+	{
+		char buf[ 160 ];
+		snprintf( buf, sizeof( buf ), "not all tensors loaded from model file - expected %zu, got %zu", m->expectedTensors(), m->loaded.size() );
+		setError( buf );
+		return WH_E_NOT_READY;
+	}
+	// DFT twiddles for the mel kernel: cos / sin of 2 pi n / 400 in double (same expression as whisper.cpp:2073-2077)
+	std::vector<double> tw( 800 );
+	for( int n = 0; n < 400; n++ )
+	{
+		tw[ n ] = cos( ( 2.0 * M_PI * n ) / 400 );
+		tw[ 400 + n ] = sin( ( 2.0 * M_PI * n ) / 400 );
+	}
+	WH_CHECK( upload( m, m->L.dft, tw.data(), 800 * 8 ) );
+	m->finalized = true;
+	return 0;
+}
+
+int wh_model_arena( wh_model* m, void** dev, int64_t* bytes )
+{
+	if( !m ) return WH_E_INVALIDARG;
+	if( dev ) *dev = m->arena;
+	if( bytes ) *bytes = m->L.total;
+	return 0;
+}
+
+int wh_model_hparams( const wh_model* m, wh_hparams* out )
+{
+	if( !m || !out ) return WH_E_INVALIDARG;
+	*out = m->hp;
+	return 0;
+}
+
+// ==================================================================================================================
+// context
+// ==================================================================================================================
+int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out )
+{
+	if( !m || !out || maxBatch <= 0 ) { setError( "context_create: bad argument" ); return WH_E_INVALIDARG; }
+	if( !m->finalized ) { setError( "context_create: model is not finalized" ); return WH_E_NOT_READY; }
+	wh_context* c = new wh_context();
+	c->m = m;
+	c->maxBatch = maxBatch;
+	c->stream = (hipStream_t)stream;
+	const wh_hparams& hp = m->hp;
+	const int64_t d = hp.n_audio_state, B = maxBatch, H = hp.n_audio_head;
+	const int T = hp.n_audio_ctx;
+	c->T = T;
+	c->Tpad = roundUp( T, 256 );
+	c->maxRows = maxBatch * hp.n_text_ctx;
+	const int64_t rowsE = B * T;
+	c->convInStride = ( 2ll * T + 2 ) * hp.n_mels;
+	c->conv1Stride = ( 2ll * T + 2 ) * d;
+	int rc = 0;
+	rc = rc ? rc : c->alloc( c->convIn, B * c->convInStride + 1024, true );
+	rc = rc ? rc : c->alloc( c->conv1Out, B * c->conv1Stride + 1024, true );
+	rc = rc ? rc : c->alloc( c->x, rowsE * d );
+	rc = rc ? rc : c->alloc( c->encOut, rowsE * d );
+	rc = rc ? rc : c->alloc( c->xn, rowsE * d );
+	rc = rc ? rc : c->alloc( c->q, rowsE * d );
+	rc = rc ? rc : c->alloc( c->k, rowsE * d );
+	rc = rc ? rc : c->alloc( c->vT, B * H * HEAD_DIM * c->Tpad, true );
+	rc = rc ? rc : c->alloc( c->attn, rowsE * d );
+	rc = rc ? rc : c->alloc( c->h, rowsE * 4 * d );
+	rc = rc ? rc : c->alloc( c->crossK, (int64_t)hp.n_text_layer * rowsE * d, true );
+	rc = rc ? rc : c->alloc( c->crossV, (int64_t)hp.n_text_layer * rowsE * d, true );
+	rc = rc ? rc : c->alloc( c->selfK, (int64_t)hp.n_text_layer * B * hp.n_text_ctx * d, true );
+	rc = rc ? rc : c->alloc( c->selfV, (int64_t)hp.n_text_layer * B * hp.n_text_ctx * d, true );
+	const int64_t rowsD = c->maxRows;
+	rc = rc ? rc : c->alloc( c->dx, rowsD * d );
+	rc = rc ? rc : c->alloc( c->dxn, rowsD * d );
+	rc = rc ? rc : c->alloc( c->dq, rowsD * d );
+	rc = rc ? rc : c->alloc( c->dattn, rowsD * d );
+	rc = rc ? rc : c->alloc( c->dh, rowsD * 4 * d );
+	rc = rc ? rc : c->alloc( c->logits, B * (int64_t)hp.n_vocab );
+	rc = rc ? rc : c->alloc( c->probs, B * (int64_t)hp.n_vocab );
+	rc = rc ? rc : c->alloc( c->tokensDev, rowsD );
+	rc = rc ? rc : c->alloc( c->melOffsetsDev, B );
+	rc = rc ? rc : c->alloc( c->tokDataDev, B );
+	rc = rc ? rc : c->alloc( c->melScratch, 64 );
+	if( rc == 0 )
+	{
+		const hipError_t e = hipStreamSynchronize( c->stream );
+		if( e != hipSuccess ) rc = hipFail( e, "hipStreamSynchronize", __FILE__, __LINE__ );
+	}
+	if( rc != 0 )
+	{
+		wh_context_destroy( c );
+		return rc;
+	}
+	*out = c;
+	return 0;
+}
+
+void wh_context_destroy( wh_context* c )
+{
+	if( !c ) return;
+	for( void* p : c->allocations ) (void)hipFree( p );
+	delete c;
+}
+
+int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
+{
+	if( !c ) return WH_E_INVALIDARG;
+	c->flags = flags;
+	c->parityThreads = parityThreads > 0 ? parityThreads : 1;
+	return 0;
+}
+
+int wh_context_memory( const wh_context* c, int64_t* vramBytes )
+{
+	if( !c || !vramBytes ) return WH_E_INVALIDARG;
+	*vramBytes = c->vram;
+	return 0;
+}
+
+int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, float* melDev, int64_t* nLenOut )
+{
+	if( !c || !pcmDev || !melDev || nSamples < 0 ) { setError( "mel: bad argument" ); return WH_E_INVALIDARG; }
+	const int64_t nLen = nSamples / 160;
+	if( nLenOut ) *nLenOut = nLen;
+	const wh_model* m = c->m;
+	return launchMel( pcmDev, nSamples, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), melDev, nLen, m->hp.n_mels, c->melScratch, c->stream );
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// encoder
+// ------------------------------------------------------------------------------------------------------------------
+static GemmArgs plainGemm( const f16* A, const f16* W, int M, int N, int K )
+{
+	GemmArgs g;
+	memset( &g, 0, sizeof( g ) );
+	g.A = A; g.W = W; g.M = M; g.N = N; g.K = K;
+	g.lda = K; g.Mb = M; g.aBatchStride = 0;
+	g.ldc = N; g.cBatchStride = 0;
+	g.scale = 1.0f;
+	return g;
+}
+
+int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets )
+{
+	if( !c || !melDev || batch <= 0 || batch > c->maxBatch || melLen <= 0 ) { setError( "encode: bad argument" ); return WH_E_INVALIDARG; }
+	const wh_model* m = c->m;
+	const wh_hparams& hp = m->hp;
+	const Layout& L = m->L;
+	hipStream_t st = c->stream;
+	const int d = hp.n_audio_state, H = hp.n_audio_head, T = c->T;
+	const int M = batch * T;
+
+	std::vector<int32_t> offs( batch, 0 );
+	if( melOffsets ) memcpy( offs.data(), melOffsets, sizeof( int32_t ) * batch );
+	WH_HIP( hipMemcpyAsync( c->melOffsetsDev, offs.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
+	WH_HIP( hipStreamSynchronize( st ) );	 // offs is a local
+	WH_CHECK( launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ) );
+
+	// conv1 (k=3, stride 1, pad 1) + bias + GELU as an implicit GEMM over the padded time-major input:
+	// row t of the im2col matrix is the contiguous slice starting at padded row t (whisper.cpp:1127-1136; ggml.c:5199-5318)
+	{
+		GemmArgs g = plainGemm( c->convIn, m->at<f16>( L.conv1w ), batch * 2 * T, d, CONV1_KPAD );
+		g.lda = hp.n_mels; g.Mb = 2 * T; g.aBatchStride = c->convInStride;
+		g.epi = EPI_F16_GELU;
+		g.bias = m->at<float>( L.conv1b );
+		g.out16 = c->conv1Out + d;	 // padded row t+1
+		g.ldc = d; g.cBatchStride = c->conv1Stride;
+		WH_CHECK( launchGemm( g, st ) );
+	}
+	// conv2 (stride 2) + bias + GELU + positional embedding -> residual stream x [batch*T][d] (whisper.cpp:1138-1167)
+	{
+		GemmArgs g = plainGemm( c->conv1Out, m->at<f16>( L.conv2w ), M, d, 3 * d );
+		g.lda = 2 * d; g.Mb = T; g.aBatchStride = c->conv1Stride;
+		g.epi = EPI_CONV2;
+		g.bias = m->at<float>( L.conv2b );
+		g.pe = m->at<float>( L.encPe );
+		g.out32 = c->x; g.ldc = d;
+		WH_CHECK( launchGemm( g, st ) );
+	}
+	for( int il = 0; il < hp.n_audio_layer; il++ )
+	{
+		const EncLayer& e = L.enc[ il ];
+		WH_CHECK( launchLayerNorm( c->x, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->xn, M, d, st ) );
+		{
+			GemmArgs g = plainGemm( c->xn, m->at<f16>( e.wqkv ), M, 3 * d, d );
+			g.epi = EPI_QKV_ENC;
+			g.bias = m->at<float>( e.bqkv );
+			g.q = c->q; g.k = c->k; g.v = c->vT;
+			g.T = T; g.Tpad = c->Tpad; g.H = H; g.B = batch;
+			WH_CHECK( launchGemm( g, st ) );
+		}
+		WH_CHECK( launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, st ) );
+		{
+			GemmArgs g = plainGemm( c->attn, m->at<f16>( e.wo ), M, d, d );
+			g.epi = EPI_F32;
+			g.bias = m->at<float>( e.bo );
+			g.res = c->x; g.out32 = c->x;
+			WH_CHECK( launchGemm( g, st ) );
+		}
+		WH_CHECK( launchLayerNorm( c->x, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->xn, M, d, st ) );
+		{
+			GemmArgs g = plainGemm( c->xn, m->at<f16>( e.w1 ), M, 4 * d, d );
+			g.epi = EPI_F16_GELU;
+			g.bias = m->at<float>( e.b1 );
+			g.out16 = c->h;
+			WH_CHECK( launchGemm( g, st ) );
+		}
+		{
+			GemmArgs g = plainGemm( c->h, m->at<f16>( e.w2 ), M, d, 4 * d );
+			g.epi = EPI_F32;
+			g.bias = m->at<float>( e.b2 );
+			g.res = c->x; g.out32 = c->x;
+			WH_CHECK( launchGemm( g, st ) );
+		}
+	}
+	WH_CHECK( launchLayerNorm( c->x, m->at<float>( L.lnPostW ), m->at<float>( L.lnPostB ), c->xn, M, d, st ) );
+	// cross-attention K/V of every decoder layer in one product (whisper.cpp:1448-1487)
+	{
+		GemmArgs g = plainGemm( c->xn, m->at<f16>( L.wcross ), M, 2 * hp.n_text_layer * d, d );
+		g.epi = EPI_CROSS_KV;
+		g.bias = m->at<float>( L.bcross );
+		g.scale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
+		g.k = c->crossK; g.v = c->crossV;
+		g.T = T; g.H = H; g.B = c->maxBatch;
+		WH_CHECK( launchGemm( g, st ) );
+	}
+	c->encoded = true;
+	c->lastBatch = batch;
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// decoder
+// ------------------------------------------------------------------------------------------------------------------
+int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int nPast, float* logitsHost, float* probsHost )
+{
+	if( !c || !tokens || batch <= 0 || batch > c->maxBatch || nTokens <= 0 || nPast < 0 ) { setError( "decode: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c->encoded ) { setError( "decode: wh_encode has not run" ); return WH_E_NOT_READY; }
+	const wh_model* m = c->m;
+	const wh_hparams& hp = m->hp;
+	if( nPast + nTokens > hp.n_text_ctx ) { setError( "decode: n_past + n_tokens exceeds n_text_ctx" ); return WH_E_BOUNDS; }
+	const Layout& L = m->L;
+	hipStream_t st = c->stream;
+	const int d = hp.n_text_state, H = hp.n_text_head;
+	const int M = batch * nTokens;
+	const float kqScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
+	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
+
+	WH_HIP( hipMemcpyAsync( c->tokensDev, tokens, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
+	WH_CHECK( launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, d, st ) );
+
+	for( int il = 0; il < hp.n_text_layer; il++ )
+	{
+		const DecLayer& e = L.dec[ il ];
+		const int64_t selfLayer = (int64_t)il * c->maxBatch * hp.n_text_ctx * d;
+		const int64_t crossLayer = (int64_t)il * c->maxBatch * c->T * d;
+		// self-attention
+		WH_CHECK( launchLayerNorm( c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d, st ) );
+		{
+			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wqkv ), M, 3 * d, d );
+			g.epi = EPI_QKV_DEC;
+			g.bias = m->at<float>( e.bqkv );
+			g.scale = kqScale;
+			g.q = c->dq; g.k = c->selfK + selfLayer; g.v = c->selfV + selfLayer;
+			g.H = H; g.nTok = nTokens; g.nPast = nPast; g.textCtx = hp.n_text_ctx;
+			WH_CHECK( launchGemmSkinny( g, st ) );
+		}
+		{
+			DecAttnArgs a;
+			a.q = c->dq; a.kc = c->selfK + selfLayer; a.vc = c->selfV + selfLayer; a.out = c->dattn;
+			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = nPast + nTokens; a.keyStride = hp.n_text_ctx;
+			a.causal = 1; a.nPast = nPast; a.parityThreads = parity;
+			WH_CHECK( launchAttentionDec( a, st ) );
+		}
+		{
+			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wo ), M, d, d );
+			g.epi = EPI_F32; g.bias = m->at<float>( e.bo ); g.res = c->dx; g.out32 = c->dx;
+			WH_CHECK( launchGemmSkinny( g, st ) );
+		}
+		// cross-attention
+		WH_CHECK( launchLayerNorm( c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d, st ) );
+		{
+			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wcq ), M, d, d );
+			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
+			WH_CHECK( launchGemmSkinny( g, st ) );
+		}
+		{
+			DecAttnArgs a;
+			a.q = c->dq; a.kc = c->crossK + crossLayer; a.vc = c->crossV + crossLayer; a.out = c->dattn;
+			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = c->T; a.keyStride = c->T;
+			a.causal = 0; a.nPast = 0; a.parityThreads = parity;
+			WH_CHECK( launchAttentionDec( a, st ) );
+		}
+		{
+			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wco ), M, d, d );
+			g.epi = EPI_F32; g.bias = m->at<float>( e.bco ); g.res = c->dx; g.out32 = c->dx;
+			WH_CHECK( launchGemmSkinny( g, st ) );
+		}
+		// MLP
+		WH_CHECK( launchLayerNorm( c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d, st ) );
+		{
+			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.w1 ), M, 4 * d, d );
+			g.epi = EPI_F16_GELU; g.bias = m->at<float>( e.b1 ); g.out16 = c->dh;
+			WH_CHECK( launchGemmSkinny( g, st ) );
+		}
+		{
+			GemmArgs g = plainGemm( c->dh, m->at<f16>( e.w2 ), M, d, 4 * d );
+			g.epi = EPI_F32; g.bias = m->at<float>( e.b2 ); g.res = c->dx; g.out32 = c->dx;
+			WH_CHECK( launchGemmSkinny( g, st ) );
+		}
+	}
+	// final norm + logits for the LAST token of every sequence only (the reference computes all rows, whisper.cpp:1840,
+	// and then consumes just the last one, ContextImpl.cpp:159-169)
+	WH_CHECK( launchLayerNorm( c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d, st ) );
+	{
+		GemmArgs g = plainGemm( c->dxn + (int64_t)( nTokens - 1 ) * d, m->at<f16>( L.te ), batch, hp.n_vocab, d );
+		g.lda = nTokens * d;
+		g.epi = EPI_F32; g.out32 = c->logits; g.ldc = hp.n_vocab;
+		WH_CHECK( launchGemmSkinny( g, st ) );
+	}
+	WH_CHECK( launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ) );
+	c->lastBatch = batch;
+	if( logitsHost ) WH_HIP( hipMemcpyAsync( logitsHost, c->logits, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
+	if( probsHost ) WH_HIP( hipMemcpyAsync( probsHost, c->probs, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
+	if( logitsHost || probsHost ) WH_HIP( hipStreamSynchronize( st ) );
+	return 0;
+}
+
+int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial, wh_token_data* out )
+{
+	if( !c || !out || batch <= 0 || batch > c->maxBatch ) { setError( "sample_best: bad argument" ); return WH_E_INVALIDARG; }
+	const wh_hparams& hp = c->m->hp;
+	// hard-coded special token ids (Whisper/Whisper/Vocabulary.h:27-41)
+	const int ml = hp.n_vocab == 51865 ? 1 : 0;
+	const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
+	WH_CHECK( launchSampleBest( c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, forceTimestamp, isInitial, c->tokDataDev, c->stream ) );
+	static_assert( sizeof( wh_token_data ) == sizeof( TokenData ), "token data layout" );
+	WH_HIP( hipMemcpyAsync( out, c->tokDataDev, sizeof( TokenData ) * batch, hipMemcpyDeviceToHost, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// debug reads
+// ------------------------------------------------------------------------------------------------------------------
+static int readHeadMajor( wh_context* c, const f16* src, int batch, int rows, int rowStride, float* dst )
+{
+	// [b][h][rowStride][64] FP16 -> [b][rows][H*64] FP32
+	const int H = c->m->hp.n_audio_head, d = H * HEAD_DIM;
+	std::vector<uint16_t> tmp( (size_t)batch * H * rowStride * HEAD_DIM );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	WH_HIP( hipMemcpy( tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost ) );
+	for( int b = 0; b < batch; b++ )
+		for( int h = 0; h < H; h++ )
+			for( int t = 0; t < rows; t++ )
+				for( int j = 0; j < HEAD_DIM; j++ )
+					dst[ ( (size_t)b * rows + t ) * d + h * HEAD_DIM + j ] = f16BitsToF32( tmp[ ( ( (size_t)b * H + h ) * rowStride + t ) * HEAD_DIM + j ] );
+	return 0;
+}
+
+int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* dstHost, int64_t dstCapFloats )
+{
+	if( !c || !what || !dstHost ) return WH_E_INVALIDARG;
+	const wh_hparams& hp = c->m->hp;
+	const int d = hp.n_audio_state;
+	const int batch = c->lastBatch;
+	const std::string w = what;
+	if( w == "encode-out" )
+	{
+		// the FP16 LayerNorm output that feeds the cross-attention projection
+		const int64_t n = (int64_t)batch * c->T * d;
+		if( dstCapFloats < n ) return WH_E_BOUNDS;
+		std::vector<uint16_t> tmp( (size_t)n );
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		WH_HIP( hipMemcpy( tmp.data(), c->xn, (size_t)n * 2, hipMemcpyDeviceToHost ) );
+		for( int64_t i = 0; i < n; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
+		return 0;
+	}
+	if( layer < 0 || layer >= hp.n_text_layer ) return WH_E_BOUNDS;
+	if( w == "cross-k" || w == "cross-v" )
+	{
+		if( dstCapFloats < (int64_t)batch * c->T * d ) return WH_E_BOUNDS;
+		const f16* base = ( w == "cross-k" ? c->crossK : c->crossV ) + (int64_t)layer * c->maxBatch * c->T * d;
+		return readHeadMajor( c, base, batch, c->T, c->T, dstHost );
+	}
+	if( w == "self-k" || w == "self-v" )
+	{
+		if( rows <= 0 || rows > hp.n_text_ctx || dstCapFloats < (int64_t)batch * rows * d ) return WH_E_BOUNDS;
+		const f16* base = ( w == "self-k" ? c->selfK : c->selfV ) + (int64_t)layer * c->maxBatch * hp.n_text_ctx * d;
+		return readHeadMajor( c, base, batch, rows, hp.n_text_ctx, dstHost );
+	}
+	setError( "debug_read: unknown item" );
+	return WH_E_INVALIDARG;
+}
+
+// ==================================================================================================================
+// op-level entry points
+// ==================================================================================================================
+int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float* bias, const float* residual, float* out, int M, int N, int K )
+{
+	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
+	g.epi = EPI_F32; g.bias = bias; g.res = residual; g.out32 = out;
+	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
+}
+
+int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16, const float* bias, void* outF16, int M, int N, int K )
+{
+	if( !bias ) { setError( "mul_mat_gelu: bias is required" ); return WH_E_INVALIDARG; }
+	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
+	g.epi = EPI_F16_GELU; g.bias = bias; g.out16 = (f16*)outF16;
+	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
+}
+
+int wh_op_layer_norm( void* stream, const float* x, const float* w, const float* b, void* outF16, int rows, int d )
+{
+	return launchLayerNorm( x, w, b, (f16*)outF16, rows, d, (hipStream_t)stream );
+}
+
+int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vT, void* out, int batch, int heads, int nCtx )
+{
+	return launchAttentionEnc( (const f16*)q, (const f16*)k, (const f16*)vT, (f16*)out, batch, heads, nCtx, roundUp( nCtx, 256 ), (hipStream_t)stream );
+}
+
+int wh_op_soft_max( void* stream, float* x, int rows, int cols )
+{
+	return launchSoftMaxRows( x, rows, cols, (hipStream_t)stream );
+}
+
+}	// extern "C"
