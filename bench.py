@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- audio-seconds/sec of the Whisper hot path (mel -> encoder -> KV-cached greedy decoder -> token ids).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run with one rank per GPU. Prints ONE JSON line on rank 0.
+
+Workload at N = 1 = BASELINE.json configs[1]: a ggml-medium-shaped model (random FP16 weights of the exact real
+shapes -- no real weights exist offline) on a clip of the length of the reference's columbia sample (198.762 s,
+Tools/PerfSummary/Summary.cs:50) = 7 windows of 30 s, processed as one lock-step batch of independent windows
+(NoContext semantics, ContextImpl.cpp:476-477): PCM resident in HBM -> GPU mel -> encoder -> 3-token prompt step +
+51 greedy steps per window (the reference's observed 511 steps / 10 windows, columbia-medium-1080ti.txt:8-10; random
+weights never emit EOT sensibly, so the step count is forced while the sampled token IS fed back). One "step" of the
+bench = one pass over the whole clip. value = audio seconds / wall seconds; weak scaling for N > 1 (every rank
+transcribes its own clip; the weight arena is broadcast once over RCCL before the timed region).
+
+Extra objects: `roofline` for the dominant kernel class (per-launch durations from hipEvent pairs on the launch stream,
+collected in a separate, identical pass because two event records per launch would perturb the launch-bound decode
+loop), and `cpu_baseline` = the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 198.762
+WINDOW_SAMPLES = 480000
+N_PROMPT = 3
+N_GREEDY = 51
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
+
+
+def synth_pcm(n_windows: int, seed: int) -> np.ndarray:
+    """Seeded band-limited noise, uniform +-0.1 envelope."""
+    rng = np.random.default_rng(seed)
+    n = n_windows * WINDOW_SAMPLES
+    x = rng.uniform(-1, 1, n).astype(np.float32)
+    k = np.hanning(33).astype(np.float32)
+    x = np.convolve(x, k / k.sum(), mode="same")
+    env = 0.1 * (0.6 + 0.4 * np.sin(np.arange(n, dtype=np.float32) * (2 * np.pi / 16000 / 2.7)))
+    return (x * env * 3).astype(np.float32).reshape(n_windows, WINDOW_SAMPLES)
+
+
+def transcribe_clip(ctx, pcm_dev, mel_dev, prompt, n_greedy, batch):
+    """One pass of the hot path over a batch of windows; returns the sampled token ids [batch][n_greedy+1]."""
+    for b in range(batch):
+        ctx.mel_spectrogram(pcm_dev[b], mel_dev[b])
+    ctx.encode(mel_dev)
+    toks = np.tile(np.asarray(prompt, np.int32), (batch, 1))
+    ctx.decode(toks, 0, want_logits=False, want_probs=False)
+    out = np.zeros((batch, n_greedy + 1), np.int32)
+    s = ctx.sample_best(batch, force_timestamp=True, is_initial=True)     # first token: timestamp <= 1.00 s (ContextImpl.cpp:613)
+    out[:, 0] = [t["id"] for t in s]
+    n_past = len(prompt)
+    for i in range(n_greedy):
+        ctx.decode(out[:, i:i + 1], n_past, want_logits=False, want_probs=False)
+        s = ctx.sample_best(batch)
+        out[:, i + 1] = [t["id"] for t in s]
+        n_past += 1
+    return out
+
+
+def cpu_baseline(model, model_kind, pcm_one_window, prompt, quick: bool):
+    """The reference's own CPU path (Whisper/source, compiled unmodified into oracle/_ref) on this host's cores."""
+    try:
+        from oracle import ref
+    except Exception as e:      # pragma: no cover
+        return {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference", "sample": "oracle unavailable: %s" % e}
+    if not ref.available():
+        return {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref/libwhisper_ref.so not present"}
+    import tempfile
+    from whisper_amd import ggml_format as gf
+    cores = os.cpu_count() or 1
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        gf.write_model(path, model)
+        w = ref.RefWhisper(path, n_threads=cores, log_level=0)
+        t0 = time.time()
+        w.pcm_to_mel(pcm_one_window)
+        t_mel = time.time() - t0
+        t0 = time.time()
+        w.encode(0)
+        t_enc = time.time() - t0
+        t0 = time.time()
+        w.decode(prompt, 0)
+        t_prompt = time.time() - t0
+        n_tok = 4 if quick else 10
+        t0 = time.time()
+        for i in range(n_tok):
+            w.decode([1000 + i], len(prompt) + i)
+        t_tok = (time.time() - t0) / n_tok
+        w.close()
+    per_window = t_mel + t_enc + t_prompt + N_GREEDY * t_tok
+    return {"value": round(30.0 / per_window, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "reference",
+            "sample": "%s-shape model, ONE 30 s window: mel %.3f s + encode %.2f s + %d-token prompt %.3f s measured, "
+                      "%d of %d greedy steps measured (%.1f ms/token) and scaled; n_threads=%d"
+                      % (model_kind, t_mel, t_enc, len(prompt), t_prompt, n_tok, N_GREEDY, 1e3 * t_tok, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="medium")
+    ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from whisper_amd import binding, ggml_format as gf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    binding.check(binding.lib().wh_device_set(local))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    hp = gf.hparams_for(args.model)
+    sp = gf.special_tokens(hp)
+    prompt = [sp["sot"], sp["sot"] + 1, sp["transcribe"]] if hp.is_multilingual else [sp["sot"], sp["not_"], sp["beg"]]
+    prompt = prompt[:N_PROMPT]
+
+    # ---- weights: rank 0 builds the model and fills its arena; the others receive one RCCL broadcast over xGMI ----
+    arena = torch.empty(binding.arena_bytes(hp), dtype=torch.uint8, device="cuda")
+    model = None
+    t0 = time.time()
+    if rank == 0:
+        model = gf.synth_model(args.model, seed=1)
+        hip_model = binding.HipModel.from_ggml(model, arena_ptr=arena.data_ptr(), keepalive=arena)
+    t_load = time.time() - t0
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.time()
+        dist.broadcast(arena, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.time() - t0
+        if rank != 0:
+            hip_model = binding.HipModel(hp, arena_ptr=arena.data_ptr(), already_filled=True, keepalive=arena)
+
+    B = args.windows
+    ctx = binding.HipContext(hip_model, B)
+    pcm_dev = torch.from_numpy(synth_pcm(B, seed=100 + rank)).cuda()
+    mel_dev = torch.empty((B, hp.n_mels, WINDOW_SAMPLES // 160), dtype=torch.float32, device="cuda")
+    audio_seconds = CLIP_SECONDS * B / 7.0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel pass (rank 0): identical work with hipEvent pairs around every launch ----
+    roofline, kernels = None, {}
+    if rank == 0 and not args.no_roofline:
+        ctx.profile(True)
+        transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
+        kernels = ctx.profile_read()
+        ctx.profile(False)
+        total_ms = sum(k["ms"] for k in kernels.values())
+        name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+        avg_us = 1e3 * dom["ms"] / dom["calls"]
+        if name in ("gemmTiled", "attentionEnc"):
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+        else:
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roofline.update({"avg_launch_us": round(avg_us, 2), "launches_per_step": dom["calls"],
+                         "share_of_gpu_time": round(dom["ms"] / total_ms, 3),
+                         "algorithmic_per_launch": round((dom["flops"] if roofline["bound"] == "mfma" else dom["bytes"]) / dom["calls"], 1)})
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        if model is None:
+            model = gf.synth_model(args.model, seed=1)
+        cpu = cpu_baseline(model, args.model, pcm_dev[0].cpu().numpy(), prompt, quick=False)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * audio_seconds * args.steps / elapsed
+        line = {
+            "metric": "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s windows per GPU as one lock-step batch, "
+                                   "GPU mel + encoder + %d-token prompt + %d greedy steps per window, device-side sampling"
+                                   % (args.model, audio_seconds, B, N_PROMPT, N_GREEDY),
+                       "model": "ggml-" + args.model, "windows_per_gpu": B, "decode_steps_per_window": N_GREEDY + 1,
+                       "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},
+            "rtf": round(elapsed / (args.steps * audio_seconds), 6),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": {k: {"calls": v["calls"], "ms": round(v["ms"], 3),
+                            "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+                        for k, v in kernels.items()},
+            "model_build_s": round(t_load, 1),
+            "tokens_checksum": int(np.asarray(toks, np.int64).sum() % 1000003),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,18 @@ typedef struct wh_token_data
  * per call (same for all sequences). out: HOST [batch]. Exact ties resolve to the lower token id. */
 WH_API int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial, wh_token_data* out );
 
+/* Per-kernel-class GPU timings, the counterpart of the reference's GpuProfiler / iContext::timingsPrint
+ * (Whisper/Utils/GpuProfiler.h:21-188, Whisper/Whisper/ContextImpl.misc.cpp:170-182). hipEvent pairs around every launch
+ * on the context's stream while enabled; flops / bytes are the algorithmic work of the launches. */
+typedef struct wh_profile_entry
+{
+	char name[ 32 ];
+	int64_t calls;
+	double ms, flops, bytes;
+} wh_profile_entry;
+WH_API int wh_profile_enable( wh_context* c, int on );	/* resets the counters */
+WH_API int wh_profile_read( wh_context* c, wh_profile_entry* out, int cap, int* count );
+
 /* Test / parity access to internal state (the reference reaches these through its Tracing probe points,
  * Whisper/Whisper/WhisperContext.cpp:142-638). All outputs HOST FP32.
  *   what = "encode-out"  [batch][n_ctx][d]           (only valid right after wh_encode)

@@ -127,10 +127,10 @@ def test_decoder_parity_mode(hip_tiny, golden, np_tiny, tiny_model):
     ctx.encode(torch.from_numpy(golden["mel"]).cuda())
     ctx.set_parity(1)
     sp = gf.special_tokens(tiny_model.hparams)
-    outs = run_steps(ctx, golden)
     pos, n_past = 0, 0
-    for i, (logits, probs) in enumerate(outs):
-        ln = int(golden["step_lens"][i])
+    for i, ln in enumerate(golden["step_lens"]):
+        ln = int(ln)
+        logits, probs = ctx.decode(golden["steps"][pos:pos + ln][None, :], n_past)
         d = report("logits step %d vs reference" % i, logits[0], golden["logits%d" % i])
         assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
         nl, npr = np_tiny.decode(golden["steps"][pos:pos + ln], n_past, n_threads=1)
@@ -144,7 +144,8 @@ def test_decoder_parity_mode(hip_tiny, golden, np_tiny, tiny_model):
         print("step", i, "sample", sb, "timestamp", st, "reference", ref_ids, golden["samplep%d" % i])
         for mine, ref_id in ((sb, ref_ids[0]), (st, ref_ids[2])):
             if mine["id"] != ref_id:
-                assert abs(probs[0][mine["id"]] - probs[0][ref_id]) < 2e-6
+                # near-uniform random-weight distribution: a swap is only legitimate inside the implementation noise
+                assert abs(probs[0][mine["id"]] - probs[0][ref_id]) < 4e-3 * probs[0][ref_id]
         # the device sampler against the host restatement on the SAME probabilities: exact
         hb = wn.sample_best(probs[0], sp["beg"], sp["sot"], sp["solm"], sp["not_"])
         ht = wn.sample_best(probs[0], sp["beg"], sp["sot"], sp["solm"], sp["not_"], True, i == 0)

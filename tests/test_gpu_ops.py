@@ -102,6 +102,8 @@ def test_gelu_table_exhaustive(golden):
     want = golden["table_gelu"][fin].astype(np.int32)
     diff = np.abs(got - want)
     print("gelu table: %d of %d entries differ, max ulp %d" % ((diff > 0).sum(), M, diff.max()))
+    for i in np.nonzero(diff)[0][:12]:
+        print("   x=%r (0x%04x) got 0x%04x want 0x%04x" % (float(xs[i]), int(xs[i:i + 1].view(np.uint16)[0]), got[i], want[i]))
     assert diff.max() <= 1 and (diff > 0).mean() < 2e-3
 
 

@@ -73,9 +73,9 @@ def test_decoder_restatement(golden, tiny_model):
         # token choice can only differ where the reference's own top-2 probabilities are within the noise
         ref_ids = golden["sample%d" % i]
         if sb["id"] != ref_ids[0]:
-            assert abs(probs[-1][sb["id"]] - probs[-1][ref_ids[0]]) < 2e-6
+            assert abs(probs[-1][sb["id"]] - probs[-1][ref_ids[0]]) < 4e-3 * probs[-1][ref_ids[0]]
         if st["id"] != ref_ids[2]:
-            assert abs(probs[-1][st["id"]] - probs[-1][ref_ids[2]]) < 2e-6
+            assert abs(probs[-1][st["id"]] - probs[-1][ref_ids[2]]) < 4e-3 * probs[-1][ref_ids[2]]
         pos += ln
         n_past += ln
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_memory",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_debug_read",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]
 
@@ -35,6 +35,10 @@ class HParamsC(C.Structure):
 
 class TokenDataC(C.Structure):
     _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float)]
+
+
+class ProfileEntryC(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("calls", C.c_int64), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 class WhisperHipError(RuntimeError):
@@ -75,6 +79,8 @@ def lib():
         L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.wh_sample_best.argtypes = [vp, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_debug_read.argtypes = [vp, C.c_char_p, i32, i32, vp, i64]
+        L.wh_profile_enable.argtypes = [vp, i32]
+        L.wh_profile_read.argtypes = [vp, C.POINTER(ProfileEntryC), i32, C.POINTER(i32)]
         L.wh_op_mul_mat.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
         L.wh_op_mul_mat_gelu.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
         L.wh_op_layer_norm.argtypes = [vp, vp, vp, vp, vp, i32, i32]
@@ -226,6 +232,17 @@ class HipContext:
         out = (TokenDataC * batch)()
         check(lib().wh_sample_best(self.handle, batch, int(force_timestamp), int(is_initial), out))
         return [dict(id=o.id, tid=o.tid, p=o.p, pt=o.pt, ptsum=o.ptsum) for o in out]
+
+    def profile(self, on: bool):
+        check(lib().wh_profile_enable(self.handle, int(on)))
+
+    def profile_read(self):
+        """Per kernel class: calls, total GPU ms, algorithmic flops and bytes since profile(True)."""
+        buf = (ProfileEntryC * 32)()
+        n = C.c_int()
+        check(lib().wh_profile_read(self.handle, buf, 32, C.byref(n)))
+        return {buf[i].name.decode(): dict(calls=buf[i].calls, ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
+                for i in range(n.value)}
 
     def debug_read(self, what: str, layer: int = 0, rows: int = 0) -> np.ndarray:
         d = self.hp.n_audio_state

@@ -137,9 +137,58 @@ struct wh_model
 	size_t expectedTensors() const { return 11 + 15 * (size_t)hp.n_audio_layer + 24 * (size_t)hp.n_text_layer; }
 };
 
+// Per-kernel-class GPU timing, the counterpart of the reference's GpuProfiler (Whisper/Utils/GpuProfiler.h:21-188: a
+// timestamp query per shader dispatch, aggregated per eComputeShader). hipEvent pairs on the context's stream; only
+// active between wh_profile_enable(1) and wh_profile_read, because two event records per launch perturb launch-bound code.
+enum eKernelClass : int
+{
+	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_ATTN_ENC, KC_ATTN_DEC, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX, KC_SAMPLE, KC_COUNT
+};
+static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "attentionEnc", "attentionDec", "layerNorm", "mel",
+	"melToConvInput", "embed", "vocabSoftMax", "sampleBest" };
+
+struct Profiler
+{
+	bool on = false;
+	struct Pending { int kc; hipEvent_t a, b; };
+	std::vector<Pending> pending;
+	std::vector<hipEvent_t> pool;
+	int64_t calls[ KC_COUNT ] = {};
+	double ms[ KC_COUNT ] = {}, flops[ KC_COUNT ] = {}, bytes[ KC_COUNT ] = {};
+	hipEvent_t get()
+	{
+		if( !pool.empty() ) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+		hipEvent_t e = nullptr;
+		(void)hipEventCreate( &e );
+		return e;
+	}
+	void resolve()
+	{
+		for( const Pending& p : pending )
+		{
+			float t = 0;
+			if( hipEventSynchronize( p.b ) == hipSuccess && hipEventElapsedTime( &t, p.a, p.b ) == hipSuccess ) ms[ p.kc ] += t;
+			pool.push_back( p.a );
+			pool.push_back( p.b );
+		}
+		pending.clear();
+	}
+	void reset()
+	{
+		resolve();
+		for( int i = 0; i < KC_COUNT; i++ ) { calls[ i ] = 0; ms[ i ] = flops[ i ] = bytes[ i ] = 0; }
+	}
+	~Profiler()
+	{
+		resolve();
+		for( hipEvent_t e : pool ) (void)hipEventDestroy( e );
+	}
+};
+
 struct wh_context
 {
 	wh_model* m = nullptr;
+	Profiler prof;
 	int maxBatch = 0;
 	hipStream_t stream = nullptr;
 	uint32_t flags = 0;
@@ -175,6 +224,44 @@ struct wh_context
 		return 0;
 	}
 };
+
+
+// Runs one launch, optionally bracketed by events. flops / bytes are the ALGORITHMIC work of the launch.
+template<class F>
+static int profiled( wh_context* c, int kc, double flops, double bytes, F&& launch )
+{
+	Profiler& p = c->prof;
+	if( !p.on ) return launch();
+	hipEvent_t a = p.get(), b = p.get();
+	WH_HIP( hipEventRecord( a, c->stream ) );
+	const int rc = launch();
+	WH_HIP( hipEventRecord( b, c->stream ) );
+	p.pending.push_back( { kc, a, b } );
+	p.calls[ kc ]++;
+	p.flops[ kc ] += flops;
+	p.bytes[ kc ] += bytes;
+	if( p.pending.size() >= 4096 ) p.resolve();
+	return rc;
+}
+static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
+{
+	const bool sk = skinny && g.M <= 32;
+	const double flops = 2.0 * g.M * g.N * g.K;
+	// algorithmic bytes: each operand once + the output once (FP16 in, 2..4 bytes out)
+	const double bytes = 2.0 * g.N * g.K + 2.0 * g.M * g.K + ( g.out32 ? 4.0 : 2.0 ) * g.M * g.N;
+	return profiled( c, sk ? KC_GEMM_SKINNY : KC_GEMM_TILED, flops, bytes, [ & ]() { return sk ? launchGemmSkinny( g, c->stream ) : launchGemm( g, c->stream ); } );
+}
+static int lnP( wh_context* c, const float* x, const float* w, const float* b, f16* out, int rows, int d )
+{
+	return profiled( c, KC_LAYER_NORM, 8.0 * rows * d, 6.0 * rows * d, [ & ]() { return launchLayerNorm( x, w, b, out, rows, d, c->stream ); } );
+}
+static int attnDecP( wh_context* c, const DecAttnArgs& a )
+{
+	const double keys = (double)a.nKeys;
+	const double bytes = 2.0 * 2.0 * a.batch * a.H * keys * HEAD_DIM * a.nTok;	// K and V rows, once per query row
+	const double flops = 4.0 * a.batch * a.H * keys * HEAD_DIM * a.nTok;
+	return profiled( c, KC_ATTN_DEC, flops, bytes, [ & ]() { return launchAttentionDec( a, c->stream ); } );
+}
 
 // ==================================================================================================================
 // device
@@ -588,11 +675,14 @@ int wh_context_memory( const wh_context* c, int64_t* vramBytes )
 
 int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, float* melDev, int64_t* nLenOut )
 {
-	if( !c || !pcmDev || !melDev || nSamples < 0 ) { setError( "mel: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c || nSamples < 0 ) { setError( "mel: bad argument" ); return WH_E_INVALIDARG; }
 	const int64_t nLen = nSamples / 160;
 	if( nLenOut ) *nLenOut = nLen;
+	if( nLen == 0 ) return 0;	// less than one hop of audio: an empty spectrogram, like the reference (whisper.cpp:2080)
+	if( !pcmDev || !melDev ) { setError( "mel: null buffer" ); return WH_E_INVALIDARG; }
 	const wh_model* m = c->m;
-	return launchMel( pcmDev, nSamples, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), melDev, nLen, m->hp.n_mels, c->melScratch, c->stream );
+	return profiled( c, KC_MEL, 2.0 * 2.0 * 400.0 * 201.0 * nLen, 4.0 * nSamples + 4.0 * 2.0 * nLen * m->hp.n_mels,
+		[ & ]() { return launchMel( pcmDev, nSamples, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), melDev, nLen, m->hp.n_mels, c->melScratch, c->stream ); } );
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -623,7 +713,8 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 	if( melOffsets ) memcpy( offs.data(), melOffsets, sizeof( int32_t ) * batch );
 	WH_HIP( hipMemcpyAsync( c->melOffsetsDev, offs.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
 	WH_HIP( hipStreamSynchronize( st ) );	 // offs is a local
-	WH_CHECK( launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ) );
+	WH_CHECK( profiled( c, KC_MEL_TO_CONV, 0.0, 6.0 * batch * 2.0 * T * hp.n_mels,
+		[ & ]() { return launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ); } ) );
 
 	// conv1 (k=3, stride 1, pad 1) + bias + GELU as an implicit GEMM over the padded time-major input:
 	// row t of the im2col matrix is the contiguous slice starting at padded row t (whisper.cpp:1127-1136; ggml.c:5199-5318)
@@ -634,7 +725,7 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		g.bias = m->at<float>( L.conv1b );
 		g.out16 = c->conv1Out + d;	 // padded row t+1
 		g.ldc = d; g.cBatchStride = c->conv1Stride;
-		WH_CHECK( launchGemm( g, st ) );
+		WH_CHECK( gemmP( c, g, false ) );
 	}
 	// conv2 (stride 2) + bias + GELU + positional embedding -> residual stream x [batch*T][d] (whisper.cpp:1138-1167)
 	{
@@ -644,45 +735,46 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		g.bias = m->at<float>( L.conv2b );
 		g.pe = m->at<float>( L.encPe );
 		g.out32 = c->x; g.ldc = d;
-		WH_CHECK( launchGemm( g, st ) );
+		WH_CHECK( gemmP( c, g, false ) );
 	}
 	for( int il = 0; il < hp.n_audio_layer; il++ )
 	{
 		const EncLayer& e = L.enc[ il ];
-		WH_CHECK( launchLayerNorm( c->x, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->xn, M, d, st ) );
+		WH_CHECK( lnP( c, c->x, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->xn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->xn, m->at<f16>( e.wqkv ), M, 3 * d, d );
 			g.epi = EPI_QKV_ENC;
 			g.bias = m->at<float>( e.bqkv );
 			g.q = c->q; g.k = c->k; g.v = c->vT;
 			g.T = T; g.Tpad = c->Tpad; g.H = H; g.B = batch;
-			WH_CHECK( launchGemm( g, st ) );
+			WH_CHECK( gemmP( c, g, false ) );
 		}
-		WH_CHECK( launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, st ) );
+		WH_CHECK( profiled( c, KC_ATTN_ENC, 4.0 * batch * H * (double)T * T * HEAD_DIM, 2.0 * 4.0 * batch * H * (double)T * HEAD_DIM,
+			[ & ]() { return launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, st ); } ) );
 		{
 			GemmArgs g = plainGemm( c->attn, m->at<f16>( e.wo ), M, d, d );
 			g.epi = EPI_F32;
 			g.bias = m->at<float>( e.bo );
 			g.res = c->x; g.out32 = c->x;
-			WH_CHECK( launchGemm( g, st ) );
+			WH_CHECK( gemmP( c, g, false ) );
 		}
-		WH_CHECK( launchLayerNorm( c->x, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->xn, M, d, st ) );
+		WH_CHECK( lnP( c, c->x, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->xn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->xn, m->at<f16>( e.w1 ), M, 4 * d, d );
 			g.epi = EPI_F16_GELU;
 			g.bias = m->at<float>( e.b1 );
 			g.out16 = c->h;
-			WH_CHECK( launchGemm( g, st ) );
+			WH_CHECK( gemmP( c, g, false ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->h, m->at<f16>( e.w2 ), M, d, 4 * d );
 			g.epi = EPI_F32;
 			g.bias = m->at<float>( e.b2 );
 			g.res = c->x; g.out32 = c->x;
-			WH_CHECK( launchGemm( g, st ) );
+			WH_CHECK( gemmP( c, g, false ) );
 		}
 	}
-	WH_CHECK( launchLayerNorm( c->x, m->at<float>( L.lnPostW ), m->at<float>( L.lnPostB ), c->xn, M, d, st ) );
+	WH_CHECK( lnP( c, c->x, m->at<float>( L.lnPostW ), m->at<float>( L.lnPostB ), c->xn, M, d ) );
 	// cross-attention K/V of every decoder layer in one product (whisper.cpp:1448-1487)
 	{
 		GemmArgs g = plainGemm( c->xn, m->at<f16>( L.wcross ), M, 2 * hp.n_text_layer * d, d );
@@ -691,7 +783,7 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		g.scale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
 		g.k = c->crossK; g.v = c->crossV;
 		g.T = T; g.H = H; g.B = c->maxBatch;
-		WH_CHECK( launchGemm( g, st ) );
+		WH_CHECK( gemmP( c, g, false ) );
 	}
 	c->encoded = true;
 	c->lastBatch = batch;
@@ -716,7 +808,8 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
 
 	WH_HIP( hipMemcpyAsync( c->tokensDev, tokens, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
-	WH_CHECK( launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, d, st ) );
+	WH_CHECK( profiled( c, KC_EMBED, 1.0 * M * d, 10.0 * M * d,
+		[ & ]() { return launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, d, st ); } ) );
 
 	for( int il = 0; il < hp.n_text_layer; il++ )
 	{
@@ -724,7 +817,7 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 		const int64_t selfLayer = (int64_t)il * c->maxBatch * hp.n_text_ctx * d;
 		const int64_t crossLayer = (int64_t)il * c->maxBatch * c->T * d;
 		// self-attention
-		WH_CHECK( launchLayerNorm( c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d, st ) );
+		WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wqkv ), M, 3 * d, d );
 			g.epi = EPI_QKV_DEC;
@@ -732,62 +825,63 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 			g.scale = kqScale;
 			g.q = c->dq; g.k = c->selfK + selfLayer; g.v = c->selfV + selfLayer;
 			g.H = H; g.nTok = nTokens; g.nPast = nPast; g.textCtx = hp.n_text_ctx;
-			WH_CHECK( launchGemmSkinny( g, st ) );
+			WH_CHECK( gemmP( c, g, true ) );
 		}
 		{
 			DecAttnArgs a;
 			a.q = c->dq; a.kc = c->selfK + selfLayer; a.vc = c->selfV + selfLayer; a.out = c->dattn;
 			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = nPast + nTokens; a.keyStride = hp.n_text_ctx;
 			a.causal = 1; a.nPast = nPast; a.parityThreads = parity;
-			WH_CHECK( launchAttentionDec( a, st ) );
+			WH_CHECK( attnDecP( c, a ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wo ), M, d, d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.bo ); g.res = c->dx; g.out32 = c->dx;
-			WH_CHECK( launchGemmSkinny( g, st ) );
+			WH_CHECK( gemmP( c, g, true ) );
 		}
 		// cross-attention
-		WH_CHECK( launchLayerNorm( c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d, st ) );
+		WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wcq ), M, d, d );
 			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
-			WH_CHECK( launchGemmSkinny( g, st ) );
+			WH_CHECK( gemmP( c, g, true ) );
 		}
 		{
 			DecAttnArgs a;
 			a.q = c->dq; a.kc = c->crossK + crossLayer; a.vc = c->crossV + crossLayer; a.out = c->dattn;
 			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = c->T; a.keyStride = c->T;
 			a.causal = 0; a.nPast = 0; a.parityThreads = parity;
-			WH_CHECK( launchAttentionDec( a, st ) );
+			WH_CHECK( attnDecP( c, a ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wco ), M, d, d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.bco ); g.res = c->dx; g.out32 = c->dx;
-			WH_CHECK( launchGemmSkinny( g, st ) );
+			WH_CHECK( gemmP( c, g, true ) );
 		}
 		// MLP
-		WH_CHECK( launchLayerNorm( c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d, st ) );
+		WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.w1 ), M, 4 * d, d );
 			g.epi = EPI_F16_GELU; g.bias = m->at<float>( e.b1 ); g.out16 = c->dh;
-			WH_CHECK( launchGemmSkinny( g, st ) );
+			WH_CHECK( gemmP( c, g, true ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->dh, m->at<f16>( e.w2 ), M, d, 4 * d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.b2 ); g.res = c->dx; g.out32 = c->dx;
-			WH_CHECK( launchGemmSkinny( g, st ) );
+			WH_CHECK( gemmP( c, g, true ) );
 		}
 	}
 	// final norm + logits for the LAST token of every sequence only (the reference computes all rows, whisper.cpp:1840,
 	// and then consumes just the last one, ContextImpl.cpp:159-169)
-	WH_CHECK( launchLayerNorm( c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d, st ) );
+	WH_CHECK( lnP( c, c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d ) );
 	{
 		GemmArgs g = plainGemm( c->dxn + (int64_t)( nTokens - 1 ) * d, m->at<f16>( L.te ), batch, hp.n_vocab, d );
 		g.lda = nTokens * d;
 		g.epi = EPI_F32; g.out32 = c->logits; g.ldc = hp.n_vocab;
-		WH_CHECK( launchGemmSkinny( g, st ) );
+		WH_CHECK( gemmP( c, g, true ) );
 	}
-	WH_CHECK( launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ) );
+	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab,
+		[ & ]() { return launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ); } ) );
 	c->lastBatch = batch;
 	if( logitsHost ) WH_HIP( hipMemcpyAsync( logitsHost, c->logits, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
 	if( probsHost ) WH_HIP( hipMemcpyAsync( probsHost, c->probs, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
@@ -802,10 +896,44 @@ int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial,
 	// hard-coded special token ids (Whisper/Whisper/Vocabulary.h:27-41)
 	const int ml = hp.n_vocab == 51865 ? 1 : 0;
 	const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
-	WH_CHECK( launchSampleBest( c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, forceTimestamp, isInitial, c->tokDataDev, c->stream ) );
+	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, 5.0 * 4.0 * batch * hp.n_vocab,
+		[ & ]() { return launchSampleBest( c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, forceTimestamp, isInitial, c->tokDataDev, c->stream ); } ) );
 	static_assert( sizeof( wh_token_data ) == sizeof( TokenData ), "token data layout" );
 	WH_HIP( hipMemcpyAsync( out, c->tokDataDev, sizeof( TokenData ) * batch, hipMemcpyDeviceToHost, c->stream ) );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int wh_profile_enable( wh_context* c, int on )
+{
+	if( !c ) return WH_E_INVALIDARG;
+	c->prof.reset();
+	c->prof.on = on != 0;
+	return 0;
+}
+
+int wh_profile_read( wh_context* c, wh_profile_entry* out, int cap, int* count )
+{
+	if( !c || !count ) return WH_E_INVALIDARG;
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	c->prof.resolve();
+	int n = 0;
+	for( int i = 0; i < KC_COUNT; i++ )
+	{
+		if( c->prof.calls[ i ] == 0 ) continue;
+		if( out && n < cap )
+		{
+			wh_profile_entry& e = out[ n ];
+			memset( &e, 0, sizeof( e ) );
+			snprintf( e.name, sizeof( e.name ), "%s", kernelClassNames[ i ] );
+			e.calls = c->prof.calls[ i ];
+			e.ms = c->prof.ms[ i ];
+			e.flops = c->prof.flops[ i ];
+			e.bytes = c->prof.bytes[ i ];
+		}
+		n++;
+	}
+	*count = n;
 	return 0;
 }
 
