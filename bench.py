@@ -30,6 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.time()
 CLIP_SECONDS = 198.762
 WINDOW_SAMPLES = 480000
 N_PROMPT = 3
@@ -68,42 +69,73 @@ def transcribe_clip(ctx, pcm_dev, mel_dev, prompt, n_greedy, batch):
     return out
 
 
-def cpu_baseline(model, model_kind, pcm_one_window, prompt, quick: bool):
-    """The reference's own CPU path (Whisper/source, compiled unmodified into oracle/_ref) on this host's cores."""
+def log(msg):
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
+CPU_BASELINE_THREADS_MAX = 16      # ggml's spin-wait thread pool stops scaling (and can collapse) far below a big host's core count
+CPU_BASELINE_TIMEOUT_S = 240
+
+
+def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, out_path):
+    """Runs in a child process (so a slow host cannot stall the bench): the reference's own CPU path, one 30 s window."""
+    from oracle import ref
+    w = ref.RefWhisper(model_path, n_threads=n_threads, log_level=0)
+    pcm = np.load(pcm_path)
+    t0 = time.time()
+    w.pcm_to_mel(pcm)
+    t_mel = time.time() - t0
+    t0 = time.time()
+    w.encode(0)
+    t_enc = time.time() - t0
+    t0 = time.time()
+    w.decode(prompt, 0)
+    t_prompt = time.time() - t0
+    n_tok = 8
+    t0 = time.time()
+    for i in range(n_tok):
+        w.decode([1000 + i], len(prompt) + i)
+    t_tok = (time.time() - t0) / n_tok
+    per_window = t_mel + t_enc + t_prompt + N_GREEDY * t_tok
+    res = {"value": round(30.0 / per_window, 4), "unit": "audio-seconds/sec", "cores": n_threads, "kind": "reference",
+           "sample": "%s-shape model, ONE 30 s window on the reference's CPU path (Whisper/source, oracle/_ref): mel %.3f s + encode "
+                     "%.2f s + %d-token prompt %.3f s measured, %d of %d greedy steps measured (%.1f ms/token) and scaled; "
+                     "n_threads=%d of %d host cpus" % (model_kind, t_mel, t_enc, len(prompt), t_prompt, n_tok, N_GREEDY, 1e3 * t_tok,
+                                                     n_threads, os.cpu_count() or 1)}
+    with open(out_path, "w") as f:
+        json.dump(res, f)
+
+
+def cpu_baseline(model, model_kind, pcm_one_window, prompt):
+    """The reference's own CPU path (compiled unmodified into oracle/_ref) timed on this host, bounded by a timeout."""
+    null = {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference"}
     try:
         from oracle import ref
+        if not ref.available():
+            return dict(null, sample="oracle/_ref/libwhisper_ref.so not present")
     except Exception as e:      # pragma: no cover
-        return {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference", "sample": "oracle unavailable: %s" % e}
-    if not ref.available():
-        return {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference",
-                "sample": "oracle/_ref/libwhisper_ref.so not present"}
+        return dict(null, sample="oracle unavailable: %s" % e)
+    import subprocess
     import tempfile
     from whisper_amd import ggml_format as gf
-    cores = os.cpu_count() or 1
+    n_threads = max(1, min(os.cpu_count() or 1, CPU_BASELINE_THREADS_MAX))
     with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "m.bin")
-        gf.write_model(path, model)
-        w = ref.RefWhisper(path, n_threads=cores, log_level=0)
-        t0 = time.time()
-        w.pcm_to_mel(pcm_one_window)
-        t_mel = time.time() - t0
-        t0 = time.time()
-        w.encode(0)
-        t_enc = time.time() - t0
-        t0 = time.time()
-        w.decode(prompt, 0)
-        t_prompt = time.time() - t0
-        n_tok = 4 if quick else 10
-        t0 = time.time()
-        for i in range(n_tok):
-            w.decode([1000 + i], len(prompt) + i)
-        t_tok = (time.time() - t0) / n_tok
-        w.close()
-    per_window = t_mel + t_enc + t_prompt + N_GREEDY * t_tok
-    return {"value": round(30.0 / per_window, 4), "unit": "audio-seconds/sec", "cores": cores, "kind": "reference",
-            "sample": "%s-shape model, ONE 30 s window: mel %.3f s + encode %.2f s + %d-token prompt %.3f s measured, "
-                      "%d of %d greedy steps measured (%.1f ms/token) and scaled; n_threads=%d"
-                      % (model_kind, t_mel, t_enc, len(prompt), t_prompt, n_tok, N_GREEDY, 1e3 * t_tok, cores)}
+        mp, pp, op = os.path.join(td, "m.bin"), os.path.join(td, "pcm.npy"), os.path.join(td, "out.json")
+        gf.write_model(mp, model)
+        np.save(pp, pcm_one_window)
+        code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%r, %r, %r, %r, %d, %r)"
+                % (ROOT, mp, model_kind, pp, list(map(int, prompt)), n_threads, op))
+        try:
+            subprocess.run([sys.executable, "-c", code], timeout=CPU_BASELINE_TIMEOUT_S, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            with open(op) as f:
+                return json.load(f)
+        except subprocess.TimeoutExpired:
+            return dict(null, cores=n_threads, sample="reference CPU path did not finish one 30 s window of the %s-shape model within "
+                                                      "%d s on %d threads" % (model_kind, CPU_BASELINE_TIMEOUT_S, n_threads))
+        except Exception as e:
+            return dict(null, cores=n_threads, sample="reference CPU run failed: %s" % str(e)[:200])
 
 
 def main():
@@ -141,7 +173,9 @@ def main():
     model = None
     t0 = time.time()
     if rank == 0:
+        log("building %s-shape random model ..." % args.model)
         model = gf.synth_model(args.model, seed=1)
+        log("uploading weights ...")
         hip_model = binding.HipModel.from_ggml(model, arena_ptr=arena.data_ptr(), keepalive=arena)
     t_load = time.time() - t0
     t_bcast = 0.0
@@ -167,9 +201,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        log("warmup ...")
     for _ in range(args.warmup):
         transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
     barrier()
+    if rank == 0:
+        log("timed region: %d steps ..." % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         toks = transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
@@ -182,6 +220,8 @@ def main():
 
     # ---- per-kernel pass (rank 0): identical work with hipEvent pairs around every launch ----
     roofline, kernels = None, {}
+    if rank == 0:
+        log("timed region done: %.3f s" % elapsed)
     if rank == 0 and not args.no_roofline:
         ctx.profile(True)
         transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
@@ -206,7 +246,9 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         if model is None:
             model = gf.synth_model(args.model, seed=1)
-        cpu = cpu_baseline(model, args.model, pcm_dev[0].cpu().numpy(), prompt, quick=False)
+        log("cpu baseline (reference CPU path, bounded) ...")
+        cpu = cpu_baseline(model, args.model, pcm_dev[0].cpu().numpy(), prompt)
+        log("cpu baseline done: %s" % cpu.get("value"))
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
