@@ -60,12 +60,9 @@ def transcribe_clip(ctx, pcm_dev, mel_dev, prompt, n_greedy, batch):
     out = np.zeros((batch, n_greedy + 1), np.int32)
     s = ctx.sample_best(batch, force_timestamp=True, is_initial=True)     # first token: timestamp <= 1.00 s (ContextImpl.cpp:613)
     out[:, 0] = [t["id"] for t in s]
-    n_past = len(prompt)
-    for i in range(n_greedy):
-        ctx.decode(out[:, i:i + 1], n_past, want_logits=False, want_probs=False)
-        s = ctx.sample_best(batch)
-        out[:, i + 1] = [t["id"] for t in s]
-        n_past += 1
+    # the remaining greedy steps run on the device: one captured hipGraph per token, sampled token fed back in HBM
+    ids, _ = ctx.decode_greedy(out[:, 0], len(prompt), n_greedy)
+    out[:, 1:] = ids.T
     return out
 
 

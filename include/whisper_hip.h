@@ -80,7 +80,9 @@ typedef enum wh_flags
 	WH_FLAG_NONE = 0,
 	/* Emulate the reference CPU path's FP16, thread-partitioned accumulation of the decoder P.V product
 	 * (Whisper/source/ggml.c:4689-4735, 4615-4644) with `parityThreads` virtual threads. Slow; for parity runs. */
-	WH_FLAG_PARITY_PV = 1
+	WH_FLAG_PARITY_PV = 1,
+	/* Launch the greedy loop's kernels one by one instead of replaying the captured hipGraph (debugging aid). */
+	WH_FLAG_NO_GRAPH = 2
 } wh_flags;
 
 WH_API int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out );
@@ -121,6 +123,16 @@ typedef struct wh_token_data
  * initial-timestamp <= 1.00 s cap, first of the top-4 that is not sot/solm/not. forceTimestamp / isInitial are
  * per call (same for all sequences). out: HOST [batch]. Exact ties resolve to the lower token id. */
 WH_API int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial, wh_token_data* out );
+
+/* The greedy loop of ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:597-673: decode -> sampleBest ->
+ * feed the token back) kept on the device for nSteps tokens: firstTokens (HOST, [batch]) are fed at position nPast, each
+ * step runs the decoder for one token per sequence, samples with the sampleBest rules and feeds the choice back, with
+ * no host round trip in between (one captured hipGraph is replayed per token; position and flags live in device
+ * memory). forceFirstTimestamp / firstIsInitial apply to the first sample only (sampleTimestamp(true) of the
+ * reference). out: HOST [nSteps][batch]. The host applies its stop rules to the returned tokens afterwards; tokens
+ * sampled after a sequence's stop condition are simply discarded by the caller. */
+WH_API int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int nPast, int nSteps, int forceFirstTimestamp,
+	int firstIsInitial, wh_token_data* out );
 
 /* Per-kernel-class GPU timings, the counterpart of the reference's GpuProfiler / iContext::timingsPrint
  * (Whisper/Utils/GpuProfiler.h:21-188, Whisper/Whisper/ContextImpl.misc.cpp:170-182). hipEvent pairs around every launch

@@ -256,3 +256,51 @@ def test_full_size_properties():
     print("medium-shape context VRAM: %.1f MB" % (ctx.vram_bytes() / 1e6))
     ctx.close()
     m.close()
+
+
+def test_device_greedy_loop_matches_host_loop(hip_tiny, golden, tiny_model):
+    """wh_decode_greedy (captured hipGraph replayed per token, position + flags in device memory, fused softmax+sampler)
+    must produce exactly the tokens of the host-driven loop wh_decode -> wh_sample_best -> feed back."""
+    sp = gf.special_tokens(tiny_model.hparams)
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    prompt = np.array([[sp["sot"], sp["transcribe"], sp["not_"]]] * 2, np.int32)
+    n_steps = 12
+    ctx = binding.HipContext(hip_tiny, 2)
+
+    def start():
+        ctx.encode(torch.stack([mel, mel]))
+        ctx.decode(prompt, 0, want_logits=False, want_probs=False)
+        return ctx.sample_best(2, True, True)
+
+    first = start()
+    toks = np.array([t["id"] for t in first], np.int32)
+    host_ids, host_p = [], []
+    cur = toks.copy()
+    for s in range(n_steps):
+        ctx.decode(cur[:, None], 3 + s, want_logits=False, want_probs=False)
+        sb = ctx.sample_best(2)
+        host_ids.append([t["id"] for t in sb])
+        host_p.append([t["p"] for t in sb])
+        cur = np.array(host_ids[-1], np.int32)
+    host_ids = np.array(host_ids, np.int32)
+
+    for flags in (0, binding.WH_FLAG_NO_GRAPH):
+        ctx.set_flags(flags)
+        assert [t["id"] for t in start()] == list(toks)
+        ids, data = ctx.decode_greedy(toks, 3, n_steps)
+        print("greedy flags=%d ids[:,0]=%s" % (flags, ids[:, 0]))
+        assert np.array_equal(ids, host_ids)
+        assert np.allclose([[t["p"] for t in row] for row in data], host_p, rtol=0, atol=1e-9)
+        assert np.array_equal(ids[:, 0], ids[:, 1])
+        # replaying the captured graph a second time (fresh state) is deterministic
+        start()
+        ids2, _ = ctx.decode_greedy(toks, 3, n_steps)
+        assert np.array_equal(ids2, ids)
+    # forced initial timestamp on the first device-side sample: one step from the prompt's last token must reproduce
+    # sampleTimestamp(true) on the same probabilities
+    ctx.set_flags(0)
+    start()
+    ctx.decode(prompt[:, :2], 0, want_logits=False, want_probs=False)
+    ids3, data3 = ctx.decode_greedy(prompt[:, 2], 2, 1, force_first_timestamp=True, first_is_initial=True)
+    assert list(ids3[0]) == list(toks)
+    ctx.close()

@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwhisper_hip.so")
 
 WH_FLAG_PARITY_PV = 1
+WH_FLAG_NO_GRAPH = 2
 
 # every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -24,7 +25,7 @@ EXPORTS = [
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_memory",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]
 
@@ -79,6 +80,7 @@ def lib():
         L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.wh_sample_best.argtypes = [vp, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_debug_read.argtypes = [vp, C.c_char_p, i32, i32, vp, i64]
+        L.wh_decode_greedy.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_profile_enable.argtypes = [vp, i32]
         L.wh_profile_read.argtypes = [vp, C.POINTER(ProfileEntryC), i32, C.POINTER(i32)]
         L.wh_op_mul_mat.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
@@ -232,6 +234,22 @@ class HipContext:
         out = (TokenDataC * batch)()
         check(lib().wh_sample_best(self.handle, batch, int(force_timestamp), int(is_initial), out))
         return [dict(id=o.id, tid=o.tid, p=o.p, pt=o.pt, ptsum=o.ptsum) for o in out]
+
+    def decode_greedy(self, first_tokens, n_past: int, n_steps: int, force_first_timestamp: bool = False,
+                      first_is_initial: bool = False):
+        """Device-side greedy loop: returns (ids [n_steps][batch] int32, token data list per step)."""
+        t = np.ascontiguousarray(first_tokens, np.int32).reshape(-1)
+        b = len(t)
+        out = (TokenDataC * (b * n_steps))()
+        check(lib().wh_decode_greedy(self.handle, b, t.ctypes.data_as(C.c_void_p), n_past, n_steps, int(force_first_timestamp),
+                                     int(first_is_initial), out))
+        ids = np.array([o.id for o in out], np.int32).reshape(n_steps, b)
+        data = [[dict(id=out[s * b + i].id, tid=out[s * b + i].tid, p=out[s * b + i].p, pt=out[s * b + i].pt, ptsum=out[s * b + i].ptsum)
+                 for i in range(b)] for s in range(n_steps)]
+        return ids, data
+
+    def set_flags(self, flags: int, parity_threads: int = 1):
+        check(lib().wh_context_set_flags(self.handle, flags, parity_threads))
 
     def profile(self, on: bool):
         check(lib().wh_profile_enable(self.handle, int(on)))

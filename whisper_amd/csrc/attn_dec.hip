@@ -8,7 +8,10 @@
 //     fast path    FP32 accumulation (what the reference's own GPU shaders do),
 //     parity path  the CPU path's FP16, key-by-key, thread-partitioned accumulation (ggml.c:4689-4735 + :4615-4644)
 //                  emulated exactly for `parityThreads` virtual threads.
-// One 256-thread workgroup per (head, sequence, query row). HBM-bound: each K/V row is read once per query row.
+// One 512-thread workgroup per (head, sequence, query row). HBM/latency-bound (each K/V row is read once per query
+// row), so the layout of the work is chosen for bytes in flight: a thread owns whole 128-byte K rows (8 x 16-byte
+// loads issued together, up to 3 rows) in the score phase and 24 x 16-byte V loads in the P.V phase; the three
+// reductions (max, sum, P.V partials) go through LDS.
 #include "kernels.h"
 
 namespace wh
@@ -17,14 +20,18 @@ namespace wh
 	{
 		constexpr int MAX_KEYS = 1536;
 		constexpr int MAX_VTHREADS = 16;
+		constexpr int NT = 512;
+		constexpr int NW = NT / 64;
+		constexpr int KPT = MAX_KEYS / NT;	 // keys per thread in the score phase
+		constexpr int SLOTS = NT / 8;		 // key slots in the P.V phase
 
-		__global__ void __launch_bounds__( 256 ) attentionDec( const DecAttnArgs a )
+		__global__ void __launch_bounds__( NT ) attentionDec( const DecAttnArgs a )
 		{
 			__shared__ float sc[ MAX_KEYS ];
 			__shared__ float qs[ HEAD_DIM ];
-			__shared__ float red[ 32 ][ HEAD_DIM ];
-			__shared__ float shf[ 4 ];
-			__shared__ double shd[ 4 ];
+			__shared__ float red[ SLOTS ][ HEAD_DIM ];
+			__shared__ float shf[ NW ];
+			__shared__ double shd[ NW ];
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
@@ -34,62 +41,101 @@ namespace wh
 			const long long rowQ = (long long)b * a.nTok + i;
 			const f16* const K = a.kc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
 			const f16* const V = a.vc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
+			int nPast = a.nPast, nKeys = a.nKeys;
+			if( a.causal && a.nPastDev )
+			{
+				nPast = *a.nPastDev;
+				nKeys = nPast + a.nTok;
+			}
 			// keys visible to this query row
-			const int nk = a.causal ? min( a.nPast + i + 1, a.nKeys ) : a.nKeys;
+			const int nk = a.causal ? min( nPast + i + 1, nKeys ) : nKeys;
 
 			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
 			__syncthreads();
 
-			// ---- scores ----
-			float mx = -INFINITY;
-			for( int key = tid; key < nk; key += 256 )
+			// ---- scores: thread t owns keys t, t + 512, t + 1024; all K loads first ----
+			f16x8 kv[ KPT ][ 8 ];
+#pragma unroll
+			for( int j = 0; j < KPT; j++ )
 			{
+				int key = tid + j * NT;
+				key = key < nk ? key : nk - 1;
 				const f16* kr = K + (long long)key * HEAD_DIM;
+#pragma unroll
+				for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+			}
+			float mx = -INFINITY;
+			float sv[ KPT ];
+#pragma unroll
+			for( int j = 0; j < KPT; j++ )
+			{
 				float s = 0.0f;
 #pragma unroll
 				for( int c8 = 0; c8 < 8; c8++ )
-				{
-					const f16x8 kv = *(const f16x8*)( kr + c8 * 8 );
 #pragma unroll
-					for( int j = 0; j < 8; j++ ) s = fmaf( (float)kv[ j ], qs[ c8 * 8 + j ], s );
-				}
-				sc[ key ] = s;
-				mx = fmaxf( mx, s );
+					for( int e = 0; e < 8; e++ ) s = fmaf( (float)kv[ j ][ c8 ][ e ], qs[ c8 * 8 + e ], s );
+				sv[ j ] = s;
+				if( tid + j * NT < nk ) mx = fmaxf( mx, s );
 			}
 			mx = waveReduceMax( mx );
 			if( lane == 0 ) shf[ wave ] = mx;
 			__syncthreads();
-			mx = fmaxf( fmaxf( shf[ 0 ], shf[ 1 ] ), fmaxf( shf[ 2 ], shf[ 3 ] ) );
+			mx = shf[ 0 ];
+#pragma unroll
+			for( int w = 1; w < NW; w++ ) mx = fmaxf( mx, shf[ w ] );
 
 			// ---- table softmax ----
 			double sum = 0.0;
-			for( int key = tid; key < nk; key += 256 )
+#pragma unroll
+			for( int j = 0; j < KPT; j++ )
 			{
-				const float e = exp16( sc[ key ] - mx );
-				sc[ key ] = e;
-				sum += (double)e;
+				const int key = tid + j * NT;
+				if( key < nk )
+				{
+					const float e = exp16( sv[ j ] - mx );
+					sv[ j ] = e;
+					sum += (double)e;
+				}
 			}
 			sum = waveReduceSumD( sum );
 			if( lane == 0 ) shd[ wave ] = sum;
 			__syncthreads();
-			const float inv = (float)( 1.0 / ( ( shd[ 0 ] + shd[ 1 ] ) + ( shd[ 2 ] + shd[ 3 ] ) ) );
-			for( int key = tid; key < nk; key += 256 ) sc[ key ] *= inv;
+			double tot = shd[ 0 ];
+#pragma unroll
+			for( int w = 1; w < NW; w++ ) tot += shd[ w ];
+			const float inv = (float)( 1.0 / tot );
+#pragma unroll
+			for( int j = 0; j < KPT; j++ )
+			{
+				const int key = tid + j * NT;
+				if( key < nk ) sc[ key ] = sv[ j ] * inv;
+			}
 			__syncthreads();
 
 			float result = 0.0f;
 			if( a.parityThreads <= 0 )
 			{
-				// ---- P.V, FP32: 32 key slots x 8 lanes of 8 dims ----
+				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; up to 24 V loads in flight per thread ----
 				const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
 				float acc[ 8 ];
 #pragma unroll
 				for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
-				for( int key = g; key < nk; key += 32 )
+				for( int k0 = g; k0 < nk; k0 += SLOTS * 8 )
 				{
-					const f16x8 vv = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
-					const float p = sc[ key ];
+					f16x8 vv[ 8 ];
+					float pp[ 8 ];
 #pragma unroll
-					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ j ], p, acc[ j ] );
+					for( int u = 0; u < 8; u++ )
+					{
+						const int key = k0 + u * SLOTS;
+						const int kc = key < nk ? key : nk - 1;
+						vv[ u ] = *(const f16x8*)( V + (long long)kc * HEAD_DIM + j8 );
+						pp[ u ] = key < nk ? sc[ kc ] : 0.0f;
+					}
+#pragma unroll
+					for( int u = 0; u < 8; u++ )
+#pragma unroll
+						for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
 				}
 #pragma unroll
 				for( int j = 0; j < 8; j++ ) red[ g ][ j8 + j ] = acc[ j ];
@@ -98,7 +144,7 @@ namespace wh
 				{
 					float t = 0.0f;
 #pragma unroll
-					for( int s = 0; s < 32; s++ ) t += red[ s ][ tid ];
+					for( int s = 0; s < SLOTS; s++ ) t += red[ s ][ tid ];
 					result = t;
 				}
 			}
@@ -106,9 +152,9 @@ namespace wh
 			{
 				// ---- P.V exactly as ggml's transposed-src0 branch: per virtual thread, y = fp16( fma( v, p, y ) ) key by key
 				const int nth = min( a.parityThreads, MAX_VTHREADS );
-				const int nc = a.nKeys;	   // the partition is over ALL key columns, masked ones contribute p = 0
+				const int nc = nKeys;	 // the partition is over ALL key columns, masked ones contribute p = 0
 				const int dc = ( nc + nth - 1 ) / nth;
-				for( int vt = wave; vt < nth; vt += 4 )
+				for( int vt = wave; vt < nth; vt += NW )
 				{
 					float y = 0.0f;
 					const int k1 = min( dc * ( vt + 1 ), nc );
@@ -140,7 +186,7 @@ namespace wh
 			setError( "attentionDec: key count out of range" );
 			return -1;
 		}
-		hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( 256 ), 0, stream, a );
+		hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

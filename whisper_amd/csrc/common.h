@@ -64,6 +64,47 @@ namespace wh
 		return v;
 	}
 
+	// One wavefront normalises one row of length d (a multiple of 64, at most 64 * MAXPER): LayerNorm + affine, the
+	// numerics of ggml_compute_forward_norm_f32 followed by w*y + b (ggml.c:4098-4156, whisper.cpp:1195-1199); see
+	// elementwise.hip. Element c = lane + 64 * i. Every load is issued (clamped, so unconditionally) before the first
+	// use, which keeps all of them in flight at once instead of one dependent round trip per element.
+	template<int MAXPER, class Store>
+	__device__ __forceinline__ void layerNormRow( const float* __restrict__ xr, const float* __restrict__ w, const float* __restrict__ b,
+		int d, int lane, Store&& store )
+	{
+		const int per = d >> 6;
+		float v[ MAXPER ], wv[ MAXPER ], bv[ MAXPER ];
+#pragma unroll
+		for( int i = 0; i < MAXPER; i++ )
+		{
+			int c = lane + 64 * i;
+			c = c < d ? c : d - 1;
+			v[ i ] = xr[ c ];
+			wv[ i ] = w[ c ];
+			bv[ i ] = b[ c ];
+		}
+		float s = 0.0f;
+#pragma unroll
+		for( int i = 0; i < MAXPER; i++ ) s += ( i < per ) ? v[ i ] : 0.0f;
+		const float mean = waveReduceSum( s ) / (float)d;
+		float s2 = 0.0f;
+#pragma unroll
+		for( int i = 0; i < MAXPER; i++ )
+		{
+			v[ i ] -= mean;
+			s2 += ( i < per ) ? v[ i ] * v[ i ] : 0.0f;
+		}
+		const float var = waveReduceSum( s2 ) / (float)d;
+		const float scale = 1.0f / sqrtf( var + 1e-5f );
+#pragma unroll
+		for( int i = 0; i < MAXPER; i++ )
+			if( i < per )
+			{
+				const float y = __fmul_rn( v[ i ], scale );
+				store( lane + 64 * i, (f16)__fadd_rn( __fmul_rn( y, wv[ i ] ), bv[ i ] ) );
+			}
+	}
+
 	// ---- host side ----
 	void setError( const std::string& s );
 	int hipFail( hipError_t e, const char* what, const char* file, int line );

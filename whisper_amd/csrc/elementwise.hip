@@ -18,37 +18,12 @@ namespace wh
 			const int lane = threadIdx.x & 63;
 			const int row = blockIdx.x * 4 + ( threadIdx.x >> 6 );
 			if( row >= rows ) return;
-			const float* xr = x + (long long)row * d;
-			const int per = d >> 6;
-			float v[ LN_MAX_PER_LANE ];
-			float s = 0.0f;
-#pragma unroll
-			for( int i = 0; i < LN_MAX_PER_LANE; i++ )
-				if( i < per )
-				{
-					v[ i ] = xr[ lane + 64 * i ];
-					s += v[ i ];
-				}
-			const float mean = waveReduceSum( s ) / (float)d;
-			float s2 = 0.0f;
-#pragma unroll
-			for( int i = 0; i < LN_MAX_PER_LANE; i++ )
-				if( i < per )
-				{
-					v[ i ] -= mean;
-					s2 += v[ i ] * v[ i ];
-				}
-			const float var = waveReduceSum( s2 ) / (float)d;
-			const float scale = 1.0f / sqrtf( var + 1e-5f );
-			f16* o = out + (long long)row * d;
-#pragma unroll
-			for( int i = 0; i < LN_MAX_PER_LANE; i++ )
-				if( i < per )
-				{
-					const int c = lane + 64 * i;
-					const float y = __fmul_rn( v[ i ], scale );
-					o[ c ] = (f16)__fadd_rn( __fmul_rn( y, w[ c ] ), b[ c ] );
-				}
+			f16* const o = out + (long long)row * d;
+			// d <= 1280 for every Whisper size: the 20-slot instance keeps the register count (and the wasted clamped loads) low
+			if( d <= 64 * 20 )
+				layerNormRow<20>( x + (long long)row * d, w, b, d, lane, [ = ]( int c, f16 v ) { o[ c ] = v; } );
+			else
+				layerNormRow<LN_MAX_PER_LANE>( x + (long long)row * d, w, b, d, lane, [ = ]( int c, f16 v ) { o[ c ] = v; } );
 		}
 
 		// ---- mel window -> padded FP16 conv input -----------------------------------------------------------------
@@ -86,11 +61,11 @@ namespace wh
 
 		// ---- token + position embedding (addRows.hlsl; whisper.cpp:1544-1548) ---------------------------------------
 		__global__ void __launch_bounds__( 256 ) embedKernel( const int* __restrict__ tokens, const f16* __restrict__ te,
-			const float* __restrict__ pe, float* __restrict__ x, int rows, int nTok, int nPast, int d )
+			const float* __restrict__ pe, float* __restrict__ x, int rows, int nTok, int nPast, const int* __restrict__ nPastDev, int d )
 		{
 			const int row = blockIdx.x;
 			const int tok = tokens[ row ];
-			const int pos = nPast + row % nTok;
+			const int pos = ( nPastDev ? *nPastDev : nPast ) + row % nTok;
 			for( int c = threadIdx.x; c < d; c += 256 )
 				x[ (long long)row * d + c ] = (float)te[ (long long)tok * d + c ] + pe[ (long long)pos * d + c ];
 		}
@@ -235,6 +210,105 @@ namespace wh
 				out[ blockIdx.x ] = r;
 			}
 		}
+		// ---- logits row -> table softmax -> sampleBest in ONE kernel, the row held in registers -----------------------
+		// Used by the captured decode step: no host round trip between the logits product and the next token. Same
+		// arithmetic as softMaxRows followed by sampleBestKernel (p = exp16(x - max) * float(1 / double sum)).
+		constexpr int SS_PER = 51;	   // ceil( 51866 / 1024 )
+		__global__ void __launch_bounds__( 1024 ) softMaxSampleKernel( const float* __restrict__ logits, float* __restrict__ probsOut,
+			int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot, const DecodeState* __restrict__ state,
+			TokenData* __restrict__ out, int* __restrict__ nextTokens )
+		{
+			__shared__ float shf[ 16 ];
+			__shared__ double shd[ 16 ];
+			__shared__ ArgMax sha[ 16 ];
+			const float* x = logits + (long long)blockIdx.x * nVocab;
+			const int forceTimestamp = state->forceTimestamp, isInitial = state->isInitial;
+			const int tsEnd = isInitial ? min( tokenBeg + 101, nVocab ) : nVocab;
+			float v[ SS_PER ];
+			float m = -INFINITY;
+#pragma unroll
+			for( int j = 0; j < SS_PER; j++ )
+			{
+				const int c = threadIdx.x + j * 1024;
+				v[ j ] = c < nVocab ? x[ c ] : -INFINITY;
+				m = fmaxf( m, v[ j ] );
+			}
+			m = blockMax<16>( m, shf );
+			double s = 0.0;
+#pragma unroll
+			for( int j = 0; j < SS_PER; j++ )
+			{
+				const float e = ( v[ j ] == -INFINITY ) ? 0.0f : exp16( v[ j ] - m );
+				v[ j ] = e;
+				s += (double)e;
+			}
+			s = blockSumD<16>( s, shd );
+			const float inv = (float)( 1.0 / s );
+			ArgMax tx = { -1.0f, 0x7fffffff }, ts = { -1.0f, 0x7fffffff };
+			double sumTs = 0.0;
+#pragma unroll
+			for( int j = 0; j < SS_PER; j++ )
+			{
+				const int c = threadIdx.x + j * 1024;
+				const float p = v[ j ] * inv;
+				v[ j ] = p;
+				if( c < nVocab )
+				{
+					if( probsOut ) probsOut[ (long long)blockIdx.x * nVocab + c ] = p;
+					if( c < tokenBeg )
+						tx = better( tx, ArgMax{ p, c } );
+					else if( c < tsEnd )
+					{
+						ts = better( ts, ArgMax{ p, c } );
+						sumTs += (double)p;
+					}
+				}
+			}
+			tx = blockArgMax( tx, sha );
+			ts = blockArgMax( ts, sha );
+			sumTs = blockSumD<16>( sumTs, shd );
+			const bool onlyTs = ( sumTs > (double)fmaxf( tx.v, -1.0f ) ) || forceTimestamp;
+			const int lo = onlyTs ? tokenBeg : 0;
+			ArgMax pick = { -INFINITY, 0 };
+			for( int round = 0; round < 4; round++ )
+			{
+				ArgMax best = { -INFINITY, 0x7fffffff };
+#pragma unroll
+				for( int j = 0; j < SS_PER; j++ )
+				{
+					const int c = threadIdx.x + j * 1024;
+					const bool ok = c < nVocab && c >= lo && !( c >= tsEnd && c >= tokenBeg );
+					if( ok ) best = better( best, ArgMax{ v[ j ], c } );
+				}
+				best = blockArgMax( best, sha );
+				pick = best;
+				// remove the winner from its owner's registers for the next round
+#pragma unroll
+				for( int j = 0; j < SS_PER; j++ )
+					if( threadIdx.x + j * 1024 == best.i ) v[ j ] = -INFINITY;
+				const bool special = best.i == tokenSot || best.i == tokenSolm || best.i == tokenNot;
+				if( !special ) break;
+			}
+			if( threadIdx.x == 0 )
+			{
+				TokenData r;
+				r.id = pick.i;
+				r.tid = ts.v > -1.0f ? ts.i : 0;
+				r.p = pick.v;
+				r.pt = (float)( (double)ts.v / ( sumTs + 1e-10 ) );
+				r.ptsum = (float)sumTs;
+				out[ (long long)state->step * gridDim.x + blockIdx.x ] = r;
+				nextTokens[ blockIdx.x ] = pick.i;
+			}
+		}
+
+		__global__ void advanceStateKernel( DecodeState* state )
+		{
+			state->nPast += 1;
+			state->step += 1;
+			state->forceTimestamp = 0;
+			state->isInitial = 0;
+		}
 	}	// namespace
 
 	int launchLayerNorm( const float* x, const float* w, const float* b, f16* out, int rows, int d, hipStream_t stream )
@@ -258,9 +332,10 @@ namespace wh
 		return 0;
 	}
 
-	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, int d, hipStream_t stream )
+	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, const int* nPastDev, int d,
+		hipStream_t stream )
 	{
-		hipLaunchKernelGGL( embedKernel, dim3( rows ), dim3( 256 ), 0, stream, tokens, te, pe, x, rows, nTok, nPast, d );
+		hipLaunchKernelGGL( embedKernel, dim3( rows ), dim3( 256 ), 0, stream, tokens, te, pe, x, rows, nTok, nPast, nPastDev, d );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -284,6 +359,27 @@ namespace wh
 	{
 		hipLaunchKernelGGL( sampleBestKernel, dim3( rows ), dim3( 1024 ), 0, stream, probs, nVocab, tokenBeg, tokenSot, tokenSolm,
 			tokenNot, forceTimestamp, isInitial, out );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchSoftMaxSample( const float* logits, float* probsOut, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm,
+		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, hipStream_t stream )
+	{
+		if( nVocab > SS_PER * 1024 )
+		{
+			setError( "softMaxSample: vocabulary larger than 52224" );
+			return -1;
+		}
+		hipLaunchKernelGGL( softMaxSampleKernel, dim3( rows ), dim3( 1024 ), 0, stream, logits, probsOut, nVocab, tokenBeg, tokenSot, tokenSolm,
+			tokenNot, state, out, nextTokens );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchAdvanceState( DecodeState* state, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( advanceStateKernel, dim3( 1 ), dim3( 1 ), 0, stream, state );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

@@ -106,7 +106,7 @@ namespace wh
 				}
 				const int h = c >> 6, dd = c & 63;
 				const int b = m / a.nTok;
-				const int pos = a.nPast + ( m - b * a.nTok );
+				const int pos = ( a.nPastDev ? *a.nPastDev : a.nPast ) + ( m - b * a.nTok );
 				const long long o = ( ( (long long)b * a.H + h ) * a.textCtx + pos ) * HEAD_DIM + dd;
 				if( sel == 1 )
 					a.k[ o ] = (f16)( v * a.scale );
@@ -359,7 +359,137 @@ namespace wh
 					epilogueOne<EPI>( a, mm, nn, acc[ r ] );
 			}
 		}
+		// ---- gemv: M <= 16 activation rows (single-token decode steps of a lock-step batch) ----
+		// HBM/latency-bound: the only thing that matters is how many weight bytes are in flight. 16 weight rows per
+		// workgroup (N/16 workgroups), 4 waves split K, and every wave issues ALL of its weight loads (16 bytes per lane
+		// each, up to GV_UNROLL at a time) before the first MFMA consumes one. v_mfma_f32_16x16x32_f16: A = 16 weight rows,
+		// B = up to 16 activation rows. With lnX != null the LayerNorm that precedes the product in the graph
+		// (norm.hlsl + fmaRepeat1.hlsl in the reference) runs as a prologue: each workgroup normalises the M rows into LDS
+		// (FP16, the rounding the product applies anyway) -- M*K*4 bytes of L2 reads per workgroup instead of a launch.
+		constexpr int GV_UNROLL = 16;
+		constexpr int GV_MAXK_LN = 1280;
+		constexpr int GV_XS_STRIDE = GV_MAXK_LN + 8;
+
+		template<int EPI, bool LN>
+		__global__ void __launch_bounds__( 256 ) gemvFused( const GemmArgs a )
+		{
+			__shared__ float red[ 3 ][ 4 ][ 64 ];
+			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[ LN ? 16 * GV_XS_STRIDE : 8 ];
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int n0 = blockIdx.x * 16;
+
+			int n = n0 + ( lane & 15 );
+			n = n < a.N ? n : a.N - 1;
+			int m = lane & 15;
+			m = m < a.M ? m : a.M - 1;
+			const int kPer = a.K / 4;
+			const int kBeg = wave * kPer + ( lane >> 4 ) * 8;
+			const f16* const pw = a.W + (long long)n * a.K + kBeg;
+			const int steps = kPer / 32;
+
+			// first batch of weight loads goes out before anything else: it does not depend on the LayerNorm prologue
+			f16x8 fw[ GV_UNROLL ], fx[ GV_UNROLL ];
+#pragma unroll
+			for( int u = 0; u < GV_UNROLL; u++ )
+				if( u < steps ) fw[ u ] = __builtin_nontemporal_load( (const f16x8*)( pw + u * 32 ) );
+
+			const f16* px;
+			if constexpr( LN )
+			{
+				for( int mr = wave; mr < 16; mr += 4 )
+				{
+					f16* const dst = xs + mr * GV_XS_STRIDE;
+					if( mr < a.M )
+						layerNormRow<GV_MAXK_LN / 64>( a.lnX + (long long)mr * a.K, a.lnW, a.lnB, a.K, lane, [ = ]( int c, f16 v ) { dst[ c ] = v; } );
+					else
+						for( int c = lane; c < a.K; c += 64 ) dst[ c ] = (f16)0.0f;
+				}
+				__syncthreads();
+				px = xs + ( lane & 15 ) * GV_XS_STRIDE + kBeg;
+			}
+			else
+				px = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
+
+			f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+			for( int u = 0; u < GV_UNROLL; u++ )
+				if( u < steps ) fx[ u ] = *(const f16x8*)( px + u * 32 );
+#pragma unroll
+			for( int u = 0; u < GV_UNROLL; u++ )
+				if( u < steps ) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ], fx[ u ], acc, 0, 0, 0 );
+			for( int s = GV_UNROLL; s < steps; s += GV_UNROLL )
+			{
+#pragma unroll
+				for( int u = 0; u < GV_UNROLL; u++ )
+					if( s + u < steps )
+					{
+						fw[ u ] = __builtin_nontemporal_load( (const f16x8*)( pw + ( s + u ) * 32 ) );
+						fx[ u ] = *(const f16x8*)( px + ( s + u ) * 32 );
+					}
+#pragma unroll
+				for( int u = 0; u < GV_UNROLL; u++ )
+					if( s + u < steps ) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ], fx[ u ], acc, 0, 0, 0 );
+			}
+
+			if( wave > 0 )
+			{
+#pragma unroll
+				for( int r = 0; r < 4; r++ ) red[ wave - 1 ][ r ][ lane ] = acc[ r ];
+			}
+			__syncthreads();
+			if( wave != 0 ) return;
+#pragma unroll
+			for( int w = 0; w < 3; w++ )
+#pragma unroll
+				for( int r = 0; r < 4; r++ ) acc[ r ] += red[ w ][ r ][ lane ];
+
+			// D[row][col]: col = lane & 15 = activation row, row = (lane >> 4) * 4 + r = weight row
+			const int mm = lane & 15;
+			if( mm >= a.M ) return;
+#pragma unroll
+			for( int r = 0; r < 4; r++ )
+			{
+				const int nn = n0 + ( lane >> 4 ) * 4 + r;
+				if( nn < a.N )
+					epilogueOne<EPI>( a, mm, nn, acc[ r ] );
+			}
+		}
 	}	// namespace
+
+	template<int EPI, bool LN>
+	static int launchGemvT( const GemmArgs& a, hipStream_t stream )
+	{
+		hipLaunchKernelGGL( ( gemvFused<EPI, LN> ), dim3( ( a.N + 15 ) / 16 ), dim3( 256 ), 0, stream, a );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchGemv( const GemmArgs& a, hipStream_t stream )
+	{
+		if( a.M <= 0 || a.M > 16 || a.N <= 0 || a.K <= 0 || ( a.K % 128 ) != 0 )
+		{
+			setError( "gemv: need 0 < M <= 16 and K a multiple of 128" );
+			return -1;
+		}
+		const bool ln = a.lnX != nullptr;
+		if( ln && a.K > GV_MAXK_LN )
+		{
+			setError( "gemv: fused LayerNorm supports rows up to 1280" );
+			return -1;
+		}
+		switch( a.epi )
+		{
+		case EPI_F32: return ln ? launchGemvT<EPI_F32, true>( a, stream ) : launchGemvT<EPI_F32, false>( a, stream );
+		case EPI_F16_GELU: return ln ? launchGemvT<EPI_F16_GELU, true>( a, stream ) : launchGemvT<EPI_F16_GELU, false>( a, stream );
+		case EPI_QKV_DEC: return ln ? launchGemvT<EPI_QKV_DEC, true>( a, stream ) : launchGemvT<EPI_QKV_DEC, false>( a, stream );
+		case EPI_Q_DEC: return ln ? launchGemvT<EPI_Q_DEC, true>( a, stream ) : launchGemvT<EPI_Q_DEC, false>( a, stream );
+		}
+		setError( "gemv: epilogue not available" );
+		return -1;
+	}
 
 	template<int EPI>
 	static int launchTiledT( const GemmArgs& a, hipStream_t stream )

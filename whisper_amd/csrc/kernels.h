@@ -45,10 +45,17 @@ namespace wh
 		f16* v;				  // ENC: [b][h][64][Tpad] CROSS: like k                 DEC: self-V like k
 		int T, Tpad, H, B;
 		int nTok, nPast, textCtx;
+		// decode-step extras (launchGemv only)
+		const int* nPastDev;  // when non-null the position comes from device memory (graph replay), else nPast
+		const float* lnX;	  // when non-null: A is produced on the fly as fp16( LayerNorm(lnX[m]) * lnW + lnB ), row length K
+		const float* lnW;
+		const float* lnB;
 	};
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
 	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream );	// M <= 32 rows (decode steps): weights streamed once
+	// M <= 16 rows, 16 weight rows per workgroup, every load of a wave in flight at once, optional fused LayerNorm prologue
+	int launchGemv( const GemmArgs& a, hipStream_t stream );
 	int gemmInit();													// one-time function attributes
 
 	// ---------------------------------------------------------------------------------------------------------------
@@ -60,7 +67,8 @@ namespace wh
 	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets,
 		f16* x16, long long xBatchStride, int nMels, int T, int batch, hipStream_t stream );
 	// x[m] = float(te[token[m]]) + pe[nPast + m % nTok]   (addRows.hlsl)
-	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, int d, hipStream_t stream );
+	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, const int* nPastDev, int d,
+		hipStream_t stream );
 	// in-place table softmax of FP32 rows (softMax*.hlsl with the CPU path's FP16 exp table semantics)
 	int launchSoftMaxRows( float* x, int rows, int cols, hipStream_t stream );
 
@@ -83,6 +91,7 @@ namespace wh
 		int causal;			   // 1: query i sees keys <= nPast + i
 		int nPast;
 		int parityThreads;	   // 0 = FP32 P.V; >0 = emulate ggml's FP16 thread-partitioned accumulation
+		const int* nPastDev;   // causal only: when non-null nPast (and nKeys = nPast + nTok) come from device memory
 	};
 	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream );
 
@@ -99,6 +108,20 @@ namespace wh
 	// ContextImpl::sampleBest on the device
 	int launchSampleBest( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
 		int forceTimestamp, int isInitial, TokenData* out, hipStream_t stream );
+
+	// Device-resident state of the greedy loop: lets one captured hipGraph be replayed for every token.
+	struct DecodeState
+	{
+		int nPast;			 // position of the token being fed
+		int step;			 // index of the next sample in the output array
+		int forceTimestamp;	 // consumed (cleared) by the sampler
+		int isInitial;
+	};
+	// logits row -> table softmax -> ContextImpl::sampleBest, one kernel; writes TokenData to out[state->step * rows + row],
+	// the chosen id to nextTokens[row]; probsOut optional.
+	int launchSoftMaxSample( const float* logits, float* probsOut, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm,
+		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, hipStream_t stream );
+	int launchAdvanceState( DecodeState* state, hipStream_t stream );
 
 	// ---------------------------------------------------------------------------------------------------------------
 	// mel spectrogram

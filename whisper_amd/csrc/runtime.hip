@@ -142,10 +142,10 @@ struct wh_model
 // active between wh_profile_enable(1) and wh_profile_read, because two event records per launch perturb launch-bound code.
 enum eKernelClass : int
 {
-	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_ATTN_ENC, KC_ATTN_DEC, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX, KC_SAMPLE, KC_COUNT
+	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX, KC_SAMPLE, KC_COUNT
 };
-static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "attentionEnc", "attentionDec", "layerNorm", "mel",
-	"melToConvInput", "embed", "vocabSoftMax", "sampleBest" };
+static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "layerNorm", "mel",
+	"melToConvInput", "embed", "vocabSoftMax", "softMaxSample" };
 
 struct Profiler
 {
@@ -210,6 +210,13 @@ struct wh_context
 	int* melOffsetsDev = nullptr;
 	TokenData* tokDataDev = nullptr;
 	float* melScratch = nullptr;
+	// device-side greedy loop
+	DecodeState* state = nullptr;
+	TokenData* greedyOut = nullptr;	   // [n_text_ctx][maxBatch]
+	hipGraphExec_t graphExec = nullptr;
+	int graphBatch = 0;
+	uint32_t graphKey = 0;
+	bool ownsStream = false;
 	std::vector<void*> allocations;
 
 	template<class T> int alloc( T*& p, int64_t count, bool zero = false )
@@ -601,6 +608,13 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 	c->m = m;
 	c->maxBatch = maxBatch;
 	c->stream = (hipStream_t)stream;
+	if( !c->stream )
+	{
+		// the legacy null stream cannot be captured into a hipGraph: own a non-blocking stream instead
+		const hipError_t e = hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking );
+		if( e != hipSuccess ) { delete c; return hipFail( e, "hipStreamCreateWithFlags", __FILE__, __LINE__ ); }
+		c->ownsStream = true;
+	}
 	const wh_hparams& hp = m->hp;
 	const int64_t d = hp.n_audio_state, B = maxBatch, H = hp.n_audio_head;
 	const int T = hp.n_audio_ctx;
@@ -637,6 +651,8 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 	rc = rc ? rc : c->alloc( c->melOffsetsDev, B );
 	rc = rc ? rc : c->alloc( c->tokDataDev, B );
 	rc = rc ? rc : c->alloc( c->melScratch, 64 );
+	rc = rc ? rc : c->alloc( c->state, 1, true );
+	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * B );
 	if( rc == 0 )
 	{
 		const hipError_t e = hipStreamSynchronize( c->stream );
@@ -654,7 +670,10 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 void wh_context_destroy( wh_context* c )
 {
 	if( !c ) return;
+	if( c->stream ) (void)hipStreamSynchronize( c->stream );
+	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
 	for( void* p : c->allocations ) (void)hipFree( p );
+	if( c->ownsStream ) (void)hipStreamDestroy( c->stream );
 	delete c;
 }
 
@@ -793,23 +812,40 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 // ------------------------------------------------------------------------------------------------------------------
 // decoder
 // ------------------------------------------------------------------------------------------------------------------
-int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int nPast, float* logitsHost, float* probsHost )
+// The decoder graph up to the logits of the last token of every sequence. With devState the position comes from device
+// memory (c->state->nPast), which makes the launch sequence identical for every token: that is what gets captured
+// into a hipGraph by wh_decode_greedy. Single-token steps of up to 16 sequences take the gemv path (weights streamed
+// once, all loads of a wave in flight, LayerNorm fused into the product that consumes it); anything larger (prompt
+// steps) takes the M <= 32 skinny or the tiled kernel.
+static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool devState )
 {
-	if( !c || !tokens || batch <= 0 || batch > c->maxBatch || nTokens <= 0 || nPast < 0 ) { setError( "decode: bad argument" ); return WH_E_INVALIDARG; }
-	if( !c->encoded ) { setError( "decode: wh_encode has not run" ); return WH_E_NOT_READY; }
 	const wh_model* m = c->m;
 	const wh_hparams& hp = m->hp;
-	if( nPast + nTokens > hp.n_text_ctx ) { setError( "decode: n_past + n_tokens exceeds n_text_ctx" ); return WH_E_BOUNDS; }
 	const Layout& L = m->L;
 	hipStream_t st = c->stream;
 	const int d = hp.n_text_state, H = hp.n_text_head;
 	const int M = batch * nTokens;
 	const float kqScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
+	const int* const nPastDev = devState ? &c->state->nPast : nullptr;
+	const bool gemv = M <= 16 && ( d % 128 ) == 0;
+	const bool fuseLn = gemv && d <= 1280;
 
-	WH_HIP( hipMemcpyAsync( c->tokensDev, tokens, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
+	auto product = [ & ]( GemmArgs& g, const float* lnW, const float* lnB ) -> int
+	{
+		g.nPastDev = nPastDev;
+		if( !gemv ) return gemmP( c, g, true );
+		if( lnW && fuseLn )
+		{
+			g.lnX = c->dx; g.lnW = lnW; g.lnB = lnB;
+		}
+		const double flops = 2.0 * g.M * g.N * g.K;
+		const double bytes = 2.0 * g.N * g.K + 2.0 * g.M * g.K + ( g.out32 ? 4.0 : 2.0 ) * g.M * g.N;
+		return profiled( c, KC_GEMV, flops, bytes, [ & ]() { return launchGemv( g, st ); } );
+	};
+
 	WH_CHECK( profiled( c, KC_EMBED, 1.0 * M * d, 10.0 * M * d,
-		[ & ]() { return launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, d, st ); } ) );
+		[ & ]() { return launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, nPastDev, d, st ); } ) );
 
 	for( int il = 0; il < hp.n_text_layer; il++ )
 	{
@@ -817,7 +853,7 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 		const int64_t selfLayer = (int64_t)il * c->maxBatch * hp.n_text_ctx * d;
 		const int64_t crossLayer = (int64_t)il * c->maxBatch * c->T * d;
 		// self-attention
-		WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d ) );
+		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wqkv ), M, 3 * d, d );
 			g.epi = EPI_QKV_DEC;
@@ -825,67 +861,149 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 			g.scale = kqScale;
 			g.q = c->dq; g.k = c->selfK + selfLayer; g.v = c->selfV + selfLayer;
 			g.H = H; g.nTok = nTokens; g.nPast = nPast; g.textCtx = hp.n_text_ctx;
-			WH_CHECK( gemmP( c, g, true ) );
+			WH_CHECK( product( g, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ) ) );
 		}
 		{
 			DecAttnArgs a;
 			a.q = c->dq; a.kc = c->selfK + selfLayer; a.vc = c->selfV + selfLayer; a.out = c->dattn;
 			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = nPast + nTokens; a.keyStride = hp.n_text_ctx;
-			a.causal = 1; a.nPast = nPast; a.parityThreads = parity;
+			a.causal = 1; a.nPast = nPast; a.parityThreads = parity; a.nPastDev = nPastDev;
+			if( devState ) a.nKeys = hp.n_text_ctx;	  // upper bound for the argument check; the kernel reads the real value
 			WH_CHECK( attnDecP( c, a ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wo ), M, d, d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.bo ); g.res = c->dx; g.out32 = c->dx;
-			WH_CHECK( gemmP( c, g, true ) );
+			WH_CHECK( product( g, nullptr, nullptr ) );
 		}
 		// cross-attention
-		WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d ) );
+		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wcq ), M, d, d );
 			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
-			WH_CHECK( gemmP( c, g, true ) );
+			WH_CHECK( product( g, m->at<float>( e.lncw ), m->at<float>( e.lncb ) ) );
 		}
 		{
 			DecAttnArgs a;
 			a.q = c->dq; a.kc = c->crossK + crossLayer; a.vc = c->crossV + crossLayer; a.out = c->dattn;
 			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = c->T; a.keyStride = c->T;
-			a.causal = 0; a.nPast = 0; a.parityThreads = parity;
+			a.causal = 0; a.nPast = 0; a.parityThreads = parity; a.nPastDev = nullptr;
 			WH_CHECK( attnDecP( c, a ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wco ), M, d, d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.bco ); g.res = c->dx; g.out32 = c->dx;
-			WH_CHECK( gemmP( c, g, true ) );
+			WH_CHECK( product( g, nullptr, nullptr ) );
 		}
 		// MLP
-		WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d ) );
+		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.w1 ), M, 4 * d, d );
 			g.epi = EPI_F16_GELU; g.bias = m->at<float>( e.b1 ); g.out16 = c->dh;
-			WH_CHECK( gemmP( c, g, true ) );
+			WH_CHECK( product( g, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ) ) );
 		}
 		{
 			GemmArgs g = plainGemm( c->dh, m->at<f16>( e.w2 ), M, d, 4 * d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.b2 ); g.res = c->dx; g.out32 = c->dx;
-			WH_CHECK( gemmP( c, g, true ) );
+			WH_CHECK( product( g, nullptr, nullptr ) );
 		}
 	}
 	// final norm + logits for the LAST token of every sequence only (the reference computes all rows, whisper.cpp:1840,
-	// and then consumes just the last one, ContextImpl.cpp:159-169)
+	// and then consumes just the last one, ContextImpl.cpp:159-169). The norm stays a separate launch here: fusing it
+	// into the 3242 workgroups of the vocabulary product would re-read the rows 3242 times.
 	WH_CHECK( lnP( c, c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d ) );
 	{
 		GemmArgs g = plainGemm( c->dxn + (int64_t)( nTokens - 1 ) * d, m->at<f16>( L.te ), batch, hp.n_vocab, d );
 		g.lda = nTokens * d;
 		g.epi = EPI_F32; g.out32 = c->logits; g.ldc = hp.n_vocab;
-		WH_CHECK( gemmP( c, g, true ) );
+		WH_CHECK( product( g, nullptr, nullptr ) );
 	}
+	return 0;
+}
+
+int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int nPast, float* logitsHost, float* probsHost )
+{
+	if( !c || !tokens || batch <= 0 || batch > c->maxBatch || nTokens <= 0 || nPast < 0 ) { setError( "decode: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c->encoded ) { setError( "decode: wh_encode has not run" ); return WH_E_NOT_READY; }
+	const wh_hparams& hp = c->m->hp;
+	if( nPast + nTokens > hp.n_text_ctx ) { setError( "decode: n_past + n_tokens exceeds n_text_ctx" ); return WH_E_BOUNDS; }
+	hipStream_t st = c->stream;
+	const int M = batch * nTokens;
+	WH_HIP( hipMemcpyAsync( c->tokensDev, tokens, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
+	WH_CHECK( decodeGraph( c, batch, nTokens, nPast, false ) );
 	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab,
 		[ & ]() { return launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ); } ) );
 	c->lastBatch = batch;
 	if( logitsHost ) WH_HIP( hipMemcpyAsync( logitsHost, c->logits, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
 	if( probsHost ) WH_HIP( hipMemcpyAsync( probsHost, c->probs, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
 	if( logitsHost || probsHost ) WH_HIP( hipStreamSynchronize( st ) );
+	return 0;
+}
+
+// One greedy token on the device: decoder graph -> softmax + sampleBest -> advance the device-resident state.
+static int greedyStep( wh_context* c, int batch )
+{
+	const wh_hparams& hp = c->m->hp;
+	const int ml = hp.n_vocab == 51865 ? 1 : 0;
+	const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
+	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
+	WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
+		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->stream ); } ) );
+	return launchAdvanceState( c->state, c->stream );
+}
+
+int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int nPast, int nSteps, int forceFirstTimestamp, int firstIsInitial,
+	wh_token_data* out )
+{
+	if( !c || !firstTokens || !out || batch <= 0 || batch > c->maxBatch || nSteps <= 0 || nPast < 0 ) { setError( "decode_greedy: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c->encoded ) { setError( "decode_greedy: wh_encode has not run" ); return WH_E_NOT_READY; }
+	const wh_hparams& hp = c->m->hp;
+	if( nPast + nSteps > hp.n_text_ctx ) { setError( "decode_greedy: n_past + n_steps exceeds n_text_ctx" ); return WH_E_BOUNDS; }
+	hipStream_t st = c->stream;
+	const DecodeState init = { nPast, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0 };
+	WH_HIP( hipMemcpyAsync( c->state, &init, sizeof( init ), hipMemcpyHostToDevice, st ) );
+	WH_HIP( hipMemcpyAsync( c->tokensDev, firstTokens, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
+	WH_HIP( hipStreamSynchronize( st ) );	 // `init` is a local
+
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH );
+	if( useGraph )
+	{
+		const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
+		if( c->graphExec && ( c->graphBatch != batch || c->graphKey != key ) )
+		{
+			(void)hipGraphExecDestroy( c->graphExec );
+			c->graphExec = nullptr;
+		}
+		if( !c->graphExec )
+		{
+			// one eager step first: it sets the per-kernel function attributes, which capture does not allow
+			WH_CHECK( greedyStep( c, batch ) );
+			WH_HIP( hipStreamSynchronize( st ) );
+			WH_HIP( hipMemcpyAsync( c->state, &init, sizeof( init ), hipMemcpyHostToDevice, st ) );
+			WH_HIP( hipMemcpyAsync( c->tokensDev, firstTokens, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
+			WH_HIP( hipStreamSynchronize( st ) );
+			hipGraph_t graph = nullptr;
+			WH_HIP( hipStreamBeginCapture( st, hipStreamCaptureModeThreadLocal ) );
+			const int rc = greedyStep( c, batch );
+			const hipError_t e = hipStreamEndCapture( st, &graph );
+			if( rc != 0 ) { if( graph ) (void)hipGraphDestroy( graph ); return rc; }
+			if( e != hipSuccess ) return hipFail( e, "hipStreamEndCapture", __FILE__, __LINE__ );
+			const hipError_t e2 = hipGraphInstantiate( &c->graphExec, graph, nullptr, nullptr, 0 );
+			(void)hipGraphDestroy( graph );
+			if( e2 != hipSuccess ) { c->graphExec = nullptr; return hipFail( e2, "hipGraphInstantiate", __FILE__, __LINE__ ); }
+			c->graphBatch = batch;
+			c->graphKey = key;
+		}
+		for( int s = 0; s < nSteps; s++ ) WH_HIP( hipGraphLaunch( c->graphExec, st ) );
+	}
+	else
+	{
+		for( int s = 0; s < nSteps; s++ ) WH_CHECK( greedyStep( c, batch ) );
+	}
+	c->lastBatch = batch;
+	static_assert( sizeof( wh_token_data ) == sizeof( TokenData ), "token data layout" );
+	WH_HIP( hipMemcpyAsync( out, c->greedyOut, sizeof( TokenData ) * (size_t)batch * nSteps, hipMemcpyDeviceToHost, st ) );
+	WH_HIP( hipStreamSynchronize( st ) );
 	return 0;
 }
 
