@@ -53,8 +53,8 @@ def synth_pcm(n_windows: int, seed: int) -> np.ndarray:
 def transcribe_clip(ctx, pcm_dev, mel_dev, prompt, n_greedy, batch):
     """One pass of the hot path over a batch of windows; returns the sampled token ids [batch][n_greedy+1]."""
     for b in range(batch):
-        ctx.mel_spectrogram(pcm_dev[b], mel_dev[b])
-    ctx.encode(mel_dev)
+        ctx.mel_spectrogram(pcm_dev[b], mel_dev[b], sync=False)      # same stream as the encoder: no host sync needed
+    ctx.encode(mel_dev, sync=False)
     toks = np.tile(np.asarray(prompt, np.int32), (batch, 1))
     ctx.decode(toks, 0, want_logits=False, want_probs=False)
     out = np.zeros((batch, n_greedy + 1), np.int32)

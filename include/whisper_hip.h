@@ -88,6 +88,10 @@ typedef enum wh_flags
 WH_API int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out );
 WH_API void wh_context_destroy( wh_context* c );
 WH_API int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads );
+/* Blocks until everything queued on the context's stream has finished. When `stream` was NULL at creation the context
+ * owns a non-blocking stream (the legacy null stream cannot be captured into a hipGraph), so callers that produce
+ * inputs or consume device outputs on another stream must order the two themselves; this is the simple way. */
+WH_API int wh_context_synchronize( wh_context* c );
 /* {RAM, VRAM} accounting like getMemoryUse() in the reference (WhisperContext.cpp:641-666) */
 WH_API int wh_context_memory( const wh_context* c, int64_t* vramBytes );
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "wh_last_error", "wh_device_count", "wh_device_info", "wh_device_set",
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
-    "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_memory",
+    "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]
@@ -75,6 +75,7 @@ def lib():
         L.wh_context_destroy.restype = None
         L.wh_context_set_flags.argtypes = [vp, C.c_uint32, i32]
         L.wh_context_memory.argtypes = [vp, C.POINTER(i64)]
+        L.wh_context_synchronize.argtypes = [vp]
         L.wh_mel_spectrogram.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
         L.wh_encode.argtypes = [vp, vp, i32, i64, i64, vp]
         L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
@@ -196,19 +197,35 @@ class HipContext:
         check(lib().wh_context_memory(self.handle, C.byref(n)))
         return n.value
 
-    def mel_spectrogram(self, pcm_dev, out_dev=None):
-        """pcm_dev: torch float32 CUDA tensor [n]. Returns torch float32 [n_mel][n//160] on the device."""
+    def synchronize(self):
+        check(lib().wh_context_synchronize(self.handle))
+
+    @staticmethod
+    def _wait_for_torch():
+        """Inputs come from torch's current stream; the context runs on its own (capturable) stream."""
         import torch
+        torch.cuda.current_stream().synchronize()
+
+    def mel_spectrogram(self, pcm_dev, out_dev=None, sync: bool = True):
+        """pcm_dev: torch float32 CUDA tensor [n]. Returns torch float32 [n_mel][n//160] on the device.
+        sync=False skips the ordering with torch's stream (caller guarantees it, e.g. bench.py inside its timed region)."""
+        import torch
+        if sync:
+            self._wait_for_torch()
         n = pcm_dev.numel()
         n_len = n // 160
         if out_dev is None:
             out_dev = torch.empty((self.hp.n_mels, n_len), dtype=torch.float32, device=pcm_dev.device)
         got = C.c_int64()
         check(lib().wh_mel_spectrogram(self.handle, C.c_void_p(pcm_dev.data_ptr()), n, C.c_void_p(out_dev.data_ptr()), C.byref(got)))
+        if sync:
+            self.synchronize()
         return out_dev
 
-    def encode(self, mel_dev, offsets: Optional[Sequence[int]] = None):
+    def encode(self, mel_dev, offsets: Optional[Sequence[int]] = None, sync: bool = True):
         """mel_dev: torch float32 CUDA tensor [batch][n_mel][mel_len] (or [n_mel][mel_len])."""
+        if sync:
+            self._wait_for_torch()
         if mel_dev.dim() == 2:
             mel_dev = mel_dev.unsqueeze(0)
         assert mel_dev.is_contiguous() and mel_dev.shape[1] == self.hp.n_mels

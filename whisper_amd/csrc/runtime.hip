@@ -685,6 +685,13 @@ int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
 	return 0;
 }
 
+int wh_context_synchronize( wh_context* c )
+{
+	if( !c ) return WH_E_INVALIDARG;
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
 int wh_context_memory( const wh_context* c, int64_t* vramBytes )
 {
 	if( !c || !vramBytes ) return WH_E_INVALIDARG;
