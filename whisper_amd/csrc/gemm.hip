@@ -370,11 +370,15 @@ namespace wh
 		constexpr int GV_MAXK_LN = 1280;
 		constexpr int GV_XS_STRIDE = GV_MAXK_LN + 8;
 
-		template<int EPI, bool LN>
+		// PRO = 0: A rows are FP16 in global memory; 1: fused LayerNorm prologue; 2: A row m = fp16( sum of nParts FP32
+		// partial rows ) -- the deterministic combine of the split cross-attention's per-key-range partial outputs.
+		template<int EPI, int PRO>
 		__global__ void __launch_bounds__( 256 ) gemvFused( const GemmArgs a )
 		{
+			constexpr bool LN = PRO == 1;
+			constexpr bool PARTS = PRO == 2;
 			__shared__ float red[ 3 ][ 4 ][ 64 ];
-			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[ LN ? 16 * GV_XS_STRIDE : 8 ];
+			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[ PRO != 0 ? 16 * GV_XS_STRIDE : 8 ];
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
@@ -396,8 +400,38 @@ namespace wh
 			for( int u = 0; u < GV_UNROLL; u++ )
 				if( u < steps ) fw[ u ] = __builtin_nontemporal_load( (const f16x8*)( pw + u * 32 ) );
 
+			// epilogue operands of the plain FP32 epilogue are fetched up front as well (wave 0 owns the epilogue)
+			const int nEp = n0 + ( lane >> 4 ) * 4;
+			const bool fastEp = EPI == EPI_F32 && ( a.N & 15 ) == 0 && a.Mb >= a.M;
+			f32x4 biasv = { 0.0f, 0.0f, 0.0f, 0.0f }, resv = { 0.0f, 0.0f, 0.0f, 0.0f };
+			if( fastEp && wave == 0 && ( lane & 15 ) < a.M )
+			{
+				if( a.bias ) biasv = *(const f32x4*)( a.bias + nEp );
+				if( a.res ) resv = *(const f32x4*)( a.res + (long long)( lane & 15 ) * a.ldc + nEp );
+			}
+
 			const f16* px;
-			if constexpr( LN )
+			if constexpr( PARTS )
+			{
+				// x[m][k] = fp16( parts[0][m][k] + parts[1][m][k] + ... ), fixed order; 4 consecutive k per thread
+				const int total = a.M * a.K / 4;
+				for( int i = tid; i < 16 * a.K / 4; i += 256 )
+				{
+					const int mr = i / ( a.K / 4 ), k4 = ( i - mr * ( a.K / 4 ) ) * 4;
+					f32x4 sum = { 0.0f, 0.0f, 0.0f, 0.0f };
+					if( i < total )
+					{
+						sum = *(const f32x4*)( a.parts + (long long)mr * a.K + k4 );
+						for( int p = 1; p < a.nParts; p++ ) sum += *(const f32x4*)( a.parts + p * a.partStride + (long long)mr * a.K + k4 );
+					}
+					f16x4 h4;
+					h4[ 0 ] = (f16)sum[ 0 ]; h4[ 1 ] = (f16)sum[ 1 ]; h4[ 2 ] = (f16)sum[ 2 ]; h4[ 3 ] = (f16)sum[ 3 ];
+					*(f16x4*)( xs + mr * GV_XS_STRIDE + k4 ) = h4;
+				}
+				__syncthreads();
+				px = xs + ( lane & 15 ) * GV_XS_STRIDE + kBeg;
+			}
+			else if constexpr( LN )
 			{
 				for( int mr = wave; mr < 16; mr += 4 )
 				{
@@ -449,6 +483,15 @@ namespace wh
 			// D[row][col]: col = lane & 15 = activation row, row = (lane >> 4) * 4 + r = weight row
 			const int mm = lane & 15;
 			if( mm >= a.M ) return;
+			if( fastEp )
+			{
+				// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
+				f32x4 o;
+#pragma unroll
+				for( int r = 0; r < 4; r++ ) o[ r ] = ( acc[ r ] + biasv[ r ] ) + resv[ r ];
+				*(f32x4*)( a.out32 + (long long)mm * a.ldc + nEp ) = o;
+				return;
+			}
 #pragma unroll
 			for( int r = 0; r < 4; r++ )
 			{
@@ -459,10 +502,10 @@ namespace wh
 		}
 	}	// namespace
 
-	template<int EPI, bool LN>
+	template<int EPI, int PRO>
 	static int launchGemvT( const GemmArgs& a, hipStream_t stream )
 	{
-		hipLaunchKernelGGL( ( gemvFused<EPI, LN> ), dim3( ( a.N + 15 ) / 16 ), dim3( 256 ), 0, stream, a );
+		hipLaunchKernelGGL( ( gemvFused<EPI, PRO> ), dim3( ( a.N + 15 ) / 16 ), dim3( 256 ), 0, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -475,17 +518,24 @@ namespace wh
 			return -1;
 		}
 		const bool ln = a.lnX != nullptr;
-		if( ln && a.K > GV_MAXK_LN )
+		const bool parts = a.parts != nullptr;
+		if( ( ln || parts ) && a.K > GV_MAXK_LN )
 		{
-			setError( "gemv: fused LayerNorm supports rows up to 1280" );
+			setError( "gemv: fused prologues support rows up to 1280" );
+			return -1;
+		}
+		if( parts )
+		{
+			if( a.epi == EPI_F32 && !ln ) return launchGemvT<EPI_F32, 2>( a, stream );
+			setError( "gemv: the partial-sum prologue is only built for the FP32 epilogue" );
 			return -1;
 		}
 		switch( a.epi )
 		{
-		case EPI_F32: return ln ? launchGemvT<EPI_F32, true>( a, stream ) : launchGemvT<EPI_F32, false>( a, stream );
-		case EPI_F16_GELU: return ln ? launchGemvT<EPI_F16_GELU, true>( a, stream ) : launchGemvT<EPI_F16_GELU, false>( a, stream );
-		case EPI_QKV_DEC: return ln ? launchGemvT<EPI_QKV_DEC, true>( a, stream ) : launchGemvT<EPI_QKV_DEC, false>( a, stream );
-		case EPI_Q_DEC: return ln ? launchGemvT<EPI_Q_DEC, true>( a, stream ) : launchGemvT<EPI_Q_DEC, false>( a, stream );
+		case EPI_F32: return ln ? launchGemvT<EPI_F32, 1>( a, stream ) : launchGemvT<EPI_F32, 0>( a, stream );
+		case EPI_F16_GELU: return ln ? launchGemvT<EPI_F16_GELU, 1>( a, stream ) : launchGemvT<EPI_F16_GELU, 0>( a, stream );
+		case EPI_QKV_DEC: return ln ? launchGemvT<EPI_QKV_DEC, 1>( a, stream ) : launchGemvT<EPI_QKV_DEC, 0>( a, stream );
+		case EPI_Q_DEC: return ln ? launchGemvT<EPI_Q_DEC, 1>( a, stream ) : launchGemvT<EPI_Q_DEC, 0>( a, stream );
 		}
 		setError( "gemv: epilogue not available" );
 		return -1;

@@ -50,6 +50,9 @@ namespace wh
 		const float* lnX;	  // when non-null: A is produced on the fly as fp16( LayerNorm(lnX[m]) * lnW + lnB ), row length K
 		const float* lnW;
 		const float* lnB;
+		const float* parts;	  // when non-null: A row m = fp16( sum_p parts[p * partStride + m * K + k] ), nParts FP32 partial rows
+		int nParts;
+		long long partStride;
 	};
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
@@ -94,6 +97,24 @@ namespace wh
 		const int* nPastDev;   // causal only: when non-null nPast (and nKeys = nPast + nTok) come from device memory
 	};
 	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream );
+
+	// Single query row per sequence, FP32 P.V, keys split over ATT_SPLITS workgroups per (sequence, head) so that all 256
+	// CUs stream K/V (one CU sustains ~24 GB/s, 112 (b,h) pairs alone would cap at ~2.7 TB/s):
+	//   scores kernel  S[b][h][key] = K[key] . q                      (each workgroup: one key range)
+	//   pv kernel      softmax over ALL keys of (b,h) (recomputed by each of the splits, 6 KB of scores), P for the
+	//                  workgroup's key range, partial O = P.V -> parts[split][b][H*64]
+	// The partials are combined in a fixed order by the prologue of the product that consumes them (GemmArgs::parts).
+	constexpr int ATT_SPLITS = 4;
+	struct SplitAttnArgs
+	{
+		const f16* q;		  // [batch][d]
+		const f16* kc;		  // [batch][H][keyStride][64]
+		const f16* vc;
+		float* scores;		  // [batch][H][keyStride]
+		float* parts;		  // [ATT_SPLITS][batch][d]
+		int batch, H, nKeys, keyStride;
+	};
+	int launchAttentionSplit( const SplitAttnArgs& a, hipStream_t stream );
 
 	// ---------------------------------------------------------------------------------------------------------------
 	// logits -> probabilities -> greedy token, on the device
