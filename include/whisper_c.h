@@ -1,0 +1,39 @@
+/* whisper_c.h -- flat C mirror of the COM-style API in whisperApi.h, exported by libWhisper.so for FFI callers that cannot
+ * consume C++ vtables (Python ctypes, cgo, JNI, N-API). Every function forwards to the iModel / iContext method named in
+ * its comment (reference: Whisper/API/iContext.cl.h:23-60); return values are the HRESULTs of those methods.
+ * Opaque handles are COM object pointers: release each with whisperc_release. */
+#ifndef WHISPER_C_H
+#define WHISPER_C_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Whisper::loadModel( path, { GPU, adapter = device }, nullptr, &model ) */
+int32_t whisperc_load_model( const char* pathUtf8, int device, void** modelOut );
+/* IUnknown::Release */
+void whisperc_release( void* unknown );
+/* iModel::createContext */
+int32_t whisperc_create_context( void* model, void** ctxOut );
+/* iModel::getSpecialTokens -> { eot, sot, prev, solm, not, beg, translate, transcribe } */
+int32_t whisperc_special_tokens( void* model, int32_t* out8 );
+/* iModel::stringFromToken (pointer into the model's vocabulary, valid while the model lives) */
+const char* whisperc_token_string( void* model, int token );
+/* iModel::isMultilingual: S_OK (0) or S_FALSE (1) */
+int32_t whisperc_is_multilingual( void* model );
+/* iModel::tokenize: returns the token count (>= 0) or a failed HRESULT */
+int32_t whisperc_tokenize( void* model, const char* text, int32_t* out, int cap );
+/* iContext::fullDefaultParams( Greedy ) + the given fields, then iContext::runFull on a mono FP32 16 kHz buffer.
+ * flags = eFullParamsFlags bits (Translate 1, NoContext 2, SingleSegment 4, PrintSpecial 8 ...). */
+int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx /* < 0 keeps the default 16384 */ );
+/* iContext::getResults( Tokens | Timestamps ) + iTranscribeResult::getSize / getSegments / getTokens; times in 100 ns ticks */
+int32_t whisperc_result_counts( void* ctx, uint32_t* segments, uint32_t* tokens );
+int32_t whisperc_result_segment( void* ctx, uint32_t index, uint64_t* t0, uint64_t* t1, uint32_t* firstToken, uint32_t* countTokens,
+	char* text, uint32_t textCap );
+int32_t whisperc_result_token( void* ctx, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum );
+/* iContext::timingsPrint */
+int32_t whisperc_timings_print( void* ctx );
+#ifdef __cplusplus
+}
+#endif
+#endif

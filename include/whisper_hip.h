@@ -95,6 +95,13 @@ WH_API int wh_context_synchronize( wh_context* c );
 /* {RAM, VRAM} accounting like getMemoryUse() in the reference (WhisperContext.cpp:641-666) */
 WH_API int wh_context_memory( const wh_context* c, int64_t* vramBytes );
 
+/* Plain device buffers for host code that does not include HIP headers (PCM in, spectrogram scratch). Replaces the
+ * buffer helpers of Whisper/D3D/createBuffer.cpp. upload / download are synchronous on the context's stream. */
+WH_API int wh_buffer_alloc( int64_t bytes, void** dev );
+WH_API int wh_buffer_free( void* dev );
+WH_API int wh_buffer_upload( wh_context* c, void* dev, const void* host, int64_t bytes );
+WH_API int wh_buffer_download( wh_context* c, void* host, const void* dev, int64_t bytes );
+
 /* PCM -> log-mel on the GPU. Replaces Spectrogram::pcmToMel (Whisper/Whisper/Spectrogram.cpp:64-122) ==
  * log_mel_spectrogram (Whisper/source/whisper.cpp:2060-2180): hop 160, Hann 400, |DFT|^2 with the reference's
  * p[j]+=p[400-j] fold, 80x201 filterbank, log10 clamp, (global max - 8) clamp, (x+4)/4.

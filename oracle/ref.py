@@ -58,7 +58,7 @@ def lib():
         L.ref_tokenize.argtypes = [C.c_void_p, C.c_char_p, _i32p, C.c_int]
         L.ref_is_multilingual.argtypes = [C.c_void_p]
         L.ref_full.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
-                               C.c_void_p, C.c_int]
+                               C.c_void_p, C.c_int, C.c_int]
         L.ref_full_n_segments.argtypes = [C.c_void_p]
         for n in ("ref_full_segment_t0", "ref_full_segment_t1"):
             getattr(L, n).restype = C.c_int64
@@ -181,12 +181,13 @@ class RefWhisper:
 
     # ---- whisper_full ----
     def full(self, pcm: np.ndarray, lang: str = "en", no_context: bool = True, single_segment: bool = False,
-             translate: bool = False, max_tokens: int = 0, audio_ctx: int = 0, prompt: Optional[Sequence[int]] = None):
+             translate: bool = False, max_tokens: int = 0, audio_ctx: int = 0, prompt: Optional[Sequence[int]] = None,
+             n_max_text_ctx: int = -1):
         pcm = np.ascontiguousarray(pcm, np.float32)
         flags = int(no_context) | (int(single_segment) << 1) | (int(translate) << 2)
         pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
         rc = self.L.ref_full(self.ctx, pcm, len(pcm), self.n_threads, lang.encode(), flags, max_tokens, audio_ctx,
-                             pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt))
+                             pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx)
         if rc != 0:
             raise RuntimeError("whisper_full rc=%d" % rc)
         segs = []

@@ -192,7 +192,7 @@ int ref_is_multilingual( whisper_context* ctx ) { return whisper_is_multilingual
 // ---- whisper_full, greedy (whisper.cpp:2765-3120): the reference's complete runFull equivalent ----
 // flags: bit0 = no_context, bit1 = single_segment, bit2 = translate
 int ref_full( whisper_context* ctx, const float* pcm, int nSamples, int nThreads, const char* lang, int flags, int maxTokens,
-	int audioCtx, const int32_t* promptTokens, int nPrompt )
+	int audioCtx, const int32_t* promptTokens, int nPrompt, int nMaxTextCtx )
 {
 	whisper_full_params p = whisper_full_default_params( WHISPER_SAMPLING_GREEDY );
 	p.n_threads = nThreads;
@@ -208,6 +208,7 @@ int ref_full( whisper_context* ctx, const float* pcm, int nSamples, int nThreads
 	p.audio_ctx = audioCtx;
 	p.prompt_tokens = promptTokens;
 	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
 	return whisper_full( ctx, p, pcm, nSamples );
 }
 int ref_full_n_segments( whisper_context* ctx ) { return whisper_full_n_segments( ctx ); }

@@ -1,0 +1,147 @@
+"""Python face of libWhisper.so, the COM-style host API (include/whisperApi.h) through its flat C mirror (include/whisper_c.h).
+
+Mirrors how the reference's own callers drive it (Examples/main/main.cpp:174-330): loadModel -> createContext ->
+fullDefaultParams -> runFull -> getResults. No fallback: without the shared libraries and a GPU every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libWhisper.so")
+
+# eFullParamsFlags (Whisper/API/sFullParams.h:21-35)
+TRANSLATE, NO_CONTEXT, SINGLE_SEGMENT, PRINT_SPECIAL = 1, 2, 4, 8
+
+CPP_EXPORTS = ["setupLogger", "loadModel", "initMediaFoundation", "findLanguageKeyW", "findLanguageKeyA", "getSupportedLanguages", "listGPUs"]
+
+_lib = None
+
+
+class WhisperError(RuntimeError):
+    def __init__(self, hr: int, what: str):
+        super().__init__("%s failed: HRESULT 0x%08x" % (what, hr & 0xFFFFFFFF))
+        self.hr = hr & 0xFFFFFFFF
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError("libWhisper.so is missing: run `python -m whisper_amd.build`")
+        L = C.CDLL(HOST_LIB_PATH)
+        vp = C.c_void_p
+        L.whisperc_load_model.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.whisperc_release.argtypes = [vp]
+        L.whisperc_release.restype = None
+        L.whisperc_create_context.argtypes = [vp, C.POINTER(vp)]
+        L.whisperc_special_tokens.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.whisperc_token_string.argtypes = [vp, C.c_int]
+        L.whisperc_token_string.restype = C.c_char_p
+        L.whisperc_is_multilingual.argtypes = [vp]
+        L.whisperc_tokenize.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.c_int]
+        L.whisperc_run_full.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int]
+        L.whisperc_result_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.whisperc_result_segment.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                              C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
+        L.whisperc_result_token.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.whisperc_timings_print.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _check(hr: int, what: str) -> int:
+    if hr < 0:
+        raise WhisperError(hr, what)
+    return hr
+
+
+class Model:
+    """iModel."""
+
+    def __init__(self, path: str, device: int = 0):
+        self.h = C.c_void_p()
+        _check(lib().whisperc_load_model(path.encode(), device, C.byref(self.h)), "loadModel")
+
+    def close(self):
+        if self.h:
+            lib().whisperc_release(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def create_context(self) -> "Context":
+        return Context(self)
+
+    def special_tokens(self):
+        a = (C.c_int32 * 8)()
+        _check(lib().whisperc_special_tokens(self.h, a), "getSpecialTokens")
+        names = ("eot", "sot", "prev", "solm", "not_", "beg", "translate", "transcribe")
+        return dict(zip(names, list(a)))
+
+    def token_string(self, token: int) -> Optional[bytes]:
+        return lib().whisperc_token_string(self.h, token)
+
+    def is_multilingual(self) -> bool:
+        return lib().whisperc_is_multilingual(self.h) == 0
+
+    def tokenize(self, text: str) -> List[int]:
+        buf = (C.c_int32 * 4096)()
+        n = _check(lib().whisperc_tokenize(self.h, text.encode(), buf, 4096), "tokenize")
+        return list(buf[:n])
+
+
+class Context:
+    """iContext."""
+
+    def __init__(self, model: Model):
+        self.model = model
+        self.h = C.c_void_p()
+        _check(lib().whisperc_create_context(model.h, C.byref(self.h)), "createContext")
+
+    def close(self):
+        if self.h:
+            lib().whisperc_release(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run_full(self, pcm: np.ndarray, language: str = "en", flags: int = 0, max_tokens: int = 0,
+                 prompt: Optional[Sequence[int]] = None, n_max_text_ctx: int = -1) -> int:
+        """runFull on mono float32 16 kHz PCM. Returns the HRESULT (0 = S_OK, 1 = S_FALSE: less than 1 s of audio)."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        return _check(lib().whisperc_run_full(self.h, pcm.ctypes.data_as(C.c_void_p), len(pcm), language.encode(), flags, max_tokens,
+                                              pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx), "runFull")
+
+    def results(self):
+        """getResults(Tokens | Timestamps): list of segments {t0, t1 (100 ns ticks), text, tokens[{id, p, pt, ptsum}]}."""
+        ns, nt = C.c_uint32(), C.c_uint32()
+        _check(lib().whisperc_result_counts(self.h, C.byref(ns), C.byref(nt)), "getResults")
+        out = []
+        for i in range(ns.value):
+            t0, t1, ft, ct = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+            text = C.create_string_buffer(4096)
+            _check(lib().whisperc_result_segment(self.h, i, C.byref(t0), C.byref(t1), C.byref(ft), C.byref(ct), text, 4096), "getSegments")
+            toks = []
+            for j in range(ft.value, ft.value + ct.value):
+                tid, p, pt, ps = C.c_int32(), C.c_float(), C.c_float(), C.c_float()
+                _check(lib().whisperc_result_token(self.h, j, C.byref(tid), C.byref(p), C.byref(pt), C.byref(ps)), "getTokens")
+                toks.append(dict(id=tid.value, p=p.value, pt=pt.value, ptsum=ps.value))
+            out.append(dict(t0=t0.value, t1=t1.value, text=text.value, tokens=toks))
+        return out
+
+    def timings_print(self):
+        _check(lib().whisperc_timings_print(self.h), "timingsPrint")

@@ -25,6 +25,7 @@ EXPORTS = [
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
+    "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
     "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]

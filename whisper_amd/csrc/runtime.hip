@@ -688,6 +688,39 @@ int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
 	return 0;
 }
 
+// ---- plain device buffers for host code that must not include HIP headers (replaces Whisper/D3D/createBuffer.cpp) ----
+int wh_buffer_alloc( int64_t bytes, void** dev )
+{
+	if( !dev || bytes <= 0 ) { setError( "buffer_alloc: bad argument" ); return WH_E_INVALIDARG; }
+	void* p = nullptr;
+	const hipError_t e = hipMalloc( &p, (size_t)bytes );
+	if( e != hipSuccess ) { hipFail( e, "hipMalloc", __FILE__, __LINE__ ); return e == hipErrorOutOfMemory ? WH_E_OUTOFMEMORY : WH_E_HIP; }
+	*dev = p;
+	return 0;
+}
+
+int wh_buffer_free( void* dev )
+{
+	if( dev ) WH_HIP( hipFree( dev ) );
+	return 0;
+}
+
+int wh_buffer_upload( wh_context* c, void* dev, const void* host, int64_t bytes )
+{
+	if( !c || !dev || !host || bytes < 0 ) { setError( "buffer_upload: bad argument" ); return WH_E_INVALIDARG; }
+	WH_HIP( hipMemcpyAsync( dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int wh_buffer_download( wh_context* c, void* host, const void* dev, int64_t bytes )
+{
+	if( !c || !dev || !host || bytes < 0 ) { setError( "buffer_download: bad argument" ); return WH_E_INVALIDARG; }
+	WH_HIP( hipMemcpyAsync( host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
 int wh_context_synchronize( wh_context* c )
 {
 	if( !c ) return WH_E_INVALIDARG;

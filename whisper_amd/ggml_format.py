@@ -275,3 +275,32 @@ def special_tokens(hp: HParams) -> Dict[str, int]:
     t["translate"] = 50358
     t["transcribe"] = 50359
     return t
+
+
+def scripted_model(script: List[int], prompt_len: int, kind: str = "test-d128-ml", seed: int = 5, gain: float = 0.12) -> GgmlModel:
+    """A model whose greedy transcript is known in advance, for testing the HOST loop (windows, stop rules, segments).
+
+    The decoder's attention and MLP output projections are zeroed, so the residual stream stays token + position
+    embedding; every position p carries a random +-1 code c_p, and the token scripted for that position gets +gain*c_p
+    added to its (tied) embedding row, which makes it win the logits by a wide margin (about 15 vs 4). Token i of a
+    window is predicted at position prompt_len - 1 + i. The audio plays no role (cross-attention output is zeroed too),
+    so every window of a NoContext run produces the same script, the way a real model repeats on repetitive audio.
+    """
+    m = synth_model(kind, seed=seed, w_std=0.02)
+    hp = m.hparams
+    d = hp.n_text_state
+    rng = np.random.default_rng(seed + 1)
+    codes = rng.choice(np.array([-1.0, 1.0], np.float32), size=(hp.n_text_ctx, d))
+    m.tensors["decoder.positional_embedding"] = codes.astype(np.float32)
+    te = (0.02 * rng.standard_normal((hp.n_vocab, d))).astype(np.float32)
+    for i, tok in enumerate(script):
+        te[tok] += gain * codes[prompt_len - 1 + i]
+    m.tensors["decoder.token_embedding.weight"] = te.astype(np.float16)
+    m.tensors["decoder.ln.weight"] = np.ones(d, np.float32)
+    m.tensors["decoder.ln.bias"] = np.zeros(d, np.float32)
+    for il in range(hp.n_text_layer):
+        p = "decoder.blocks.%d" % il
+        for nm in (".attn.out", ".cross_attn.out", ".mlp.2"):
+            m.tensors[p + nm + ".weight"] = np.zeros_like(m.tensors[p + nm + ".weight"])
+            m.tensors[p + nm + ".bias"] = np.zeros_like(m.tensors[p + nm + ".bias"])
+    return m

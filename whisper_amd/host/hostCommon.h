@@ -1,0 +1,98 @@
+// Internal helpers of libWhisper.so (plain C++17, no HIP headers: the GPU is reached only through include/whisper_hip.h).
+#pragma once
+#include "whisperApi.h"
+#include "whisper_hip.h"
+#include <atomic>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace Whisper
+{
+	// ---- logging (Whisper/Utils/Logger.cpp: a sink callback with a level filter, or stderr) ----
+	void logMessage( eLogLevel lvl, const char* fmt, ... ) __attribute__( ( format( printf, 2, 3 ) ) );
+#define logError( ... ) ::Whisper::logMessage( ::Whisper::eLogLevel::Error, __VA_ARGS__ )
+#define logWarning( ... ) ::Whisper::logMessage( ::Whisper::eLogLevel::Warning, __VA_ARGS__ )
+#define logInfo( ... ) ::Whisper::logMessage( ::Whisper::eLogLevel::Info, __VA_ARGS__ )
+#define logDebug( ... ) ::Whisper::logMessage( ::Whisper::eLogLevel::Debug, __VA_ARGS__ )
+
+	// wh_status -> HRESULT, logging the library's message
+	HRESULT hrFromStatus( int status, const char* what );
+#define CHECK_WH( expr )                                         \
+	do                                                           \
+	{                                                            \
+		const int st__ = ( expr );                               \
+		if( st__ != 0 ) return ::Whisper::hrFromStatus( st__, #expr ); \
+	} while( 0 )
+#define CHECK( expr )                     \
+	do                                    \
+	{                                     \
+		const HRESULT hr__ = ( expr );    \
+		if( FAILED( hr__ ) ) return hr__; \
+	} while( 0 )
+
+	std::string utf8( const wchar_t* w );
+
+	// ---- intrusive ref-counting for the COM-style objects (the role of ComLight::ObjectRoot / Object<T>) ----
+	template<class I>
+	class ComObject : public I
+	{
+		std::atomic<uint32_t> refs{ 1 };
+	public:
+		virtual ~ComObject() = default;
+		HRESULT QueryInterface( const ComLight::GUID& riid, void** ppv ) override
+		{
+			if( !ppv ) return E_POINTER;
+			if( riid == I::iid() || riid == ComLight::IID_IUnknown )
+			{
+				*ppv = static_cast<I*>( this );
+				AddRef();
+				return S_OK;
+			}
+			*ppv = nullptr;
+			return E_NOINTERFACE;
+		}
+		uint32_t AddRef() override { return ++refs; }
+		uint32_t Release() override
+		{
+			const uint32_t r = --refs;
+			if( r == 0 ) delete this;
+			return r;
+		}
+	};
+
+	// ---- vocabulary (Whisper/Whisper/Vocabulary.{h,cpp}; whisper.cpp:540-606) ----
+	struct Vocabulary
+	{
+		int n_vocab = 0;
+		int token_eot = 50256, token_sot = 50257, token_prev = 50360, token_solm = 50361, token_not = 50362, token_beg = 50363;
+		static constexpr int token_translate = 50358, token_transcribe = 50359;
+		std::vector<std::string> idToToken;
+		std::map<std::string, int> tokenToId;
+		bool isMultilingual() const { return n_vocab == 51865; }
+		const char* string( int id ) const { return ( id >= 0 && id < (int)idToToken.size() ) ? idToToken[ id ].c_str() : nullptr; }
+		// fills the special ids and synthesises the tokens the file does not store
+		void finalize( int nVocabModel );
+		// GPT-2 style greedy longest-match over the regex-split words (whisper.cpp:2186-2248 "tokenize")
+		HRESULT tokenize( const char* text, std::vector<int>& out ) const;
+	};
+
+	// ---- languages (Whisper/Whisper/Languages.cpp, languageCodez.inl; whisper.cpp:31-133) ----
+	int lookupLanguageId( uint32_t key );
+	const sLanguageList& languageList();
+
+	// ---- ggml model file (Whisper/Whisper/WhisperModel.cpp:434-492, 257-340) ----
+	struct LoadedModel
+	{
+		wh_hparams hp{};
+		wh_model* gpu = nullptr;
+		Vocabulary vocab;
+		~LoadedModel();
+	};
+	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out );
+
+	HRESULT createContextImpl( const std::shared_ptr<LoadedModel>& model, iModel* owner, iContext** pp );
+	HRESULT createModelImpl( const std::shared_ptr<LoadedModel>& model, iModel** pp );
+	HRESULT createAudioBuffer( std::vector<float>&& mono, std::vector<float>&& stereo, iAudioBuffer** pp );
+}

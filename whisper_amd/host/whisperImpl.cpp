@@ -1,0 +1,777 @@
+// iModel / iContext / iTranscribeResult / iAudioBuffer / iMediaFoundation implementations and the library exports.
+//
+// Host logic only (plain C++): windows, prompts, stop rules and segment assembly follow the reference's
+// ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:452-793, itself a port of whisper_full), the arithmetic is
+// behind include/whisper_hip.h. Structure here is ours: one WindowDecoder per 30 s window feeds a token stream (filled
+// from the device-side greedy loop in chunks) through the reference's stop rules, then SegmentBuilder cuts it at the
+// timestamp tokens.
+#include "hostCommon.h"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace Whisper
+{
+	namespace
+	{
+		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
+		constexpr int GREEDY_CHUNK = 8;		   // tokens fetched per device-side greedy call
+
+		struct TokenData
+		{
+			int id = 0, tid = 0;
+			float p = 0, pt = 0, ptsum = 0, vlen = 0;
+			int64_t t0 = -1, t1 = -1;
+		};
+		struct Segment
+		{
+			int64_t t0 = 0, t1 = 0;	   // 10 ms units
+			std::string text;
+			std::vector<TokenData> tokens;
+		};
+
+		// ---- iTranscribeResult ------------------------------------------------------------------------------------
+		struct ResultData
+		{
+			std::vector<sSegment> segments;
+			std::vector<sToken> tokens;
+			std::vector<std::string> texts;
+		};
+		class TranscribeResult : public ComObject<iTranscribeResult>, public ResultData
+		{
+		public:
+			HRESULT getSize( sTranscribeLength& rdi ) const override
+			{
+				rdi.countSegments = (uint32_t)segments.size();
+				rdi.countTokens = (uint32_t)tokens.size();
+				return S_OK;
+			}
+			const sSegment* getSegments() const override { return segments.empty() ? nullptr : segments.data(); }
+			const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
+		};
+		// The object embedded in a context: handed out without NewObject, it lives as long as the context and its
+		// Release never deletes (Whisper/Whisper/TranscribeResult.h:34-43)
+		class TranscribeResultStatic : public iTranscribeResult, public ResultData
+		{
+		public:
+			HRESULT QueryInterface( const ComLight::GUID& riid, void** ppv ) override
+			{
+				if( !ppv ) return E_POINTER;
+				if( riid == iTranscribeResult::iid() || riid == ComLight::IID_IUnknown ) { *ppv = this; return S_OK; }
+				return E_NOINTERFACE;
+			}
+			uint32_t AddRef() override { return 1; }
+			uint32_t Release() override { return 1; }
+			HRESULT getSize( sTranscribeLength& rdi ) const override
+			{
+				rdi.countSegments = (uint32_t)segments.size();
+				rdi.countTokens = (uint32_t)tokens.size();
+				return S_OK;
+			}
+			const sSegment* getSegments() const override { return segments.empty() ? nullptr : segments.data(); }
+			const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
+		};
+
+		// ---- iAudioBuffer -----------------------------------------------------------------------------------------
+		class AudioBuffer : public ComObject<iAudioBuffer>
+		{
+		public:
+			std::vector<float> mono, stereo;
+			uint32_t countSamples() const override { return (uint32_t)mono.size(); }
+			const float* getPcmMono() const override { return mono.empty() ? nullptr : mono.data(); }
+			const float* getPcmStereo() const override { return stereo.empty() ? nullptr : stereo.data(); }
+			HRESULT getTime( int64_t& rdi ) const override { rdi = 0; return S_OK; }
+		};
+
+		// ---- iContext ---------------------------------------------------------------------------------------------
+		class ContextImpl : public ComObject<iContext>
+		{
+			std::shared_ptr<LoadedModel> model;
+			iModel* owner;	  // strong reference, like ContextImpl::modelPtr (ContextImpl.h:16)
+			wh_context* gpu = nullptr;
+			void* melDev = nullptr;
+			int64_t melCapacity = 0;
+			void* pcmDev = nullptr;
+			int64_t pcmCapacity = 0;
+			std::vector<Segment> resultAll;
+			std::vector<int> promptPast;
+			int64_t mediaTimeOffset = 0;
+			mutable TranscribeResultStatic results;
+			// timings, the blocks of ProfileCollection (Whisper/Utils/ProfileCollection.h)
+			double msSpectrogram = 0, msEncode = 0, msDecode = 0, msRun = 0;
+			int nEncode = 0, nDecodeSteps = 0;
+
+			using Clock = std::chrono::steady_clock;
+			static double msSince( Clock::time_point t ) { return std::chrono::duration<double, std::milli>( Clock::now() - t ).count(); }
+
+			HRESULT ensureBuffer( void*& dev, int64_t& cap, int64_t bytes )
+			{
+				if( bytes <= cap ) return S_OK;
+				if( dev ) { wh_buffer_free( dev ); dev = nullptr; cap = 0; }
+				CHECK_WH( wh_buffer_alloc( bytes, &dev ) );
+				cap = bytes;
+				return S_OK;
+			}
+			HRESULT fillResults( eResultFlags flags, ResultData& res ) const;
+			HRESULT runFullImpl( const sFullParams& params, int64_t melLen );
+
+		public:
+			ContextImpl( const std::shared_ptr<LoadedModel>& m, iModel* o ) : model( m ), owner( o )
+			{
+				if( owner ) owner->AddRef();
+			}
+			~ContextImpl() override
+			{
+				if( melDev ) wh_buffer_free( melDev );
+				if( pcmDev ) wh_buffer_free( pcmDev );
+				if( gpu ) wh_context_destroy( gpu );
+				if( owner ) owner->Release();
+			}
+			HRESULT init()
+			{
+				CHECK_WH( wh_context_create( model->gpu, 1, nullptr, &gpu ) );
+				return S_OK;
+			}
+
+			HRESULT runFull( const sFullParams& params, const iAudioBuffer* buffer ) override;
+			HRESULT runStreamed( const sFullParams&, const sProgressSink&, const iAudioReader* ) override
+			{
+				logError( "runStreamed: Media Foundation readers do not exist on this platform; load the audio and call runFull" );
+				return E_NOTIMPL;
+			}
+			HRESULT runCapture( const sFullParams&, const sCaptureCallbacks&, const iAudioCapture* ) override { return E_NOTIMPL; }
+			HRESULT getResults( eResultFlags flags, iTranscribeResult** pp ) const override;
+			HRESULT detectSpeaker( const sTimeInterval&, eSpeakerChannel& result ) const override
+			{
+				result = eSpeakerChannel::NoStereoData;
+				return S_FALSE;
+			}
+			HRESULT getModel( iModel** pp ) override
+			{
+				if( !pp ) return E_POINTER;
+				if( !owner ) return E_UNEXPECTED;
+				owner->AddRef();
+				*pp = owner;
+				return S_OK;
+			}
+			HRESULT fullDefaultParams( eSamplingStrategy strategy, sFullParams* rdi ) override;
+			HRESULT timingsPrint() override;
+			HRESULT timingsReset() override
+			{
+				msSpectrogram = msEncode = msDecode = msRun = 0;
+				nEncode = nDecodeSteps = 0;
+				return S_OK;
+			}
+		};
+
+		HRESULT ContextImpl::fullDefaultParams( eSamplingStrategy strategy, sFullParams* rdi )
+		{
+			// whisper_full_default_params as the reference restates it (ContextImpl.misc.cpp:61-93)
+			if( !rdi ) return E_POINTER;
+			memset( rdi, 0, sizeof( sFullParams ) );
+			rdi->strategy = strategy;
+			rdi->cpuThreads = 4;
+			rdi->n_max_text_ctx = 16384;
+			rdi->flags = eFullParamsFlags::PrintProgress | eFullParamsFlags::PrintTimestamps;
+			rdi->thold_pt = rdi->thold_ptsum = 0.01f;
+			rdi->language = makeLanguageKey( "en" );
+			switch( strategy )
+			{
+			case eSamplingStrategy::Greedy:
+				rdi->beam_search.n_past = rdi->beam_search.beam_width = rdi->beam_search.n_best = -1;
+				return S_OK;
+			case eSamplingStrategy::BeamSearch:
+				rdi->greedy.n_past = -1;
+				rdi->beam_search.beam_width = 10;
+				rdi->beam_search.n_best = 5;
+				return S_OK;
+			}
+			logError( "Unknown sampling strategy %i", (int)strategy );
+			return E_INVALIDARG;
+		}
+
+		HRESULT ContextImpl::timingsPrint()
+		{
+			// same block names as the reference's profiler output (SampleClips/*.txt) so logs stay comparable
+			logInfo( "    CPU Tasks" );
+			logInfo( "RunComplete\t%g milliseconds", msRun );
+			logInfo( "Spectrogram\t%g milliseconds (GPU)", msSpectrogram );
+			logInfo( "Encode\t%g milliseconds, %i calls, %g milliseconds average", msEncode, nEncode, nEncode ? msEncode / nEncode : 0.0 );
+			logInfo( "Decode\t%g milliseconds, %i steps, %g milliseconds average", msDecode, nDecodeSteps, nDecodeSteps ? msDecode / nDecodeSteps : 0.0 );
+			int64_t vram = 0;
+			wh_context_memory( gpu, &vram );
+			logInfo( "    Memory Usage" );
+			logInfo( "Context\t%.1f MB VRAM", vram / 1048576.0 );
+			return S_OK;
+		}
+
+		HRESULT ContextImpl::runFull( const sFullParams& params, const iAudioBuffer* buffer )
+		{
+			if( !buffer ) return E_POINTER;
+			const auto tRun = Clock::now();
+			CHECK( buffer->getTime( mediaTimeOffset ) );
+			const uint32_t n = buffer->countSamples();
+			const float* pcm = buffer->getPcmMono();
+			const int64_t melLen = n / 160;
+			if( melLen > 0 )
+			{
+				const auto t = Clock::now();
+				CHECK( ensureBuffer( pcmDev, pcmCapacity, (int64_t)n * 4 ) );
+				CHECK( ensureBuffer( melDev, melCapacity, melLen * model->hp.n_mels * 4 ) );
+				CHECK_WH( wh_buffer_upload( gpu, pcmDev, pcm, (int64_t)n * 4 ) );
+				int64_t got = 0;
+				CHECK_WH( wh_mel_spectrogram( gpu, (const float*)pcmDev, n, (float*)melDev, &got ) );
+				CHECK_WH( wh_context_synchronize( gpu ) );
+				msSpectrogram += msSince( t );
+			}
+			const HRESULT hr = runFullImpl( params, melLen );
+			msRun += msSince( tRun );
+			return hr;
+		}
+
+		// The token stream of one window: first token from sampleTimestamp(true) on the prompt's probabilities, the rest
+		// from the device-side greedy loop, fetched GREEDY_CHUNK tokens at a time.
+		class WindowDecoder
+		{
+			wh_context* gpu;
+			int nPast, nTextCtx;
+			std::vector<wh_token_data> chunk;
+			size_t cursor = 0;
+			int lastId = 0;
+		public:
+			int steps = 0;
+			WindowDecoder( wh_context* c, int nTextCtx_ ) : gpu( c ), nPast( 0 ), nTextCtx( nTextCtx_ ) {}
+			HRESULT start( const std::vector<int>& prompt, TokenData& first )
+			{
+				CHECK_WH( wh_decode( gpu, prompt.data(), 1, (int)prompt.size(), 0, nullptr, nullptr ) );
+				nPast = (int)prompt.size();
+				wh_token_data t;
+				CHECK_WH( wh_sample_best( gpu, 1, 1, 1, &t ) );
+				first.id = t.id; first.tid = t.tid; first.p = t.p; first.pt = t.pt; first.ptsum = t.ptsum;
+				lastId = t.id;
+				steps = 1;
+				return S_OK;
+			}
+			HRESULT next( TokenData& out )
+			{
+				if( cursor >= chunk.size() )
+				{
+					const int room = nTextCtx - nPast;
+					if( room <= 0 ) return E_BOUNDS;
+					const int n = std::min( GREEDY_CHUNK, room );
+					chunk.resize( n );
+					cursor = 0;
+					CHECK_WH( wh_decode_greedy( gpu, 1, &lastId, nPast, n, 0, 0, chunk.data() ) );
+					nPast += n;
+					lastId = chunk.back().id;
+					steps += n;
+				}
+				const wh_token_data& t = chunk[ cursor++ ];
+				out.id = t.id; out.tid = t.tid; out.p = t.p; out.pt = t.pt; out.ptsum = t.ptsum;
+				return S_OK;
+			}
+		};
+
+		HRESULT ContextImpl::runFullImpl( const sFullParams& params, int64_t melLen )
+		{
+			const Vocabulary& vocab = model->vocab;
+			const wh_hparams& hp = model->hp;
+			resultAll.clear();
+			if( params.flag( eFullParamsFlags::SpeedupAudio ) )
+			{
+				logError( "GPU model doesn't implement the SpeedupAudio flag" );
+				return E_NOTIMPL;
+			}
+			if( params.audio_ctx != 0 && params.audio_ctx != hp.n_audio_ctx )
+			{
+				logError( "audio_ctx override is not supported by this build" );
+				return E_NOTIMPL;
+			}
+			if( params.flag( eFullParamsFlags::TokenTimestamps ) )
+				logWarning( "TokenTimestamps is not implemented: token times are left unset" );
+
+			const int seekStart = params.offset_ms / 10;
+			const int seekEnd = seekStart + ( params.duration_ms == 0 ? (int)melLen : params.duration_ms / 10 );
+			// nothing shorter than one second is processed (ContextImpl.cpp:469-473)
+			if( seekEnd < 100 + seekStart ) return S_FALSE;
+
+			if( params.flag( eFullParamsFlags::NoContext ) ) promptPast.clear();
+			if( params.prompt_tokens && params.prompt_n_tokens > 0 )
+				promptPast.insert( promptPast.begin(), params.prompt_tokens, params.prompt_tokens + params.prompt_n_tokens );
+
+			// the tokens that select the task
+			std::vector<int> promptInit = { vocab.token_sot };
+			if( vocab.isMultilingual() )
+			{
+				const int langId = lookupLanguageId( params.language );
+				if( langId < 0 )
+				{
+					char lang[ 5 ] = { 0 };
+					memcpy( lang, &params.language, 4 );
+					logError( "runFull: unknown language '%s'", lang );
+					return E_INVALIDARG;
+				}
+				promptInit.push_back( vocab.token_sot + 1 + langId );
+				promptInit.push_back( params.flag( eFullParamsFlags::Translate ) ? Vocabulary::token_translate : Vocabulary::token_transcribe );
+			}
+
+			const int nMax = hp.n_text_ctx / 2 - 4;
+			std::vector<TokenData> tokensCur;
+			std::vector<int> prompt;
+			int seek = seekStart;
+			while( seek + 100 < seekEnd )
+			{
+				if( params.encoder_begin_callback )
+				{
+					const HRESULT hr = params.encoder_begin_callback( this, params.encoder_begin_callback_user_data );
+					if( FAILED( hr ) ) return hr;
+					if( hr != S_OK ) break;
+				}
+				{
+					const auto t = Clock::now();
+					const int32_t off = seek;
+					CHECK_WH( wh_encode( gpu, (const float*)melDev, 1, melLen, melLen * hp.n_mels, &off ) );
+					CHECK_WH( wh_context_synchronize( gpu ) );
+					msEncode += msSince( t );
+					nEncode++;
+				}
+
+				// previous text conditions this window: [prev] + the last n_take tokens + the task tokens (ContextImpl.cpp:565-576)
+				prompt.clear();
+				if( !promptPast.empty() )
+				{
+					const int nTake = std::min( std::min( params.n_max_text_ctx, hp.n_text_ctx / 2 ), (int)promptPast.size() );
+					prompt.push_back( vocab.token_prev );
+					prompt.insert( prompt.end(), promptPast.end() - nTake, promptPast.end() );
+					promptPast.assign( prompt.begin() + 1, prompt.end() );
+				}
+				prompt.insert( prompt.end(), promptInit.begin(), promptInit.end() );
+
+				int seekDelta = CHUNK_FRAMES;
+				int resultLen = 0;
+				bool failed = false, hasTs = false;
+				tokensCur.clear();
+				const auto tDec = Clock::now();
+				WindowDecoder dec( gpu, hp.n_text_ctx );
+				for( int i = 0; i < nMax; i++ )
+				{
+					TokenData token;
+					if( i == 0 )
+						CHECK( dec.start( prompt, token ) );
+					else
+						CHECK( dec.next( token ) );
+
+					if( token.id > vocab.token_beg )
+					{
+						// a timestamp token moves the sliding window; going back in time ends the window
+						const int seekDeltaNew = 2 * ( token.id - vocab.token_beg );
+						if( hasTs && seekDelta > seekDeltaNew && resultLen < i ) break;
+						seekDelta = seekDeltaNew;
+						resultLen = i + 1;
+						hasTs = true;
+					}
+					tokensCur.push_back( token );
+
+					const bool endOfAudio = hasTs && seek + seekDelta + 100 >= seekEnd;
+					if( token.id == vocab.token_eot || ( params.max_tokens > 0 && i >= params.max_tokens ) || endOfAudio )
+					{
+						if( resultLen == 0 )
+						{
+							if( seek + seekDelta + 100 >= seekEnd )
+								resultLen = i + 1;
+							else
+							{
+								failed = true;
+								break;
+							}
+						}
+						if( params.flag( eFullParamsFlags::SingleSegment ) )
+						{
+							resultLen = i + 1;
+							seekDelta = CHUNK_FRAMES;
+						}
+						break;
+					}
+					// stuck in a repetition loop: give up on this window (ContextImpl.cpp:665-672)
+					if( i == nMax - 1 && ( resultLen == 0 || seekDelta < CHUNK_FRAMES / 2 ) )
+					{
+						failed = true;
+						break;
+					}
+				}
+				msDecode += msSince( tDec );
+				nDecodeSteps += dec.steps;
+				if( failed )
+				{
+					logError( "runFull: failed to generate timestamp token - skipping one second" );
+					seek += 100;
+					continue;
+				}
+
+				tokensCur.resize( std::min( (size_t)resultLen, tokensCur.size() ) );
+				for( const TokenData& t : tokensCur ) promptPast.push_back( t.id );
+
+				// cut the window's tokens into segments at the timestamp tokens (ContextImpl.cpp:689-784)
+				if( !tokensCur.empty() )
+				{
+					const bool special = params.flag( eFullParamsFlags::PrintSpecial );
+					const bool single = params.flag( eFullParamsFlags::SingleSegment );
+					int i0 = 0;
+					int t0 = seek + 2 * ( tokensCur.front().tid - vocab.token_beg );
+					std::string text;
+					auto emit = [ & ]( int t1, int last ) -> HRESULT
+					{
+						Segment s;
+						s.t0 = t0; s.t1 = t1; s.text = text;
+						s.tokens.assign( tokensCur.begin() + i0, tokensCur.begin() + last + 1 );
+						if( params.flag( eFullParamsFlags::PrintRealtime ) ) logDebug( "[%d --> %d]  %s", t0, t1, text.c_str() );
+						resultAll.push_back( std::move( s ) );
+						if( params.new_segment_callback )
+						{
+							const HRESULT hr = params.new_segment_callback( this, 1, params.new_segment_callback_user_data );
+							if( FAILED( hr ) ) return hr;
+						}
+						return S_OK;
+					};
+					for( int i = 0; i < (int)tokensCur.size(); i++ )
+					{
+						const int id = tokensCur[ i ].id;
+						if( special || id < vocab.token_eot ) text += vocab.string( id );
+						if( id > vocab.token_beg && !single )
+						{
+							const int t1 = seek + 2 * ( tokensCur[ i ].tid - vocab.token_beg );
+							if( !text.empty() ) CHECK( emit( t1, i ) );
+							text.clear();
+							while( i < (int)tokensCur.size() && tokensCur[ i ].id > vocab.token_beg ) i++;
+							i--;
+							t0 = t1;
+							i0 = i + 1;
+						}
+					}
+					if( !text.empty() ) CHECK( emit( seek + seekDelta, (int)tokensCur.size() - 1 ) );
+				}
+				seek += seekDelta;
+			}
+			return S_OK;
+		}
+
+		HRESULT ContextImpl::fillResults( eResultFlags flags, ResultData& res ) const
+		{
+			const Vocabulary& vocab = model->vocab;
+			const bool withTokens = flags & eResultFlags::Tokens, withTimes = flags & eResultFlags::Timestamps;
+			res.segments.resize( resultAll.size() );
+			res.texts.resize( resultAll.size() );
+			size_t tc = 0;
+			if( withTokens )
+				for( const Segment& s : resultAll ) tc += s.tokens.size();
+			res.tokens.resize( tc );
+			size_t soFar = 0;
+			auto ticks = []( int64_t t10ms ) { return (uint64_t)( t10ms * 100000 ); };	 // 10 ms -> 100 ns
+			for( size_t i = 0; i < resultAll.size(); i++ )
+			{
+				const Segment& src = resultAll[ i ];
+				sSegment& dst = res.segments[ i ];
+				res.texts[ i ] = src.text;
+				dst.text = res.texts[ i ].c_str();
+				dst.time.begin.ticks = withTimes ? ticks( src.t0 ) + (uint64_t)mediaTimeOffset : 0;
+				dst.time.end.ticks = withTimes ? ticks( src.t1 ) + (uint64_t)mediaTimeOffset : 0;
+				dst.firstToken = (uint32_t)soFar;
+				dst.countTokens = (uint32_t)src.tokens.size();
+				if( withTokens )
+					for( size_t j = 0; j < src.tokens.size(); j++ )
+					{
+						const TokenData& t = src.tokens[ j ];
+						sToken& o = res.tokens[ soFar + j ];
+						o.text = vocab.string( t.id );
+						o.time.begin.ticks = ( withTimes && t.t0 >= 0 ) ? ticks( t.t0 ) + (uint64_t)mediaTimeOffset : 0;
+						o.time.end.ticks = ( withTimes && t.t1 >= 0 ) ? ticks( t.t1 ) + (uint64_t)mediaTimeOffset : 0;
+						o.probability = t.p; o.probabilityTimestamp = t.pt; o.ptsum = t.ptsum; o.vlen = t.vlen;
+						o.id = t.id;
+						o.flags = t.id >= vocab.token_eot ? eTokenFlags::Special : eTokenFlags::None;
+					}
+				soFar += src.tokens.size();
+			}
+			return S_OK;
+		}
+
+		HRESULT ContextImpl::getResults( eResultFlags flags, iTranscribeResult** pp ) const
+		{
+			if( !pp ) return E_POINTER;
+			if( flags & eResultFlags::NewObject )
+			{
+				TranscribeResult* r = new TranscribeResult();
+				const HRESULT hr = fillResults( flags, *r );
+				if( FAILED( hr ) ) { r->Release(); return hr; }
+				*pp = r;
+				return S_OK;
+			}
+			CHECK( fillResults( flags, results ) );
+			*pp = &results;
+			return S_OK;
+		}
+
+		// ---- iModel -----------------------------------------------------------------------------------------------
+		class ModelImpl : public ComObject<iModel>
+		{
+			std::shared_ptr<LoadedModel> model;
+		public:
+			explicit ModelImpl( const std::shared_ptr<LoadedModel>& m ) : model( m ) {}
+			HRESULT createContext( iContext** pp ) override { return createContextImpl( model, this, pp ); }
+			HRESULT tokenize( const char* text, pfnDecodedTokens pfn, void* pv ) override
+			{
+				if( !pfn ) return E_POINTER;
+				std::vector<int> toks;
+				CHECK( model->vocab.tokenize( text, toks ) );
+				pfn( toks.empty() ? nullptr : toks.data(), (int)toks.size(), pv );
+				return S_OK;
+			}
+			HRESULT isMultilingual() override { return model->vocab.isMultilingual() ? S_OK : S_FALSE; }
+			HRESULT getSpecialTokens( SpecialTokens& r ) override
+			{
+				const Vocabulary& v = model->vocab;
+				r.TranscriptionEnd = v.token_eot; r.TranscriptionStart = v.token_sot; r.PreviousWord = v.token_prev;
+				r.SentenceStart = v.token_solm; r.Not = v.token_not; r.TranscriptionBegin = v.token_beg;
+				r.TaskTranslate = Vocabulary::token_translate; r.TaskTranscribe = Vocabulary::token_transcribe;
+				return S_OK;
+			}
+			const char* stringFromToken( whisper_token token ) override { return model->vocab.string( token ); }
+			// Weights are immutable and shared (WhisperModel.h:28-30): a clone is another handle on the same arena, so that
+			// a second context can run from another host thread (ModelImpl.cpp:40-60 needs OpenSharedResource for this).
+			HRESULT clone( iModel** rdi ) override { return createModelImpl( model, rdi ); }
+		};
+
+		// ---- iMediaFoundation stand-in: WAV (PCM16 / float32, 16 kHz) ------------------------------------------------
+		class WavLoader : public ComObject<iMediaFoundation>
+		{
+		public:
+			HRESULT loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const override;
+			HRESULT openAudioFile( const wchar_t*, bool, iAudioReader** ) override { return E_NOTIMPL; }
+			HRESULT loadAudioFileData( const void*, uint64_t, bool, iAudioReader** ) override { return E_NOTIMPL; }
+			HRESULT listCaptureDevices( pfnFoundCaptureDevices, void* ) override { return E_NOTIMPL; }
+			HRESULT openCaptureDevice( const wchar_t*, const sCaptureParams&, iAudioCapture** ) override { return E_NOTIMPL; }
+		};
+
+		HRESULT WavLoader::loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const
+		{
+			if( !pp || !path ) return E_POINTER;
+			const std::string p = utf8( path );
+			std::ifstream f( p, std::ios::binary );
+			if( !f ) { logError( "failed to open audio file '%s'", p.c_str() ); return (HRESULT)0x80070002; }
+			std::vector<char> data( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
+			if( data.size() < 44 || memcmp( data.data(), "RIFF", 4 ) || memcmp( data.data() + 8, "WAVE", 4 ) )
+			{
+				logError( "'%s' is not a RIFF/WAVE file (only WAV is supported on this platform)", p.c_str() );
+				return E_INVALIDARG;
+			}
+			uint16_t fmt = 0, channels = 0, bits = 0;
+			uint32_t rate = 0;
+			const char* pcm = nullptr;
+			size_t pcmBytes = 0;
+			for( size_t o = 12; o + 8 <= data.size(); )
+			{
+				uint32_t len;
+				memcpy( &len, data.data() + o + 4, 4 );
+				const char* body = data.data() + o + 8;
+				if( !memcmp( data.data() + o, "fmt ", 4 ) && len >= 16 )
+				{
+					memcpy( &fmt, body, 2 ); memcpy( &channels, body + 2, 2 ); memcpy( &rate, body + 4, 4 ); memcpy( &bits, body + 14, 2 );
+				}
+				else if( !memcmp( data.data() + o, "data", 4 ) )
+				{
+					pcm = body;
+					pcmBytes = std::min( (size_t)len, data.size() - ( o + 8 ) );
+				}
+				o += 8 + (size_t)len + ( len & 1 );
+			}
+			const bool isFloat = fmt == 3 && bits == 32, isPcm16 = fmt == 1 && bits == 16;
+			if( !pcm || !( isFloat || isPcm16 ) || channels < 1 || channels > 2 || rate != 16000 )
+			{
+				logError( "'%s': need 16 kHz mono/stereo PCM16 or float32 WAV (got format %u, %u bit, %u ch, %u Hz)", p.c_str(), fmt, bits, channels, rate );
+				return E_INVALIDARG;
+			}
+			const size_t frames = pcmBytes / ( ( bits / 8 ) * channels );
+			std::vector<float> mono( frames ), st;
+			if( stereo ) st.resize( frames * 2 );
+			auto sample = [ & ]( size_t i ) -> float
+			{
+				if( isFloat ) { float v; memcpy( &v, pcm + i * 4, 4 ); return v; }
+				int16_t v; memcpy( &v, pcm + i * 2, 2 ); return (float)v / 32768.0f;
+			};
+			for( size_t i = 0; i < frames; i++ )
+			{
+				const float l = sample( i * channels ), r = channels == 2 ? sample( i * 2 + 1 ) : l;
+				mono[ i ] = channels == 2 ? 0.5f * ( l + r ) : l;
+				if( stereo ) { st[ 2 * i ] = l; st[ 2 * i + 1 ] = r; }
+			}
+			return createAudioBuffer( std::move( mono ), std::move( st ), pp );
+		}
+	}	// namespace
+
+	HRESULT createContextImpl( const std::shared_ptr<LoadedModel>& model, iModel* owner, iContext** pp )
+	{
+		if( !pp ) return E_POINTER;
+		ContextImpl* c = new ContextImpl( model, owner );
+		const HRESULT hr = c->init();
+		if( FAILED( hr ) ) { c->Release(); return hr; }
+		*pp = c;
+		return S_OK;
+	}
+	HRESULT createModelImpl( const std::shared_ptr<LoadedModel>& model, iModel** pp )
+	{
+		if( !pp ) return E_POINTER;
+		*pp = new ModelImpl( model );
+		return S_OK;
+	}
+	HRESULT createAudioBuffer( std::vector<float>&& mono, std::vector<float>&& stereo, iAudioBuffer** pp )
+	{
+		if( !pp ) return E_POINTER;
+		AudioBuffer* b = new AudioBuffer();
+		b->mono = std::move( mono );
+		b->stereo = std::move( stereo );
+		*pp = b;
+		return S_OK;
+	}
+
+	// ---- exports ----------------------------------------------------------------------------------------------------
+	HRESULT loadModel( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, iModel** pp )
+	{
+		if( !path || !pp ) return E_POINTER;
+		if( setup.impl != eModelImplementation::GPU )
+		{
+			// Hybrid is compiled out in the reference as well (stdafx.h:34); Reference is the vendored CPU model, which this
+			// repository keeps as its test oracle (oracle/) and never links into the product.
+			logError( "loadModel: only eModelImplementation::GPU is available in this build" );
+			return E_NOTIMPL;
+		}
+		int device = 0;
+		if( setup.adapter && *setup.adapter )
+		{
+			// adapter names come from listGPUs: "<index>: <name>"
+			const std::string a = utf8( setup.adapter );
+			device = atoi( a.c_str() );
+			if( device < 0 || device >= wh_device_count() )
+			{
+				logError( "loadModel: adapter '%s' not found", a.c_str() );
+				return E_INVALIDARG;
+			}
+		}
+		std::shared_ptr<LoadedModel> lm;
+		CHECK( loadGgmlFile( utf8( path ), device, callbacks, lm ) );
+		return createModelImpl( lm, pp );
+	}
+
+	HRESULT initMediaFoundation( iMediaFoundation** pp )
+	{
+		if( !pp ) return E_POINTER;
+		*pp = new WavLoader();
+		return S_OK;
+	}
+}
+
+// ---- flat C mirror for FFI callers (ctypes / cgo / JNI): see include/whisper_c.h -----------------------------------
+extern "C" {
+using namespace Whisper;
+
+WHISPER_EXPORT int32_t whisperc_load_model( const char* pathUtf8, int device, void** modelOut )
+{
+	if( !pathUtf8 || !modelOut ) return E_POINTER;
+	std::wstring w;
+	for( const unsigned char* p = (const unsigned char*)pathUtf8; *p; p++ ) w += (wchar_t)*p;	// paths used by the tests are ASCII
+	std::wstring adapter = std::to_wstring( device ) + L":";
+	sModelSetup setup;
+	setup.adapter = adapter.c_str();
+	iModel* m = nullptr;
+	const HRESULT hr = loadModel( w.c_str(), setup, nullptr, &m );
+	*modelOut = m;
+	return hr;
+}
+WHISPER_EXPORT void whisperc_release( void* unknown )
+{
+	if( unknown ) ( (ComLight::IUnknown*)unknown )->Release();
+}
+WHISPER_EXPORT int32_t whisperc_create_context( void* model, void** ctxOut )
+{
+	if( !model || !ctxOut ) return E_POINTER;
+	iContext* c = nullptr;
+	const HRESULT hr = ( (iModel*)model )->createContext( &c );
+	*ctxOut = c;
+	return hr;
+}
+WHISPER_EXPORT int32_t whisperc_special_tokens( void* model, int32_t* out8 )
+{
+	SpecialTokens st;
+	const HRESULT hr = ( (iModel*)model )->getSpecialTokens( st );
+	memcpy( out8, &st, sizeof( st ) );
+	return hr;
+}
+WHISPER_EXPORT const char* whisperc_token_string( void* model, int token ) { return ( (iModel*)model )->stringFromToken( token ); }
+WHISPER_EXPORT int32_t whisperc_is_multilingual( void* model ) { return ( (iModel*)model )->isMultilingual(); }
+// flags: eFullParamsFlags bits; language: ASCII code; returns the HRESULT of runFull
+WHISPER_EXPORT int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx )
+{
+	if( !ctx || ( !pcm && nSamples ) ) return E_POINTER;
+	iContext* c = (iContext*)ctx;
+	sFullParams p;
+	CHECK( c->fullDefaultParams( eSamplingStrategy::Greedy, &p ) );
+	p.flags = (eFullParamsFlags)flags;
+	p.language = makeLanguageKey( language ? language : "en" );
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	iAudioBuffer* buf = nullptr;
+	CHECK( createAudioBuffer( std::vector<float>( pcm, pcm + nSamples ), {}, &buf ) );
+	const HRESULT hr = c->runFull( p, buf );
+	buf->Release();
+	return hr;
+}
+// Copies the results out: segment times in 10 ms units are returned as 100 ns ticks like the COM API.
+WHISPER_EXPORT int32_t whisperc_result_counts( void* ctx, uint32_t* segments, uint32_t* tokens )
+{
+	iTranscribeResult* r = nullptr;
+	CHECK( ( (iContext*)ctx )->getResults( eResultFlags::Tokens | eResultFlags::Timestamps, &r ) );
+	sTranscribeLength len;
+	r->getSize( len );
+	*segments = len.countSegments;
+	*tokens = len.countTokens;
+	return S_OK;
+}
+WHISPER_EXPORT int32_t whisperc_result_segment( void* ctx, uint32_t index, uint64_t* t0, uint64_t* t1, uint32_t* firstToken, uint32_t* countTokens,
+	char* text, uint32_t textCap )
+{
+	iTranscribeResult* r = nullptr;
+	CHECK( ( (iContext*)ctx )->getResults( eResultFlags::Tokens | eResultFlags::Timestamps, &r ) );
+	sTranscribeLength len;
+	r->getSize( len );
+	if( index >= len.countSegments ) return E_BOUNDS;
+	const sSegment& s = r->getSegments()[ index ];
+	*t0 = s.time.begin.ticks; *t1 = s.time.end.ticks; *firstToken = s.firstToken; *countTokens = s.countTokens;
+	if( text && textCap ) snprintf( text, textCap, "%s", s.text ? s.text : "" );
+	return S_OK;
+}
+WHISPER_EXPORT int32_t whisperc_result_token( void* ctx, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum )
+{
+	iTranscribeResult* r = nullptr;
+	CHECK( ( (iContext*)ctx )->getResults( eResultFlags::Tokens | eResultFlags::Timestamps, &r ) );
+	sTranscribeLength len;
+	r->getSize( len );
+	if( index >= len.countTokens ) return E_BOUNDS;
+	const sToken& t = r->getTokens()[ index ];
+	*id = t.id; *p = t.probability; *pt = t.probabilityTimestamp; *ptsum = t.ptsum;
+	return S_OK;
+}
+WHISPER_EXPORT int32_t whisperc_tokenize( void* model, const char* text, int32_t* out, int cap )
+{
+	struct Sink { int32_t* out; int cap; int n; } sink{ out, cap, 0 };
+	const HRESULT hr = ( (iModel*)model )->tokenize( text, []( const int* toks, int n, void* pv ) {
+		Sink* s = (Sink*)pv;
+		s->n = n;
+		for( int i = 0; i < n && i < s->cap; i++ ) s->out[ i ] = toks[ i ];
+	}, &sink );
+	return FAILED( hr ) ? hr : sink.n;
+}
+WHISPER_EXPORT int32_t whisperc_timings_print( void* ctx ) { return ( (iContext*)ctx )->timingsPrint(); }
+}
