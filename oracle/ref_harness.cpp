@@ -218,6 +218,7 @@ const char* ref_full_segment_text( whisper_context* ctx, int i ) { return whispe
 int ref_full_n_tokens( whisper_context* ctx, int i ) { return whisper_full_n_tokens( ctx, i ); }
 int ref_full_token_id( whisper_context* ctx, int i, int j ) { return whisper_full_get_token_id( ctx, i, j ); }
 float ref_full_token_p( whisper_context* ctx, int i, int j ) { return whisper_full_get_token_p( ctx, i, j ); }
+int ref_full_token_tid( whisper_context* ctx, int i, int j ) { return whisper_full_get_token_data( ctx, i, j ).tid; }
 
 // timing counters the reference keeps itself (whisper.cpp:2557-2568), microseconds
 void ref_timings( whisper_context* ctx, int64_t* out5 )

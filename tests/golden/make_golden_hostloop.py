@@ -57,8 +57,20 @@ def main():
                    segments=[dict(t0=s["t0"], t1=s["t1"], text=s["text"].decode(), tokens=s["tokens"]) for s in segs])
         print(c["name"], "->", len(segs), "segments", [(s["t0"], s["t1"]) for s in segs][:8])
         out.append(rec)
+    # tokenizer: whisper_tokenize of the reference (whisper.cpp:2186-2248) on the stand-in vocabulary
+    model = gf.synth_model("test-d128-ml")
+    tok = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        gf.write_model(path, model)
+        w = ref.RefWhisper(path, n_threads=1, log_level=0)
+        for text in [" w300 w4242", "hello, world! 123", "it's  a\ttest", "", "\u00e9t\u00e9 na\u00efve"]:
+            buf = np.zeros(256, np.int32)
+            n = w.L.ref_tokenize(w.ctx, text.encode(), buf, 256)
+            tok[text] = [int(x) for x in buf[:n]]
+        w.close()
     with open(os.path.join(HERE, "ref_hostloop.json"), "w") as f:
-        json.dump(out, f, indent=1)
+        json.dump(dict(cases=out, tokenize=tok), f, indent=1)
 
 
 if __name__ == "__main__":

@@ -54,6 +54,11 @@ def lib():
     return _lib
 
 
+def set_host_loop_rules(mode: int):
+    """0 = the reference CPU model's whisper_full rules (default), 1 = its GPU model's ContextImpl rules."""
+    _check(lib().whisperc_set_host_loop_rules(mode), "set_host_loop_rules")
+
+
 def _check(hr: int, what: str) -> int:
     if hr < 0:
         raise WhisperError(hr, what)

@@ -16,6 +16,14 @@ namespace Whisper
 {
 	namespace
 	{
+		// The reference ships TWO host loops that differ in two rules: its CPU model (Whisper/source/whisper.cpp:2765-3120,
+		// the oracle every parity test is pinned to) drops the past prompt when < 5 s of audio remain and retries a failed
+		// window once without it; its GPU model's port (Whisper/Whisper/ContextImpl.cpp:452-793) does neither. The default
+		// follows the CPU path, because that is what north_star asks token ids to match; whisperc_set_host_loop_rules( 1 )
+		// selects the GPU model's behaviour for callers that depended on it.
+		enum struct eHostLoopRules : int { ReferenceCpu = 0, ContextImpl = 1 };
+		eHostLoopRules g_hostLoopRules = eHostLoopRules::ReferenceCpu;
+
 		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
 		constexpr int GREEDY_CHUNK = 8;		   // tokens fetched per device-side greedy call
 
@@ -323,6 +331,10 @@ namespace Whisper
 			int seek = seekStart;
 			while( seek + 100 < seekEnd )
 			{
+				// whisper.cpp only: with less than 5 s left the past prompt is dropped, "since it tends to confuse the decoder"
+				// (Whisper/source/whisper.cpp:2874-2878; absent from ContextImpl.cpp)
+				if( g_hostLoopRules == eHostLoopRules::ReferenceCpu && seek > seekStart && seek + 500 >= seekEnd ) promptPast.clear();
+
 				if( params.encoder_begin_callback )
 				{
 					const HRESULT hr = params.encoder_begin_callback( this, params.encoder_begin_callback_user_data );
@@ -405,6 +417,13 @@ namespace Whisper
 				nDecodeSteps += dec.steps;
 				if( failed )
 				{
+					// whisper.cpp retries the same window once without the past prompt before skipping a second
+					// (whisper.cpp:3006-3016); ContextImpl.cpp:675-680 skips right away
+					if( g_hostLoopRules == eHostLoopRules::ReferenceCpu && !promptPast.empty() )
+					{
+						promptPast.clear();
+						continue;
+					}
 					logError( "runFull: failed to generate timestamp token - skipping one second" );
 					seek += 100;
 					continue;
@@ -774,4 +793,10 @@ WHISPER_EXPORT int32_t whisperc_tokenize( void* model, const char* text, int32_t
 	return FAILED( hr ) ? hr : sink.n;
 }
 WHISPER_EXPORT int32_t whisperc_timings_print( void* ctx ) { return ( (iContext*)ctx )->timingsPrint(); }
+WHISPER_EXPORT int32_t whisperc_set_host_loop_rules( int mode )
+{
+	if( mode != 0 && mode != 1 ) return E_INVALIDARG;
+	g_hostLoopRules = (eHostLoopRules)mode;
+	return S_OK;
+}
 }
