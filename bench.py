@@ -50,20 +50,23 @@ def synth_pcm(n_windows: int, seed: int) -> np.ndarray:
     return (x * env * 3).astype(np.float32).reshape(n_windows, WINDOW_SAMPLES)
 
 
-def transcribe_clip(ctx, pcm_dev, mel_dev, prompt, n_greedy, batch):
-    """One pass of the hot path over a batch of windows; returns the sampled token ids [batch][n_greedy+1]."""
-    for b in range(batch):
-        ctx.mel_spectrogram(pcm_dev[b], mel_dev[b], sync=False)      # same stream as the encoder: no host sync needed
-    ctx.encode(mel_dev, sync=False)
-    toks = np.tile(np.asarray(prompt, np.int32), (batch, 1))
-    ctx.decode(toks, 0, want_logits=False, want_probs=False)
-    out = np.zeros((batch, n_greedy + 1), np.int32)
-    s = ctx.sample_best(batch, force_timestamp=True, is_initial=True)     # first token: timestamp <= 1.00 s (ContextImpl.cpp:613)
-    out[:, 0] = [t["id"] for t in s]
-    # the remaining greedy steps run on the device: one captured hipGraph per token, sampled token fed back in HBM
-    ids, _ = ctx.decode_greedy(out[:, 0], len(prompt), n_greedy)
-    out[:, 1:] = ids.T
-    return out
+def transcribe_clip(groups, prompt, n_greedy):
+    """One pass of the hot path over the clip. `groups` = [(ctx, pcm_dev [k][480000], mel_dev [k][80][3000])]: every group is a
+    lock-step batch of windows on its own context (= its own HIP stream and captured decode graph). Everything is enqueued
+    without a host sync -- GPU mel, encoder, prompt step, first sample, n_greedy device-side greedy steps -- group after
+    group, so the latency-bound decode steps of one group overlap the encoder GEMMs and decode steps of the others; then
+    the sampled token ids are collected. Returns [n_windows][n_greedy + 1] token ids."""
+    for ctx, pcm_dev, mel_dev in groups:
+        k = pcm_dev.shape[0]
+        for b in range(k):
+            ctx.mel_spectrogram(pcm_dev[b], mel_dev[b], sync=False)
+        ctx.encode(mel_dev, sync=False)
+        ctx.decode_window_start(np.tile(np.asarray(prompt, np.int32), (k, 1)), n_greedy, force_first_timestamp=True, first_is_initial=True)
+    outs = []
+    for ctx, _, _ in groups:
+        ids, _ = ctx.decode_window_finish()
+        outs.append(ids.T)
+    return np.concatenate(outs, axis=0)
 
 
 def log(msg):
@@ -142,6 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="medium")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
+    ap.add_argument("--groups", type=int, default=4, help="independent lock-step groups (contexts / HIP streams) the windows are split into")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -187,9 +191,15 @@ def main():
             hip_model = binding.HipModel(hp, arena_ptr=arena.data_ptr(), already_filled=True, keepalive=arena)
 
     B = args.windows
-    ctx = binding.HipContext(hip_model, B)
-    pcm_dev = torch.from_numpy(synth_pcm(B, seed=100 + rank)).cuda()
-    mel_dev = torch.empty((B, hp.n_mels, WINDOW_SAMPLES // 160), dtype=torch.float32, device="cuda")
+    from whisper_amd.distributed import shard_range
+    G = max(1, min(args.groups, B))
+    pcm_all = torch.from_numpy(synth_pcm(B, seed=100 + rank)).cuda()
+    mel_all = torch.empty((B, hp.n_mels, WINDOW_SAMPLES // 160), dtype=torch.float32, device="cuda")
+    groups = []
+    for g in range(G):
+        b0, b1 = shard_range(B, g, G)
+        groups.append((binding.HipContext(hip_model, b1 - b0), pcm_all[b0:b1], mel_all[b0:b1]))
+    torch.cuda.synchronize()
     audio_seconds = CLIP_SECONDS * B / 7.0
 
     def barrier():
@@ -201,13 +211,13 @@ def main():
     if rank == 0:
         log("warmup ...")
     for _ in range(args.warmup):
-        transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
+        transcribe_clip(groups, prompt, N_GREEDY)
     barrier()
     if rank == 0:
         log("timed region: %d steps ..." % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        toks = transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
+        toks = transcribe_clip(groups, prompt, N_GREEDY)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -220,10 +230,16 @@ def main():
     if rank == 0:
         log("timed region done: %.3f s" % elapsed)
     if rank == 0 and not args.no_roofline:
-        ctx.profile(True)
-        transcribe_clip(ctx, pcm_dev, mel_dev, prompt, N_GREEDY, B)
-        kernels = ctx.profile_read()
-        ctx.profile(False)
+        # one group at a time (events on concurrent streams would time each other's kernels), summed over the groups
+        kernels = {}
+        for grp in groups:
+            grp[0].profile(True)
+            transcribe_clip([grp], prompt, N_GREEDY)
+            for k, v in grp[0].profile_read().items():
+                acc = kernels.setdefault(k, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+                for f in acc:
+                    acc[f] += v[f]
+            grp[0].profile(False)
         total_ms = sum(k["ms"] for k in kernels.values())
         name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
         avg_us = 1e3 * dom["ms"] / dom["calls"]
@@ -244,7 +260,7 @@ def main():
         if model is None:
             model = gf.synth_model(args.model, seed=1)
         log("cpu baseline (reference CPU path, bounded) ...")
-        cpu = cpu_baseline(model, args.model, pcm_dev[0].cpu().numpy(), prompt)
+        cpu = cpu_baseline(model, args.model, pcm_all[0].cpu().numpy(), prompt)
         log("cpu baseline done: %s" % cpu.get("value"))
 
     if rank == 0:
@@ -255,10 +271,10 @@ def main():
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s windows per GPU as one lock-step batch, "
-                                   "GPU mel + encoder + %d-token prompt + %d greedy steps per window, device-side sampling"
-                                   % (args.model, audio_seconds, B, N_PROMPT, N_GREEDY),
-                       "model": "ggml-" + args.model, "windows_per_gpu": B, "decode_steps_per_window": N_GREEDY + 1,
+            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, "
+                                   "split into %d lock-step groups on concurrent HIP streams; GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
+                                   "device-side sampling (captured hipGraph per token)" % (args.model, audio_seconds, B, G, N_PROMPT, N_GREEDY),
+                       "model": "ggml-" + args.model, "windows_per_gpu": B, "groups": G, "decode_steps_per_window": N_GREEDY + 1,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,

@@ -145,6 +145,14 @@ WH_API int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isI
 WH_API int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int nPast, int nSteps, int forceFirstTimestamp,
 	int firstIsInitial, wh_token_data* out );
 
+/* One whole window's decode, enqueued without blocking the host: prompt step (HOST tokens [batch][nPrompt] at position 0)
+ * -> first sample -> nSteps greedy steps; wh_decode_window_finish blocks and returns the 1 + nSteps samples as HOST
+ * [1 + nSteps][batch]. Contexts own their streams, so several windows (or groups of windows) started back to back from
+ * one host thread overlap on the GPU: a single-token decode step is latency-bound and occupies a fraction of the CUs. */
+WH_API int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp,
+	int firstIsInitial );
+WH_API int wh_decode_window_finish( wh_context* c, wh_token_data* out );
+
 /* Per-kernel-class GPU timings, the counterpart of the reference's GpuProfiler / iContext::timingsPrint
  * (Whisper/Utils/GpuProfiler.h:21-188, Whisper/Whisper/ContextImpl.misc.cpp:170-182). hipEvent pairs around every launch
  * on the context's stream while enabled; flops / bytes are the algorithmic work of the launches. */

@@ -304,3 +304,37 @@ def test_device_greedy_loop_matches_host_loop(hip_tiny, golden, tiny_model):
     ids3, data3 = ctx.decode_greedy(prompt[:, 2], 2, 1, force_first_timestamp=True, first_is_initial=True)
     assert list(ids3[0]) == list(toks)
     ctx.close()
+
+
+def test_async_window_decode_and_concurrent_contexts(hip_tiny, golden, tiny_model):
+    """wh_decode_window_start/finish (prompt + first sample + greedy steps, no host sync) equals the blocking path, and
+    two contexts driven back to back from one host thread (they overlap on the GPU) do not disturb each other."""
+    sp = gf.special_tokens(tiny_model.hparams)
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    rng = np.random.default_rng(4)
+    mel2 = torch.from_numpy(rng.uniform(-1, 1, (80, 3000)).astype(np.float32)).cuda()
+    prompt = np.array([sp["sot"], sp["transcribe"], sp["not_"]], np.int32)
+    n_steps = 10
+
+    def blocking(m):
+        ctx = binding.HipContext(hip_tiny, 1)
+        ctx.encode(m)
+        ctx.decode(prompt[None, :], 0, want_logits=False, want_probs=False)
+        first = ctx.sample_best(1, True, True)[0]["id"]
+        ids, _ = ctx.decode_greedy([first], 3, n_steps)
+        ctx.close()
+        return [first] + [int(x) for x in ids[:, 0]]
+
+    want1, want2 = blocking(mel), blocking(mel2)
+    a, b = binding.HipContext(hip_tiny, 1), binding.HipContext(hip_tiny, 1)
+    for rep in range(2):                      # second repetition replays the captured graphs
+        a.encode(mel)
+        a.decode_window_start(prompt, n_steps)
+        b.encode(mel2)
+        b.decode_window_start(prompt, n_steps)
+        ids_a, p_a = a.decode_window_finish()
+        ids_b, p_b = b.decode_window_finish()
+        assert [int(x) for x in ids_a[:, 0]] == want1 and [int(x) for x in ids_b[:, 0]] == want2
+        assert (p_a > 0).all() and (p_b > 0).all()
+    a.close()
+    b.close()

@@ -26,7 +26,7 @@ EXPORTS = [
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]
 
@@ -83,6 +83,8 @@ def lib():
         L.wh_sample_best.argtypes = [vp, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_debug_read.argtypes = [vp, C.c_char_p, i32, i32, vp, i64]
         L.wh_decode_greedy.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
+        L.wh_decode_window_start.argtypes = [vp, i32, vp, i32, i32, i32, i32]
+        L.wh_decode_window_finish.argtypes = [vp, C.POINTER(TokenDataC)]
         L.wh_profile_enable.argtypes = [vp, i32]
         L.wh_profile_read.argtypes = [vp, C.POINTER(ProfileEntryC), i32, C.POINTER(i32)]
         L.wh_op_mul_mat.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
@@ -265,6 +267,24 @@ class HipContext:
         data = [[dict(id=out[s * b + i].id, tid=out[s * b + i].tid, p=out[s * b + i].p, pt=out[s * b + i].pt, ptsum=out[s * b + i].ptsum)
                  for i in range(b)] for s in range(n_steps)]
         return ids, data
+
+    def decode_window_start(self, prompt_tokens, n_steps: int, force_first_timestamp: bool = True, first_is_initial: bool = True):
+        """Non-blocking: prompt step + first sample + n_steps greedy steps are enqueued on the context's stream."""
+        t = np.ascontiguousarray(prompt_tokens, np.int32)
+        if t.ndim == 1:
+            t = t[None, :]
+        self._win = (t.shape[0], 1 + n_steps)
+        check(lib().wh_decode_window_start(self.handle, t.shape[0], t.ctypes.data_as(C.c_void_p), t.shape[1], n_steps,
+                                           int(force_first_timestamp), int(first_is_initial)))
+
+    def decode_window_finish(self):
+        """Blocks; returns (ids [1 + n_steps][batch], probabilities of the chosen tokens, same shape)."""
+        b, n = self._win
+        out = (TokenDataC * (b * n))()
+        check(lib().wh_decode_window_finish(self.handle, out))
+        ids = np.array([o.id for o in out], np.int32).reshape(n, b)
+        ps = np.array([o.p for o in out], np.float32).reshape(n, b)
+        return ids, ps
 
     def set_flags(self, flags: int, parity_threads: int = 1):
         check(lib().wh_context_set_flags(self.handle, flags, parity_threads))

@@ -217,7 +217,11 @@ struct wh_context
 	hipGraphExec_t graphExec = nullptr;
 	int graphBatch = 0;
 	uint32_t graphKey = 0;
+	int windowSamples = 0;
 	bool ownsStream = false;
+	// pinned host staging for fully asynchronous enqueues (offsets, tokens, state)
+	int32_t* pinned = nullptr;
+	static constexpr int PINNED_INTS = 4096;
 	std::vector<void*> allocations;
 
 	template<class T> int alloc( T*& p, int64_t count, bool zero = false )
@@ -653,6 +657,11 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 	rc = rc ? rc : c->alloc( c->tokDataDev, B );
 	rc = rc ? rc : c->alloc( c->melScratch, 64 );
 	rc = rc ? rc : c->alloc( c->state, 1, true );
+	if( rc == 0 )
+	{
+		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * wh_context::PINNED_INTS, hipHostMallocDefault );
+		if( e != hipSuccess ) rc = hipFail( e, "hipHostMalloc", __FILE__, __LINE__ );
+	}
 	rc = rc ? rc : c->alloc( c->attScores, B * H * (int64_t)T );
 	rc = rc ? rc : c->alloc( c->attParts, (int64_t)ATT_SPLITS * B * d );
 	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * B );
@@ -676,6 +685,7 @@ void wh_context_destroy( wh_context* c )
 	if( c->stream ) (void)hipStreamSynchronize( c->stream );
 	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
 	for( void* p : c->allocations ) (void)hipFree( p );
+	if( c->pinned ) (void)hipHostFree( c->pinned );
 	if( c->ownsStream ) (void)hipStreamDestroy( c->stream );
 	delete c;
 }
@@ -771,10 +781,12 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 	const int d = hp.n_audio_state, H = hp.n_audio_head, T = c->T;
 	const int M = batch * T;
 
-	std::vector<int32_t> offs( batch, 0 );
-	if( melOffsets ) memcpy( offs.data(), melOffsets, sizeof( int32_t ) * batch );
-	WH_HIP( hipMemcpyAsync( c->melOffsetsDev, offs.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
-	WH_HIP( hipStreamSynchronize( st ) );	 // offs is a local
+	if( batch > 1024 ) { setError( "encode: batch too large" ); return WH_E_INVALIDARG; }
+	// offsets go through pinned staging (ints [0, 1024)): the copy is truly asynchronous and the call never blocks.
+	// The staging is rewritten by the next wh_encode only, which the stream orders after this copy has been consumed
+	// as long as the caller synchronises once per window (wh_decode / wh_decode_window_finish do).
+	for( int i = 0; i < batch; i++ ) c->pinned[ i ] = melOffsets ? melOffsets[ i ] : 0;
+	WH_HIP( hipMemcpyAsync( c->melOffsetsDev, c->pinned, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
 	WH_CHECK( profiled( c, KC_MEL_TO_CONV, 0.0, 6.0 * batch * 2.0 * T * hp.n_mels,
 		[ & ]() { return launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ); } ) );
 
@@ -1064,6 +1076,82 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	static_assert( sizeof( wh_token_data ) == sizeof( TokenData ), "token data layout" );
 	WH_HIP( hipMemcpyAsync( out, c->greedyOut, sizeof( TokenData ) * (size_t)batch * nSteps, hipMemcpyDeviceToHost, st ) );
 	WH_HIP( hipStreamSynchronize( st ) );
+	return 0;
+}
+
+// Enqueues, without ever blocking the host: prompt step -> first sample (sampleTimestamp rules when requested) -> nSteps
+// captured greedy steps. Token data of the 1 + nSteps samples stay on the device until wh_decode_window_finish.
+// Several contexts driven this way from one host thread overlap on the GPU (each owns a stream): single-token decode
+// steps are latency-bound and use a fraction of the chip, so independent windows fill it concurrently.
+int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp, int firstIsInitial )
+{
+	if( !c || !promptTokens || batch <= 0 || batch > c->maxBatch || nPrompt <= 0 || nSteps < 0 ) { setError( "decode_window_start: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c->encoded ) { setError( "decode_window_start: wh_encode has not run" ); return WH_E_NOT_READY; }
+	const wh_hparams& hp = c->m->hp;
+	if( nPrompt + nSteps > hp.n_text_ctx || batch * nPrompt + 8 > wh_context::PINNED_INTS - 1024 ) { setError( "decode_window_start: too many tokens" ); return WH_E_BOUNDS; }
+	hipStream_t st = c->stream;
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && nSteps > 0;
+	const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
+	if( useGraph && c->graphExec && ( c->graphBatch != batch || c->graphKey != key ) )
+	{
+		WH_HIP( hipStreamSynchronize( st ) );
+		(void)hipGraphExecDestroy( c->graphExec );
+		c->graphExec = nullptr;
+	}
+	if( useGraph && !c->graphExec )
+	{
+		// first use for this batch size: one eager step (sets the per-kernel function attributes), then capture. Blocking,
+		// once per context; the state it leaves behind is overwritten below.
+		const DecodeState warm = { 0, 0, 0, 0 };
+		WH_HIP( hipMemcpyAsync( c->state, &warm, sizeof( warm ), hipMemcpyHostToDevice, st ) );
+		WH_HIP( hipMemsetAsync( c->tokensDev, 0, sizeof( int32_t ) * batch, st ) );
+		WH_HIP( hipStreamSynchronize( st ) );
+		WH_CHECK( greedyStep( c, batch ) );
+		WH_HIP( hipStreamSynchronize( st ) );
+		hipGraph_t graph = nullptr;
+		WH_HIP( hipStreamBeginCapture( st, hipStreamCaptureModeThreadLocal ) );
+		const int rc = greedyStep( c, batch );
+		const hipError_t e = hipStreamEndCapture( st, &graph );
+		if( rc != 0 ) { if( graph ) (void)hipGraphDestroy( graph ); return rc; }
+		if( e != hipSuccess ) return hipFail( e, "hipStreamEndCapture", __FILE__, __LINE__ );
+		const hipError_t e2 = hipGraphInstantiate( &c->graphExec, graph, nullptr, nullptr, 0 );
+		(void)hipGraphDestroy( graph );
+		if( e2 != hipSuccess ) { c->graphExec = nullptr; return hipFail( e2, "hipGraphInstantiate", __FILE__, __LINE__ ); }
+		c->graphBatch = batch;
+		c->graphKey = key;
+	}
+	// staging: ints [1024, 1024 + batch*nPrompt) = prompt tokens, then 4 ints of DecodeState
+	int32_t* const stTok = c->pinned + 1024;
+	const int M = batch * nPrompt;
+	for( int i = 0; i < M; i++ ) stTok[ i ] = promptTokens[ i ];
+	DecodeState* const stState = (DecodeState*)( stTok + M );
+	// after the sampler's advance the position must be nPrompt: start one below it
+	*stState = DecodeState{ nPrompt - 1, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0 };
+	WH_HIP( hipMemcpyAsync( c->tokensDev, stTok, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
+	WH_HIP( hipMemcpyAsync( c->state, stState, sizeof( DecodeState ), hipMemcpyHostToDevice, st ) );
+	WH_CHECK( decodeGraph( c, batch, nPrompt, 0, false ) );
+	{
+		const int ml = hp.n_vocab == 51865 ? 1 : 0;
+		const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
+		WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
+			[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, st ); } ) );
+		WH_CHECK( launchAdvanceState( c->state, st ) );
+	}
+	if( useGraph )
+		for( int s = 0; s < nSteps; s++ ) WH_HIP( hipGraphLaunch( c->graphExec, st ) );
+	else
+		for( int s = 0; s < nSteps; s++ ) WH_CHECK( greedyStep( c, batch ) );
+	c->lastBatch = batch;
+	c->windowSamples = 1 + nSteps;
+	return 0;
+}
+
+int wh_decode_window_finish( wh_context* c, wh_token_data* out )
+{
+	if( !c || !out || c->windowSamples <= 0 ) { setError( "decode_window_finish: nothing was started" ); return WH_E_INVALIDARG; }
+	WH_HIP( hipMemcpyAsync( out, c->greedyOut, sizeof( TokenData ) * (size_t)c->lastBatch * c->windowSamples, hipMemcpyDeviceToHost, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	c->windowSamples = 0;
 	return 0;
 }
 
