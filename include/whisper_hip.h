@@ -185,9 +185,11 @@ WH_API int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16,
 /* MlContext::norm + fmaRepeat (norm.hlsl, fmaRepeat1.hlsl): out FP16 [rows][d] = fp16( norm(x) * w + b ) */
 WH_API int wh_op_layer_norm( void* stream, const float* x, const float* w, const float* b, void* outF16, int rows, int d );
 /* MlContext::flashAttention, unmasked (flashAttention.hlsl:76-169 == ggml.c:5912-6097).
- * q, k: FP16 [batch*heads][nCtx][64]; vT: FP16 [batch*heads][64][nCtxPad] with nCtxPad = roundup(nCtx, 64) ... see DESIGN.md;
+ * q, k: FP16 [batch*heads][nCtx][64]. vFrag: FP16 [batch*heads][64 * nCtxPad], nCtxPad = roundup(nCtx, 256), zero beyond
+ * nCtx, in the operand order of the P.V matrix instruction (what the QKV product's epilogue writes):
+ *   index(key, dd) = (((key>>4)*2 + (dd>>5))*64 + ((key>>2)&1)*32 + (dd&31))*8 + ((key>>3)&1)*4 + (key&3)
  * out: FP16 [batch][nCtx][heads*64]. */
-WH_API int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vT, void* out, int batch, int heads, int nCtx );
+WH_API int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vFrag, void* out, int batch, int heads, int nCtx );
 /* softMax over rows with the reference's FP16 exp table semantics (softMax.hlsl / ggml.c:5030-5090): in place, FP32 */
 WH_API int wh_op_soft_max( void* stream, float* x, int rows, int cols );
 

@@ -149,8 +149,11 @@ def test_flash_attention(batch, heads, T):
     k = (rng.standard_normal((batch * heads, T, D)) * 1.5).astype(np.float16)
     v = rng.standard_normal((batch * heads, T, D)).astype(np.float16)
     Tpad = (T + 255) // 256 * 256
-    vT = np.zeros((batch * heads, D, Tpad), np.float16)
-    vT[:, :, :T] = v.transpose(0, 2, 1)
+    # V in the kernel's operand order (whisper_hip.h, gemm.hip vFragIndex): blocks of 16 keys x 32 dims, lane-major 8-half fragments
+    key, dd = np.meshgrid(np.arange(T), np.arange(D), indexing="ij")
+    idx = (((key >> 4) * 2 + (dd >> 5)) * 64 + ((key >> 2) & 1) * 32 + (dd & 31)) * 8 + ((key >> 3) & 1) * 4 + (key & 3)
+    vT = np.zeros((batch * heads, D * Tpad), np.float16)
+    vT[:, idx.ravel()] = v.reshape(batch * heads, T * D)
     want = np.zeros((batch, T, heads * D), np.float32)
     for bh in range(batch * heads):
         S = ((q[bh].astype(np.float32) @ k[bh].astype(np.float32).T) * np.float32(0.125)).astype(np.float32)
@@ -167,3 +170,26 @@ def test_flash_attention(batch, heads, T):
     # S differs by FP32 summation order only; that can flip the FP16 rounding of (S - max) for a few keys, each worth
     # <= 1.6 % of that key's probability, plus the final FP16 rounding of the output
     assert d.max() < 6e-3 and d.mean() < 2e-4
+
+
+def test_exp_table_exhaustive(golden):
+    """exp16 (the FP16 exp table semantics, ggml.c:1382) for EVERY non-positive finite FP16 input, through the row softmax:
+    with max = 0 the arguments are exactly the FP16 inputs and p = e * float(1 / double sum)."""
+    bits = np.arange(0x8000, 0xFC00, dtype=np.uint16)                  # -0.0 ... -65504
+    x = np.concatenate([[np.float32(0.0)], bits.view(np.float16).astype(np.float32)])
+    table = golden["table_exp"].view(np.float16)
+    e = np.concatenate([[np.float32(1.0)], table[bits].astype(np.float32)])
+    inv = np.float32(1.0 / e.astype(np.float64).sum())
+    want = (e * inv).astype(np.float32)
+    xd = dev(x[None, :].copy())
+    binding.check(binding.lib().wh_op_soft_max(None, ptr(xd), 1, len(x)))
+    torch.cuda.synchronize()
+    got = xd.cpu().numpy()[0]
+    rel = np.abs(got - want) / np.maximum(want, 1e-30)
+    bad = np.nonzero(got != want)[0]
+    print("exp table: %d of %d entries differ, worst relative difference %.3e" % (len(bad), len(x), rel.max() if len(bad) else 0.0))
+    for i in bad[:8]:
+        print("   x=%r got %r want %r" % (float(x[i]), float(got[i]), float(want[i])))
+    # a differing entry is one FP16 ulp of e (<= 2^-10 relative); the sum (hence inv) may move by one FP32 ulp with it
+    assert len(bad) <= 0.002 * len(x) or rel.max() < 2e-7
+    assert rel.max() < 1.1e-3

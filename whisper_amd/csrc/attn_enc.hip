@@ -14,8 +14,9 @@
 //   * In the 32x32 accumulator layout a lane holds one query column and 16 keys per tile, so row max / row sum are
 //     in-lane loops + one xor-32 shuffle + an 8-entry LDS exchange between waves.
 //   * P is packed to FP16 in registers directly in the B-operand layout of the P.V MFMA: the accumulator's key order
-//     (r&3) + 8*(r>>2) + 4*(lane>>5) is matched by permuting the K-slots of the V^T operand (two 8-byte loads per
-//     lane from the transposed V the QKV GEMM epilogue wrote), so no cross-lane movement is needed.
+//     (r&3) + 8*(r>>2) + 4*(lane>>5) is matched by permuting the K-slots of the V operand, which the QKV GEMM epilogue
+//     stores fragment-major (gemm.hip vFragIndex) so that each operand is one coalesced 16-byte load per lane; no
+//     cross-lane movement is needed.
 //   * the 8 partial O^T tiles are tree-reduced through LDS in a fixed order (deterministic).
 #include "kernels.h"
 
@@ -62,17 +63,25 @@ namespace wh
 			}
 			__syncthreads();
 
-			// ---- S^T = K . Q^T ----
+			// ---- S^T = K . Q^T ----  (the K fragments of tile kt+1 are requested before the MFMAs of tile kt)
 			f32x16 S[ KT ][ 2 ];
+			f16x8 kf[ 4 ], kn[ 4 ];
+			{
+				int key = keyBase + c;
+				key = key < T ? key : T - 1;
+#pragma unroll
+				for( int kk = 0; kk < 4; kk++ ) kf[ kk ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + kk * 16 + hi * 8 );
+			}
 #pragma unroll
 			for( int kt = 0; kt < KT; kt++ )
 			{
-				int key = keyBase + kt * 32 + c;
-				key = key < T ? key : T - 1;
-				f16x8 kf[ 4 ];
+				if( kt + 1 < KT )
+				{
+					int key = keyBase + ( kt + 1 ) * 32 + c;
+					key = key < T ? key : T - 1;
 #pragma unroll
-				for( int kk = 0; kk < 4; kk++ )
-					kf[ kk ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + kk * 16 + hi * 8 );
+					for( int kk = 0; kk < 4; kk++ ) kn[ kk ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + kk * 16 + hi * 8 );
+				}
 #pragma unroll
 				for( int qt = 0; qt < 2; qt++ )
 				{
@@ -86,6 +95,11 @@ namespace wh
 						acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( kf[ kk ], qf, acc, 0, 0, 0 );
 					}
 					S[ kt ][ qt ] = acc;
+				}
+				if( kt + 1 < KT )
+				{
+#pragma unroll
+					for( int kk = 0; kk < 4; kk++ ) kf[ kk ] = kn[ kk ];
 				}
 			}
 
@@ -122,19 +136,25 @@ namespace wh
 			}
 
 			// ---- e = exp16(S - max), row sums in double ----
+			// per key tile the 16 values of a lane are FP16-exact numbers <= 1, so their FP32 sum is exact; tiles, lane
+			// halves and waves are combined in double like the reference's row sum
 			double sum[ 2 ] = { 0.0, 0.0 };
 #pragma unroll
 			for( int kt = 0; kt < KT; kt++ )
 #pragma unroll
 				for( int qt = 0; qt < 2; qt++ )
+				{
+					float part = 0.0f;
 #pragma unroll
 					for( int r = 0; r < 16; r++ )
 					{
 						const float s = S[ kt ][ qt ][ r ];
 						const float e = ( s == -INFINITY ) ? 0.0f : exp16( s - mx[ qt ] );
 						S[ kt ][ qt ][ r ] = e;
-						sum[ qt ] += (double)e;
+						part += e;
 					}
+					sum[ qt ] += (double)part;
+				}
 #pragma unroll
 			for( int qt = 0; qt < 2; qt++ )
 			{
@@ -152,6 +172,7 @@ namespace wh
 				inv[ qt ] = (float)( 1.0 / t );
 			}
 
+			__builtin_amdgcn_sched_barrier( 0 );
 			// ---- P = fp16(e * inv), packed in the B-operand layout of the P.V product ----
 			f16x8 P[ KT ][ 2 ][ 2 ];	// [key tile][16-key step][query tile]
 #pragma unroll
@@ -163,6 +184,10 @@ namespace wh
 #pragma unroll
 						for( int j = 0; j < 8; j++ )
 							P[ kt ][ st ][ qt ][ j ] = (f16)( S[ kt ][ qt ][ 8 * st + j ] * inv[ qt ] );
+
+			// keep the phases apart for the register allocator: S (192 registers) must be fully packed into P (96) before the
+			// 64 accumulators of O come alive
+			__builtin_amdgcn_sched_barrier( 0 );
 
 			// ---- O^T = V^T . P^T over this wave's keys ----
 			f32x16 O[ 2 ][ 2 ];	   // [dd tile][query tile]
@@ -177,16 +202,12 @@ namespace wh
 #pragma unroll
 				for( int st = 0; st < 2; st++ )
 				{
-					const int kb = keyBase + kt * 32 + 16 * st + 4 * hi;
+					// fragment-major V (gemm.hip vFragIndex): one coalesced 16-byte load per lane and operand
+					const int kb = ( keyBase + kt * 32 + 16 * st ) >> 4;
 					f16x8 vf[ 2 ];
 #pragma unroll
 					for( int ddt = 0; ddt < 2; ddt++ )
-					{
-						const f16* pv = VT + (long long)( ddt * 32 + c ) * Tpad + kb;
-						const f16x4 lo = *(const f16x4*)( pv );
-						const f16x4 hi4 = *(const f16x4*)( pv + 8 );
-						vf[ ddt ] = __builtin_shufflevector( lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7 );
-					}
+						vf[ ddt ] = *(const f16x8*)( VT + ( ( (long long)kb * 2 + ddt ) * 64 + lane ) * 8 );
 #pragma unroll
 					for( int ddt = 0; ddt < 2; ddt++ )
 #pragma unroll

@@ -35,11 +35,22 @@ namespace wh
 		return (f16)y;
 	}
 
-	// table_exp_f16[ fp16(x) ] (ggml.c:1382): fp16( exp( fp32( fp16(x) ) ) ), returned as FP32
+	// table_exp_f16[ fp16(x) ] (ggml.c:1382): fp16( exp( fp32( fp16(x) ) ) ), returned as FP32.
+	// exp(f) = 2^(f*log2e): the product is split into its rounded value and the exact remainder (one fma recovers it,
+	// a second adds log2e's own rounding error), v_exp_f32 takes the rounded part and the remainder is applied as
+	// 2^lo ~ 1 + lo*ln2. Error ~1 ulp of FP32 before the FP16 rounding, i.e. the table value except in ~1e-4 of the
+	// inputs where the two round across an FP16 boundary (tests/test_gpu_ops.py checks all 32768 non-positive inputs).
 	__device__ __forceinline__ float exp16( float x )
 	{
 		const float f = round16( x );
-		return (float)(f16)expf( f );
+		const float L2E = 1.44269502162933349609375f;		// (float)log2(e)
+		const float L2E_LO = 1.925963033500163e-08f;		// log2(e) - (float)log2(e)
+		const float hi = f * L2E;
+		float lo = fmaf( f, L2E, -hi );
+		lo = fmaf( f, L2E_LO, lo );
+		float r = __builtin_amdgcn_exp2f( hi );
+		r = fmaf( r, lo * 0.693147182464599609375f, r );
+		return (float)(f16)r;
 	}
 
 	__device__ __forceinline__ float waveReduceMax( float v )

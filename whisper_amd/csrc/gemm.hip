@@ -13,6 +13,7 @@
 // gemmSkinny: M <= 32 rows (decode steps). The weight matrix is the MFMA A operand (32 rows per workgroup), the few
 //   activation rows are the B operand; 4 waves split K and reduce through LDS. Weights are streamed exactly once.
 #include "kernels.h"
+#include <type_traits>
 
 namespace wh
 {
@@ -29,6 +30,14 @@ namespace wh
 			const int b = m / Mb;
 			const int t = m - b * Mb;
 			return (long long)b * batchStride + (long long)t * ld;
+		}
+
+		// V of the encoder attention is stored in the operand order of attentionEnc's P.V MFMA (attn_enc.hip): per (b, h),
+		// blocks of 16 keys x 32 dims hold lane-major 8-half fragments, so a wave reads 1 KiB contiguous per MFMA operand.
+		//   index( key, dd ) = ( ( (key >> 4) * 2 + (dd >> 5) ) * 64 + ((key >> 2) & 1) * 32 + (dd & 31) ) * 8 + ((key >> 3) & 1) * 4 + (key & 3)
+		__device__ __forceinline__ long long vFragIndex( int key, int dd )
+		{
+			return ( ( (long long)( key >> 4 ) * 2 + ( dd >> 5 ) ) * 64 + ( ( key >> 2 ) & 1 ) * 32 + ( dd & 31 ) ) * 8 + ( ( key >> 3 ) & 1 ) * 4 + ( key & 3 );
 		}
 
 		// One output element. m = global row, n = global column, v = FP32 accumulator.
@@ -74,7 +83,7 @@ namespace wh
 				else if( sel == 1 )
 					a.k[ ( bh * a.T + t ) * HEAD_DIM + dd ] = (f16)x;
 				else
-					a.v[ ( bh * HEAD_DIM + dd ) * a.Tpad + t ] = (f16)x;
+					a.v[ bh * HEAD_DIM * a.Tpad + vFragIndex( t, dd ) ] = (f16)x;
 				break;
 			}
 			case EPI_CROSS_KV:
@@ -171,42 +180,41 @@ namespace wh
 					for( int r = 0; r < 16; r++ )
 						acc[ i ][ j ][ r ] = 0.0f;
 
-			u32x4 ra[ 4 ], rw[ 4 ];
+			// Two-tile-deep register prefetch: while tile kt is consumed from LDS, tile kt+1 sits in one register set (it is
+			// written to the other LDS buffer after the MFMAs) and the loads of tile kt+2 are issued into the other set.
+			// A global load therefore has one whole K step plus the MFMAs of the next one to land before its first use,
+			// instead of half a K step; the loop is unrolled by two so that both register sets are statically indexed.
+			u32x4 ra[ 2 ][ 4 ], rw[ 2 ][ 4 ];
 			const int nk = a.K / BK;
-
-#pragma unroll
-			for( int i = 0; i < 4; i++ )
-			{
-				ra[ i ] = *(const u32x4*)( gA[ i ] );
-				rw[ i ] = *(const u32x4*)( gW[ i ] );
-			}
-#pragma unroll
-			for( int i = 0; i < 4; i++ )
-			{
-				*(u32x4*)( lds + ldsOff[ i ] ) = ra[ i ];
-				*(u32x4*)( lds + TILE_HALFS + ldsOff[ i ] ) = rw[ i ];
-			}
-			__syncthreads();
-
 			const int fragRow = lane & 31;
 			const int fragK = ( lane >> 5 ) * 8;
 
-			for( int kt = 0; kt < nk; kt++ )
+			auto loadTile = [ & ]( auto set, int kt )
 			{
-				const int cur = kt & 1;
-				const f16* const ldsA = lds + cur * 2 * TILE_HALFS;
-				const f16* const ldsW = ldsA + TILE_HALFS;
-				const bool more = kt + 1 < nk;
-				if( more )
-				{
-					const int ko = ( kt + 1 ) * BK;
+				constexpr int S = decltype( set )::value;
+				const int ko = kt * BK;
 #pragma unroll
-					for( int i = 0; i < 4; i++ )
-					{
-						ra[ i ] = *(const u32x4*)( gA[ i ] + ko );
-						rw[ i ] = *(const u32x4*)( gW[ i ] + ko );
-					}
+				for( int i = 0; i < 4; i++ )
+				{
+					ra[ S ][ i ] = *(const u32x4*)( gA[ i ] + ko );
+					rw[ S ][ i ] = *(const u32x4*)( gW[ i ] + ko );
 				}
+			};
+			auto storeTile = [ & ]( auto set, int buf )
+			{
+				constexpr int S = decltype( set )::value;
+				f16* const dst = lds + buf * 2 * TILE_HALFS;
+#pragma unroll
+				for( int i = 0; i < 4; i++ )
+				{
+					*(u32x4*)( dst + ldsOff[ i ] ) = ra[ S ][ i ];
+					*(u32x4*)( dst + TILE_HALFS + ldsOff[ i ] ) = rw[ S ][ i ];
+				}
+			};
+			auto compute = [ & ]( int buf )
+			{
+				const f16* const ldsA = lds + buf * 2 * TILE_HALFS;
+				const f16* const ldsW = ldsA + TILE_HALFS;
 #pragma unroll
 				for( int ks = 0; ks < BK / 16; ks++ )
 				{
@@ -223,16 +231,27 @@ namespace wh
 						for( int j = 0; j < 2; j++ )
 							acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ], fb[ j ], acc[ i ][ j ], 0, 0, 0 );
 				}
-				if( more )
-				{
-					f16* const nxt = lds + ( cur ^ 1 ) * 2 * TILE_HALFS;
-#pragma unroll
-					for( int i = 0; i < 4; i++ )
-					{
-						*(u32x4*)( nxt + ldsOff[ i ] ) = ra[ i ];
-						*(u32x4*)( nxt + TILE_HALFS + ldsOff[ i ] ) = rw[ i ];
-					}
-				}
+			};
+			using Set0 = std::integral_constant<int, 0>;
+			using Set1 = std::integral_constant<int, 1>;
+
+			loadTile( Set0{}, 0 );
+			if( nk > 1 ) loadTile( Set1{}, 1 );
+			storeTile( Set0{}, 0 );
+			__syncthreads();
+
+			for( int kt = 0; kt < nk; kt += 2 )
+			{
+				// even step: tile kt in LDS buffer 0, tile kt+1 in register set 1
+				if( kt + 2 < nk ) loadTile( Set0{}, kt + 2 );
+				compute( 0 );
+				if( kt + 1 < nk ) storeTile( Set1{}, 1 );
+				__syncthreads();
+				if( kt + 1 >= nk ) break;
+				// odd step: tile kt+1 in LDS buffer 1, tile kt+2 in register set 0
+				if( kt + 3 < nk ) loadTile( Set1{}, kt + 3 );
+				compute( 1 );
+				if( kt + 2 < nk ) storeTile( Set0{}, 0 );
 				__syncthreads();
 			}
 
@@ -252,7 +271,7 @@ namespace wh
 						packedV = nOk && n >= 2 * a.H * HEAD_DIM && ( a.T & 3 ) == 0;
 					if( packedV )
 					{
-						// transposed V: the 4 rows (r & 3) are 4 consecutive time steps of one (b, h, dd) row of vT
+						// fragment-major V: the 4 rows (r & 3) are 4 consecutive keys = 4 consecutive halfs of one fragment
 						const int c = n - 2 * a.H * HEAD_DIM;
 						const int h = c >> 6, dd = c & 63;
 						const float bias = a.bias[ n ];
@@ -269,7 +288,7 @@ namespace wh
 								pk[ 1 ] = (f16)( acc[ i ][ j ][ 4 * g + 1 ] + bias );
 								pk[ 2 ] = (f16)( acc[ i ][ j ][ 4 * g + 2 ] + bias );
 								pk[ 3 ] = (f16)( acc[ i ][ j ][ 4 * g + 3 ] + bias );
-								*(f16x4*)( a.v + ( ( (long long)b * a.H + h ) * HEAD_DIM + dd ) * a.Tpad + t ) = pk;
+								*(f16x4*)( a.v + ( (long long)b * a.H + h ) * HEAD_DIM * a.Tpad + vFragIndex( t, dd ) ) = pk;
 							}
 						}
 					}
