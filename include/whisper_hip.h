@@ -173,6 +173,10 @@ WH_API int wh_profile_read( wh_context* c, wh_profile_entry* out, int cap, int* 
  */
 WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* dstHost, int64_t dstCapFloats );
 
+/* Development micro-benchmarks (tools/gemm_probe.py): kind 0 = chain of empty kernels (variant = workgroups), 2 = the same
+ * replayed from a hipGraph, 1 = tiled GEMM tile-shape variant on an M x N x K problem. Returns milliseconds per iteration. */
+WH_API int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter );
+
 /* ---- op-level entry points (replace the MlContext methods, Whisper/ML/MlContext.h:13-113). Device pointers. ---- */
 
 /* MlContext::mulMat with an FP16 weight (ComputeShaders/mulMatTiled.hlsl, mulMatByRowTiled.hlsl):

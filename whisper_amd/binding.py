@@ -26,7 +26,7 @@ EXPORTS = [
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]
 
@@ -85,6 +85,7 @@ def lib():
         L.wh_decode_greedy.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_decode_window_start.argtypes = [vp, i32, vp, i32, i32, i32, i32]
         L.wh_decode_window_finish.argtypes = [vp, C.POINTER(TokenDataC)]
+        L.wh_debug_probe.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
         L.wh_profile_enable.argtypes = [vp, i32]
         L.wh_profile_read.argtypes = [vp, C.POINTER(ProfileEntryC), i32, C.POINTER(i32)]
         L.wh_op_mul_mat.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32]
@@ -288,6 +289,11 @@ class HipContext:
 
     def set_flags(self, flags: int, parity_threads: int = 1):
         check(lib().wh_context_set_flags(self.handle, flags, parity_threads))
+
+    def probe(self, kind: int, variant: int, M: int = 0, N: int = 0, K: int = 0, iters: int = 100) -> float:
+        ms = C.c_float()
+        check(lib().wh_debug_probe(self.handle, kind, variant, M, N, K, iters, C.byref(ms)))
+        return ms.value
 
     def profile(self, on: bool):
         check(lib().wh_profile_enable(self.handle, int(on)))

@@ -19,10 +19,6 @@ namespace wh
 {
 	namespace
 	{
-		constexpr int BM = 128, BN = 128, BK = 64;
-		constexpr int LDS_STRIDE = BK + 8;						  // halfs per LDS row (144 bytes)
-		constexpr int TILE_HALFS = BM * LDS_STRIDE;				  // one operand tile
-		constexpr int GEMM_LDS_BYTES = 2 * 2 * TILE_HALFS * 2;	  // [buffer][A|W]
 
 		__device__ __forceinline__ long long rowOffset( int m, int Mb, int ld, long long batchStride )
 		{
@@ -129,16 +125,33 @@ namespace wh
 			}
 		}
 
-		template<int EPI>
-		__global__ void __launch_bounds__( 256, 2 ) gemmTiled( const GemmArgs a )
+		// Tile configuration: every wave owns a 64x64 sub-tile (2x2 MFMA 32x32x16 tiles), waves are laid out WAVES_M x WAVES_N.
+		// MINW = waves per SIMD the register allocator must leave room for (blocks per CU * waves per block / 4).
+		template<int BM_, int BN_, int BK_, int MINW_, int PF_>
+		struct TileCfg
 		{
+			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_;
+			static constexpr int WAVES_M = BM / 64, WAVES_N = BN / 64, NT = WAVES_M * WAVES_N * 64;
+			static constexpr int STRIDE = BK + 8;				 // halfs per LDS row: 144 B (BK 64) / 80 B (BK 32), both conflict free
+			static constexpr int A_HALFS = BM * STRIDE, W_HALFS = BN * STRIDE, STAGE = A_HALFS + W_HALFS;
+			static constexpr int LDS_BYTES = 2 * STAGE * 2;
+			static constexpr int CPR = BK / 8;					 // 16-byte chunks per tile row
+			static constexpr int CA = BM * CPR / NT, CW = BN * CPR / NT;
+			static_assert( CA >= 1 && CW >= 1 && BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile does not divide over the threads" );
+		};
+		using CfgDefault = TileCfg<128, 128, 64, 2, 2>;
+
+		template<int EPI, class C>
+		__global__ void __launch_bounds__( C::NT, C::MINW ) gemmTiled( const GemmArgs a )
+		{
+			constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDS_STRIDE = C::STRIDE;
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[];
 			f16* const lds = (f16*)smem;
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
 			const int wave = tid >> 6;
-			const int wm = wave >> 1, wn = wave & 1;
+			const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
 
 			const int tilesN = ( a.N + BN - 1 ) / BN;
 			// XCD-aware, bijective block remap (each XCD gets a contiguous range of linear tile ids)
@@ -152,23 +165,31 @@ namespace wh
 			const int tm = lin / tilesN;
 			const int tn = lin - tm * tilesN;
 
-			// global -> register staging: 4 chunks of 16 bytes per thread per operand
-			const f16* gA[ 4 ];
-			const f16* gW[ 4 ];
-			int ldsOff[ 4 ];
+			// global -> register staging: CA / CW chunks of 16 bytes per thread
+			const f16* gA[ C::CA ];
+			const f16* gW[ C::CW ];
+			int offA[ C::CA ], offW[ C::CW ];
 #pragma unroll
-			for( int i = 0; i < 4; i++ )
+			for( int i = 0; i < C::CA; i++ )
 			{
-				const int c = tid + i * 256;
-				const int row = c >> 3;
-				const int kc = ( c & 7 ) * 8;
+				const int c = tid + i * C::NT;
+				const int row = c / C::CPR;
+				const int kc = ( c % C::CPR ) * 8;
 				int m = tm * BM + row;
 				m = m < a.M ? m : a.M - 1;
+				gA[ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kc;
+				offA[ i ] = row * LDS_STRIDE + kc;
+			}
+#pragma unroll
+			for( int i = 0; i < C::CW; i++ )
+			{
+				const int c = tid + i * C::NT;
+				const int row = c / C::CPR;
+				const int kc = ( c % C::CPR ) * 8;
 				int n = tn * BN + row;
 				n = n < a.N ? n : a.N - 1;
-				gA[ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kc;
 				gW[ i ] = a.W + (long long)n * a.K + kc;
-				ldsOff[ i ] = row * LDS_STRIDE + kc;
+				offW[ i ] = C::A_HALFS + row * LDS_STRIDE + kc;
 			}
 
 			f32x16 acc[ 2 ][ 2 ];
@@ -180,11 +201,10 @@ namespace wh
 					for( int r = 0; r < 16; r++ )
 						acc[ i ][ j ][ r ] = 0.0f;
 
-			// Two-tile-deep register prefetch: while tile kt is consumed from LDS, tile kt+1 sits in one register set (it is
-			// written to the other LDS buffer after the MFMAs) and the loads of tile kt+2 are issued into the other set.
-			// A global load therefore has one whole K step plus the MFMAs of the next one to land before its first use,
-			// instead of half a K step; the loop is unrolled by two so that both register sets are statically indexed.
-			u32x4 ra[ 2 ][ 4 ], rw[ 2 ][ 4 ];
+			// Register prefetch, PF tiles deep: while tile kt is consumed from LDS, tile kt+1 sits in a register set (written
+			// to the other LDS buffer after the MFMAs) and, with PF == 2, the loads of tile kt+2 are already in flight in the
+			// second set. The loop is unrolled by two so that the sets are statically indexed.
+			u32x4 ra[ 2 ][ C::CA ], rw[ 2 ][ C::CW ];
 			const int nk = a.K / BK;
 			const int fragRow = lane & 31;
 			const int fragK = ( lane >> 5 ) * 8;
@@ -194,27 +214,23 @@ namespace wh
 				constexpr int S = decltype( set )::value;
 				const int ko = kt * BK;
 #pragma unroll
-				for( int i = 0; i < 4; i++ )
-				{
-					ra[ S ][ i ] = *(const u32x4*)( gA[ i ] + ko );
-					rw[ S ][ i ] = *(const u32x4*)( gW[ i ] + ko );
-				}
+				for( int i = 0; i < C::CA; i++ ) ra[ S ][ i ] = *(const u32x4*)( gA[ i ] + ko );
+#pragma unroll
+				for( int i = 0; i < C::CW; i++ ) rw[ S ][ i ] = *(const u32x4*)( gW[ i ] + ko );
 			};
 			auto storeTile = [ & ]( auto set, int buf )
 			{
 				constexpr int S = decltype( set )::value;
-				f16* const dst = lds + buf * 2 * TILE_HALFS;
+				f16* const dst = lds + buf * C::STAGE;
 #pragma unroll
-				for( int i = 0; i < 4; i++ )
-				{
-					*(u32x4*)( dst + ldsOff[ i ] ) = ra[ S ][ i ];
-					*(u32x4*)( dst + TILE_HALFS + ldsOff[ i ] ) = rw[ S ][ i ];
-				}
+				for( int i = 0; i < C::CA; i++ ) *(u32x4*)( dst + offA[ i ] ) = ra[ S ][ i ];
+#pragma unroll
+				for( int i = 0; i < C::CW; i++ ) *(u32x4*)( dst + offW[ i ] ) = rw[ S ][ i ];
 			};
 			auto compute = [ & ]( int buf )
 			{
-				const f16* const ldsA = lds + buf * 2 * TILE_HALFS;
-				const f16* const ldsW = ldsA + TILE_HALFS;
+				const f16* const ldsA = lds + buf * C::STAGE;
+				const f16* const ldsW = ldsA + C::A_HALFS;
 #pragma unroll
 				for( int ks = 0; ks < BK / 16; ks++ )
 				{
@@ -235,24 +251,40 @@ namespace wh
 			using Set0 = std::integral_constant<int, 0>;
 			using Set1 = std::integral_constant<int, 1>;
 
-			loadTile( Set0{}, 0 );
-			if( nk > 1 ) loadTile( Set1{}, 1 );
-			storeTile( Set0{}, 0 );
-			__syncthreads();
-
-			for( int kt = 0; kt < nk; kt += 2 )
+			if constexpr( C::PF == 2 )
 			{
-				// even step: tile kt in LDS buffer 0, tile kt+1 in register set 1
-				if( kt + 2 < nk ) loadTile( Set0{}, kt + 2 );
-				compute( 0 );
-				if( kt + 1 < nk ) storeTile( Set1{}, 1 );
+				loadTile( Set0{}, 0 );
+				if( nk > 1 ) loadTile( Set1{}, 1 );
+				storeTile( Set0{}, 0 );
 				__syncthreads();
-				if( kt + 1 >= nk ) break;
-				// odd step: tile kt+1 in LDS buffer 1, tile kt+2 in register set 0
-				if( kt + 3 < nk ) loadTile( Set1{}, kt + 3 );
-				compute( 1 );
-				if( kt + 2 < nk ) storeTile( Set0{}, 0 );
+				for( int kt = 0; kt < nk; kt += 2 )
+				{
+					// even step: tile kt in LDS buffer 0, tile kt+1 in register set 1
+					if( kt + 2 < nk ) loadTile( Set0{}, kt + 2 );
+					compute( 0 );
+					if( kt + 1 < nk ) storeTile( Set1{}, 1 );
+					__syncthreads();
+					if( kt + 1 >= nk ) break;
+					// odd step: tile kt+1 in LDS buffer 1, tile kt+2 in register set 0
+					if( kt + 3 < nk ) loadTile( Set1{}, kt + 3 );
+					compute( 1 );
+					if( kt + 2 < nk ) storeTile( Set0{}, 0 );
+					__syncthreads();
+				}
+			}
+			else
+			{
+				loadTile( Set0{}, 0 );
+				storeTile( Set0{}, 0 );
 				__syncthreads();
+				for( int kt = 0; kt < nk; kt++ )
+				{
+					const int cur = kt & 1;
+					if( kt + 1 < nk ) loadTile( Set0{}, kt + 1 );
+					compute( cur );
+					if( kt + 1 < nk ) storeTile( Set0{}, cur ^ 1 );
+					__syncthreads();
+				}
 			}
 
 			// epilogue: D[row][col], col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -560,20 +592,40 @@ namespace wh
 		return -1;
 	}
 
-	template<int EPI>
+	template<int EPI, class C = CfgDefault>
 	static int launchTiledT( const GemmArgs& a, hipStream_t stream )
 	{
 		static bool attrSet = false;
 		if( !attrSet )
 		{
-			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES ) );
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES ) );
 			attrSet = true;
 		}
-		const int tilesM = ( a.M + BM - 1 ) / BM, tilesN = ( a.N + BN - 1 ) / BN;
-		hipLaunchKernelGGL( gemmTiled<EPI>, dim3( tilesM * tilesN ), dim3( 256 ), GEMM_LDS_BYTES, stream, a );
+		const int tilesM = ( a.M + C::BM - 1 ) / C::BM, tilesN = ( a.N + C::BN - 1 ) / C::BN;
+		hipLaunchKernelGGL( ( gemmTiled<EPI, C> ), dim3( tilesM * tilesN ), dim3( C::NT ), C::LDS_BYTES, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
+
+	// Tile-shape experiments on the plain FP32 epilogue (tools/gemm_probe.py): variant -> configuration
+	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream )
+	{
+		switch( variant )
+		{
+		case 0: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 2>>( a, stream );
+		case 1: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 1>>( a, stream );
+		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );
+		case 3: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1>>( a, stream );
+		case 4: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 2>>( a, stream );
+		case 5: return launchTiledT<EPI_F32, TileCfg<256, 128, 32, 4, 1>>( a, stream );
+		case 6: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1>>( a, stream );
+		case 7: return launchTiledT<EPI_F32, TileCfg<128, 256, 64, 2, 1>>( a, stream );
+		case 8: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1>>( a, stream );
+		}
+		setError( "gemm: unknown variant" );
+		return -1;
+	}
+
 	template<int EPI>
 	static int launchSkinnyT( const GemmArgs& a, hipStream_t stream )
 	{

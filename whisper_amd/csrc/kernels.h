@@ -59,6 +59,7 @@ namespace wh
 	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream );	// M <= 32 rows (decode steps): weights streamed once
 	// M <= 16 rows, 16 weight rows per workgroup, every load of a wave in flight at once, optional fused LayerNorm prologue
 	int launchGemv( const GemmArgs& a, hipStream_t stream );
+	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream );	// tile-shape experiments, EPI_F32 only
 	int gemmInit();													// one-time function attributes
 
 	// ---------------------------------------------------------------------------------------------------------------

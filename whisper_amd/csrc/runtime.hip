@@ -1289,4 +1289,90 @@ int wh_op_soft_max( void* stream, float* x, int rows, int cols )
 	return launchSoftMaxRows( x, rows, cols, (hipStream_t)stream );
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// micro-benchmarks used by tools/gemm_probe.py (development aid; not on the product path)
+// ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+	__global__ void probeEmpty( int* p ) { if( p && threadIdx.x == 0xFFFF ) *p = 1; }
+	__global__ void probeFill( _Float16* p, long long n, unsigned seed )
+	{
+		for( long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x )
+		{
+			unsigned h = (unsigned)i * 2654435761u + seed;
+			h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+			p[ i ] = (_Float16)( ( (float)( h & 0xFFFF ) / 32768.0f - 1.0f ) * 0.5f );
+		}
+	}
+}
+
+int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter )
+{
+	if( !c || !msPerIter || iters <= 0 ) return WH_E_INVALIDARG;
+	hipStream_t st = c->stream;
+	hipEvent_t e0, e1;
+	WH_HIP( hipEventCreate( &e0 ) );
+	WH_HIP( hipEventCreate( &e1 ) );
+	int rc = 0;
+	float ms = 0;
+	if( kind == 0 || kind == 2 )
+	{
+		// chain of dependent empty kernels, `variant` workgroups of 256 threads each; kind 2 replays them from a graph
+		const int grid = variant > 0 ? variant : 1;
+		hipGraphExec_t exec = nullptr;
+		const int perGraph = 100;
+		if( kind == 2 )
+		{
+			hipGraph_t g = nullptr;
+			WH_HIP( hipStreamBeginCapture( st, hipStreamCaptureModeThreadLocal ) );
+			for( int i = 0; i < perGraph; i++ ) hipLaunchKernelGGL( probeEmpty, dim3( grid ), dim3( 256 ), 0, st, (int*)nullptr );
+			WH_HIP( hipStreamEndCapture( st, &g ) );
+			WH_HIP( hipGraphInstantiate( &exec, g, nullptr, nullptr, 0 ) );
+			(void)hipGraphDestroy( g );
+			WH_HIP( hipGraphLaunch( exec, st ) );
+		}
+		for( int i = 0; i < 20; i++ ) hipLaunchKernelGGL( probeEmpty, dim3( grid ), dim3( 256 ), 0, st, (int*)nullptr );
+		WH_HIP( hipStreamSynchronize( st ) );
+		WH_HIP( hipEventRecord( e0, st ) );
+		if( kind == 2 )
+			for( int i = 0; i < ( iters + perGraph - 1 ) / perGraph; i++ ) WH_HIP( hipGraphLaunch( exec, st ) );
+		else
+			for( int i = 0; i < iters; i++ ) hipLaunchKernelGGL( probeEmpty, dim3( grid ), dim3( 256 ), 0, st, (int*)nullptr );
+		WH_HIP( hipEventRecord( e1, st ) );
+		WH_HIP( hipEventSynchronize( e1 ) );
+		WH_HIP( hipEventElapsedTime( &ms, e0, e1 ) );
+		if( kind == 2 ) ms = ms * (float)iters / (float)( ( iters + perGraph - 1 ) / perGraph * perGraph );
+		if( exec ) (void)hipGraphExecDestroy( exec );
+	}
+	else if( kind == 1 )
+	{
+		void *A = nullptr, *W = nullptr, *out = nullptr;
+		WH_HIP( hipMalloc( &A, (size_t)M * K * 2 ) );
+		WH_HIP( hipMalloc( &W, (size_t)N * K * 2 ) );
+		WH_HIP( hipMalloc( &out, (size_t)M * N * 4 ) );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)A, (long long)M * K, 1u );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)W, (long long)N * K, 2u );
+		GemmArgs g = plainGemm( (const f16*)A, (const f16*)W, M, N, K );
+		g.epi = EPI_F32; g.out32 = (float*)out;
+		for( int i = 0; i < 2 && rc == 0; i++ ) rc = launchGemmVariant( g, variant, st );
+		if( rc == 0 )
+		{
+			WH_HIP( hipStreamSynchronize( st ) );
+			WH_HIP( hipEventRecord( e0, st ) );
+			for( int i = 0; i < iters && rc == 0; i++ ) rc = launchGemmVariant( g, variant, st );
+			WH_HIP( hipEventRecord( e1, st ) );
+			WH_HIP( hipEventSynchronize( e1 ) );
+			WH_HIP( hipEventElapsedTime( &ms, e0, e1 ) );
+		}
+		(void)hipFree( A ); (void)hipFree( W ); (void)hipFree( out );
+	}
+	else
+		rc = WH_E_INVALIDARG;
+	(void)hipEventDestroy( e0 );
+	(void)hipEventDestroy( e1 );
+	*msPerIter = ms / (float)iters;
+	return rc;
+}
+
 }	// extern "C"
