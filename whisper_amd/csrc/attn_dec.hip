@@ -50,20 +50,32 @@ namespace wh
 			// keys visible to this query row
 			const int nk = a.causal ? min( nPast + i + 1, nKeys ) : nKeys;
 
-			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
-			__syncthreads();
-
-			// ---- scores: thread t owns keys t, t + 512, t + 1024; all K loads first ----
+			// ---- every load that does not depend on the softmax goes out first (one memory round trip instead of three):
+			// K rows (thread t owns keys t, t + 512, t + 1024), the first 8 V rows of this thread's P.V slot, and q.
+			// Rows are clamped to the allocation, not to nk, so the addresses do not wait for the position either.
+			const int lastRow = a.keyStride - 1;
 			f16x8 kv[ KPT ][ 8 ];
 #pragma unroll
 			for( int j = 0; j < KPT; j++ )
 			{
 				int key = tid + j * NT;
-				key = key < nk ? key : nk - 1;
+				key = key < lastRow ? key : lastRow;
 				const f16* kr = K + (long long)key * HEAD_DIM;
 #pragma unroll
 				for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
 			}
+			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
+			f16x8 v0[ 8 ];
+#pragma unroll
+			for( int u = 0; u < 8; u++ )
+			{
+				int key = g + u * SLOTS;
+				key = key < lastRow ? key : lastRow;
+				v0[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
+			}
+			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
+			__syncthreads();
+
 			float mx = -INFINITY;
 			float sv[ KPT ];
 #pragma unroll
@@ -115,12 +127,19 @@ namespace wh
 			float result = 0.0f;
 			if( a.parityThreads <= 0 )
 			{
-				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; up to 24 V loads in flight per thread ----
-				const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
+				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; the first 8 V rows were prefetched above ----
 				float acc[ 8 ];
 #pragma unroll
 				for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
-				for( int k0 = g; k0 < nk; k0 += SLOTS * 8 )
+#pragma unroll
+				for( int u = 0; u < 8; u++ )
+				{
+					const int key = g + u * SLOTS;
+					const float p = key < nk ? sc[ key ] : 0.0f;
+#pragma unroll
+					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)v0[ u ][ j ], p, acc[ j ] );
+				}
+				for( int k0 = g + SLOTS * 8; k0 < nk; k0 += SLOTS * 8 )
 				{
 					f16x8 vv[ 8 ];
 					float pp[ 8 ];
@@ -209,9 +228,7 @@ namespace wh
 			const int k0 = sp * per, k1 = min( k0 + per, a.nKeys );
 			const f16* const K = a.kc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
 			float* const S = a.scores + ( (long long)b * a.H + h ) * a.keyStride;
-			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ (long long)b * d + h * HEAD_DIM + tid ];
-			__syncthreads();
-			// up to 2 keys per thread, all 16 loads in flight
+			// up to 2 keys per thread, all 16 loads in flight; issued before q so that there is a single memory round trip
 			f16x8 kv[ 2 ][ 8 ];
 #pragma unroll
 			for( int j = 0; j < 2; j++ )
@@ -222,6 +239,8 @@ namespace wh
 #pragma unroll
 				for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
 			}
+			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ (long long)b * d + h * HEAD_DIM + tid ];
+			__syncthreads();
 #pragma unroll
 			for( int j = 0; j < 2; j++ )
 			{
@@ -248,6 +267,18 @@ namespace wh
 			const int k0 = sp * per, k1 = min( k0 + per, a.nKeys );
 			const f16* const V = a.vc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
 			const float* const S = a.scores + ( (long long)b * a.H + h ) * a.keyStride;
+
+			// this workgroup's V rows do not depend on the probabilities: request them first (12 x 16 bytes per thread)
+			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
+			const int nk = k1 - k0;
+			f16x8 vv[ 12 ];
+#pragma unroll
+			for( int u = 0; u < 12; u++ )
+			{
+				const int key = g + u * 32;
+				const int kc = key < nk ? key : nk - 1;
+				vv[ u ] = *(const f16x8*)( V + (long long)( k0 + kc ) * HEAD_DIM + j8 );
+			}
 
 			// softmax statistics over ALL keys of this (b, h): identical in each of the ATT_SPLITS workgroups
 			constexpr int SPT = MAX_KEYS / 256;
@@ -286,28 +317,17 @@ namespace wh
 			}
 			__syncthreads();
 
-			// partial P.V over [k0, k1): 32 key slots x 8 lanes of 8 dims
-			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
+			// partial P.V over [k0, k1): 32 key slots x 8 lanes of 8 dims (at most 12 keys per slot: 384 keys per split)
 			float acc[ 8 ];
 #pragma unroll
 			for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
-			const int nk = k1 - k0;
-			for( int kk = g; kk < nk; kk += 32 * 12 )
+#pragma unroll
+			for( int u = 0; u < 12; u++ )
 			{
-				f16x8 vv[ 12 ];
-				float pp[ 12 ];
+				const int key = g + u * 32;
+				const float p = key < nk ? pl[ key ] : 0.0f;
 #pragma unroll
-				for( int u = 0; u < 12; u++ )
-				{
-					const int key = kk + u * 32;
-					const int kc = key < nk ? key : nk - 1;
-					vv[ u ] = *(const f16x8*)( V + (long long)( k0 + kc ) * HEAD_DIM + j8 );
-					pp[ u ] = key < nk ? pl[ kc ] : 0.0f;
-				}
-#pragma unroll
-				for( int u = 0; u < 12; u++ )
-#pragma unroll
-					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
+				for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], p, acc[ j ] );
 			}
 #pragma unroll
 			for( int j = 0; j < 8; j++ ) red[ g ][ j8 + j ] = acc[ j ];

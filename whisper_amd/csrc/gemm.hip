@@ -139,7 +139,11 @@ namespace wh
 			static constexpr int CA = BM * CPR / NT, CW = BN * CPR / NT;
 			static_assert( CA >= 1 && CW >= 1 && BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile does not divide over the threads" );
 		};
-		using CfgDefault = TileCfg<128, 128, 64, 2, 2>;
+		// Measured on MI355X (tools/gemm_probe.py, profiles/r01_gemm_tile_probe.txt), M = 10500: 256x256x64 wins when the grid
+		// still fills the chip (N >= 2048: 593-662 TFLOP/s), 128x128x32 (3 blocks per CU) wins on narrow outputs and small M;
+		// the two-tile-deep prefetch (PF = 2) measured 3-5 % slower than PF = 1 at every shape.
+		using CfgDefault = TileCfg<128, 128, 32, 3, 1>;
+		using CfgBig = TileCfg<256, 256, 64, 4, 1>;
 
 		template<int EPI, class C>
 		__global__ void __launch_bounds__( C::NT, C::MINW ) gemmTiled( const GemmArgs a )
@@ -423,24 +427,27 @@ namespace wh
 
 		// PRO = 0: A rows are FP16 in global memory; 1: fused LayerNorm prologue; 2: A row m = fp16( sum of nParts FP32
 		// partial rows ) -- the deterministic combine of the split cross-attention's per-key-range partial outputs.
-		template<int EPI, int PRO>
-		__global__ void __launch_bounds__( 256 ) gemvFused( const GemmArgs a )
+		// ROWS = weight rows per workgroup: 16 fills the MFMA; 4 (rows replicated across the operand's 16 row slots) gives 4x
+		// the workgroups when N is small and K large -- a CU streams only ~24 GB/s, so 8 MB over 64 CUs would take 5 us.
+		// NW = waves per workgroup that split K (8 for the LayerNorm prologue: one activation row per wave).
+		template<int EPI, int PRO, int ROWS, int NW>
+		__global__ void __launch_bounds__( NW * 64 ) gemvFused( const GemmArgs a )
 		{
 			constexpr bool LN = PRO == 1;
 			constexpr bool PARTS = PRO == 2;
-			__shared__ float red[ 3 ][ 4 ][ 64 ];
+			__shared__ float red[ NW - 1 ][ 4 ][ 64 ];
 			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[ PRO != 0 ? 16 * GV_XS_STRIDE : 8 ];
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
 			const int wave = tid >> 6;
-			const int n0 = blockIdx.x * 16;
+			const int n0 = blockIdx.x * ROWS;
 
-			int n = n0 + ( lane & 15 );
+			int n = n0 + ( lane & 15 ) % ROWS;
 			n = n < a.N ? n : a.N - 1;
 			int m = lane & 15;
 			m = m < a.M ? m : a.M - 1;
-			const int kPer = a.K / 4;
+			const int kPer = a.K / NW;
 			const int kBeg = wave * kPer + ( lane >> 4 ) * 8;
 			const f16* const pw = a.W + (long long)n * a.K + kBeg;
 			const int steps = kPer / 32;
@@ -454,8 +461,9 @@ namespace wh
 			// epilogue operands of the plain FP32 epilogue are fetched up front as well (wave 0 owns the epilogue)
 			const int nEp = n0 + ( lane >> 4 ) * 4;
 			const bool fastEp = EPI == EPI_F32 && ( a.N & 15 ) == 0 && a.Mb >= a.M;
+			const bool ownsRows = ( lane >> 4 ) * 4 < ROWS;	  // with ROWS == 4 only the first 16 lanes hold distinct output rows
 			f32x4 biasv = { 0.0f, 0.0f, 0.0f, 0.0f }, resv = { 0.0f, 0.0f, 0.0f, 0.0f };
-			if( fastEp && wave == 0 && ( lane & 15 ) < a.M )
+			if( fastEp && wave == 0 && ( lane & 15 ) < a.M && ownsRows )
 			{
 				if( a.bias ) biasv = *(const f32x4*)( a.bias + nEp );
 				if( a.res ) resv = *(const f32x4*)( a.res + (long long)( lane & 15 ) * a.ldc + nEp );
@@ -466,7 +474,7 @@ namespace wh
 			{
 				// x[m][k] = fp16( parts[0][m][k] + parts[1][m][k] + ... ), fixed order; 4 consecutive k per thread
 				const int total = a.M * a.K / 4;
-				for( int i = tid; i < 16 * a.K / 4; i += 256 )
+				for( int i = tid; i < 16 * a.K / 4; i += NW * 64 )
 				{
 					const int mr = i / ( a.K / 4 ), k4 = ( i - mr * ( a.K / 4 ) ) * 4;
 					f32x4 sum = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -484,7 +492,7 @@ namespace wh
 			}
 			else if constexpr( LN )
 			{
-				for( int mr = wave; mr < 16; mr += 4 )
+				for( int mr = wave; mr < 16; mr += NW )
 				{
 					f16* const dst = xs + mr * GV_XS_STRIDE;
 					if( mr < a.M )
@@ -527,13 +535,13 @@ namespace wh
 			__syncthreads();
 			if( wave != 0 ) return;
 #pragma unroll
-			for( int w = 0; w < 3; w++ )
+			for( int w = 0; w < NW - 1; w++ )
 #pragma unroll
 				for( int r = 0; r < 4; r++ ) acc[ r ] += red[ w ][ r ][ lane ];
 
-			// D[row][col]: col = lane & 15 = activation row, row = (lane >> 4) * 4 + r = weight row
+			// D[row][col]: col = lane & 15 = activation row, row = (lane >> 4) * 4 + r = weight row slot
 			const int mm = lane & 15;
-			if( mm >= a.M ) return;
+			if( mm >= a.M || !ownsRows ) return;
 			if( fastEp )
 			{
 				// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
@@ -553,10 +561,10 @@ namespace wh
 		}
 	}	// namespace
 
-	template<int EPI, int PRO>
+	template<int EPI, int PRO, int ROWS = 16, int NW = 4>
 	static int launchGemvT( const GemmArgs& a, hipStream_t stream )
 	{
-		hipLaunchKernelGGL( ( gemvFused<EPI, PRO> ), dim3( ( a.N + 15 ) / 16 ), dim3( 256 ), 0, stream, a );
+		hipLaunchKernelGGL( ( gemvFused<EPI, PRO, ROWS, NW> ), dim3( ( a.N + ROWS - 1 ) / ROWS ), dim3( NW * 64 ), 0, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -581,12 +589,24 @@ namespace wh
 			setError( "gemv: the partial-sum prologue is only built for the FP32 epilogue" );
 			return -1;
 		}
+		// LayerNorm prologue: 8 waves (one activation row each for a batch of up to 8) when K splits 8 ways
+		const bool ln8 = ln && ( a.K % 256 ) == 0;
+		// small N, large K (the MLP down projection): 4 weight rows per workgroup so that every CU streams
+		const bool rows4 = !ln && a.epi == EPI_F32 && ( a.N % 16 ) == 0 && a.N <= 2048 && a.K >= 2048;
 		switch( a.epi )
 		{
-		case EPI_F32: return ln ? launchGemvT<EPI_F32, 1>( a, stream ) : launchGemvT<EPI_F32, 0>( a, stream );
-		case EPI_F16_GELU: return ln ? launchGemvT<EPI_F16_GELU, 1>( a, stream ) : launchGemvT<EPI_F16_GELU, 0>( a, stream );
-		case EPI_QKV_DEC: return ln ? launchGemvT<EPI_QKV_DEC, 1>( a, stream ) : launchGemvT<EPI_QKV_DEC, 0>( a, stream );
-		case EPI_Q_DEC: return ln ? launchGemvT<EPI_Q_DEC, 1>( a, stream ) : launchGemvT<EPI_Q_DEC, 0>( a, stream );
+		case EPI_F32:
+			if( ln ) return ln8 ? launchGemvT<EPI_F32, 1, 16, 8>( a, stream ) : launchGemvT<EPI_F32, 1>( a, stream );
+			return rows4 ? launchGemvT<EPI_F32, 0, 4, 4>( a, stream ) : launchGemvT<EPI_F32, 0>( a, stream );
+		case EPI_F16_GELU:
+			if( ln ) return ln8 ? launchGemvT<EPI_F16_GELU, 1, 16, 8>( a, stream ) : launchGemvT<EPI_F16_GELU, 1>( a, stream );
+			return launchGemvT<EPI_F16_GELU, 0>( a, stream );
+		case EPI_QKV_DEC:
+			if( ln ) return ln8 ? launchGemvT<EPI_QKV_DEC, 1, 16, 8>( a, stream ) : launchGemvT<EPI_QKV_DEC, 1>( a, stream );
+			return launchGemvT<EPI_QKV_DEC, 0>( a, stream );
+		case EPI_Q_DEC:
+			if( ln ) return ln8 ? launchGemvT<EPI_Q_DEC, 1, 16, 8>( a, stream ) : launchGemvT<EPI_Q_DEC, 1>( a, stream );
+			return launchGemvT<EPI_Q_DEC, 0>( a, stream );
 		}
 		setError( "gemv: epilogue not available" );
 		return -1;
@@ -613,6 +633,7 @@ namespace wh
 		switch( variant )
 		{
 		case 0: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 2>>( a, stream );
+		case 9: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );
 		case 1: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 1>>( a, stream );
 		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );
 		case 3: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1>>( a, stream );
@@ -654,13 +675,15 @@ namespace wh
 	int launchGemm( const GemmArgs& a, hipStream_t stream )
 	{
 		WH_CHECK( checkArgs( a ) );
+		// big tiles only when they still give every CU a workgroup
+		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300;
 		switch( a.epi )
 		{
-		case EPI_F32: return launchTiledT<EPI_F32>( a, stream );
-		case EPI_F16_GELU: return launchTiledT<EPI_F16_GELU>( a, stream );
+		case EPI_F32: return big ? launchTiledT<EPI_F32, CfgBig>( a, stream ) : launchTiledT<EPI_F32>( a, stream );
+		case EPI_F16_GELU: return big ? launchTiledT<EPI_F16_GELU, CfgBig>( a, stream ) : launchTiledT<EPI_F16_GELU>( a, stream );
 		case EPI_CONV2: return launchTiledT<EPI_CONV2>( a, stream );
-		case EPI_QKV_ENC: return launchTiledT<EPI_QKV_ENC>( a, stream );
-		case EPI_CROSS_KV: return launchTiledT<EPI_CROSS_KV>( a, stream );
+		case EPI_QKV_ENC: return big ? launchTiledT<EPI_QKV_ENC, CfgBig>( a, stream ) : launchTiledT<EPI_QKV_ENC>( a, stream );
+		case EPI_CROSS_KV: return big ? launchTiledT<EPI_CROSS_KV, CfgBig>( a, stream ) : launchTiledT<EPI_CROSS_KV>( a, stream );
 		case EPI_QKV_DEC: return launchTiledT<EPI_QKV_DEC>( a, stream );
 		case EPI_Q_DEC: return launchTiledT<EPI_Q_DEC>( a, stream );
 		}
