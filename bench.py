@@ -145,7 +145,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="medium")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--groups", type=int, default=4, help="independent lock-step groups (contexts / HIP streams) the windows are split into")
+    ap.add_argument("--groups", type=int, default=1, help="independent lock-step groups (contexts / HIP streams) the windows are split into; "
+                    "1 is fastest: decode is a latency-bound dependent chain and concurrent chains slow each other down (DESIGN.md section 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -272,7 +273,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, "
-                                   "split into %d lock-step groups on concurrent HIP streams; GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
+                                   "%d lock-step group(s); GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
                                    "device-side sampling (captured hipGraph per token)" % (args.model, audio_seconds, B, G, N_PROMPT, N_GREEDY),
                        "model": "ggml-" + args.model, "windows_per_gpu": B, "groups": G, "decode_steps_per_window": N_GREEDY + 1,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},

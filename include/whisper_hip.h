@@ -175,6 +175,9 @@ WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, 
 
 /* Development micro-benchmarks (tools/gemm_probe.py): kind 0 = chain of empty kernels (variant = workgroups), 2 = the same
  * replayed from a hipGraph, 1 = tiled GEMM tile-shape variant on an M x N x K problem. Returns milliseconds per iteration. */
+/* Bit mask of kernel-variant switches (whisper_amd/csrc/kernels.h eTuning) for in-process A/B runs; contexts created
+ * afterwards (and their captured graphs) use the new setting. */
+WH_API int wh_debug_set_tuning( uint32_t mask );
 WH_API int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter );
 
 /* ---- op-level entry points (replace the MlContext methods, Whisper/ML/MlContext.h:13-113). Device pointers. ---- */

@@ -26,7 +26,7 @@ EXPORTS = [
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
 ]
 

@@ -50,31 +50,52 @@ namespace wh
 			// keys visible to this query row
 			const int nk = a.causal ? min( nPast + i + 1, nKeys ) : nKeys;
 
-			// ---- every load that does not depend on the softmax goes out first (one memory round trip instead of three):
-			// K rows (thread t owns keys t, t + 512, t + 1024), the first 8 V rows of this thread's P.V slot, and q.
-			// Rows are clamped to the allocation, not to nk, so the addresses do not wait for the position either.
+			// ---- loads that do not wait for the position or the softmax go out first, for the first PRE = 64 keys only (a
+			// decode step rarely sees more self-attention keys; the cross path is the split kernel): K row min(t, 63),
+			// V row of this thread's P.V slot, and q. One memory round trip serves the common case; more keys take the
+			// dependent loads below.
+			constexpr int PRE = 64;
 			const int lastRow = a.keyStride - 1;
 			f16x8 kv[ KPT ][ 8 ];
-#pragma unroll
-			for( int j = 0; j < KPT; j++ )
 			{
-				int key = tid + j * NT;
+				int key = tid < PRE ? tid : PRE - 1;
 				key = key < lastRow ? key : lastRow;
 				const f16* kr = K + (long long)key * HEAD_DIM;
 #pragma unroll
-				for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+				for( int c8 = 0; c8 < 8; c8++ ) kv[ 0 ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
 			}
 			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
-			f16x8 v0[ 8 ];
-#pragma unroll
-			for( int u = 0; u < 8; u++ )
+			f16x8 v0;
 			{
-				int key = g + u * SLOTS;
-				key = key < lastRow ? key : lastRow;
-				v0[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
+				const int key = g < lastRow ? g : lastRow;
+				v0 = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
 			}
 			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
 			__syncthreads();
+			// keys beyond the prefetched block (thread t owns keys t, t + 512, t + 1024)
+			if( tid >= PRE && tid < nk )
+			{
+				const f16* kr = K + (long long)tid * HEAD_DIM;
+#pragma unroll
+				for( int c8 = 0; c8 < 8; c8++ ) kv[ 0 ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+			}
+#pragma unroll
+			for( int j = 1; j < KPT; j++ )
+			{
+				int key = tid + j * NT;
+				key = key < nk ? key : nk - 1;
+				const f16* kr = K + (long long)key * HEAD_DIM;
+				if( j * NT < nk )
+				{
+#pragma unroll
+					for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+				}
+				else
+				{
+#pragma unroll
+					for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = kv[ 0 ][ c8 ];
+				}
+			}
 
 			float mx = -INFINITY;
 			float sv[ KPT ];
@@ -127,17 +148,29 @@ namespace wh
 			float result = 0.0f;
 			if( a.parityThreads <= 0 )
 			{
-				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; the first 8 V rows were prefetched above ----
+				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; the slot's first V row was prefetched above ----
 				float acc[ 8 ];
-#pragma unroll
-				for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
-#pragma unroll
-				for( int u = 0; u < 8; u++ )
 				{
-					const int key = g + u * SLOTS;
-					const float p = key < nk ? sc[ key ] : 0.0f;
+					const float p = g < nk ? sc[ g ] : 0.0f;
 #pragma unroll
-					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)v0[ u ][ j ], p, acc[ j ] );
+					for( int j = 0; j < 8; j++ ) acc[ j ] = (float)v0[ j ] * p;
+				}
+				if( g + SLOTS < nk )
+				{
+					f16x8 vv[ 7 ];
+					float pp[ 7 ];
+#pragma unroll
+					for( int u = 0; u < 7; u++ )
+					{
+						const int key = g + ( u + 1 ) * SLOTS;
+						const int kc = key < nk ? key : nk - 1;
+						vv[ u ] = *(const f16x8*)( V + (long long)kc * HEAD_DIM + j8 );
+						pp[ u ] = key < nk ? sc[ kc ] : 0.0f;
+					}
+#pragma unroll
+					for( int u = 0; u < 7; u++ )
+#pragma unroll
+						for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
 				}
 				for( int k0 = g + SLOTS * 8; k0 < nk; k0 += SLOTS * 8 )
 				{

@@ -590,9 +590,9 @@ namespace wh
 			return -1;
 		}
 		// LayerNorm prologue: 8 waves (one activation row each for a batch of up to 8) when K splits 8 ways
-		const bool ln8 = ln && ( a.K % 256 ) == 0;
+		const bool ln8 = ln && ( a.K % 256 ) == 0 && ( g_tuning & TUNE_GEMV_LN8 );
 		// small N, large K (the MLP down projection): 4 weight rows per workgroup so that every CU streams
-		const bool rows4 = !ln && a.epi == EPI_F32 && ( a.N % 16 ) == 0 && a.N <= 2048 && a.K >= 2048;
+		const bool rows4 = !ln && a.epi == EPI_F32 && ( a.N % 16 ) == 0 && a.N <= 2048 && a.K >= 2048 && ( g_tuning & TUNE_GEMV_ROWS4 );
 		switch( a.epi )
 		{
 		case EPI_F32:
@@ -676,7 +676,7 @@ namespace wh
 	{
 		WH_CHECK( checkArgs( a ) );
 		// big tiles only when they still give every CU a workgroup
-		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300;
+		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && ( g_tuning & TUNE_GEMM_BIG );
 		switch( a.epi )
 		{
 		case EPI_F32: return big ? launchTiledT<EPI_F32, CfgBig>( a, stream ) : launchTiledT<EPI_F32>( a, stream );

@@ -4,6 +4,19 @@
 
 namespace wh
 {
+	// Runtime switches for A/B measurements of kernel variants inside one process (tools/ab_bench.py, wh_debug_set_tuning).
+	enum eTuning : unsigned
+	{
+		TUNE_GEMV_LN8 = 1,		 // 8-wave LayerNorm prologue in the fused gemv (else 4 waves)
+		TUNE_GEMV_ROWS4 = 2,	 // 4 weight rows per workgroup for small-N / large-K gemv (else 16)
+		TUNE_SPLIT_CROSS = 4,	 // cross-attention keys split over 4 workgroups + combine in the next prologue (else 1 workgroup)
+		TUNE_GEMM_BIG = 8,		 // 256x256x64 tiles for large tiled GEMMs (else 128x128x32 everywhere)
+		// measured in one process on one MI355X (tools/ab_bench.py, profiles/r01_ab_variants.txt): rows4 -1.1 ms per clip pass,
+		// ln8 +3.4 ms, splitCross +6.7 ms (since attentionDec hoists its loads), gemmBig +1.0 ms => only rows4 is on.
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4
+	};
+	extern unsigned g_tuning;
+
 	// ---------------------------------------------------------------------------------------------------------------
 	// NT GEMM: acc[m][n] = sum_k A[m][k] * W[n][k], FP16 operands, FP32 accumulate on MFMA (32x32x16).
 	// Replaces mulMatTiled.hlsl / mulMatByRowTiled.hlsl and, through the row mapping below, the five convolution*.hlsl

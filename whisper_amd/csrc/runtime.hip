@@ -23,6 +23,7 @@
 
 namespace wh
 {
+	unsigned g_tuning = TUNE_DEFAULT;
 	static thread_local std::string g_lastError;
 	void setError( const std::string& s ) { g_lastError = s; }
 	int hipFail( hipError_t e, const char* what, const char* file, int line )
@@ -938,7 +939,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
 			WH_CHECK( product( g, m->at<float>( e.lncw ), m->at<float>( e.lncb ) ) );
 		}
-		const bool splitCross = gemv && fuseLn && nTokens == 1 && parity == 0 && c->T >= ATT_SPLITS;
+		const bool splitCross = gemv && fuseLn && nTokens == 1 && parity == 0 && c->T >= ATT_SPLITS && ( g_tuning & TUNE_SPLIT_CROSS );
 		if( splitCross )
 		{
 			// keys split over ATT_SPLITS workgroups per (sequence, head); the partial outputs are combined by the prologue
@@ -1305,6 +1306,12 @@ namespace
 			p[ i ] = (_Float16)( ( (float)( h & 0xFFFF ) / 32768.0f - 1.0f ) * 0.5f );
 		}
 	}
+}
+
+int wh_debug_set_tuning( uint32_t mask )
+{
+	g_tuning = mask;
+	return 0;
 }
 
 int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter )
