@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-NAMES = {1: "ln8", 2: "rows4", 4: "splitCross", 8: "gemmBig"}
+NAMES = {2: "rows4", 4: "splitCross", 8: "gemmBig", 16: "crossPrefetch"}
 
 
 def main():
@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--model", default="medium")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--masks", default="15,14,13,11,7,0")
+    ap.add_argument("--masks", default="2,0,6,10,18")
     args = ap.parse_args()
     import torch
     from whisper_amd import binding, ggml_format as gf
@@ -49,7 +49,7 @@ def main():
             torch.cuda.synchronize()
             ms = 1e3 * (time.perf_counter() - t0) / args.steps
             res[m].append(ms)
-            print("round %d mask %2d %-32s %8.2f ms  checksum %d" % (r, m, "+".join(n for b, n in NAMES.items() if m & b) or "-", ms,
+            print("round %d mask %6d %-36s %8.2f ms  checksum %d" % (r, m, "+".join(n for b, n in NAMES.items() if m & b) or "-", ms,
                                                                       int(np.asarray(toks, np.int64).sum() % 1000003)), flush=True)
     for m in masks:
         print("mask %2d best %8.2f ms  median %8.2f ms" % (m, min(res[m]), float(np.median(res[m]))))

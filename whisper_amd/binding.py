@@ -60,6 +60,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float)
         L.wh_last_error.restype = C.c_char_p
+        L.wh_debug_set_tuning.argtypes = [C.c_uint32]
+        if os.environ.get("WH_TUNING"):          # kernel-variant mask for A/B runs and for testing a candidate variant
+            L.wh_debug_set_tuning(int(os.environ["WH_TUNING"], 0))
         L.wh_device_info.argtypes = [i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.wh_model_arena_bytes.restype = i64
         L.wh_model_arena_bytes.argtypes = [C.POINTER(HParamsC)]

@@ -25,6 +25,9 @@ namespace wh
 		constexpr int KPT = MAX_KEYS / NT;	 // keys per thread in the score phase
 		constexpr int SLOTS = NT / 8;		 // key slots in the P.V phase
 
+		// CROSS: non-causal with a key count known at launch (the encoder keys): every K row and every V row of the thread
+		// is requested before anything else, one memory phase for the whole 2 x 192 KB of a head.
+		template<bool CROSS>
 		__global__ void __launch_bounds__( NT ) attentionDec( const DecAttnArgs a )
 		{
 			__shared__ float sc[ MAX_KEYS ];
@@ -55,45 +58,70 @@ namespace wh
 			// V row of this thread's P.V slot, and q. One memory round trip serves the common case; more keys take the
 			// dependent loads below.
 			constexpr int PRE = 64;
+			constexpr int VPRE = CROSS ? MAX_KEYS / SLOTS : 1;
 			const int lastRow = a.keyStride - 1;
-			f16x8 kv[ KPT ][ 8 ];
-			{
-				int key = tid < PRE ? tid : PRE - 1;
-				key = key < lastRow ? key : lastRow;
-				const f16* kr = K + (long long)key * HEAD_DIM;
-#pragma unroll
-				for( int c8 = 0; c8 < 8; c8++ ) kv[ 0 ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
-			}
 			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
-			f16x8 v0;
+			f16x8 kv[ KPT ][ 8 ];
+			f16x8 v0[ VPRE ];
+			if constexpr( CROSS )
 			{
-				const int key = g < lastRow ? g : lastRow;
-				v0 = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
-			}
-			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
-			__syncthreads();
-			// keys beyond the prefetched block (thread t owns keys t, t + 512, t + 1024)
-			if( tid >= PRE && tid < nk )
-			{
-				const f16* kr = K + (long long)tid * HEAD_DIM;
 #pragma unroll
-				for( int c8 = 0; c8 < 8; c8++ ) kv[ 0 ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
-			}
-#pragma unroll
-			for( int j = 1; j < KPT; j++ )
-			{
-				int key = tid + j * NT;
-				key = key < nk ? key : nk - 1;
-				const f16* kr = K + (long long)key * HEAD_DIM;
-				if( j * NT < nk )
+				for( int j = 0; j < KPT; j++ )
 				{
+					int key = tid + j * NT;
+					key = key < nk ? key : nk - 1;
+					const f16* kr = K + (long long)key * HEAD_DIM;
 #pragma unroll
 					for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
 				}
-				else
-				{
+				if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
 #pragma unroll
-					for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = kv[ 0 ][ c8 ];
+				for( int u = 0; u < VPRE; u++ )
+				{
+					int key = g + u * SLOTS;
+					key = key < nk ? key : nk - 1;
+					v0[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
+				}
+				__syncthreads();
+			}
+			else
+			{
+				{
+					int key = tid < PRE ? tid : PRE - 1;
+					key = key < lastRow ? key : lastRow;
+					const f16* kr = K + (long long)key * HEAD_DIM;
+#pragma unroll
+					for( int c8 = 0; c8 < 8; c8++ ) kv[ 0 ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+				}
+				{
+					const int key = g < lastRow ? g : lastRow;
+					v0[ 0 ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
+				}
+				if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
+				__syncthreads();
+				// keys beyond the prefetched block (thread t owns keys t, t + 512, t + 1024)
+				if( tid >= PRE && tid < nk )
+				{
+					const f16* kr = K + (long long)tid * HEAD_DIM;
+#pragma unroll
+					for( int c8 = 0; c8 < 8; c8++ ) kv[ 0 ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+				}
+#pragma unroll
+				for( int j = 1; j < KPT; j++ )
+				{
+					int key = tid + j * NT;
+					key = key < nk ? key : nk - 1;
+					const f16* kr = K + (long long)key * HEAD_DIM;
+					if( j * NT < nk )
+					{
+#pragma unroll
+						for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+					}
+					else
+					{
+#pragma unroll
+						for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = kv[ 0 ][ c8 ];
+					}
 				}
 			}
 
@@ -148,46 +176,54 @@ namespace wh
 			float result = 0.0f;
 			if( a.parityThreads <= 0 )
 			{
-				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; the slot's first V row was prefetched above ----
+				// ---- P.V, FP32: 64 key slots x 8 lanes of 8 dims; the first VPRE rows of the slot were prefetched above ----
 				float acc[ 8 ];
-				{
-					const float p = g < nk ? sc[ g ] : 0.0f;
 #pragma unroll
-					for( int j = 0; j < 8; j++ ) acc[ j ] = (float)v0[ j ] * p;
+				for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
+#pragma unroll
+				for( int u = 0; u < VPRE; u++ )
+				{
+					const int key = g + u * SLOTS;
+					const float p = key < nk ? sc[ key ] : 0.0f;
+#pragma unroll
+					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)v0[ u ][ j ], p, acc[ j ] );
 				}
-				if( g + SLOTS < nk )
+				if constexpr( !CROSS )
 				{
-					f16x8 vv[ 7 ];
-					float pp[ 7 ];
-#pragma unroll
-					for( int u = 0; u < 7; u++ )
+					if( g + SLOTS < nk )
 					{
-						const int key = g + ( u + 1 ) * SLOTS;
-						const int kc = key < nk ? key : nk - 1;
-						vv[ u ] = *(const f16x8*)( V + (long long)kc * HEAD_DIM + j8 );
-						pp[ u ] = key < nk ? sc[ kc ] : 0.0f;
+						f16x8 vv[ 7 ];
+						float pp[ 7 ];
+#pragma unroll
+						for( int u = 0; u < 7; u++ )
+						{
+							const int key = g + ( u + 1 ) * SLOTS;
+							const int kc = key < nk ? key : nk - 1;
+							vv[ u ] = *(const f16x8*)( V + (long long)kc * HEAD_DIM + j8 );
+							pp[ u ] = key < nk ? sc[ kc ] : 0.0f;
+						}
+#pragma unroll
+						for( int u = 0; u < 7; u++ )
+#pragma unroll
+							for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
 					}
-#pragma unroll
-					for( int u = 0; u < 7; u++ )
-#pragma unroll
-						for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
-				}
-				for( int k0 = g + SLOTS * 8; k0 < nk; k0 += SLOTS * 8 )
-				{
-					f16x8 vv[ 8 ];
-					float pp[ 8 ];
-#pragma unroll
-					for( int u = 0; u < 8; u++ )
+					for( int k0 = g + SLOTS * 8; k0 < nk; k0 += SLOTS * 8 )
 					{
-						const int key = k0 + u * SLOTS;
-						const int kc = key < nk ? key : nk - 1;
-						vv[ u ] = *(const f16x8*)( V + (long long)kc * HEAD_DIM + j8 );
-						pp[ u ] = key < nk ? sc[ kc ] : 0.0f;
+						f16x8 vv[ 8 ];
+						float pp[ 8 ];
+#pragma unroll
+						for( int u = 0; u < 8; u++ )
+						{
+							const int key = k0 + u * SLOTS;
+							const int kc = key < nk ? key : nk - 1;
+							vv[ u ] = *(const f16x8*)( V + (long long)kc * HEAD_DIM + j8 );
+							pp[ u ] = key < nk ? sc[ kc ] : 0.0f;
+						}
+#pragma unroll
+						for( int u = 0; u < 8; u++ )
+#pragma unroll
+							for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
 					}
-#pragma unroll
-					for( int u = 0; u < 8; u++ )
-#pragma unroll
-						for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
 				}
 #pragma unroll
 				for( int j = 0; j < 8; j++ ) red[ g ][ j8 + j ] = acc[ j ];
@@ -238,7 +274,12 @@ namespace wh
 			setError( "attentionDec: key count out of range" );
 			return -1;
 		}
-		hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
+		// the all-loads-first variant needs a launch-time key count and the FP32 P.V path
+		const bool cross = !a.causal && a.parityThreads <= 0 && ( g_tuning & TUNE_CROSS_PREFETCH );
+		if( cross )
+			hipLaunchKernelGGL( attentionDec<true>, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
+		else
+			hipLaunchKernelGGL( attentionDec<false>, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

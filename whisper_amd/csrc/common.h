@@ -75,45 +75,92 @@ namespace wh
 		return v;
 	}
 
-	// One wavefront normalises one row of length d (a multiple of 64, at most 64 * MAXPER): LayerNorm + affine, the
-	// numerics of ggml_compute_forward_norm_f32 followed by w*y + b (ggml.c:4098-4156, whisper.cpp:1195-1199); see
-	// elementwise.hip. Element c = lane + 64 * i. Every load is issued (clamped, so unconditionally) before the first
-	// use, which keeps all of them in flight at once instead of one dependent round trip per element.
-	template<int MAXPER, class Store>
-	__device__ __forceinline__ void layerNormRow( const float* __restrict__ xr, const float* __restrict__ w, const float* __restrict__ b,
-		int d, int lane, Store&& store )
+	// LayerNorm + affine for NR rows by one wavefront: the numerics of ggml_compute_forward_norm_f32 followed by w*y + b
+	// (ggml.c:4098-4156, whisper.cpp:1195-1199), FP16 result (the consumer is always a GEMM that rounds its activations).
+	// The reference sums in double; FP32 two-pass with a wavefront shuffle tree differs by ~1e-7 relative.
+	// Rows are xr + j * rowStride, j < NR; rows at or beyond nRows are skipped. A lane owns 4 consecutive columns of every
+	// 256-column chunk, so x, w and b arrive as 16-byte loads, all requested before the first use, and the NR reduction
+	// chains are interleaved. d is a multiple of 4, at most 256 * MAXC. store( j, c, f16x4 ).
+	// Every rounding is spelled out (no contraction), so a row gets the same bits from every instantiation and caller:
+	// the standalone kernel, the gemv prologue, any NR.
+	template<int MAXC, int NR, class Store>
+	__device__ __forceinline__ void layerNormRows( const float* __restrict__ xr, long long rowStride, int nRows, const float* __restrict__ w,
+		const float* __restrict__ b, int d, int lane, Store&& store )
 	{
-		const int per = d >> 6;
-		float v[ MAXPER ], wv[ MAXPER ], bv[ MAXPER ];
+		f32x4 v[ NR ][ MAXC ], wv[ MAXC ], bv[ MAXC ];
 #pragma unroll
-		for( int i = 0; i < MAXPER; i++ )
+		for( int i = 0; i < MAXC; i++ )
 		{
-			int c = lane + 64 * i;
-			c = c < d ? c : d - 1;
-			v[ i ] = xr[ c ];
-			wv[ i ] = w[ c ];
-			bv[ i ] = b[ c ];
-		}
-		float s = 0.0f;
+			int c = ( lane + 64 * i ) * 4;
+			c = c < d ? c : d - 4;
 #pragma unroll
-		for( int i = 0; i < MAXPER; i++ ) s += ( i < per ) ? v[ i ] : 0.0f;
-		const float mean = waveReduceSum( s ) / (float)d;
-		float s2 = 0.0f;
-#pragma unroll
-		for( int i = 0; i < MAXPER; i++ )
-		{
-			v[ i ] -= mean;
-			s2 += ( i < per ) ? v[ i ] * v[ i ] : 0.0f;
-		}
-		const float var = waveReduceSum( s2 ) / (float)d;
-		const float scale = 1.0f / sqrtf( var + 1e-5f );
-#pragma unroll
-		for( int i = 0; i < MAXPER; i++ )
-			if( i < per )
+			for( int j = 0; j < NR; j++ )
 			{
-				const float y = __fmul_rn( v[ i ], scale );
-				store( lane + 64 * i, (f16)__fadd_rn( __fmul_rn( y, wv[ i ] ), bv[ i ] ) );
+				const int jr = j < nRows ? j : ( nRows > 0 ? nRows - 1 : 0 );
+				v[ j ][ i ] = *(const f32x4*)( xr + jr * rowStride + c );
 			}
+			wv[ i ] = *(const f32x4*)( w + c );
+			bv[ i ] = *(const f32x4*)( b + c );
+		}
+		const float invD = 1.0f / (float)d;
+		float s[ NR ];
+#pragma unroll
+		for( int j = 0; j < NR; j++ )
+		{
+			s[ j ] = 0.0f;
+#pragma unroll
+			for( int i = 0; i < MAXC; i++ )
+				if( ( lane + 64 * i ) * 4 < d )
+					s[ j ] = __fadd_rn( s[ j ], __fadd_rn( __fadd_rn( v[ j ][ i ][ 0 ], v[ j ][ i ][ 1 ] ), __fadd_rn( v[ j ][ i ][ 2 ], v[ j ][ i ][ 3 ] ) ) );
+		}
+#pragma unroll
+		for( int o = 32; o > 0; o >>= 1 )
+#pragma unroll
+			for( int j = 0; j < NR; j++ ) s[ j ] = __fadd_rn( s[ j ], __shfl_xor( s[ j ], o, 64 ) );
+		float s2[ NR ];
+#pragma unroll
+		for( int j = 0; j < NR; j++ )
+		{
+			const float mean = __fmul_rn( s[ j ], invD );
+			s2[ j ] = 0.0f;
+#pragma unroll
+			for( int i = 0; i < MAXC; i++ )
+			{
+#pragma unroll
+				for( int e = 0; e < 4; e++ ) v[ j ][ i ][ e ] = __fsub_rn( v[ j ][ i ][ e ], mean );
+				if( ( lane + 64 * i ) * 4 < d )
+				{
+					float t = __fmul_rn( v[ j ][ i ][ 0 ], v[ j ][ i ][ 0 ] );
+					t = fmaf( v[ j ][ i ][ 1 ], v[ j ][ i ][ 1 ], t );
+					t = fmaf( v[ j ][ i ][ 2 ], v[ j ][ i ][ 2 ], t );
+					t = fmaf( v[ j ][ i ][ 3 ], v[ j ][ i ][ 3 ], t );
+					s2[ j ] = __fadd_rn( s2[ j ], t );
+				}
+			}
+		}
+#pragma unroll
+		for( int o = 32; o > 0; o >>= 1 )
+#pragma unroll
+			for( int j = 0; j < NR; j++ ) s2[ j ] = __fadd_rn( s2[ j ], __shfl_xor( s2[ j ], o, 64 ) );
+#pragma unroll
+		for( int j = 0; j < NR; j++ )
+		{
+			if( j >= nRows ) continue;
+			const float scale = 1.0f / sqrtf( __fadd_rn( __fmul_rn( s2[ j ], invD ), 1e-5f ) );
+#pragma unroll
+			for( int i = 0; i < MAXC; i++ )
+			{
+				const int c = ( lane + 64 * i ) * 4;
+				if( c < d )
+				{
+					f16x4 h;
+#pragma unroll
+					for( int e = 0; e < 4; e++ )
+						h[ e ] = (f16)__fadd_rn( __fmul_rn( __fmul_rn( v[ j ][ i ][ e ], scale ), wv[ i ][ e ] ), bv[ i ][ e ] );
+					store( j, c, h );
+				}
+			}
+		}
 	}
 
 	// ---- host side ----

@@ -10,7 +10,7 @@ namespace wh
 		// (Whisper/source/ggml.c:4098-4156): mean, centred sum of squares, 1/sqrt(var + 1e-5), then w*y + b as two
 		// separate FP32 operations (whisper.cpp:1195-1199), then the FP16 rounding the next weight product applies.
 		// The reference sums in double; FP32 two-pass with a wavefront shuffle tree differs by ~1e-7 relative.
-		constexpr int LN_MAX_PER_LANE = 32;
+		constexpr int LN_MAX_CHUNKS = 8;	 // rows up to 2048 columns
 
 		__global__ void __launch_bounds__( 256 ) layerNormKernel( const float* __restrict__ x, const float* __restrict__ w,
 			const float* __restrict__ b, f16* __restrict__ out, int rows, int d )
@@ -19,11 +19,11 @@ namespace wh
 			const int row = blockIdx.x * 4 + ( threadIdx.x >> 6 );
 			if( row >= rows ) return;
 			f16* const o = out + (long long)row * d;
-			// d <= 1280 for every Whisper size: the 20-slot instance keeps the register count (and the wasted clamped loads) low
-			if( d <= 64 * 20 )
-				layerNormRow<20>( x + (long long)row * d, w, b, d, lane, [ = ]( int c, f16 v ) { o[ c ] = v; } );
+			// d <= 1280 for every Whisper size: the 5-chunk instance keeps the register count (and the wasted clamped loads) low
+			if( d <= 256 * 5 )
+				layerNormRows<5, 1>( x + (long long)row * d, 0, 1, w, b, d, lane, [ = ]( int, int c, f16x4 v ) { *(f16x4*)( o + c ) = v; } );
 			else
-				layerNormRow<LN_MAX_PER_LANE>( x + (long long)row * d, w, b, d, lane, [ = ]( int c, f16 v ) { o[ c ] = v; } );
+				layerNormRows<LN_MAX_CHUNKS, 1>( x + (long long)row * d, 0, 1, w, b, d, lane, [ = ]( int, int c, f16x4 v ) { *(f16x4*)( o + c ) = v; } );
 		}
 
 		// ---- mel window -> padded FP16 conv input -----------------------------------------------------------------
@@ -313,9 +313,9 @@ namespace wh
 
 	int launchLayerNorm( const float* x, const float* w, const float* b, f16* out, int rows, int d, hipStream_t stream )
 	{
-		if( ( d & 63 ) != 0 || d > 64 * LN_MAX_PER_LANE || rows <= 0 )
+		if( ( d & 3 ) != 0 || d > 256 * LN_MAX_CHUNKS || rows <= 0 )
 		{
-			setError( "layerNorm: d must be a multiple of 64, at most 2048" );
+			setError( "layerNorm: d must be a multiple of 4, at most 2048" );
 			return -1;
 		}
 		hipLaunchKernelGGL( layerNormKernel, dim3( ( rows + 3 ) / 4 ), dim3( 256 ), 0, stream, x, w, b, out, rows, d );

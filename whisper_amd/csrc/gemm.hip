@@ -492,13 +492,14 @@ namespace wh
 			}
 			else if constexpr( LN )
 			{
-				for( int mr = wave; mr < 16; mr += NW )
+				// rows wave and wave + NW together, then wave + 2 NW and wave + 3 NW when the batch has more than 2 NW rows.
+				// Rows at or beyond M stay unwritten: an MFMA output column depends on its own activation row only, and
+				// those columns are never stored.
+				for( int r0 = wave; r0 < a.M; r0 += 2 * NW )
 				{
-					f16* const dst = xs + mr * GV_XS_STRIDE;
-					if( mr < a.M )
-						layerNormRow<GV_MAXK_LN / 64>( a.lnX + (long long)mr * a.K, a.lnW, a.lnB, a.K, lane, [ = ]( int c, f16 v ) { dst[ c ] = v; } );
-					else
-						for( int c = lane; c < a.K; c += 64 ) dst[ c ] = (f16)0.0f;
+					const int nr = ( a.M - r0 + NW - 1 ) / NW;
+					layerNormRows<GV_MAXK_LN / 256, 2>( a.lnX + (long long)r0 * a.K, (long long)NW * a.K, nr, a.lnW, a.lnB, a.K, lane,
+						[ = ]( int j, int c, f16x4 v ) { *(f16x4*)( xs + ( r0 + j * NW ) * GV_XS_STRIDE + c ) = v; } );
 				}
 				__syncthreads();
 				px = xs + ( lane & 15 ) * GV_XS_STRIDE + kBeg;
@@ -589,24 +590,19 @@ namespace wh
 			setError( "gemv: the partial-sum prologue is only built for the FP32 epilogue" );
 			return -1;
 		}
-		// LayerNorm prologue: 8 waves (one activation row each for a batch of up to 8) when K splits 8 ways
-		const bool ln8 = ln && ( a.K % 256 ) == 0 && ( g_tuning & TUNE_GEMV_LN8 );
 		// small N, large K (the MLP down projection): 4 weight rows per workgroup so that every CU streams
 		const bool rows4 = !ln && a.epi == EPI_F32 && ( a.N % 16 ) == 0 && a.N <= 2048 && a.K >= 2048 && ( g_tuning & TUNE_GEMV_ROWS4 );
 		switch( a.epi )
 		{
 		case EPI_F32:
-			if( ln ) return ln8 ? launchGemvT<EPI_F32, 1, 16, 8>( a, stream ) : launchGemvT<EPI_F32, 1>( a, stream );
+			if( ln ) return launchGemvT<EPI_F32, 1>( a, stream );
 			return rows4 ? launchGemvT<EPI_F32, 0, 4, 4>( a, stream ) : launchGemvT<EPI_F32, 0>( a, stream );
 		case EPI_F16_GELU:
-			if( ln ) return ln8 ? launchGemvT<EPI_F16_GELU, 1, 16, 8>( a, stream ) : launchGemvT<EPI_F16_GELU, 1>( a, stream );
-			return launchGemvT<EPI_F16_GELU, 0>( a, stream );
+			return ln ? launchGemvT<EPI_F16_GELU, 1>( a, stream ) : launchGemvT<EPI_F16_GELU, 0>( a, stream );
 		case EPI_QKV_DEC:
-			if( ln ) return ln8 ? launchGemvT<EPI_QKV_DEC, 1, 16, 8>( a, stream ) : launchGemvT<EPI_QKV_DEC, 1>( a, stream );
-			return launchGemvT<EPI_QKV_DEC, 0>( a, stream );
+			return ln ? launchGemvT<EPI_QKV_DEC, 1>( a, stream ) : launchGemvT<EPI_QKV_DEC, 0>( a, stream );
 		case EPI_Q_DEC:
-			if( ln ) return ln8 ? launchGemvT<EPI_Q_DEC, 1, 16, 8>( a, stream ) : launchGemvT<EPI_Q_DEC, 1>( a, stream );
-			return launchGemvT<EPI_Q_DEC, 0>( a, stream );
+			return ln ? launchGemvT<EPI_Q_DEC, 1>( a, stream ) : launchGemvT<EPI_Q_DEC, 0>( a, stream );
 		}
 		setError( "gemv: epilogue not available" );
 		return -1;

@@ -7,12 +7,13 @@ namespace wh
 	// Runtime switches for A/B measurements of kernel variants inside one process (tools/ab_bench.py, wh_debug_set_tuning).
 	enum eTuning : unsigned
 	{
-		TUNE_GEMV_LN8 = 1,		 // 8-wave LayerNorm prologue in the fused gemv (else 4 waves)
 		TUNE_GEMV_ROWS4 = 2,	 // 4 weight rows per workgroup for small-N / large-K gemv (else 16)
 		TUNE_SPLIT_CROSS = 4,	 // cross-attention keys split over 4 workgroups + combine in the next prologue (else 1 workgroup)
 		TUNE_GEMM_BIG = 8,		 // 256x256x64 tiles for large tiled GEMMs (else 128x128x32 everywhere)
-		// measured in one process on one MI355X (tools/ab_bench.py, profiles/r01_ab_variants.txt): rows4 -1.1 ms per clip pass,
-		// ln8 +3.4 ms, splitCross +6.7 ms (since attentionDec hoists its loads), gemmBig +1.0 ms => only rows4 is on.
+		TUNE_CROSS_PREFETCH = 16,	 // cross-attention: every K and V row of the thread requested up front
+		// measured in one process on one MI355X (tools/ab_bench.py, profiles/r01_ab_variants.txt), ms per clip pass:
+		// rows4 -1.1, splitCross +6.7 (since attentionDec hoists its loads), gemmBig +1.0, crossPrefetch +1.5 => only rows4.
+		// Retired after measuring: 8-wave LayerNorm prologue (+3.4, spills), rows4 for K = d (+0.5).
 		TUNE_DEFAULT = TUNE_GEMV_ROWS4
 	};
 	extern unsigned g_tuning;
@@ -78,7 +79,7 @@ namespace wh
 	// ---------------------------------------------------------------------------------------------------------------
 	// elementwise / normalisation
 	// ---------------------------------------------------------------------------------------------------------------
-	// out16[row] = fp16( norm(x[row]) * w + b ); rows of length d (multiple of 64, <= 2048). norm.hlsl + fmaRepeat1.hlsl
+	// out16[row] = fp16( norm(x[row]) * w + b ); rows of length d (multiple of 4, <= 2048). norm.hlsl + fmaRepeat1.hlsl
 	int launchLayerNorm( const float* x, const float* w, const float* b, f16* out, int rows, int d, hipStream_t stream );
 	// x16[b][t+1][c] = fp16( mel[b][c][off_b + t] ), zero outside the spectrogram; rows 0 and T+1 are the conv padding
 	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets,
