@@ -338,3 +338,41 @@ def test_async_window_decode_and_concurrent_contexts(hip_tiny, golden, tiny_mode
         assert (p_a > 0).all() and (p_b > 0).all()
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_passes_in_flight(hip_tiny, golden, tiny_model):
+    """bench.py's steady state: three contexts, each pass (encoder + prompt + greedy steps) enqueued without a host sync while
+    the two before it are still running; every pass must return what a lone blocking pass returns."""
+    sp = gf.special_tokens(tiny_model.hparams)
+    rng = np.random.default_rng(11)
+    mels = [torch.from_numpy(golden["mel"]).cuda(),
+            torch.from_numpy(rng.uniform(-1, 1, (80, 3000)).astype(np.float32)).cuda(),
+            torch.from_numpy(rng.uniform(-1, 1, (80, 3000)).astype(np.float32)).cuda()]
+    torch.cuda.synchronize()
+    prompt = np.array([sp["sot"], sp["transcribe"], sp["not_"]], np.int32)
+    n_steps = 12
+    want = []
+    for m in mels:
+        ctx = binding.HipContext(hip_tiny, 1)
+        ctx.encode(m)
+        ctx.decode_window_start(prompt, n_steps)
+        want.append([int(x) for x in ctx.decode_window_finish()[0][:, 0]])
+        ctx.close()
+    ctxs = [binding.HipContext(hip_tiny, 1) for _ in range(3)]
+    pending, got = [], []
+    for i in range(9):
+        if len(pending) == 3:
+            j, c = pending.pop(0)
+            got.append((j, [int(x) for x in c.decode_window_finish()[0][:, 0]]))
+        c = ctxs[i % 3]
+        c.encode(mels[(i * 2) % 3], sync=False)           # the mel a context sees changes from pass to pass
+        c.decode_window_start(prompt, n_steps)
+        pending.append(((i * 2) % 3, c))
+    for j, c in pending:
+        got.append((j, [int(x) for x in c.decode_window_finish()[0][:, 0]]))
+    assert len(got) == 9
+    for j, ids in got:
+        assert ids == want[j]
+    for c in ctxs:
+        c.close()

@@ -1297,6 +1297,57 @@ int wh_op_soft_max( void* stream, float* x, int rows, int cols )
 namespace
 {
 	__global__ void probeEmpty( int* p ) { if( p && threadIdx.x == 0xFFFF ) *p = 1; }
+
+	// Grid-wide barrier cost probe: `n` rounds of { every workgroup publishes 64 bytes, barrier, reads another workgroup's
+	// line and checks it }. One monotonic counter, agent-scope release on arrival, acquire polling, bounded spin.
+	// mode 0: every workgroup polls the one counter; mode 1: arrivals are counted per XCD (workgroup id % 8) and the last
+	// arrival of an XCD bumps the global counter by its XCD's population, so only 8 RMWs hit the shared line.
+	__global__ void __launch_bounds__( 256 ) probeGridBarrier( unsigned* counters, float* buf, int n, int mode, int* err )
+	{
+		const unsigned G = gridDim.x, wg = blockIdx.x;
+		const int lane = threadIdx.x;
+		unsigned* const global = counters;
+		unsigned* const perXcd = counters + 64 + ( wg & 7 ) * 64;	// own 256-byte line per counter
+		const unsigned xcdPop = ( G + 7 - ( wg & 7 ) ) / 8;
+		__shared__ int dead;
+		if( lane == 0 ) dead = 0;
+		for( int it = 0; it < n; it++ )
+		{
+			float* const slot = buf + ( it & 1 ) * G * 16;
+			if( lane < 16 ) slot[ wg * 16 + lane ] = (float)( it * 7 + (int)wg + lane );
+			__syncthreads();
+			if( lane == 0 )
+			{
+				const unsigned target = (unsigned)( it + 1 ) * G;
+				if( mode == 0 )
+					__hip_atomic_fetch_add( global, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT );
+				else
+				{
+					const unsigned prev = __hip_atomic_fetch_add( perXcd, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT );
+					if( ( prev + 1 ) % xcdPop == 0 )
+						__hip_atomic_fetch_add( global, xcdPop, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT );
+				}
+				unsigned spins = 0;
+				while( __hip_atomic_load( global, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT ) < target )
+				{
+					if( ++spins > ( 1u << 21 ) )
+					{
+						*err = 2;
+						dead = 1;
+						break;
+					}
+				}
+			}
+			__syncthreads();
+			if( dead ) return;
+			const unsigned other = ( wg + 97 ) % G;
+			if( lane < 16 )
+			{
+				const float got = __builtin_nontemporal_load( slot + other * 16 + lane );
+				if( got != (float)( it * 7 + (int)other + lane ) ) *err = 1;
+			}
+		}
+	}
 	__global__ void probeFill( _Float16* p, long long n, unsigned seed )
 	{
 		for( long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x )
@@ -1373,6 +1424,36 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 			WH_HIP( hipEventElapsedTime( &ms, e0, e1 ) );
 		}
 		(void)hipFree( A ); (void)hipFree( W ); (void)hipFree( out );
+	}
+	else if( kind == 3 )
+	{
+		// grid barrier: `variant` workgroups (must all be resident: <= number of CUs), M = mode, iters barriers per launch
+		const int grid = variant > 0 ? variant : 256;
+		unsigned* counters = nullptr;
+		float* buf = nullptr;
+		int* err = nullptr;
+		WH_HIP( hipMalloc( &counters, 4096 ) );
+		WH_HIP( hipMalloc( &buf, (size_t)grid * 16 * 2 * 4 ) );
+		WH_HIP( hipMalloc( &err, 4 ) );
+		WH_HIP( hipMemsetAsync( err, 0, 4, st ) );
+		for( int rep = 0; rep < 2; rep++ )
+		{
+			WH_HIP( hipMemsetAsync( counters, 0, 4096, st ) );
+			WH_HIP( hipStreamSynchronize( st ) );
+			WH_HIP( hipEventRecord( e0, st ) );
+			hipLaunchKernelGGL( probeGridBarrier, dim3( grid ), dim3( 256 ), 0, st, counters, buf, iters, M, err );
+			WH_HIP( hipEventRecord( e1, st ) );
+			WH_HIP( hipEventSynchronize( e1 ) );
+			WH_HIP( hipEventElapsedTime( &ms, e0, e1 ) );
+		}
+		int herr = 0;
+		WH_HIP( hipMemcpy( &herr, err, 4, hipMemcpyDeviceToHost ) );
+		if( herr != 0 )
+		{
+			setError( herr == 1 ? "grid barrier probe: stale data after the barrier" : "grid barrier probe: spin limit reached" );
+			rc = -1;
+		}
+		(void)hipFree( counters ); (void)hipFree( buf ); (void)hipFree( err );
 	}
 	else
 		rc = WH_E_INVALIDARG;
