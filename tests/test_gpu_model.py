@@ -192,6 +192,18 @@ def test_decoder_batch_invariance_and_kv_consistency(hip_tiny, golden):
     for (l1, p1), (l3, p3) in zip(single, triple):
         for b in range(3):
             assert np.array_equal(l1[0], l3[b]) and np.array_equal(p1[0], p3[b])
+    # 20 sequences: single-token steps use both MFMA column tiles of the gemv (rows 0-15 and 16-19), the prompt step the tiled GEMM
+    ctx20 = binding.HipContext(hip_tiny, 20)
+    ctx20.encode(torch.stack([mel] * 20))
+    many = run_steps(ctx20, golden, batch=20)
+    for (l1, p1), (l20, p20) in zip(single, many):
+        # the 60-row prompt step runs on the tiled GEMM: its FP32 summation order differs from the gemv's of the 3-row one, which
+        # flips FP16 roundings of activations and cached K/V (the implementation noise floor of the module docstring), so
+        # against the batch of one this is a noise bound; within the batch it is exact
+        d = report("batch of 20 vs batch of 1", l20[0], l1[0])
+        assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
+        assert all(np.array_equal(l20[0], l20[b]) and np.array_equal(p20[0], p20[b]) for b in range(20))
+    ctx20.close()
     # prompt in one step vs token by token
     prompt = golden["steps"][:int(golden["step_lens"][0])]
     ctx1.encode(mel)

@@ -417,11 +417,11 @@ namespace wh
 		// ---- gemv: M <= 16 activation rows (single-token decode steps of a lock-step batch) ----
 		// HBM/latency-bound: the only thing that matters is how many weight bytes are in flight. 16 weight rows per
 		// workgroup (N/16 workgroups), 4 waves split K, and every wave issues ALL of its weight loads (16 bytes per lane
-		// each, up to GV_UNROLL at a time) before the first MFMA consumes one. v_mfma_f32_16x16x32_f16: A = 16 weight rows,
+		// each, up to GV_UNROLL (8 or 16) at a time) before the first MFMA consumes one. v_mfma_f32_16x16x32_f16: A = 16 weight rows,
 		// B = up to 16 activation rows. With lnX != null the LayerNorm that precedes the product in the graph
 		// (norm.hlsl + fmaRepeat1.hlsl in the reference) runs as a prologue: each workgroup normalises the M rows into LDS
 		// (FP16, the rounding the product applies anyway) -- M*K*4 bytes of L2 reads per workgroup instead of a launch.
-		constexpr int GV_UNROLL = 16;
+		constexpr int GV_UNROLL_MAX = 16;
 		constexpr int GV_MAXK_LN = 1280;
 		constexpr int GV_XS_STRIDE = GV_MAXK_LN + 8;
 
@@ -430,13 +430,14 @@ namespace wh
 		// ROWS = weight rows per workgroup: 16 fills the MFMA; 4 (rows replicated across the operand's 16 row slots) gives 4x
 		// the workgroups when N is small and K large -- a CU streams only ~24 GB/s, so 8 MB over 64 CUs would take 5 us.
 		// NW = waves per workgroup that split K (8 for the LayerNorm prologue: one activation row per wave).
-		template<int EPI, int PRO, int ROWS, int NW>
+		template<int EPI, int PRO, int ROWS, int NW, int GV_UNROLL, int MT>
 		__global__ void __launch_bounds__( NW * 64 ) gemvFused( const GemmArgs a )
 		{
 			constexpr bool LN = PRO == 1;
 			constexpr bool PARTS = PRO == 2;
-			__shared__ float red[ NW - 1 ][ 4 ][ 64 ];
-			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[ PRO != 0 ? 16 * GV_XS_STRIDE : 8 ];
+			constexpr int MROWS = 16 * MT;	  // activation rows held by the workgroup: MT column tiles of the 16x16x32 MFMA
+			__shared__ float red[ NW - 1 ][ MT * 4 ][ 64 ];
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[];	 // [MROWS][GV_XS_STRIDE] when there is a prologue
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
@@ -445,15 +446,13 @@ namespace wh
 
 			int n = n0 + ( lane & 15 ) % ROWS;
 			n = n < a.N ? n : a.N - 1;
-			int m = lane & 15;
-			m = m < a.M ? m : a.M - 1;
 			const int kPer = a.K / NW;
 			const int kBeg = wave * kPer + ( lane >> 4 ) * 8;
 			const f16* const pw = a.W + (long long)n * a.K + kBeg;
 			const int steps = kPer / 32;
 
 			// first batch of weight loads goes out before anything else: it does not depend on the LayerNorm prologue
-			f16x8 fw[ GV_UNROLL ], fx[ GV_UNROLL ];
+			f16x8 fw[ GV_UNROLL ], fx[ MT ][ GV_UNROLL ];
 #pragma unroll
 			for( int u = 0; u < GV_UNROLL; u++ )
 				if( u < steps ) fw[ u ] = __builtin_nontemporal_load( (const f16x8*)( pw + u * 32 ) );
@@ -462,39 +461,37 @@ namespace wh
 			const int nEp = n0 + ( lane >> 4 ) * 4;
 			const bool fastEp = EPI == EPI_F32 && ( a.N & 15 ) == 0 && a.Mb >= a.M;
 			const bool ownsRows = ( lane >> 4 ) * 4 < ROWS;	  // with ROWS == 4 only the first 16 lanes hold distinct output rows
-			f32x4 biasv = { 0.0f, 0.0f, 0.0f, 0.0f }, resv = { 0.0f, 0.0f, 0.0f, 0.0f };
-			if( fastEp && wave == 0 && ( lane & 15 ) < a.M && ownsRows )
+			f32x4 biasv = { 0.0f, 0.0f, 0.0f, 0.0f }, resv[ MT ];
+#pragma unroll
+			for( int t = 0; t < MT; t++ ) resv[ t ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			if( fastEp && wave == 0 && ownsRows )
 			{
 				if( a.bias ) biasv = *(const f32x4*)( a.bias + nEp );
-				if( a.res ) resv = *(const f32x4*)( a.res + (long long)( lane & 15 ) * a.ldc + nEp );
+#pragma unroll
+				for( int t = 0; t < MT; t++ )
+					if( a.res && t * 16 + ( lane & 15 ) < a.M ) resv[ t ] = *(const f32x4*)( a.res + (long long)( t * 16 + ( lane & 15 ) ) * a.ldc + nEp );
 			}
 
-			const f16* px;
+			const f16* px[ MT ];
 			if constexpr( PARTS )
 			{
 				// x[m][k] = fp16( parts[0][m][k] + parts[1][m][k] + ... ), fixed order; 4 consecutive k per thread
 				const int total = a.M * a.K / 4;
-				for( int i = tid; i < 16 * a.K / 4; i += NW * 64 )
+				for( int i = tid; i < total; i += NW * 64 )
 				{
 					const int mr = i / ( a.K / 4 ), k4 = ( i - mr * ( a.K / 4 ) ) * 4;
-					f32x4 sum = { 0.0f, 0.0f, 0.0f, 0.0f };
-					if( i < total )
-					{
-						sum = *(const f32x4*)( a.parts + (long long)mr * a.K + k4 );
-						for( int p = 1; p < a.nParts; p++ ) sum += *(const f32x4*)( a.parts + p * a.partStride + (long long)mr * a.K + k4 );
-					}
+					f32x4 sum = *(const f32x4*)( a.parts + (long long)mr * a.K + k4 );
+					for( int p = 1; p < a.nParts; p++ ) sum += *(const f32x4*)( a.parts + p * a.partStride + (long long)mr * a.K + k4 );
 					f16x4 h4;
 					h4[ 0 ] = (f16)sum[ 0 ]; h4[ 1 ] = (f16)sum[ 1 ]; h4[ 2 ] = (f16)sum[ 2 ]; h4[ 3 ] = (f16)sum[ 3 ];
 					*(f16x4*)( xs + mr * GV_XS_STRIDE + k4 ) = h4;
 				}
 				__syncthreads();
-				px = xs + ( lane & 15 ) * GV_XS_STRIDE + kBeg;
 			}
 			else if constexpr( LN )
 			{
-				// rows wave and wave + NW together, then wave + 2 NW and wave + 3 NW when the batch has more than 2 NW rows.
-				// Rows at or beyond M stay unwritten: an MFMA output column depends on its own activation row only, and
-				// those columns are never stored.
+				// rows wave and wave + NW together, then the next pair. Rows at or beyond M stay unwritten: an MFMA output
+				// column depends on its own activation row only, and those columns are never stored.
 				for( int r0 = wave; r0 < a.M; r0 += 2 * NW )
 				{
 					const int nr = ( a.M - r0 + NW - 1 ) / NW;
@@ -502,18 +499,37 @@ namespace wh
 						[ = ]( int j, int c, f16x4 v ) { *(f16x4*)( xs + ( r0 + j * NW ) * GV_XS_STRIDE + c ) = v; } );
 				}
 				__syncthreads();
-				px = xs + ( lane & 15 ) * GV_XS_STRIDE + kBeg;
 			}
-			else
-				px = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
+#pragma unroll
+			for( int t = 0; t < MT; t++ )
+			{
+				if constexpr( PRO != 0 )
+					px[ t ] = xs + ( t * 16 + ( lane & 15 ) ) * GV_XS_STRIDE + kBeg;
+				else
+				{
+					int m = t * 16 + ( lane & 15 );
+					m = m < a.M ? m : a.M - 1;
+					px[ t ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
+				}
+			}
 
-			f32x4 acc = { 0.0f, 0.0f, 0.0f, 0.0f };
+			f32x4 acc[ MT ];
+#pragma unroll
+			for( int t = 0; t < MT; t++ ) acc[ t ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
 			for( int u = 0; u < GV_UNROLL; u++ )
-				if( u < steps ) fx[ u ] = *(const f16x8*)( px + u * 32 );
+				if( u < steps )
+				{
+#pragma unroll
+					for( int t = 0; t < MT; t++ ) fx[ t ][ u ] = *(const f16x8*)( px[ t ] + u * 32 );
+				}
 #pragma unroll
 			for( int u = 0; u < GV_UNROLL; u++ )
-				if( u < steps ) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ], fx[ u ], acc, 0, 0, 0 );
+				if( u < steps )
+				{
+#pragma unroll
+					for( int t = 0; t < MT; t++ ) acc[ t ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ], fx[ t ][ u ], acc[ t ], 0, 0, 0 );
+				}
 			for( int s = GV_UNROLL; s < steps; s += GV_UNROLL )
 			{
 #pragma unroll
@@ -521,60 +537,96 @@ namespace wh
 					if( s + u < steps )
 					{
 						fw[ u ] = __builtin_nontemporal_load( (const f16x8*)( pw + ( s + u ) * 32 ) );
-						fx[ u ] = *(const f16x8*)( px + ( s + u ) * 32 );
+#pragma unroll
+						for( int t = 0; t < MT; t++ ) fx[ t ][ u ] = *(const f16x8*)( px[ t ] + ( s + u ) * 32 );
 					}
 #pragma unroll
 				for( int u = 0; u < GV_UNROLL; u++ )
-					if( s + u < steps ) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ], fx[ u ], acc, 0, 0, 0 );
+					if( s + u < steps )
+					{
+#pragma unroll
+						for( int t = 0; t < MT; t++ ) acc[ t ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ], fx[ t ][ u ], acc[ t ], 0, 0, 0 );
+					}
 			}
 
 			if( wave > 0 )
 			{
 #pragma unroll
-				for( int r = 0; r < 4; r++ ) red[ wave - 1 ][ r ][ lane ] = acc[ r ];
+				for( int t = 0; t < MT; t++ )
+#pragma unroll
+					for( int r = 0; r < 4; r++ ) red[ wave - 1 ][ t * 4 + r ][ lane ] = acc[ t ][ r ];
 			}
 			__syncthreads();
 			if( wave != 0 ) return;
 #pragma unroll
 			for( int w = 0; w < NW - 1; w++ )
 #pragma unroll
-				for( int r = 0; r < 4; r++ ) acc[ r ] += red[ w ][ r ][ lane ];
+				for( int t = 0; t < MT; t++ )
+#pragma unroll
+					for( int r = 0; r < 4; r++ ) acc[ t ][ r ] += red[ w ][ t * 4 + r ][ lane ];
 
-			// D[row][col]: col = lane & 15 = activation row, row = (lane >> 4) * 4 + r = weight row slot
-			const int mm = lane & 15;
-			if( mm >= a.M || !ownsRows ) return;
-			if( fastEp )
-			{
-				// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
-				f32x4 o;
+			// D[row][col]: col = lane & 15 = activation row within the tile, row = (lane >> 4) * 4 + r = weight row slot
+			if( !ownsRows ) return;
 #pragma unroll
-				for( int r = 0; r < 4; r++ ) o[ r ] = ( acc[ r ] + biasv[ r ] ) + resv[ r ];
-				*(f32x4*)( a.out32 + (long long)mm * a.ldc + nEp ) = o;
-				return;
-			}
-#pragma unroll
-			for( int r = 0; r < 4; r++ )
+			for( int t = 0; t < MT; t++ )
 			{
-				const int nn = n0 + ( lane >> 4 ) * 4 + r;
-				if( nn < a.N )
-					epilogueOne<EPI>( a, mm, nn, acc[ r ] );
+				const int mm = t * 16 + ( lane & 15 );
+				if( mm >= a.M ) continue;
+				if( fastEp )
+				{
+					// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
+					f32x4 o;
+#pragma unroll
+					for( int r = 0; r < 4; r++ ) o[ r ] = ( acc[ t ][ r ] + biasv[ r ] ) + resv[ t ][ r ];
+					*(f32x4*)( a.out32 + (long long)mm * a.ldc + nEp ) = o;
+					continue;
+				}
+#pragma unroll
+				for( int r = 0; r < 4; r++ )
+				{
+					const int nn = n0 + ( lane >> 4 ) * 4 + r;
+					if( nn < a.N )
+						epilogueOne<EPI>( a, mm, nn, acc[ t ][ r ] );
+				}
 			}
 		}
 	}	// namespace
 
-	template<int EPI, int PRO, int ROWS = 16, int NW = 4>
-	static int launchGemvT( const GemmArgs& a, hipStream_t stream )
+	template<int EPI, int PRO, int ROWS, int NW, int UNROLL, int MT>
+	static int launchGemvK( const GemmArgs& a, hipStream_t stream )
 	{
-		hipLaunchKernelGGL( ( gemvFused<EPI, PRO, ROWS, NW> ), dim3( ( a.N + ROWS - 1 ) / ROWS ), dim3( NW * 64 ), 0, stream, a );
+		const size_t lds = PRO != 0 ? (size_t)16 * MT * GV_XS_STRIDE * sizeof( f16 ) : 0;
+		if( lds > 64 * 1024 )
+		{
+			static bool attrSet = false;
+			if( !attrSet )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)gemvFused<EPI, PRO, ROWS, NW, UNROLL, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds ) );
+				attrSet = true;
+			}
+		}
+		hipLaunchKernelGGL( ( gemvFused<EPI, PRO, ROWS, NW, UNROLL, MT> ), dim3( ( a.N + ROWS - 1 ) / ROWS ), dim3( NW * 64 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
 
+	template<int EPI, int PRO, int ROWS = 16, int NW = 4>
+	static int launchGemvT( const GemmArgs& a, hipStream_t stream )
+	{
+		// a wave holds K / NW / 32 weight fragments; when they fit in 8 slots the 8-slot instance does the same work with
+		// half the registers, which lets kernels of concurrent decode chains share a CU. More than 16 activation rows
+		// (up to 32) take a second MFMA column tile per weight fragment.
+		const bool small = a.K / NW / 32 <= 8 && ( g_tuning & TUNE_GEMV_SMALLREG );
+		if( a.M > 16 )
+			return small ? launchGemvK<EPI, PRO, ROWS, NW, 8, 2>( a, stream ) : launchGemvK<EPI, PRO, ROWS, NW, GV_UNROLL_MAX, 2>( a, stream );
+		return small ? launchGemvK<EPI, PRO, ROWS, NW, 8, 1>( a, stream ) : launchGemvK<EPI, PRO, ROWS, NW, GV_UNROLL_MAX, 1>( a, stream );
+	}
+
 	int launchGemv( const GemmArgs& a, hipStream_t stream )
 	{
-		if( a.M <= 0 || a.M > 16 || a.N <= 0 || a.K <= 0 || ( a.K % 128 ) != 0 )
+		if( a.M <= 0 || a.M > 32 || a.N <= 0 || a.K <= 0 || ( a.K % 128 ) != 0 )
 		{
-			setError( "gemv: need 0 < M <= 16 and K a multiple of 128" );
+			setError( "gemv: need 0 < M <= 32 and K a multiple of 128" );
 			return -1;
 		}
 		const bool ln = a.lnX != nullptr;

@@ -884,7 +884,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const float kqScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
 	const int* const nPastDev = devState ? &c->state->nPast : nullptr;
-	const bool gemv = M <= 16 && ( d % 128 ) == 0;
+	const bool gemv = M <= 32 && ( d % 128 ) == 0;
 	const bool fuseLn = gemv && d <= 1280;
 
 	auto product = [ & ]( GemmArgs& g, const float* lnW, const float* lnB ) -> int
@@ -1264,6 +1264,8 @@ int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float
 {
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F32; g.bias = bias; g.res = residual; g.out32 = out;
+	// the same choice the decoder makes: up to 32 rows go to the gemv when K allows it
+	if( M <= 32 && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -1272,6 +1274,7 @@ int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16, const 
 	if( !bias ) { setError( "mul_mat_gelu: bias is required" ); return WH_E_INVALIDARG; }
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F16_GELU; g.bias = bias; g.out16 = (f16*)outF16;
+	if( M <= 32 && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
