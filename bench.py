@@ -84,15 +84,14 @@ def clip_finish(group):
     return ids.T
 
 
-def transcribe_clips_pipelined(slots, prompt, n_greedy, n_clips):
-    """n_clips passes with up to len(slots) clips in flight, each on its own context / HIP stream: the MFMA-bound encoder
-    of clip i+1 runs under the latency-bound decode chain of clip i. Every clip does the full work; results come back in
-    order. Returns the token ids of the last clip."""
+def run_passes(sequence, prompt, n_greedy, max_in_flight):
+    """Runs the slots of `sequence` in order with up to max_in_flight of them enqueued at once, each on its own context /
+    HIP stream: the MFMA-bound encoder of one pass runs under the latency-bound decode chains of its neighbours. Every
+    pass does the full work; results come back in order. Returns the token ids of the last pass."""
     pending, toks = [], None
-    for i in range(n_clips):
-        if len(pending) == len(slots):
+    for g in sequence:
+        while len(pending) >= max_in_flight or any(p is g for p in pending):
             toks = clip_finish(pending.pop(0))
-        g = slots[i % len(slots)]
         clip_start(g, prompt, n_greedy)
         pending.append(g)
     while pending:
@@ -177,8 +176,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="medium")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--groups", type=int, default=1, help="independent lock-step groups (contexts / HIP streams) the windows are split into; "
-                    "1 is fastest: decode is a latency-bound dependent chain and concurrent chains slow each other down (DESIGN.md section 5)")
+    ap.add_argument("--clips-per-batch", type=int, default=1, help="clip passes decoded as ONE lock-step batch (7 windows each, at most 4: the decode "
+                    "gemv holds 32 rows); a step stays one clip pass, K steps run as K // C batches plus one batch with the remainder")
     ap.add_argument("--inflight", type=int, default=3, help="clip passes in flight, each on its own context and HIP stream: the decode chain of one "
                     "pass is latency-bound, so the encoder GEMMs and the decode chains of its neighbours run underneath it "
                     "(measured on MI355X: 107 / 74 / 66 / 65 ms per pass with 1 / 2 / 3 / 6 in flight)")
@@ -227,20 +226,22 @@ def main():
             hip_model = binding.HipModel(hp, arena_ptr=arena.data_ptr(), already_filled=True, keepalive=arena)
 
     B = args.windows
-    from whisper_amd.distributed import shard_range
-    G = max(1, min(args.groups, B))
-    pcm_all = torch.from_numpy(synth_pcm(B, seed=100 + rank)).cuda()
-    mel_all = torch.empty((B, hp.n_mels, WINDOW_SAMPLES // 160), dtype=torch.float32, device="cuda")
-    groups = []
-    for g in range(G):
-        b0, b1 = shard_range(B, g, G)
-        groups.append((binding.HipContext(hip_model, b1 - b0), pcm_all[b0:b1], mel_all[b0:b1]))
-    slots = [groups]
-    if args.inflight > 1:
-        if G != 1:
-            raise SystemExit("--inflight needs --groups 1")
-        for _ in range(args.inflight - 1):
-            slots.append([(binding.HipContext(hip_model, B), pcm_all, torch.empty_like(mel_all))])
+    C = max(1, args.clips_per_batch)
+    if B * C > 32:
+        raise SystemExit("windows x clips-per-batch must not exceed 32 (rows of the decode gemv)")
+    n_frames = WINDOW_SAMPLES // 160
+
+    def make_slot(n_clips):
+        """A context for n_clips clip passes in lock step + its inputs; clip j of every slot is the same seeded clip."""
+        pcm = torch.from_numpy(np.concatenate([synth_pcm(B, seed=100 + rank + 1000 * j) for j in range(n_clips)])).cuda()
+        mel = torch.empty((B * n_clips, hp.n_mels, n_frames), dtype=torch.float32, device="cuda")
+        return (binding.HipContext(hip_model, B * n_clips), pcm, mel)
+
+    slots = [make_slot(C) for _ in range(max(1, args.inflight))]
+    n_full, rem = divmod(args.steps, C)
+    rem_slot = make_slot(rem) if rem else None
+    sequence = [slots[i % len(slots)] for i in range(n_full)] + ([rem_slot] if rem_slot else [])
+    groups = [slots[0]]
     torch.cuda.synchronize()
     audio_seconds = CLIP_SECONDS * B / 7.0
 
@@ -253,17 +254,12 @@ def main():
     if rank == 0:
         log("warmup ...")
     for _ in range(args.warmup):
-        for sl in slots:
-            transcribe_clip(sl, prompt, N_GREEDY)
+        run_passes(slots + ([rem_slot] if rem_slot else []), prompt, N_GREEDY, len(slots))
     barrier()
     if rank == 0:
         log("timed region: %d steps ..." % args.steps)
     t0 = time.perf_counter()
-    if args.inflight > 1:
-        toks = transcribe_clips_pipelined([sl[0] for sl in slots], prompt, N_GREEDY, args.steps)
-    else:
-        for _ in range(args.steps):
-            toks = transcribe_clip(groups, prompt, N_GREEDY)
+    toks = run_passes(sequence, prompt, N_GREEDY, len(slots))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -308,7 +304,7 @@ def main():
             ach = dom["bytes"] / (dom_ms * 1e-3) / 1e9
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        roofline.update({"avg_launch_us": round(avg_us, 2), "launches_per_step": dom["calls"],
+        roofline.update({"avg_launch_us": round(avg_us, 2), "launches_per_batch_pass": dom["calls"],
                          "share_of_gpu_time": round(dom["ms"] / total_ms, 3),
                          "algorithmic_per_launch": round((dom["flops"] if roofline["bound"] == "mfma" else dom["bytes"]) / dom["calls"], 1),
                          "timing": "hipEvent pairs around every launch of one lone pass (eager, sum %.1f ms), rescaled by %.3f to the "
@@ -331,9 +327,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, "
-                                   "%d lock-step group(s), %d clip passes in flight on separate HIP streams; GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
-                                   "device-side sampling (captured hipGraph per token)" % (args.model, audio_seconds, B, G, len(slots), N_PROMPT, N_GREEDY),
-                       "model": "ggml-" + args.model, "windows_per_gpu": B, "groups": G, "passes_in_flight": len(slots), "decode_steps_per_window": N_GREEDY + 1,
+                                   "%d clip pass(es) per lock-step batch, %d batches in flight on separate HIP streams; GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
+                                   "device-side sampling (captured hipGraph per token)" % (args.model, audio_seconds, B, C, len(slots), N_PROMPT, N_GREEDY),
+                       "model": "ggml-" + args.model, "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": len(slots), "decode_steps_per_window": N_GREEDY + 1,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,
@@ -342,7 +338,7 @@ def main():
                             "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                         for k, v in kernels.items()},
             "model_build_s": round(t_load, 1),
-            "tokens_checksum": int(np.asarray(toks, np.int64).sum() % 1000003),
+            "tokens_checksum": int(np.asarray(toks, np.int64)[:B].sum() % 1000003),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -42,7 +42,7 @@ def main():
         # single host thread, n in flight
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        bench.transcribe_clips_pipelined(slots[:n], prompt, bench.N_GREEDY, args.clips)
+        bench.run_passes([slots[i % n] for i in range(args.clips)], prompt, bench.N_GREEDY, n)
         torch.cuda.synchronize()
         single = 1e3 * (time.perf_counter() - t0) / args.clips
         # one host thread per context
