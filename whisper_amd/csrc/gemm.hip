@@ -127,12 +127,22 @@ namespace wh
 
 		// Tile configuration: every wave owns a 64x64 sub-tile (2x2 MFMA 32x32x16 tiles), waves are laid out WAVES_M x WAVES_N.
 		// MINW = waves per SIMD the register allocator must leave room for (blocks per CU * waves per block / 4).
-		template<int BM_, int BN_, int BK_, int MINW_, int PF_>
+		// GL = tiles go global -> LDS directly (global_load_lds_dwordx4, no staging registers): the LDS image of a wave's
+		// instruction is lane-linear (base + lane * 16 bytes), so rows are unpadded and the bank-conflict-free placement is
+		// an XOR of the 16-byte chunk index applied to the SOURCE address and again when the fragments are read.
+		// A wave owns TI x TJ MFMA tiles of 32x32 (default 2 x 2 = 64x64); 4 x 2 reads 6 fragments for 8 MFMAs instead of 4 for 4,
+		// which is what the LDS bandwidth of a CU asks for.
+		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2>
 		struct TileCfg
 		{
-			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_;
-			static constexpr int WAVES_M = BM / 64, WAVES_N = BN / 64, NT = WAVES_M * WAVES_N * 64;
-			static constexpr int STRIDE = BK + 8;				 // halfs per LDS row: 144 B (BK 64) / 80 B (BK 32), both conflict free
+			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_;
+			static constexpr bool GL = GL_;
+			static constexpr int WAVES_M = BM / ( 32 * TI ), WAVES_N = BN / ( 32 * TJ ), NT = WAVES_M * WAVES_N * 64;
+			static_assert( GL || ( TI == 2 && TJ == 2 ), "the register-staged path is written for 64x64 wave tiles" );
+			static constexpr int STRIDE = GL ? BK : BK + 8;		 // halfs per LDS row: padded 144 B (BK 64) / 80 B (BK 32) are conflict free
+			static constexpr int RPI = 512 / BK;				 // GL: tile rows one wave instruction covers (1 KB)
+			static constexpr int RPB = 128 / BK;				 // GL: tile rows per 256-byte bank row
+			static constexpr int IA = BM / RPI / ( NT / 64 ), IW = BN / RPI / ( NT / 64 );	 // GL: instructions per wave and tile
 			static constexpr int A_HALFS = BM * STRIDE, W_HALFS = BN * STRIDE, STAGE = A_HALFS + W_HALFS;
 			static constexpr int LDS_BYTES = 2 * STAGE * 2;
 			static constexpr int CPR = BK / 8;					 // 16-byte chunks per tile row
@@ -144,6 +154,204 @@ namespace wh
 		// the two-tile-deep prefetch (PF = 2) measured 3-5 % slower than PF = 1 at every shape.
 		using CfgDefault = TileCfg<128, 128, 32, 3, 1>;
 		using CfgBig = TileCfg<256, 256, 64, 4, 1>;
+		using CfgGl = TileCfg<128, 128, 64, 2, 1, true>;
+
+		// physical position (in halfs) of logical 16-byte chunk c of tile row `row` in a GL tile
+		template<class C>
+		__device__ __forceinline__ int glOffset( int row, int c )
+		{
+			return row * C::BK + ( ( c ^ ( ( row / C::RPB ) % C::CPR ) ) << 3 );
+		}
+
+		// Tile epilogue shared by the staging variants: D[row][col], col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+		// Same arithmetic per element as epilogueOne, organised for the memory system: the row-dependent index math (the
+		// divisions by T) is done once per row instead of once per element, and everything the epilogue READS (residual,
+		// position embedding, bias) is requested -- with clamped, hence unconditional, addresses -- before the first store, so
+		// a wave pays one memory round trip instead of one per element (the residual is updated in place: a load may not be
+		// moved above the preceding store by the compiler).
+		template<int EPI, class C>
+		__device__ __forceinline__ void tileEpilogue( const GemmArgs& a, f32x16 ( &acc )[ C::TI ][ C::TJ ], int tm, int tn, int wm, int wn, int lane )
+		{
+			constexpr int BM = C::BM, BN = C::BN;
+			const int hi = lane >> 5;
+			const int d = a.H * HEAD_DIM;
+			int nn[ C::TJ ];
+			float bias[ C::TJ ];
+#pragma unroll
+			for( int j = 0; j < C::TJ; j++ )
+			{
+				nn[ j ] = tn * BN + wn * 32 * C::TJ + j * 32 + ( lane & 31 );
+				const int nc = nn[ j ] < a.N ? nn[ j ] : a.N - 1;
+				bias[ j ] = a.bias ? a.bias[ nc ] : 0.0f;
+			}
+#pragma unroll
+			for( int i = 0; i < C::TI; i++ )
+			{
+				const int mBase = tm * BM + wm * 32 * C::TI + i * 32 + 4 * hi;
+				if constexpr( EPI == EPI_F32 || EPI == EPI_CONV2 )
+				{
+					long long ro[ 16 ], po[ 16 ];
+#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						int m = mBase + ( r & 3 ) + 8 * ( r >> 2 );
+						m = m < a.M ? m : a.M - 1;
+						if constexpr( EPI == EPI_F32 )
+							ro[ r ] = rowOffset( m, a.Mb, a.ldc, a.cBatchStride );
+						else
+						{
+							const int b = m / a.Mb;
+							ro[ r ] = (long long)m * a.ldc;
+							po[ r ] = (long long)( m - b * a.Mb ) * a.N;
+						}
+					}
+					float ex[ C::TJ ][ 16 ];
+#pragma unroll
+					for( int j = 0; j < C::TJ; j++ )
+					{
+						const int nc = nn[ j ] < a.N ? nn[ j ] : a.N - 1;
+#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							if constexpr( EPI == EPI_F32 )
+								ex[ j ][ r ] = a.res ? a.res[ ro[ r ] + nc ] : 0.0f;
+							else
+								ex[ j ][ r ] = a.pe[ po[ r ] + nc ];
+						}
+					}
+#pragma unroll
+					for( int j = 0; j < C::TJ; j++ )
+					{
+						if( nn[ j ] >= a.N ) continue;
+#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							const int m = mBase + ( r & 3 ) + 8 * ( r >> 2 );
+							if( m >= a.M ) continue;
+							if constexpr( EPI == EPI_F32 )
+								a.out32[ ro[ r ] + nn[ j ] ] = ( acc[ i ][ j ][ r ] + bias[ j ] ) + ex[ j ][ r ];
+							else
+								a.out32[ ro[ r ] + nn[ j ] ] = ex[ j ][ r ] + (float)gelu16( acc[ i ][ j ][ r ] + bias[ j ] );
+						}
+					}
+				}
+				else if constexpr( EPI == EPI_F16_GELU )
+				{
+#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const int m = mBase + ( r & 3 ) + 8 * ( r >> 2 );
+						if( m >= a.M ) continue;
+						const long long ro = rowOffset( m, a.Mb, a.ldc, a.cBatchStride );
+#pragma unroll
+						for( int j = 0; j < C::TJ; j++ )
+							if( nn[ j ] < a.N ) a.out16[ ro + nn[ j ] ] = gelu16( acc[ i ][ j ][ r ] + bias[ j ] );
+					}
+				}
+				else if constexpr( EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV )
+				{
+					// column-dependent part of the destination, once per j
+					int sel[ C::TJ ];
+					long long colOff[ C::TJ ];
+#pragma unroll
+					for( int j = 0; j < C::TJ; j++ )
+					{
+						const int n = nn[ j ] < a.N ? nn[ j ] : a.N - 1;
+						if constexpr( EPI == EPI_QKV_ENC )
+						{
+							sel[ j ] = n / d;
+							const int c = n - sel[ j ] * d;
+							colOff[ j ] = (long long)( c >> 6 ) * ( sel[ j ] == 2 ? (long long)HEAD_DIM * a.Tpad : (long long)a.T * HEAD_DIM ) + ( sel[ j ] == 2 ? 0 : ( c & 63 ) );
+						}
+						else
+						{
+							const int layer = n / ( 2 * d );
+							const int c2 = n - layer * 2 * d;
+							sel[ j ] = c2 >= d ? 1 : 0;
+							const int c = sel[ j ] ? c2 - d : c2;
+							colOff[ j ] = ( (long long)layer * a.B * a.H + ( c >> 6 ) ) * a.T * HEAD_DIM + ( c & 63 );
+						}
+					}
+					const bool packT = ( a.T & 3 ) == 0;
+#pragma unroll
+					for( int g = 0; g < 4; g++ )
+					{
+						// rows mBase + 8 g + {0,1,2,3}: 4 consecutive time steps of one sequence when T % 4 == 0
+						const int m0 = mBase + 8 * g;
+						const int mc = m0 < a.M ? m0 : a.M - 1;
+						const int b0 = mc / a.T;
+						const int t0 = mc - b0 * a.T;
+#pragma unroll
+						for( int j = 0; j < C::TJ; j++ )
+						{
+							if( nn[ j ] >= a.N ) continue;
+							if constexpr( EPI == EPI_QKV_ENC )
+							{
+								if( sel[ j ] == 2 && packT )
+								{
+									// fragment-major V: the 4 rows are 4 consecutive keys = 4 consecutive halfs of one fragment
+									if( m0 < a.M )
+									{
+										const int c = nn[ j ] - 2 * d;
+										f16x4 pk;
+#pragma unroll
+										for( int e = 0; e < 4; e++ ) pk[ e ] = (f16)( acc[ i ][ j ][ 4 * g + e ] + bias[ j ] );
+										*(f16x4*)( a.v + (long long)b0 * a.H * HEAD_DIM * a.Tpad + colOff[ j ] + vFragIndex( t0, c & 63 ) ) = pk;
+									}
+									continue;
+								}
+							}
+#pragma unroll
+							for( int e = 0; e < 4; e++ )
+							{
+								const int m = m0 + e;
+								if( m >= a.M ) continue;
+								int b = b0, t = t0 + e;
+								if( !packT && t >= a.T )
+								{
+									b = m / a.T;
+									t = m - b * a.T;
+								}
+								const float v = acc[ i ][ j ][ 4 * g + e ];
+								if constexpr( EPI == EPI_QKV_ENC )
+								{
+									const float x = v + bias[ j ];
+									if( sel[ j ] == 0 )
+										a.q[ ( (long long)b * a.H * a.T + t ) * HEAD_DIM + colOff[ j ] ] = (f16)x;
+									else if( sel[ j ] == 1 )
+										a.k[ ( (long long)b * a.H * a.T + t ) * HEAD_DIM + colOff[ j ] ] = (f16)x;
+									else
+										a.v[ (long long)b * a.H * HEAD_DIM * a.Tpad + colOff[ j ] + vFragIndex( t, ( nn[ j ] - 2 * d ) & 63 ) ] = (f16)x;
+								}
+								else
+								{
+									const long long o = ( (long long)b * a.H * a.T + t ) * HEAD_DIM + colOff[ j ];
+									if( sel[ j ] )
+										a.v[ o ] = (f16)( v + bias[ j ] );
+									else
+										a.k[ o ] = (f16)( v * a.scale );
+								}
+							}
+						}
+					}
+				}
+				else
+				{
+#pragma unroll
+					for( int j = 0; j < C::TJ; j++ )
+					{
+						if( nn[ j ] >= a.N ) continue;
+#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							const int m = mBase + ( r & 3 ) + 8 * ( r >> 2 );
+							if( m < a.M )
+								epilogueOne<EPI>( a, m, nn[ j ], acc[ i ][ j ][ r ] );
+						}
+					}
+				}
+			}
+		}
 
 		template<int EPI, class C>
 		__global__ void __launch_bounds__( C::NT, C::MINW ) gemmTiled( const GemmArgs a )
@@ -169,6 +377,85 @@ namespace wh
 			const int tm = lin / tilesN;
 			const int tn = lin - tm * tilesN;
 
+			if constexpr( C::GL )
+			{
+				// ---- direct-to-LDS pipeline: one barrier per K step, tile kt+1 lands while tile kt is multiplied ----
+				const f16* gA[ C::IA ];
+				const f16* gW[ C::IW ];
+				const int rIn = lane / C::CPR, cPhys = lane % C::CPR;
+#pragma unroll
+				for( int i = 0; i < C::IA; i++ )
+				{
+					const int row = ( wave * C::IA + i ) * C::RPI + rIn;
+					const int c = cPhys ^ ( ( row / C::RPB ) % C::CPR );
+					int m = tm * BM + row;
+					m = m < a.M ? m : a.M - 1;
+					gA[ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + c * 8;
+				}
+#pragma unroll
+				for( int i = 0; i < C::IW; i++ )
+				{
+					const int row = ( wave * C::IW + i ) * C::RPI + rIn;
+					const int c = cPhys ^ ( ( row / C::RPB ) % C::CPR );
+					int n = tn * BN + row;
+					n = n < a.N ? n : a.N - 1;
+					gW[ i ] = a.W + (long long)n * a.K + c * 8;
+				}
+				f32x16 acc[ C::TI ][ C::TJ ];
+#pragma unroll
+				for( int i = 0; i < C::TI; i++ )
+#pragma unroll
+					for( int j = 0; j < C::TJ; j++ )
+#pragma unroll
+						for( int r = 0; r < 16; r++ )
+							acc[ i ][ j ][ r ] = 0.0f;
+				const int nk = a.K / BK;
+				const int fragRow = lane & 31;
+				const int fragC = lane >> 5;
+				typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+				typedef const __attribute__( ( address_space( 1 ) ) ) void* GlobalPtr;
+				auto issue = [ & ]( int kt, int buf )
+				{
+					f16* const dstA = lds + buf * C::STAGE + wave * C::IA * C::RPI * BK;
+					f16* const dstW = lds + buf * C::STAGE + C::A_HALFS + wave * C::IW * C::RPI * BK;
+					const int ko = kt * BK;
+#pragma unroll
+					for( int i = 0; i < C::IA; i++ )
+						__builtin_amdgcn_global_load_lds( (GlobalPtr)( gA[ i ] + ko ), (LdsPtr)( dstA + i * C::RPI * BK ), 16, 0, 0 );
+#pragma unroll
+					for( int i = 0; i < C::IW; i++ )
+						__builtin_amdgcn_global_load_lds( (GlobalPtr)( gW[ i ] + ko ), (LdsPtr)( dstW + i * C::RPI * BK ), 16, 0, 0 );
+				};
+				issue( 0, 0 );
+				for( int kt = 0; kt < nk; kt++ )
+				{
+					const int buf = kt & 1;
+					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+					__syncthreads();
+					if( kt + 1 < nk ) issue( kt + 1, buf ^ 1 );
+					const f16* const ldsA = lds + buf * C::STAGE;
+					const f16* const ldsW = ldsA + C::A_HALFS;
+#pragma unroll
+					for( int ks = 0; ks < BK / 16; ks++ )
+					{
+						f16x8 fa[ C::TI ], fb[ C::TJ ];
+#pragma unroll
+						for( int i = 0; i < C::TI; i++ )
+							fa[ i ] = *(const f16x8*)( ldsA + glOffset<C>( wm * 32 * C::TI + i * 32 + fragRow, ks * 2 + fragC ) );
+#pragma unroll
+						for( int j = 0; j < C::TJ; j++ )
+							fb[ j ] = *(const f16x8*)( ldsW + glOffset<C>( wn * 32 * C::TJ + j * 32 + fragRow, ks * 2 + fragC ) );
+#pragma unroll
+						for( int i = 0; i < C::TI; i++ )
+#pragma unroll
+							for( int j = 0; j < C::TJ; j++ )
+								acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ], fb[ j ], acc[ i ][ j ], 0, 0, 0 );
+					}
+				}
+				tileEpilogue<EPI, C>( a, acc, tm, tn, wm, wn, lane );
+			}
+			else
+			{
 			// global -> register staging: CA / CW chunks of 16 bytes per thread
 			const f16* gA[ C::CA ];
 			const f16* gW[ C::CW ];
@@ -291,54 +578,7 @@ namespace wh
 				}
 			}
 
-			// epilogue: D[row][col], col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-			const int hi = lane >> 5;
-#pragma unroll
-			for( int i = 0; i < 2; i++ )
-			{
-#pragma unroll
-				for( int j = 0; j < 2; j++ )
-				{
-					const int n = tn * BN + wn * 64 + j * 32 + ( lane & 31 );
-					const int mBase = tm * BM + wm * 64 + i * 32 + 4 * hi;
-					const bool nOk = n < a.N;
-					bool packedV = false;
-					if constexpr( EPI == EPI_QKV_ENC )
-						packedV = nOk && n >= 2 * a.H * HEAD_DIM && ( a.T & 3 ) == 0;
-					if( packedV )
-					{
-						// fragment-major V: the 4 rows (r & 3) are 4 consecutive keys = 4 consecutive halfs of one fragment
-						const int c = n - 2 * a.H * HEAD_DIM;
-						const int h = c >> 6, dd = c & 63;
-						const float bias = a.bias[ n ];
-#pragma unroll
-						for( int g = 0; g < 4; g++ )
-						{
-							const int m0 = mBase + 8 * g;
-							if( m0 < a.M )
-							{
-								const int b = m0 / a.T;
-								const int t = m0 - b * a.T;
-								f16x4 pk;
-								pk[ 0 ] = (f16)( acc[ i ][ j ][ 4 * g + 0 ] + bias );
-								pk[ 1 ] = (f16)( acc[ i ][ j ][ 4 * g + 1 ] + bias );
-								pk[ 2 ] = (f16)( acc[ i ][ j ][ 4 * g + 2 ] + bias );
-								pk[ 3 ] = (f16)( acc[ i ][ j ][ 4 * g + 3 ] + bias );
-								*(f16x4*)( a.v + ( (long long)b * a.H + h ) * HEAD_DIM * a.Tpad + vFragIndex( t, dd ) ) = pk;
-							}
-						}
-					}
-					else if( nOk )
-					{
-#pragma unroll
-						for( int r = 0; r < 16; r++ )
-						{
-							const int m = mBase + ( r & 3 ) + 8 * ( r >> 2 );
-							if( m < a.M )
-								epilogueOne<EPI>( a, m, n, acc[ i ][ j ][ r ] );
-						}
-					}
-				}
+			tileEpilogue<EPI, C>( a, acc, tm, tn, wm, wn, lane );
 			}
 		}
 
@@ -680,6 +920,15 @@ namespace wh
 	{
 		switch( variant )
 		{
+		case 10: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 1, true>>( a, stream );
+		case 11: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true>>( a, stream );
+		case 12: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true>>( a, stream );
+		case 13: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1, true>>( a, stream );
+		case 14: return launchTiledT<EPI_F32, TileCfg<256, 128, 32, 2, 1, true, 4, 2>>( a, stream );
+		case 15: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 1, 1, true, 4, 2>>( a, stream );
+		case 16: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 2, 1, true, 4, 2>>( a, stream );
+		case 17: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 2, 1, true, 4, 2>>( a, stream );
+		case 18: return launchTiledT<EPI_F32, TileCfg<128, 256, 32, 2, 1, true, 2, 4>>( a, stream );
 		case 0: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 2>>( a, stream );
 		case 9: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );
 		case 1: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 1>>( a, stream );
@@ -723,18 +972,24 @@ namespace wh
 	int launchGemm( const GemmArgs& a, hipStream_t stream )
 	{
 		WH_CHECK( checkArgs( a ) );
-		// big tiles only when they still give every CU a workgroup
-		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && ( g_tuning & TUNE_GEMM_BIG );
+		// big tiles only when they still give every CU a workgroup and M is several clips deep
+		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
+		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
+#define WH_TILED( E )                                                    \
+	if( gl ) return launchTiledT<E, CfgGl>( a, stream );                 \
+	if( big ) return launchTiledT<E, CfgBig>( a, stream );               \
+	return launchTiledT<E>( a, stream );
 		switch( a.epi )
 		{
-		case EPI_F32: return big ? launchTiledT<EPI_F32, CfgBig>( a, stream ) : launchTiledT<EPI_F32>( a, stream );
-		case EPI_F16_GELU: return big ? launchTiledT<EPI_F16_GELU, CfgBig>( a, stream ) : launchTiledT<EPI_F16_GELU>( a, stream );
-		case EPI_CONV2: return launchTiledT<EPI_CONV2>( a, stream );
-		case EPI_QKV_ENC: return big ? launchTiledT<EPI_QKV_ENC, CfgBig>( a, stream ) : launchTiledT<EPI_QKV_ENC>( a, stream );
-		case EPI_CROSS_KV: return big ? launchTiledT<EPI_CROSS_KV, CfgBig>( a, stream ) : launchTiledT<EPI_CROSS_KV>( a, stream );
-		case EPI_QKV_DEC: return launchTiledT<EPI_QKV_DEC>( a, stream );
-		case EPI_Q_DEC: return launchTiledT<EPI_Q_DEC>( a, stream );
+		case EPI_F32: WH_TILED( EPI_F32 )
+		case EPI_F16_GELU: WH_TILED( EPI_F16_GELU )
+		case EPI_CONV2: if( gl ) return launchTiledT<EPI_CONV2, CfgGl>( a, stream ); return launchTiledT<EPI_CONV2>( a, stream );
+		case EPI_QKV_ENC: WH_TILED( EPI_QKV_ENC )
+		case EPI_CROSS_KV: WH_TILED( EPI_CROSS_KV )
+		case EPI_QKV_DEC: if( gl ) return launchTiledT<EPI_QKV_DEC, CfgGl>( a, stream ); return launchTiledT<EPI_QKV_DEC>( a, stream );
+		case EPI_Q_DEC: if( gl ) return launchTiledT<EPI_Q_DEC, CfgGl>( a, stream ); return launchTiledT<EPI_Q_DEC>( a, stream );
 		}
+#undef WH_TILED
 		setError( "gemm: unknown epilogue" );
 		return -1;
 	}
