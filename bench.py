@@ -172,15 +172,16 @@ def cpu_baseline(model, model_kind, pcm_one_window, prompt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="medium")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--clips-per-batch", type=int, default=1, help="clip passes decoded as ONE lock-step batch (7 windows each, at most 4: the decode "
+    ap.add_argument("--clips-per-batch", type=int, default=4, help="clip passes decoded as ONE lock-step batch (7 windows each, at most 4: the decode "
                     "gemv holds 32 rows); a step stays one clip pass, K steps run as K // C batches plus one batch with the remainder")
     ap.add_argument("--inflight", type=int, default=3, help="clip passes in flight, each on its own context and HIP stream: the decode chain of one "
                     "pass is latency-bound, so the encoder GEMMs and the decode chains of its neighbours run underneath it "
-                    "(measured on MI355X: 107 / 74 / 66 / 65 ms per pass with 1 / 2 / 3 / 6 in flight)")
+                    "(measured on MI355X, one clip per batch: 107 / 74 / 66 / 65 ms per pass with 1 / 2 / 3 / 6 in flight; four clips "
+                    "per batch: 62.6 / 48.8 / 45.6 with 1 / 2 / 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -154,7 +154,8 @@ namespace wh
 		// the two-tile-deep prefetch (PF = 2) measured 3-5 % slower than PF = 1 at every shape.
 		using CfgDefault = TileCfg<128, 128, 32, 3, 1>;
 		using CfgBig = TileCfg<256, 256, 64, 4, 1>;
-		using CfgGl = TileCfg<128, 128, 64, 2, 1, true>;
+		using CfgGl = TileCfg<128, 128, 32, 3, 1, true>;
+		using CfgGlBig = TileCfg<256, 256, 64, 4, 1, true>;
 
 		// physical position (in halfs) of logical 16-byte chunk c of tile row `row` in a GL tile
 		template<class C>
@@ -976,6 +977,7 @@ namespace wh
 		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
 #define WH_TILED( E )                                                    \
+	if( gl && big ) return launchTiledT<E, CfgGlBig>( a, stream );       \
 	if( gl ) return launchTiledT<E, CfgGl>( a, stream );                 \
 	if( big ) return launchTiledT<E, CfgBig>( a, stream );               \
 	return launchTiledT<E>( a, stream );

@@ -885,7 +885,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
 	const int* const nPastDev = devState ? &c->state->nPast : nullptr;
 	const bool gemv = M <= 32 && ( d % 128 ) == 0;
-	const bool fuseLn = gemv && d <= 1280;
+	const bool fuseLn = gemv && d <= 1280 && !( M > 16 && ( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
 
 	auto product = [ & ]( GemmArgs& g, const float* lnW, const float* lnB ) -> int
 	{
