@@ -183,6 +183,8 @@ def main():
                     "(measured on MI355X, one clip per batch: 107 / 74 / 66 / 65 ms per pass with 1 / 2 / 3 / 6 in flight; four clips "
                     "per batch: 62.6 / 48.8 / 45.6 with 1 / 2 / 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in a dry run)")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device for this rank (default LOCAL_RANK)")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -193,12 +195,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.device >= 0:
+        local = args.device
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     binding.check(binding.lib().wh_device_set(local))
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     hp = gf.hparams_for(args.model)
     sp = gf.special_tokens(hp)
@@ -312,11 +319,11 @@ def main():
                                    "%.1f ms the same pass takes from the captured graph" % (total_ms, scale, graph_ms)})
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if model is None:
             model = gf.synth_model(args.model, seed=1)
         log("cpu baseline (reference CPU path, bounded) ...")
-        cpu = cpu_baseline(model, args.model, pcm_all[0].cpu().numpy(), prompt)
+        cpu = cpu_baseline(model, args.model, slots[0][1][0].cpu().numpy(), prompt)
         log("cpu baseline done: %s" % cpu.get("value"))
 
     if rank == 0:
