@@ -14,10 +14,11 @@ namespace wh
 		TUNE_GEMV_SMALLREG = 32,	 // 8-slot gemv instance when a wave's K slice fits (fewer registers, same loads in flight)
 		TUNE_GEMM_GL = 64,		 // tiled GEMM stages its tiles global -> LDS directly (128x128x64, swizzled source)
 		TUNE_LN_SEPARATE_BIGM = 128,	 // more than 16 decode rows: LayerNorm as its own launch instead of 192-256 redundant prologues
+		TUNE_ATTN_XCD = 256,		 // encoder attention: the query blocks of one (sequence, head) run on one XCD
 		// measured in one process on one MI355X (tools/ab_bench.py, profiles/r01_ab_variants.txt), ms per clip pass:
 		// rows4 -1.1, splitCross +6.7 (since attentionDec hoists its loads), gemmBig +1.0, crossPrefetch +1.5 => only rows4.
 		// Retired after measuring: 8-wave LayerNorm prologue (+3.4, spills), rows4 for K = d (+0.5).
-		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD
 	};
 	extern unsigned g_tuning;
 
