@@ -312,6 +312,16 @@ def main():
             ach = dom["bytes"] / (dom_ms * 1e-3) / 1e9
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 cannot run inside this process):
+        # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of the eager single-token decode steps, tools/pmc_probe.py
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("kernel") == name:
+                roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
+                roofline["traffic_source"] = pmc["source"] + " (" + pmc["note"] + ")"
+        except (OSError, ValueError, KeyError):
+            pass
         roofline.update({"avg_launch_us": round(avg_us, 2), "launches_per_batch_pass": dom["calls"],
                          "share_of_gpu_time": round(dom["ms"] / total_ms, 3),
                          "algorithmic_per_launch": round((dom["flops"] if roofline["bound"] == "mfma" else dom["bytes"]) / dom["calls"], 1),

@@ -72,7 +72,11 @@ WH_API int wh_model_hparams( const wh_model* m, wh_hparams* out );
 /* ---- context (replaces DirectCompute::WhisperContext, Whisper/Whisper/WhisperContext.h:20-140) ----
  * One context owns activations, the FP16 self- and cross-attention KV caches (KeyValueBuffers.h:7-53) for up to
  * maxBatch independent 30 s windows that are processed in lock step, and its workspace.  Single-threaded use,
- * like the reference (Whisper/ML/Device.cpp:163-177). */
+ * like the reference (Whisper/ML/Device.cpp:163-177); several contexts of one model may be driven concurrently (each
+ * has its own stream): a decode step is a chain of small dependent launches, so the work of other contexts runs
+ * underneath it.  Sizing: a decode step costs about the same for 1 and for 32 windows (the weight-streaming kernel
+ * holds up to 32 rows), beyond 32 the decoder falls back to the tiled GEMM; 28 windows (four 198 s clips) per context
+ * and three contexts in flight is what bench.py measures. */
 typedef struct wh_context wh_context;
 
 typedef enum wh_flags

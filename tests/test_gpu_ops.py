@@ -144,7 +144,8 @@ def test_soft_max(rows, cols):
     assert d.max() < 1e-3 * want.max() and (d > 0).mean() < 0.01
 
 
-@pytest.mark.parametrize("batch,heads,T", [(1, 2, 1500), (2, 3, 200), (1, 1, 64), (1, 2, 777)])
+@pytest.mark.parametrize("batch,heads,T", [(1, 2, 1500), (2, 3, 200), (1, 1, 64), (1, 2, 777),
+                                           (2, 4, 300), (4, 6, 130)])        # batch x heads a multiple of 8: XCD-grouped block order
 def test_flash_attention(batch, heads, T):
     """Unmasked encoder attention against ggml_flash_attn_f16 semantics (ggml.c:5912-6097)."""
     rng = np.random.default_rng(T)

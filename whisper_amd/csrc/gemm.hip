@@ -4,14 +4,18 @@
 // reference, with the numerics of the reference's CPU path: activations are FP16 (rounded by the producer, which is
 // what ggml does before every weight product, Whisper/source/ggml.c:4588-4611), weights FP16, accumulation FP32.
 //
-// gemmTiled: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA tiles), BK = 64,
-//   register-staged global->LDS double buffering, one barrier per K step. LDS rows are padded to 72 halfs (144 B):
-//   with the 32x32x16 operand layout (lane l reads row l&31, halfs (l>>5)*8..+8) every ds_read_b128 lane group then
-//   hits 16 distinct 16-byte slots of the 256-byte bank row, i.e. conflict free.
+// gemmTiled<EPI, TileCfg>: every wave owns a 64x64 output sub-tile (2x2 MFMA tiles); a workgroup is 128x128x32 (4 waves,
+//   3 workgroups per CU) or, for GEMMs several clips deep, 256x256x64 (16 waves). Tiles go global -> LDS directly
+//   (global_load_lds_dwordx4, double buffered, one barrier per K step): the LDS image of such a load is lane-linear, so
+//   rows are unpadded and the conflict-free placement is an XOR of the 16-byte chunk index with the row, applied to the
+//   per-lane SOURCE address and again when the 32x32x16 fragments are read (lane l reads row l&31, chunk (l>>5)). The
+//   register-staged pipeline with padded rows (144 B / 80 B, conflict free as well) is kept as the A/B alternative.
 //   Block ids are remapped so that each XCD (block id % 8) owns a contiguous band of M tiles: the band's A rows are
 //   fetched from HBM once per XCD and stay in that XCD's 4 MiB L2 while the (small) weight matrix is re-read from L2.
-// gemmSkinny: M <= 32 rows (decode steps). The weight matrix is the MFMA A operand (32 rows per workgroup), the few
-//   activation rows are the B operand; 4 waves split K and reduce through LDS. Weights are streamed exactly once.
+//   The epilogue requests everything it reads before its first store and does the per-row index math once per row.
+// gemmSkinny: M <= 32 rows when K is not a multiple of 128. The weight matrix is the MFMA A operand (32 rows per
+//   workgroup), the few activation rows are the B operand; 4 waves split K and reduce through LDS.
+// gemvFused: the decode-step kernel, up to 32 activation rows (see below).
 #include "kernels.h"
 #include <type_traits>
 
@@ -655,7 +659,7 @@ namespace wh
 					epilogueOne<EPI>( a, mm, nn, acc[ r ] );
 			}
 		}
-		// ---- gemv: M <= 16 activation rows (single-token decode steps of a lock-step batch) ----
+		// ---- gemv: M <= 32 activation rows (single-token decode steps of a lock-step batch; MT = 2 above 16 rows) ----
 		// HBM/latency-bound: the only thing that matters is how many weight bytes are in flight. 16 weight rows per
 		// workgroup (N/16 workgroups), 4 waves split K, and every wave issues ALL of its weight loads (16 bytes per lane
 		// each, up to GV_UNROLL (8 or 16) at a time) before the first MFMA consumes one. v_mfma_f32_16x16x32_f16: A = 16 weight rows,

@@ -74,8 +74,9 @@ namespace wh
 	};
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
-	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream );	// M <= 32 rows (decode steps): weights streamed once
-	// M <= 16 rows, 16 weight rows per workgroup, every load of a wave in flight at once, optional fused LayerNorm prologue
+	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream );	// M <= 32 rows, any K % 64 == 0: weights streamed once
+	// M <= 32 rows, K % 128 == 0: 16 (or 4) weight rows per workgroup, every load of a wave in flight at once, optional
+	// fused LayerNorm prologue; the decode-step kernel
 	int launchGemv( const GemmArgs& a, hipStream_t stream );
 	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream );	// tile-shape experiments, EPI_F32 only
 	int gemmInit();													// one-time function attributes
