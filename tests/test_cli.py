@@ -1,0 +1,94 @@
+"""whisper-main, the command-line tool over libWhisper.so (whisper_amd/host/cli): the counterpart of the reference's
+Examples/main (main.cpp:174-330, params.cpp, textWriter.cpp).
+
+CPU tests: option handling and exit codes, and the .txt / .srt / .vtt writers byte for byte (UTF-8 BOM, CRLF, hh:mm:ss.mmm
+with hours running past 24, leading blanks of a segment dropped -- textWriter.cpp:52-63, 96-190).
+GPU test: a scripted model + a WAV file through the tool must print and write the segments the reference's whisper_full
+produced for that model (tests/golden/ref_hostloop.json)."""
+import json
+import os
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from whisper_amd import build, ggml_format as gf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "ref_hostloop.json")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(build.CLI_BIN):
+        build.build_all()
+    return build.CLI_BIN
+
+
+def run(exe, *args):
+    return subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+
+
+def stamp(t10ms, comma=False):
+    ms = t10ms * 10
+    return "%02d:%02d:%02d%s%03d" % (ms // 3600000, ms // 60000 % 60, ms // 1000 % 60, "," if comma else ".", ms % 1000)
+
+
+def test_writers_byte_for_byte(exe, tmp_path):
+    prefix = str(tmp_path / "sample")
+    assert run(exe, "--format-sample", prefix).returncode == 0
+    bom = b"\xef\xbb\xbf"
+    t = [("00:00:00.000", "00:00:03.600", "And so my fellow Americans,"),
+         ("00:00:03.600", "01:02:03.456", "ask not what your country can do for you"),
+         ("25:01:01.001", "25:01:01.999", "ask what you can do for your country.")]
+    txt = bom + b"".join(("[%s --> %s]  %s\r\n" % x).encode() for x in t)
+    assert open(prefix + ".txt", "rb").read() == txt
+    assert open(prefix + ".nostamps.txt", "rb").read() == bom + b"".join((x[2] + "\r\n").encode() for x in t)
+    srt = bom + b"".join(("%d\r\n%s --> %s\r\n%s\r\n\r\n" % (i + 1, a.replace(".", ","), b.replace(".", ","), c)).encode()
+                         for i, (a, b, c) in enumerate(t))
+    assert open(prefix + ".srt", "rb").read() == srt
+    vtt = bom + b"WEBVTT\r\n\r\n" + b"".join(("%s --> %s\r\n%s\r\n\r\n" % x).encode() for x in t)
+    assert open(prefix + ".vtt", "rb").read() == vtt
+
+
+def test_options_and_exit_codes(exe, tmp_path):
+    r = run(exe, "--help")
+    assert r.returncode == 1 and b"--output-srt" in r.stderr and b"--max-context" in r.stderr
+    assert run(exe).returncode == 2                                   # no input files
+    assert run(exe, "-l", "xx", "a.wav").returncode == 3              # unknown language
+    assert run(exe, "--bogus").returncode == 1
+    assert run(exe, "-t").returncode == 1                             # missing value
+    r = run(exe, "-m", str(tmp_path / "missing.bin"), "a.wav")
+    assert r.returncode == 4 and b"failed to load the model" in r.stderr
+
+
+@pytest.mark.gpu
+def test_transcribes_like_the_reference_host_loop(exe, tmp_path):
+    case = [c for c in json.load(open(GOLDEN))["cases"] if c["name"] == "first_window_no_prompt"][0]
+    model = str(tmp_path / "m.bin")
+    gf.write_model(model, gf.scripted_model(case["script"], case["prompt_len"]))
+    rng = np.random.default_rng(case["pcm_seed"])
+    pcm = (0.05 * rng.standard_normal(case["n_samples"])).astype(np.float32)
+    wav = str(tmp_path / "clip.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2").tobytes())
+    r = run(exe, "-m", model, "-f", wav, "-l", case["lang"], "-nc", "-otxt", "-osrt", "-ovtt")
+    print(r.stdout.decode(), r.stderr.decode()[-2000:])
+    assert r.returncode == 0
+    segs = case["segments"]
+    want_console = "\n" + "".join("[%s --> %s]  %s\n" % (stamp(s["t0"]), stamp(s["t1"]), s["text"]) for s in segs)
+    assert r.stdout.decode() == want_console
+    bom = b"\xef\xbb\xbf"
+    base = str(tmp_path / "clip")
+    assert open(base + ".txt", "rb").read() == bom + b"".join(
+        ("[%s --> %s]  %s\r\n" % (stamp(s["t0"]), stamp(s["t1"]), s["text"].lstrip(" \t"))).encode() for s in segs)
+    assert open(base + ".srt", "rb").read() == bom + b"".join(
+        ("%d\r\n%s --> %s\r\n%s\r\n\r\n" % (i + 1, stamp(s["t0"], True), stamp(s["t1"], True), s["text"].lstrip(" \t"))).encode()
+        for i, s in enumerate(segs))
+    assert open(base + ".vtt", "rb").read() == bom + b"WEBVTT\r\n\r\n" + b"".join(
+        ("%s --> %s\r\n%s\r\n\r\n" % (stamp(s["t0"]), stamp(s["t1"]), s["text"].lstrip(" \t"))).encode() for s in segs)
+    assert b"RunComplete" in r.stderr                # timingsPrint, block names of the reference's profiler output

@@ -18,6 +18,7 @@ HOST = os.path.join(HERE, "host")
 LIB_DIR = os.path.join(HERE, "lib")
 HIP_LIB = os.path.join(LIB_DIR, "libwhisper_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "libWhisper.so")
+CLI_BIN = os.path.join(LIB_DIR, "whisper-main")
 
 HIP_SOURCES = ["gemm.hip", "attn_enc.hip", "attn_dec.hip", "elementwise.hip", "mel.hip", "runtime.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -73,10 +74,24 @@ def build_host(force: bool = False):
     return HOST_LIB
 
 
+def build_cli(force: bool = False):
+    """whisper-main: the command-line tool over libWhisper.so (counterpart of the reference's Examples/main)."""
+    cli = os.path.join(HOST, "cli")
+    if not os.path.isdir(cli):
+        return None
+    srcs = sorted(os.path.join(cli, f) for f in os.listdir(cli) if f.endswith(".cpp"))
+    hdrs = [os.path.join(cli, f) for f in os.listdir(cli) if f.endswith(".h")] + [os.path.join(ROOT, "include", "whisperApi.h")]
+    if force or _newer(CLI_BIN, srcs + hdrs + [HOST_LIB]):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + cli, "-o", CLI_BIN] + srcs +
+             ["-L" + LIB_DIR, "-lWhisper", "-Wl,-rpath,$ORIGIN"])
+    return CLI_BIN
+
+
 def build_all(force: bool = False):
     t = time.time()
     build_hip(force)
     build_host(force)
+    build_cli(force)
     print("native build ok in %.1fs" % (time.time() - t), flush=True)
 
 
