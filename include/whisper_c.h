@@ -33,6 +33,9 @@ int32_t whisperc_result_segment( void* ctx, uint32_t index, uint64_t* t0, uint64
 int32_t whisperc_result_token( void* ctx, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum );
 /* iContext::timingsPrint */
 int32_t whisperc_timings_print( void* ctx );
+/* One line of the profiler output, formatted like ProfileCollection::Measure::print (Whisper/Utils/ProfileCollection.cpp:113-170):
+ * `ticks` of 100 ns scaled to seconds / milliseconds / microseconds. Returns the length written (without the terminator). */
+int32_t whisperc_format_measure( const char* name, double ticks, uint64_t count, char* out, uint32_t outCap );
 /* Process-wide choice between the two host loops the reference ships: 0 (default) = its CPU model's whisper_full
  * (Whisper/source/whisper.cpp:2765-3120: drops the past prompt when < 5 s remain, retries a failed window once without it),
  * 1 = its GPU model's ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:452-793: neither rule). */

@@ -26,8 +26,9 @@ def exe():
     return build.CLI_BIN
 
 
-def run(exe, *args):
-    return subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+def run(exe, *args, env=None):
+    return subprocess.run([exe] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120,
+                          env=dict(os.environ, **env) if env else None)
 
 
 def stamp(t10ms, comma=False):
@@ -91,4 +92,15 @@ def test_transcribes_like_the_reference_host_loop(exe, tmp_path):
         for i, s in enumerate(segs))
     assert open(base + ".vtt", "rb").read() == bom + b"WEBVTT\r\n\r\n" + b"".join(
         ("%s --> %s\r\n%s\r\n\r\n" % (stamp(s["t0"]), stamp(s["t1"]), s["text"].lstrip(" \t"))).encode() for s in segs)
-    assert b"RunComplete" in r.stderr                # timingsPrint, block names of the reference's profiler output
+    # timingsPrint: sections and block names of the reference's profiler output (SampleClips/*.txt)
+    err = r.stderr.decode()
+    for needle in ("    CPU Tasks", "RunComplete\t", "Spectrogram\t", "Encode\t", "Decode\t", "DecodeStep\t", "    Memory Usage", "Model\t", "Context\t", "Total\t"):
+        assert needle in err, needle
+    assert "Compute Shaders" not in err
+    # WHISPER_PROFILE=1 adds the per-kernel table (eager launches with event pairs); the transcript does not change
+    r2 = run(exe, "-m", model, "-f", wav, "-l", case["lang"], "-nc", env={"WHISPER_PROFILE": "1"})
+    assert r2.returncode == 0 and r2.stdout == r.stdout
+    err2 = r2.stderr.decode()
+    table = err2[err2.index("    Compute Shaders"):err2.index("    Memory Usage")].splitlines()[1:]
+    assert any(t.startswith("gemvFused\t") for t in table) and any(t.startswith("attentionEnc\t") for t in table)
+    assert all(" calls, " in t or t.endswith("seconds") for t in table)

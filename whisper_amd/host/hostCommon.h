@@ -34,6 +34,14 @@ namespace Whisper
 
 	std::string utf8( const wchar_t* w );
 
+	// ================================================================================================================
+	// profiler output -- one line per measure, the format of ProfileCollection::Measure::print
+	// (Whisper/Utils/ProfileCollection.cpp:113-170): time in 100 ns ticks scaled to seconds / milliseconds / microseconds,
+	// "%g"; a measure taken once prints only its total, otherwise "total, N calls, avg average"
+	std::string formatMeasure( const char* name, double ticks, uint64_t count );
+	// "877.966 KB" / "1.42785 GB": bytes scaled by 1024 steps, "%g"
+	std::string formatBytes( double bytes );
+
 	// ---- intrusive ref-counting for the COM-style objects (the role of ComLight::ObjectRoot / Object<T>) ----
 	template<class I>
 	class ComObject : public I

@@ -10,6 +10,48 @@
 namespace Whisper
 {
 	// ================================================================================================================
+	// profiler output
+	namespace
+	{
+		struct ScaledTime
+		{
+			double value;
+			const char* unit;
+			explicit ScaledTime( double ticks )
+			{
+				if( ticks >= 1.0e7 ) { value = ticks / 1.0e7; unit = "seconds"; }
+				else if( ticks >= 1.0e4 ) { value = ticks / 1.0e4; unit = "milliseconds"; }
+				else { value = ticks / 10.0; unit = "microseconds"; }
+			}
+		};
+	}
+
+	std::string formatMeasure( const char* name, double ticks, uint64_t count )
+	{
+		char buf[ 256 ];
+		const ScaledTime total( ticks );
+		if( count == 1 )
+			snprintf( buf, sizeof( buf ), "%s\t%g %s", name, total.value, total.unit );
+		else
+		{
+			const ScaledTime avg( count ? ticks / (double)count : 0.0 );
+			snprintf( buf, sizeof( buf ), "%s\t%g %s, %zu calls, %g %s average", name, total.value, total.unit, (size_t)count, avg.value, avg.unit );
+		}
+		return buf;
+	}
+
+	std::string formatBytes( double bytes )
+	{
+		const char* unit = "bytes";
+		if( bytes >= 1024.0 * 1024.0 * 1024.0 ) { bytes /= 1024.0 * 1024.0 * 1024.0; unit = "GB"; }
+		else if( bytes >= 1024.0 * 1024.0 ) { bytes /= 1024.0 * 1024.0; unit = "MB"; }
+		else if( bytes >= 1024.0 ) { bytes /= 1024.0; unit = "KB"; }
+		char buf[ 64 ];
+		snprintf( buf, sizeof( buf ), "%g %s", bytes, unit );
+		return buf;
+	}
+
+	// ================================================================================================================
 	// logger -- Whisper/Utils/Logger.cpp: messages go to the sink registered with setupLogger, filtered by level
 	// ================================================================================================================
 	namespace

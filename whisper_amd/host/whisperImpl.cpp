@@ -109,7 +109,8 @@ namespace Whisper
 			mutable TranscribeResultStatic results;
 			// timings, the blocks of ProfileCollection (Whisper/Utils/ProfileCollection.h)
 			double msSpectrogram = 0, msEncode = 0, msDecode = 0, msRun = 0;
-			int nEncode = 0, nDecodeSteps = 0;
+			int nEncode = 0, nDecodeSteps = 0, nRuns = 0, nSpectrogram = 0, nDecodeWindows = 0;
+			bool gpuProfile = false;	  // WHISPER_PROFILE=1: per-kernel hipEvent timing, printed as the "Compute Shaders" table
 
 			using Clock = std::chrono::steady_clock;
 			static double msSince( Clock::time_point t ) { return std::chrono::duration<double, std::milli>( Clock::now() - t ).count(); }
@@ -140,6 +141,11 @@ namespace Whisper
 			HRESULT init()
 			{
 				CHECK_WH( wh_context_create( model->gpu, 1, nullptr, &gpu ) );
+				// The reference profiles every dispatch all the time (GpuProfiler). Here the event pairs force eager launches
+				// (no hipGraph replay), so the per-kernel table is opt-in.
+				const char* const env = getenv( "WHISPER_PROFILE" );
+				gpuProfile = env && env[ 0 ] && env[ 0 ] != '0';
+				if( gpuProfile ) CHECK_WH( wh_profile_enable( gpu, 1 ) );
 				return S_OK;
 			}
 
@@ -169,7 +175,8 @@ namespace Whisper
 			HRESULT timingsReset() override
 			{
 				msSpectrogram = msEncode = msDecode = msRun = 0;
-				nEncode = nDecodeSteps = 0;
+				nEncode = nDecodeSteps = nRuns = nSpectrogram = nDecodeWindows = 0;
+				if( gpuProfile ) wh_profile_enable( gpu, 1 );
 				return S_OK;
 			}
 		};
@@ -202,16 +209,39 @@ namespace Whisper
 
 		HRESULT ContextImpl::timingsPrint()
 		{
-			// same block names as the reference's profiler output (SampleClips/*.txt) so logs stay comparable
+			// Sections, block names and line format of the reference's profiler output (ProfileCollection::print,
+			// ContextImpl.misc.cpp:170-182, e.g. SampleClips/columbia-medium-1080ti.txt) so that logs stay comparable.
+			constexpr double ticksPerMs = 1.0e4;
 			logInfo( "    CPU Tasks" );
-			logInfo( "RunComplete\t%g milliseconds", msRun );
-			logInfo( "Spectrogram\t%g milliseconds (GPU)", msSpectrogram );
-			logInfo( "Encode\t%g milliseconds, %i calls, %g milliseconds average", msEncode, nEncode, nEncode ? msEncode / nEncode : 0.0 );
-			logInfo( "Decode\t%g milliseconds, %i steps, %g milliseconds average", msDecode, nDecodeSteps, nDecodeSteps ? msDecode / nDecodeSteps : 0.0 );
-			int64_t vram = 0;
-			wh_context_memory( gpu, &vram );
+			if( nRuns ) logInfo( "%s", formatMeasure( "RunComplete", msRun * ticksPerMs, nRuns ).c_str() );
+			if( nSpectrogram ) logInfo( "%s", formatMeasure( "Spectrogram", msSpectrogram * ticksPerMs, nSpectrogram ).c_str() );
+			if( nEncode ) logInfo( "%s", formatMeasure( "Encode", msEncode * ticksPerMs, nEncode ).c_str() );
+			if( nDecodeWindows ) logInfo( "%s", formatMeasure( "Decode", msDecode * ticksPerMs, nDecodeWindows ).c_str() );
+			if( nDecodeSteps ) logInfo( "%s", formatMeasure( "DecodeStep", msDecode * ticksPerMs, nDecodeSteps ).c_str() );
+			if( gpuProfile )
+			{
+				// one row per kernel class, longest first -- the "Compute Shaders" table of the reference
+				wh_profile_entry rows[ 32 ];
+				int n = 0;
+				if( 0 == wh_profile_read( gpu, rows, 32, &n ) && n > 0 )
+				{
+					std::sort( rows, rows + n, []( const wh_profile_entry& a, const wh_profile_entry& b ) { return a.ms > b.ms; } );
+					logInfo( "    Compute Shaders" );
+					for( int i = 0; i < n; i++ )
+						if( rows[ i ].calls > 0 ) logInfo( "%s", formatMeasure( rows[ i ].name, rows[ i ].ms * ticksPerMs, (uint64_t)rows[ i ].calls ).c_str() );
+				}
+			}
+			int64_t ctxVram = 0, modelVram = 0;
+			void* arena = nullptr;
+			wh_context_memory( gpu, &ctxVram );
+			wh_model_arena( model->gpu, &arena, &modelVram );
+			int64_t modelRam = 0;
+			for( const std::string& t : model->vocab.idToToken ) modelRam += (int64_t)t.size() * 2 + 2 * (int64_t)sizeof( std::string );
+			const int64_t ctxRam = (int64_t)( resultAll.capacity() * sizeof( Segment ) + promptPast.capacity() * sizeof( int ) );
 			logInfo( "    Memory Usage" );
-			logInfo( "Context\t%.1f MB VRAM", vram / 1048576.0 );
+			logInfo( "Model\t%s RAM, %s VRAM", formatBytes( (double)modelRam ).c_str(), formatBytes( (double)modelVram ).c_str() );
+			logInfo( "Context\t%s RAM, %s VRAM", formatBytes( (double)ctxRam ).c_str(), formatBytes( (double)ctxVram ).c_str() );
+			logInfo( "Total\t%s RAM, %s VRAM", formatBytes( (double)( modelRam + ctxRam ) ).c_str(), formatBytes( (double)( modelVram + ctxVram ) ).c_str() );
 			return S_OK;
 		}
 
@@ -233,9 +263,11 @@ namespace Whisper
 				CHECK_WH( wh_mel_spectrogram( gpu, (const float*)pcmDev, n, (float*)melDev, &got ) );
 				CHECK_WH( wh_context_synchronize( gpu ) );
 				msSpectrogram += msSince( t );
+				nSpectrogram++;
 			}
 			const HRESULT hr = runFullImpl( params, melLen );
 			msRun += msSince( tRun );
+			nRuns++;
 			return hr;
 		}
 
@@ -415,6 +447,7 @@ namespace Whisper
 				}
 				msDecode += msSince( tDec );
 				nDecodeSteps += dec.steps;
+				nDecodeWindows++;
 				if( failed )
 				{
 					// whisper.cpp retries the same window once without the past prompt before skipping a second
@@ -793,6 +826,15 @@ WHISPER_EXPORT int32_t whisperc_tokenize( void* model, const char* text, int32_t
 	return FAILED( hr ) ? hr : sink.n;
 }
 WHISPER_EXPORT int32_t whisperc_timings_print( void* ctx ) { return ( (iContext*)ctx )->timingsPrint(); }
+WHISPER_EXPORT int32_t whisperc_format_measure( const char* name, double ticks, uint64_t count, char* out, uint32_t outCap )
+{
+	if( !name || !out || outCap == 0 ) return -1;
+	const std::string s = Whisper::formatMeasure( name, ticks, count );
+	const size_t n = std::min( s.size(), (size_t)outCap - 1 );
+	memcpy( out, s.data(), n );
+	out[ n ] = 0;
+	return (int32_t)n;
+}
 WHISPER_EXPORT int32_t whisperc_set_host_loop_rules( int mode )
 {
 	if( mode != 0 && mode != 1 ) return E_INVALIDARG;
