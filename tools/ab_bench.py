@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-NAMES = {2: "rows4", 4: "splitCross", 8: "gemmBig", 16: "crossPrefetch"}
+NAMES = {2: "rows4", 8: "gemmBig", 32: "gemvSmallReg", 64: "gemmGlds", 128: "lnSeparateBigM", 256: "attnXcd"}
 
 
 def main():
@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--model", default="medium")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--masks", default="2,0,6,10,18")
+    ap.add_argument("--masks", default="490,488,426,362,234")
     args = ap.parse_args()
     import torch
     from whisper_amd import binding, ggml_format as gf

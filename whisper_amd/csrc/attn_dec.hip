@@ -25,9 +25,6 @@ namespace wh
 		constexpr int KPT = MAX_KEYS / NT;	 // keys per thread in the score phase
 		constexpr int SLOTS = NT / 8;		 // key slots in the P.V phase
 
-		// CROSS: non-causal with a key count known at launch (the encoder keys): every K row and every V row of the thread
-		// is requested before anything else, one memory phase for the whole 2 x 192 KB of a head.
-		template<bool CROSS>
 		__global__ void __launch_bounds__( NT ) attentionDec( const DecAttnArgs a )
 		{
 			__shared__ float sc[ MAX_KEYS ];
@@ -54,37 +51,15 @@ namespace wh
 			const int nk = a.causal ? min( nPast + i + 1, nKeys ) : nKeys;
 
 			// ---- loads that do not wait for the position or the softmax go out first, for the first PRE = 64 keys only (a
-			// decode step rarely sees more self-attention keys; the cross path is the split kernel): K row min(t, 63),
+			// decode step rarely sees more self-attention keys; cross-attention takes the dependent loads too): K row min(t, 63),
 			// V row of this thread's P.V slot, and q. One memory round trip serves the common case; more keys take the
 			// dependent loads below.
 			constexpr int PRE = 64;
-			constexpr int VPRE = CROSS ? MAX_KEYS / SLOTS : 1;
+			constexpr int VPRE = 1;
 			const int lastRow = a.keyStride - 1;
 			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
 			f16x8 kv[ KPT ][ 8 ];
 			f16x8 v0[ VPRE ];
-			if constexpr( CROSS )
-			{
-#pragma unroll
-				for( int j = 0; j < KPT; j++ )
-				{
-					int key = tid + j * NT;
-					key = key < nk ? key : nk - 1;
-					const f16* kr = K + (long long)key * HEAD_DIM;
-#pragma unroll
-					for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
-				}
-				if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ rowQ * d + h * HEAD_DIM + tid ];
-#pragma unroll
-				for( int u = 0; u < VPRE; u++ )
-				{
-					int key = g + u * SLOTS;
-					key = key < nk ? key : nk - 1;
-					v0[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + j8 );
-				}
-				__syncthreads();
-			}
-			else
 			{
 				{
 					int key = tid < PRE ? tid : PRE - 1;
@@ -188,7 +163,6 @@ namespace wh
 #pragma unroll
 					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)v0[ u ][ j ], p, acc[ j ] );
 				}
-				if constexpr( !CROSS )
 				{
 					if( g + SLOTS < nk )
 					{
@@ -274,157 +248,7 @@ namespace wh
 			setError( "attentionDec: key count out of range" );
 			return -1;
 		}
-		// the all-loads-first variant needs a launch-time key count and the FP32 P.V path
-		const bool cross = !a.causal && a.parityThreads <= 0 && ( g_tuning & TUNE_CROSS_PREFETCH );
-		if( cross )
-			hipLaunchKernelGGL( attentionDec<true>, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
-		else
-			hipLaunchKernelGGL( attentionDec<false>, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
-		WH_HIP( hipGetLastError() );
-		return 0;
-	}
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// split cross-attention for single-token steps (fast path)
-// ---------------------------------------------------------------------------------------------------------------------
-namespace wh
-{
-	namespace
-	{
-		__global__ void __launch_bounds__( 256 ) attnSplitScores( const SplitAttnArgs a )
-		{
-			__shared__ float qs[ HEAD_DIM ];
-			const int tid = threadIdx.x;
-			const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
-			const int d = a.H * HEAD_DIM;
-			const int per = ( a.nKeys + ATT_SPLITS - 1 ) / ATT_SPLITS;
-			const int k0 = sp * per, k1 = min( k0 + per, a.nKeys );
-			const f16* const K = a.kc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
-			float* const S = a.scores + ( (long long)b * a.H + h ) * a.keyStride;
-			// up to 2 keys per thread, all 16 loads in flight; issued before q so that there is a single memory round trip
-			f16x8 kv[ 2 ][ 8 ];
-#pragma unroll
-			for( int j = 0; j < 2; j++ )
-			{
-				int key = k0 + tid + j * 256;
-				key = key < k1 ? key : k1 - 1;
-				const f16* kr = K + (long long)key * HEAD_DIM;
-#pragma unroll
-				for( int c8 = 0; c8 < 8; c8++ ) kv[ j ][ c8 ] = *(const f16x8*)( kr + c8 * 8 );
-			}
-			if( tid < HEAD_DIM ) qs[ tid ] = (float)a.q[ (long long)b * d + h * HEAD_DIM + tid ];
-			__syncthreads();
-#pragma unroll
-			for( int j = 0; j < 2; j++ )
-			{
-				const int key = k0 + tid + j * 256;
-				float s = 0.0f;
-#pragma unroll
-				for( int c8 = 0; c8 < 8; c8++ )
-#pragma unroll
-					for( int e = 0; e < 8; e++ ) s = fmaf( (float)kv[ j ][ c8 ][ e ], qs[ c8 * 8 + e ], s );
-				if( key < k1 ) S[ key ] = s;
-			}
-		}
-
-		__global__ void __launch_bounds__( 256 ) attnSplitPV( const SplitAttnArgs a )
-		{
-			__shared__ float pl[ MAX_KEYS / ATT_SPLITS + 4 ];
-			__shared__ float red[ 32 ][ HEAD_DIM ];
-			__shared__ float shf[ 4 ];
-			__shared__ double shd[ 4 ];
-			const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-			const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
-			const int d = a.H * HEAD_DIM;
-			const int per = ( a.nKeys + ATT_SPLITS - 1 ) / ATT_SPLITS;
-			const int k0 = sp * per, k1 = min( k0 + per, a.nKeys );
-			const f16* const V = a.vc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
-			const float* const S = a.scores + ( (long long)b * a.H + h ) * a.keyStride;
-
-			// this workgroup's V rows do not depend on the probabilities: request them first (12 x 16 bytes per thread)
-			const int g = tid >> 3, j8 = ( tid & 7 ) * 8;
-			const int nk = k1 - k0;
-			f16x8 vv[ 12 ];
-#pragma unroll
-			for( int u = 0; u < 12; u++ )
-			{
-				const int key = g + u * 32;
-				const int kc = key < nk ? key : nk - 1;
-				vv[ u ] = *(const f16x8*)( V + (long long)( k0 + kc ) * HEAD_DIM + j8 );
-			}
-
-			// softmax statistics over ALL keys of this (b, h): identical in each of the ATT_SPLITS workgroups
-			constexpr int SPT = MAX_KEYS / 256;
-			float sv[ SPT ];
-			float mx = -INFINITY;
-#pragma unroll
-			for( int j = 0; j < SPT; j++ )
-			{
-				const int key = tid + j * 256;
-				sv[ j ] = key < a.nKeys ? S[ key ] : -INFINITY;
-				mx = fmaxf( mx, sv[ j ] );
-			}
-			mx = waveReduceMax( mx );
-			if( lane == 0 ) shf[ wave ] = mx;
-			__syncthreads();
-			mx = fmaxf( fmaxf( shf[ 0 ], shf[ 1 ] ), fmaxf( shf[ 2 ], shf[ 3 ] ) );
-			double sum = 0.0;
-#pragma unroll
-			for( int j = 0; j < SPT; j++ )
-			{
-				const int key = tid + j * 256;
-				const float e = key < a.nKeys ? exp16( sv[ j ] - mx ) : 0.0f;
-				sv[ j ] = e;
-				sum += (double)e;
-			}
-			sum = waveReduceSumD( sum );
-			if( lane == 0 ) shd[ wave ] = sum;
-			__syncthreads();
-			// same association as the single-workgroup kernel would use is irrelevant: doubles of FP16-exact values add exactly
-			const float inv = (float)( 1.0 / ( ( shd[ 0 ] + shd[ 1 ] ) + ( shd[ 2 ] + shd[ 3 ] ) ) );
-#pragma unroll
-			for( int j = 0; j < SPT; j++ )
-			{
-				const int key = tid + j * 256;
-				if( key >= k0 && key < k1 ) pl[ key - k0 ] = sv[ j ] * inv;
-			}
-			__syncthreads();
-
-			// partial P.V over [k0, k1): 32 key slots x 8 lanes of 8 dims (at most 12 keys per slot: 384 keys per split)
-			float acc[ 8 ];
-#pragma unroll
-			for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
-#pragma unroll
-			for( int u = 0; u < 12; u++ )
-			{
-				const int key = g + u * 32;
-				const float p = key < nk ? pl[ key ] : 0.0f;
-#pragma unroll
-				for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], p, acc[ j ] );
-			}
-#pragma unroll
-			for( int j = 0; j < 8; j++ ) red[ g ][ j8 + j ] = acc[ j ];
-			__syncthreads();
-			if( tid < HEAD_DIM )
-			{
-				float t = 0.0f;
-#pragma unroll
-				for( int s = 0; s < 32; s++ ) t += red[ s ][ tid ];
-				a.parts[ ( (long long)sp * a.batch + b ) * d + h * HEAD_DIM + tid ] = t;
-			}
-		}
-	}	// namespace
-
-	int launchAttentionSplit( const SplitAttnArgs& a, hipStream_t stream )
-	{
-		if( a.nKeys < ATT_SPLITS || a.nKeys > MAX_KEYS || a.batch <= 0 )
-		{
-			setError( "attentionSplit: key count out of range" );
-			return -1;
-		}
-		hipLaunchKernelGGL( attnSplitScores, dim3( a.H, a.batch, ATT_SPLITS ), dim3( 256 ), 0, stream, a );
-		hipLaunchKernelGGL( attnSplitPV, dim3( a.H, a.batch, ATT_SPLITS ), dim3( 256 ), 0, stream, a );
+		hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

@@ -670,16 +670,15 @@ namespace wh
 		constexpr int GV_MAXK_LN = 1280;
 		constexpr int GV_XS_STRIDE = GV_MAXK_LN + 8;
 
-		// PRO = 0: A rows are FP16 in global memory; 1: fused LayerNorm prologue; 2: A row m = fp16( sum of nParts FP32
-		// partial rows ) -- the deterministic combine of the split cross-attention's per-key-range partial outputs.
+		// PRO = 0: A rows are FP16 in global memory; 1: fused LayerNorm prologue.
 		// ROWS = weight rows per workgroup: 16 fills the MFMA; 4 (rows replicated across the operand's 16 row slots) gives 4x
 		// the workgroups when N is small and K large -- a CU streams only ~24 GB/s, so 8 MB over 64 CUs would take 5 us.
-		// NW = waves per workgroup that split K (8 for the LayerNorm prologue: one activation row per wave).
+		// NW = waves per workgroup that split K. GV_UNROLL = fragment slots per wave (8 halves the registers when K / NW / 32 <= 8).
+		// MT = MFMA column tiles = 16 activation rows each.
 		template<int EPI, int PRO, int ROWS, int NW, int GV_UNROLL, int MT>
 		__global__ void __launch_bounds__( NW * 64 ) gemvFused( const GemmArgs a )
 		{
 			constexpr bool LN = PRO == 1;
-			constexpr bool PARTS = PRO == 2;
 			constexpr int MROWS = 16 * MT;	  // activation rows held by the workgroup: MT column tiles of the 16x16x32 MFMA
 			__shared__ float red[ NW - 1 ][ MT * 4 ][ 64 ];
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[];	 // [MROWS][GV_XS_STRIDE] when there is a prologue
@@ -718,22 +717,7 @@ namespace wh
 			}
 
 			const f16* px[ MT ];
-			if constexpr( PARTS )
-			{
-				// x[m][k] = fp16( parts[0][m][k] + parts[1][m][k] + ... ), fixed order; 4 consecutive k per thread
-				const int total = a.M * a.K / 4;
-				for( int i = tid; i < total; i += NW * 64 )
-				{
-					const int mr = i / ( a.K / 4 ), k4 = ( i - mr * ( a.K / 4 ) ) * 4;
-					f32x4 sum = *(const f32x4*)( a.parts + (long long)mr * a.K + k4 );
-					for( int p = 1; p < a.nParts; p++ ) sum += *(const f32x4*)( a.parts + p * a.partStride + (long long)mr * a.K + k4 );
-					f16x4 h4;
-					h4[ 0 ] = (f16)sum[ 0 ]; h4[ 1 ] = (f16)sum[ 1 ]; h4[ 2 ] = (f16)sum[ 2 ]; h4[ 3 ] = (f16)sum[ 3 ];
-					*(f16x4*)( xs + mr * GV_XS_STRIDE + k4 ) = h4;
-				}
-				__syncthreads();
-			}
-			else if constexpr( LN )
+			if constexpr( LN )
 			{
 				// rows wave and wave + NW together, then the next pair. Rows at or beyond M stay unwritten: an MFMA output
 				// column depends on its own activation row only, and those columns are never stored.
@@ -875,16 +859,9 @@ namespace wh
 			return -1;
 		}
 		const bool ln = a.lnX != nullptr;
-		const bool parts = a.parts != nullptr;
-		if( ( ln || parts ) && a.K > GV_MAXK_LN )
+		if( ln && a.K > GV_MAXK_LN )
 		{
-			setError( "gemv: fused prologues support rows up to 1280" );
-			return -1;
-		}
-		if( parts )
-		{
-			if( a.epi == EPI_F32 && !ln ) return launchGemvT<EPI_F32, 2>( a, stream );
-			setError( "gemv: the partial-sum prologue is only built for the FP32 epilogue" );
+			setError( "gemv: the fused LayerNorm prologue supports rows up to 1280" );
 			return -1;
 		}
 		// small N, large K (the MLP down projection): 4 weight rows per workgroup so that every CU streams

@@ -8,16 +8,15 @@ namespace wh
 	enum eTuning : unsigned
 	{
 		TUNE_GEMV_ROWS4 = 2,	 // 4 weight rows per workgroup for small-N / large-K gemv (else 16)
-		TUNE_SPLIT_CROSS = 4,	 // cross-attention keys split over 4 workgroups + combine in the next prologue (else 1 workgroup)
 		TUNE_GEMM_BIG = 8,		 // 256x256x64 tiles for large tiled GEMMs (else 128x128x32 everywhere)
-		TUNE_CROSS_PREFETCH = 16,	 // cross-attention: every K and V row of the thread requested up front
 		TUNE_GEMV_SMALLREG = 32,	 // 8-slot gemv instance when a wave's K slice fits (fewer registers, same loads in flight)
 		TUNE_GEMM_GL = 64,		 // tiled GEMM stages its tiles global -> LDS directly (128x128x64, swizzled source)
 		TUNE_LN_SEPARATE_BIGM = 128,	 // more than 16 decode rows: LayerNorm as its own launch instead of 192-256 redundant prologues
 		TUNE_ATTN_XCD = 256,		 // encoder attention: the query blocks of one (sequence, head) run on one XCD
-		// measured in one process on one MI355X (tools/ab_bench.py, profiles/r01_ab_variants.txt), ms per clip pass:
-		// rows4 -1.1, splitCross +6.7 (since attentionDec hoists its loads), gemmBig +1.0, crossPrefetch +1.5 => only rows4.
-		// Retired after measuring: 8-wave LayerNorm prologue (+3.4, spills), rows4 for K = d (+0.5).
+		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
+		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
+		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
+		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
 		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD
 	};
 	extern unsigned g_tuning;
@@ -68,9 +67,6 @@ namespace wh
 		const float* lnX;	  // when non-null: A is produced on the fly as fp16( LayerNorm(lnX[m]) * lnW + lnB ), row length K
 		const float* lnW;
 		const float* lnB;
-		const float* parts;	  // when non-null: A row m = fp16( sum_p parts[p * partStride + m * K + k] ), nParts FP32 partial rows
-		int nParts;
-		long long partStride;
 	};
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
@@ -118,23 +114,6 @@ namespace wh
 	};
 	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream );
 
-	// Single query row per sequence, FP32 P.V, keys split over ATT_SPLITS workgroups per (sequence, head) so that all 256
-	// CUs stream K/V (one CU sustains ~24 GB/s, 112 (b,h) pairs alone would cap at ~2.7 TB/s):
-	//   scores kernel  S[b][h][key] = K[key] . q                      (each workgroup: one key range)
-	//   pv kernel      softmax over ALL keys of (b,h) (recomputed by each of the splits, 6 KB of scores), P for the
-	//                  workgroup's key range, partial O = P.V -> parts[split][b][H*64]
-	// The partials are combined in a fixed order by the prologue of the product that consumes them (GemmArgs::parts).
-	constexpr int ATT_SPLITS = 4;
-	struct SplitAttnArgs
-	{
-		const f16* q;		  // [batch][d]
-		const f16* kc;		  // [batch][H][keyStride][64]
-		const f16* vc;
-		float* scores;		  // [batch][H][keyStride]
-		float* parts;		  // [ATT_SPLITS][batch][d]
-		int batch, H, nKeys, keyStride;
-	};
-	int launchAttentionSplit( const SplitAttnArgs& a, hipStream_t stream );
 
 	// ---------------------------------------------------------------------------------------------------------------
 	// logits -> probabilities -> greedy token, on the device

@@ -143,9 +143,9 @@ struct wh_model
 // active between wh_profile_enable(1) and wh_profile_read, because two event records per launch perturb launch-bound code.
 enum eKernelClass : int
 {
-	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_ATTN_SPLIT, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX, KC_SAMPLE, KC_COUNT
+	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX, KC_SAMPLE, KC_COUNT
 };
-static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "attentionSplit(2 kernels)", "layerNorm", "mel",
+static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "layerNorm", "mel",
 	"melToConvInput", "embed", "vocabSoftMax", "softMaxSample" };
 
 struct Profiler
@@ -212,7 +212,6 @@ struct wh_context
 	TokenData* tokDataDev = nullptr;
 	float* melScratch = nullptr;
 	// device-side greedy loop
-	float *attScores = nullptr, *attParts = nullptr;
 	DecodeState* state = nullptr;
 	TokenData* greedyOut = nullptr;	   // [n_text_ctx][maxBatch]
 	hipGraphExec_t graphExec = nullptr;
@@ -663,8 +662,6 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * wh_context::PINNED_INTS, hipHostMallocDefault );
 		if( e != hipSuccess ) rc = hipFail( e, "hipHostMalloc", __FILE__, __LINE__ );
 	}
-	rc = rc ? rc : c->alloc( c->attScores, B * H * (int64_t)T );
-	rc = rc ? rc : c->alloc( c->attParts, (int64_t)ATT_SPLITS * B * d );
 	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * B );
 	if( rc == 0 )
 	{
@@ -939,19 +936,6 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
 			WH_CHECK( product( g, m->at<float>( e.lncw ), m->at<float>( e.lncb ) ) );
 		}
-		const bool splitCross = gemv && fuseLn && nTokens == 1 && parity == 0 && c->T >= ATT_SPLITS && ( g_tuning & TUNE_SPLIT_CROSS );
-		if( splitCross )
-		{
-			// keys split over ATT_SPLITS workgroups per (sequence, head); the partial outputs are combined by the prologue
-			// of the output projection below
-			SplitAttnArgs a;
-			a.q = c->dq; a.kc = c->crossK + crossLayer; a.vc = c->crossV + crossLayer;
-			a.scores = c->attScores; a.parts = c->attParts;
-			a.batch = batch; a.H = H; a.nKeys = c->T; a.keyStride = c->T;
-			const double bytes = 2.0 * 2.0 * batch * H * (double)c->T * HEAD_DIM;
-			WH_CHECK( profiled( c, KC_ATTN_SPLIT, 4.0 * batch * H * (double)c->T * HEAD_DIM, bytes, [ & ]() { return launchAttentionSplit( a, st ); } ) );
-		}
-		else
 		{
 			DecAttnArgs a;
 			a.q = c->dq; a.kc = c->crossK + crossLayer; a.vc = c->crossV + crossLayer; a.out = c->dattn;
@@ -962,10 +946,6 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wco ), M, d, d );
 			g.epi = EPI_F32; g.bias = m->at<float>( e.bco ); g.res = c->dx; g.out32 = c->dx;
-			if( splitCross )
-			{
-				g.parts = c->attParts; g.nParts = ATT_SPLITS; g.partStride = (long long)batch * d;
-			}
 			WH_CHECK( product( g, nullptr, nullptr ) );
 		}
 		// MLP
