@@ -26,16 +26,29 @@ int32_t whisperc_tokenize( void* model, const char* text, int32_t* out, int cap 
  * flags = eFullParamsFlags bits (Translate 1, NoContext 2, SingleSegment 4, PrintSpecial 8 ...). */
 int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx /* < 0 keeps the default 16384 */ );
+/* whisperc_run_full + the token-timestamp fields of sFullParams (set TokenTimestamps = 0x100 in flags): thold_pt, thold_ptsum, max_len */
+int32_t whisperc_run_full_tt( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, float tholdPt, float tholdPtsum, int maxLen );
 /* iContext::getResults( Tokens | Timestamps ) + iTranscribeResult::getSize / getSegments / getTokens; times in 100 ns ticks */
 int32_t whisperc_result_counts( void* ctx, uint32_t* segments, uint32_t* tokens );
 int32_t whisperc_result_segment( void* ctx, uint32_t index, uint64_t* t0, uint64_t* t1, uint32_t* firstToken, uint32_t* countTokens,
 	char* text, uint32_t textCap );
 int32_t whisperc_result_token( void* ctx, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum );
+/* sToken::time (100 ns ticks; 0 when unknown) and sToken::vlen of token `index` */
+int32_t whisperc_result_token_times( void* ctx, uint32_t index, uint64_t* t0, uint64_t* t1, float* vlen );
 /* iContext::timingsPrint */
 int32_t whisperc_timings_print( void* ctx );
 /* One line of the profiler output, formatted like ProfileCollection::Measure::print (Whisper/Utils/ProfileCollection.cpp:113-170):
  * `ticks` of 100 ns scaled to seconds / milliseconds / microseconds. Returns the length written (without the terminator). */
 int32_t whisperc_format_measure( const char* name, double ticks, uint64_t count, char* out, uint32_t outCap );
+/* The TokenTimestamps post-processing on its own (host only, no device): token data of finished segments in, token times
+ * (10 ms units) and -- with maxLen > 0 -- the segments wrapped to maxLen characters out; iContext::runFull applies exactly
+ * this per segment (whisper.cpp:3374-3575, 2711-2760). segTimes / outSegTimes / outTokTimes hold (t0, t1) pairs, tokens are
+ * concatenated over the segments, outTexts receives the segment texts NUL-separated. */
+int32_t whisperc_debug_token_timestamps( const char* modelPath, const float* pcm, uint64_t nSamples, int32_t nSegments,
+	const int64_t* segTimes, const int32_t* segTokenCounts, const int32_t* ids, const int32_t* tids, const float* p, const float* pt,
+	const float* ptsum, float tholdPt, float tholdPtsum, int32_t maxLen, int32_t segCap, int32_t tokCap, int32_t* outSegCount,
+	int64_t* outSegTimes, int32_t* outSegTokenCounts, char* outTexts, uint32_t textCap, int64_t* outTokTimes, float* outVlen );
 /* Process-wide choice between the two host loops the reference ships: 0 (default) = its CPU model's whisper_full
  * (Whisper/source/whisper.cpp:2765-3120: drops the past prompt when < 5 s remain, retries a failed window once without it),
  * 1 = its GPU model's ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:452-793: neither rule). */

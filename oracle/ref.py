@@ -59,6 +59,10 @@ def lib():
         L.ref_is_multilingual.argtypes = [C.c_void_p]
         L.ref_full.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_int]
+        L.ref_full_token_timestamps.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_float, C.c_float, C.c_int]
+        L.ref_full_token_data.argtypes = [C.c_void_p, C.c_int, C.c_int, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"),
+                                          np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")]
         L.ref_full_n_segments.argtypes = [C.c_void_p]
         for n in ("ref_full_segment_t0", "ref_full_segment_t1"):
             getattr(L, n).restype = C.c_int64
@@ -67,6 +71,7 @@ def lib():
         L.ref_full_segment_text.argtypes = [C.c_void_p, C.c_int]
         L.ref_full_n_tokens.argtypes = [C.c_void_p, C.c_int]
         L.ref_full_token_id.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_full_token_tid.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ref_full_token_p.restype = C.c_float
         L.ref_full_token_p.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ref_timings.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")]
@@ -198,6 +203,28 @@ class RefWhisper:
                 text=self.L.ref_full_segment_text(self.ctx, i),
                 tokens=[self.L.ref_full_token_id(self.ctx, i, j) for j in range(nt)],
                 probs=[self.L.ref_full_token_p(self.ctx, i, j) for j in range(nt)]))
+        return segs
+
+    def full_token_timestamps(self, pcm: np.ndarray, lang: str = "en", no_context: bool = True, prompt: Optional[Sequence[int]] = None,
+                              n_max_text_ctx: int = -1, thold_pt: float = 0.01, thold_ptsum: float = 0.01, max_len: int = 0):
+        """whisper_full with token_timestamps = true; every token comes back with t0 / t1 / vlen next to id / tid / p / pt / ptsum."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        rc = self.L.ref_full_token_timestamps(self.ctx, pcm, len(pcm), self.n_threads, lang.encode(), int(no_context),
+                                              pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx,
+                                              thold_pt, thold_ptsum, max_len)
+        if rc != 0:
+            raise RuntimeError("whisper_full rc=%d" % rc)
+        segs = []
+        t, f = np.zeros(2, np.int64), np.zeros(4, np.float32)
+        for i in range(self.L.ref_full_n_segments(self.ctx)):
+            toks = []
+            for j in range(self.L.ref_full_n_tokens(self.ctx, i)):
+                self.L.ref_full_token_data(self.ctx, i, j, t, f)
+                toks.append(dict(id=self.L.ref_full_token_id(self.ctx, i, j), tid=self.L.ref_full_token_tid(self.ctx, i, j),
+                                 t0=int(t[0]), t1=int(t[1]), p=float(f[0]), pt=float(f[1]), ptsum=float(f[2]), vlen=float(f[3])))
+            segs.append(dict(t0=self.L.ref_full_segment_t0(self.ctx, i), t1=self.L.ref_full_segment_t1(self.ctx, i),
+                             text=self.L.ref_full_segment_text(self.ctx, i).decode(), tokens=toks))
         return segs
 
     def timings_us(self):

@@ -211,6 +211,36 @@ int ref_full( whisper_context* ctx, const float* pcm, int nSamples, int nThreads
 	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
 	return whisper_full( ctx, p, pcm, nSamples );
 }
+// whisper_full with token-level timestamps (whisper.cpp:2803-2808, 3063-3069): thold_pt / thold_ptsum / max_len as given
+int ref_full_token_timestamps( whisper_context* ctx, const float* pcm, int nSamples, int nThreads, const char* lang, int flags,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, float tholdPt, float tholdPtsum, int maxLen )
+{
+	whisper_full_params p = whisper_full_default_params( WHISPER_SAMPLING_GREEDY );
+	p.n_threads = nThreads;
+	p.print_progress = false;
+	p.print_realtime = false;
+	p.print_timestamps = false;
+	p.print_special = false;
+	p.language = lang;
+	p.no_context = ( flags & 1 ) != 0;
+	p.single_segment = ( flags & 2 ) != 0;
+	p.translate = ( flags & 4 ) != 0;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	p.token_timestamps = true;
+	p.thold_pt = tholdPt;
+	p.thold_ptsum = tholdPtsum;
+	p.max_len = maxLen;
+	return whisper_full( ctx, p, pcm, nSamples );
+}
+// t[2] = { t0, t1 } in 10 ms units, f[4] = { p, pt, ptsum, vlen }
+void ref_full_token_data( whisper_context* ctx, int i, int j, int64_t* t, float* f )
+{
+	const whisper_token_data d = whisper_full_get_token_data( ctx, i, j );
+	t[ 0 ] = d.t0; t[ 1 ] = d.t1;
+	f[ 0 ] = d.p; f[ 1 ] = d.pt; f[ 2 ] = d.ptsum; f[ 3 ] = d.vlen;
+}
 int ref_full_n_segments( whisper_context* ctx ) { return whisper_full_n_segments( ctx ); }
 int64_t ref_full_segment_t0( whisper_context* ctx, int i ) { return whisper_full_get_segment_t0( ctx, i ); }
 int64_t ref_full_segment_t1( whisper_context* ctx, int i ) { return whisper_full_get_segment_t1( ctx, i ); }

@@ -16,6 +16,7 @@ HOST_LIB_PATH = os.path.join(_HERE, "lib", "libWhisper.so")
 
 # eFullParamsFlags (Whisper/API/sFullParams.h:21-35)
 TRANSLATE, NO_CONTEXT, SINGLE_SEGMENT, PRINT_SPECIAL = 1, 2, 4, 8
+TOKEN_TIMESTAMPS = 0x100
 
 CPP_EXPORTS = ["setupLogger", "loadModel", "initMediaFoundation", "findLanguageKeyW", "findLanguageKeyA", "getSupportedLanguages", "listGPUs"]
 
@@ -48,6 +49,8 @@ def lib():
         L.whisperc_result_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.whisperc_result_segment.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
                                               C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
+        L.whisperc_run_full_tt.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+        L.whisperc_result_token_times.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.whisperc_result_token.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.whisperc_timings_print.argtypes = [vp]
         _lib = L
@@ -124,10 +127,16 @@ class Context:
             pass
 
     def run_full(self, pcm: np.ndarray, language: str = "en", flags: int = 0, max_tokens: int = 0,
-                 prompt: Optional[Sequence[int]] = None, n_max_text_ctx: int = -1) -> int:
-        """runFull on mono float32 16 kHz PCM. Returns the HRESULT (0 = S_OK, 1 = S_FALSE: less than 1 s of audio)."""
+                 prompt: Optional[Sequence[int]] = None, n_max_text_ctx: int = -1, max_len: int = 0, thold_pt: float = 0.01,
+                 thold_ptsum: float = 0.01) -> int:
+        """runFull on mono float32 16 kHz PCM. Returns the HRESULT (0 = S_OK, 1 = S_FALSE: less than 1 s of audio).
+        With TOKEN_TIMESTAMPS in flags the tokens of results() carry t0 / t1 / vlen and max_len > 0 wraps the segments."""
         pcm = np.ascontiguousarray(pcm, np.float32)
         pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        if flags & TOKEN_TIMESTAMPS:
+            return _check(lib().whisperc_run_full_tt(self.h, pcm.ctypes.data_as(C.c_void_p), len(pcm), language.encode(), flags, max_tokens,
+                                                     pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx,
+                                                     thold_pt, thold_ptsum, max_len), "runFull")
         return _check(lib().whisperc_run_full(self.h, pcm.ctypes.data_as(C.c_void_p), len(pcm), language.encode(), flags, max_tokens,
                                               pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx), "runFull")
 
@@ -144,7 +153,9 @@ class Context:
             for j in range(ft.value, ft.value + ct.value):
                 tid, p, pt, ps = C.c_int32(), C.c_float(), C.c_float(), C.c_float()
                 _check(lib().whisperc_result_token(self.h, j, C.byref(tid), C.byref(p), C.byref(pt), C.byref(ps)), "getTokens")
-                toks.append(dict(id=tid.value, p=p.value, pt=pt.value, ptsum=ps.value))
+                k0, k1, vl = C.c_uint64(), C.c_uint64(), C.c_float()
+                _check(lib().whisperc_result_token_times(self.h, j, C.byref(k0), C.byref(k1), C.byref(vl)), "getTokens")
+                toks.append(dict(id=tid.value, p=p.value, pt=pt.value, ptsum=ps.value, t0=k0.value, t1=k1.value, vlen=vl.value))
             out.append(dict(t0=t0.value, t1=t1.value, text=text.value, tokens=toks))
         return out
 

@@ -86,6 +86,39 @@ namespace Whisper
 		HRESULT tokenize( const char* text, std::vector<int>& out ) const;
 	};
 
+	// ---- transcript under construction (whisper_segment / whisper_token_data, whisper.cpp:398-407, whisper.h:71-85) ----
+	struct TokenData
+	{
+		int id = 0, tid = 0;
+		float p = 0, pt = 0, ptsum = 0, vlen = 0;
+		int64_t t0 = -1, t1 = -1;	// 10 ms units, -1 = unknown
+	};
+	struct Segment
+	{
+		int64_t t0 = 0, t1 = 0;	   // 10 ms units
+		std::string text;
+		std::vector<TokenData> tokens;
+	};
+
+	// ---- token-level timestamps + max_len wrapping (TokenTimestamps flag; whisper.cpp:3320-3575, 2711-2760) ----
+	class TokenTimestamper
+	{
+		std::vector<float> energy;
+		int64_t tBeg = 0, tLast = 0;
+		int tidLast = 0;
+	public:
+		// start of a run: smoothed |signal| (65-sample box) and a clean timestamp state (whisper.cpp:2803-2808, 3352-3369)
+		void begin( const float* pcm, size_t samples );
+		bool ready() const { return !energy.empty(); }
+		// Fills t0 / t1 / vlen of the segment's tokens: timestamp tokens the model is confident about anchor the text tokens
+		// before them, the gaps are split in proportion to a "voice length" of the token text, then every token is grown or
+		// shrunk to the nearest change of voice activity.
+		void compute( Segment& segment, const Vocabulary& vocab, float tholdPt, float tholdPtsum );
+		// Splits the LAST segment into pieces of at most maxLen characters at token boundaries; returns the number of
+		// segments it became (>= 1).
+		static int wrapLast( std::vector<Segment>& all, const Vocabulary& vocab, int maxLen );
+	};
+
 	// ---- languages (Whisper/Whisper/Languages.cpp, languageCodez.inl; whisper.cpp:31-133) ----
 	int lookupLanguageId( uint32_t key );
 	const sLanguageList& languageList();
@@ -99,6 +132,8 @@ namespace Whisper
 		~LoadedModel();
 	};
 	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out );
+	// only the vocabulary of a model file (no device needed)
+	HRESULT loadVocabulary( const std::string& path, Vocabulary& vocab );
 
 	HRESULT createContextImpl( const std::shared_ptr<LoadedModel>& model, iModel* owner, iContext** pp );
 	HRESULT createModelImpl( const std::shared_ptr<LoadedModel>& model, iModel** pp );

@@ -280,6 +280,47 @@ namespace Whisper
 		}
 	}
 
+	// magic, hparams, mel filters, vocabulary: everything in front of the tensors (Appendix A of SURVEY.md); host only
+	static HRESULT readGgmlHeader( std::ifstream& f, const std::string& path, wh_hparams& hp, int32_t& nMel, int32_t& nFft,
+		std::vector<float>& filters, Vocabulary& vocab )
+	{
+		uint32_t magic = 0;
+		if( !rd( f, magic ) || magic != 0x67676d6c )
+		{
+			logError( "invalid model file '%s' (bad magic)", path.c_str() );
+			return E_INVALIDARG;
+		}
+		static_assert( sizeof( wh_hparams ) == 44, "hparams are 11 x int32 in file order" );
+		if( !rd( f, hp ) ) return E_INVALIDARG;
+		if( !rd( f, nMel ) || !rd( f, nFft ) || nMel <= 0 || nFft <= 0 || (int64_t)nMel * nFft > ( 1 << 20 ) ) return E_INVALIDARG;
+		filters.resize( (size_t)nMel * nFft );
+		f.read( (char*)filters.data(), filters.size() * 4 );
+		int32_t nWords = 0;
+		if( !rd( f, nWords ) || nWords < 0 || nWords > ( 1 << 20 ) ) return E_INVALIDARG;
+		vocab.idToToken.resize( nWords );
+		for( int i = 0; i < nWords; i++ )
+		{
+			uint32_t len = 0;
+			if( !rd( f, len ) || len > ( 1u << 16 ) ) return E_INVALIDARG;
+			std::string w( len, '\0' );
+			if( len ) f.read( &w[ 0 ], len );
+			vocab.idToToken[ i ] = std::move( w );
+		}
+		if( !f ) return E_INVALIDARG;
+		vocab.finalize( hp.n_vocab );
+		return S_OK;
+	}
+
+	HRESULT loadVocabulary( const std::string& path, Vocabulary& vocab )
+	{
+		std::ifstream f( path, std::ios::binary );
+		if( !f ) return (HRESULT)0x80070002;
+		wh_hparams hp{};
+		int32_t nMel = 0, nFft = 0;
+		std::vector<float> filters;
+		return readGgmlHeader( f, path, hp, nMel, nFft, filters, vocab );
+	}
+
 	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out )
 	{
 		std::ifstream f( path, std::ios::binary );
@@ -291,34 +332,10 @@ namespace Whisper
 		f.seekg( 0, std::ios::end );
 		const int64_t fileSize = (int64_t)f.tellg();
 		f.seekg( 0 );
-		uint32_t magic = 0;
-		if( !rd( f, magic ) || magic != 0x67676d6c )
-		{
-			logError( "invalid model file '%s' (bad magic)", path.c_str() );
-			return E_INVALIDARG;
-		}
 		auto lm = std::make_shared<LoadedModel>();
-		static_assert( sizeof( wh_hparams ) == 44, "hparams are 11 x int32 in file order" );
-		if( !rd( f, lm->hp ) ) return E_INVALIDARG;
-
 		int32_t nMel = 0, nFft = 0;
-		if( !rd( f, nMel ) || !rd( f, nFft ) || nMel <= 0 || nFft <= 0 || (int64_t)nMel * nFft > ( 1 << 20 ) ) return E_INVALIDARG;
-		std::vector<float> filters( (size_t)nMel * nFft );
-		f.read( (char*)filters.data(), filters.size() * 4 );
-
-		int32_t nWords = 0;
-		if( !rd( f, nWords ) || nWords < 0 || nWords > ( 1 << 20 ) ) return E_INVALIDARG;
-		lm->vocab.idToToken.resize( nWords );
-		for( int i = 0; i < nWords; i++ )
-		{
-			uint32_t len = 0;
-			if( !rd( f, len ) || len > ( 1u << 16 ) ) return E_INVALIDARG;
-			std::string w( len, '\0' );
-			if( len ) f.read( &w[ 0 ], len );
-			lm->vocab.idToToken[ i ] = std::move( w );
-		}
-		if( !f ) return E_INVALIDARG;
-		lm->vocab.finalize( lm->hp.n_vocab );
+		std::vector<float> filters;
+		CHECK( readGgmlHeader( f, path, lm->hp, nMel, nFft, filters, lm->vocab ) );
 
 		CHECK_WH( wh_device_set( device ) );
 		CHECK_WH( wh_model_create( &lm->hp, nullptr, 0, &lm->gpu ) );

@@ -27,18 +27,6 @@ namespace Whisper
 		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
 		constexpr int GREEDY_CHUNK = 8;		   // tokens fetched per device-side greedy call
 
-		struct TokenData
-		{
-			int id = 0, tid = 0;
-			float p = 0, pt = 0, ptsum = 0, vlen = 0;
-			int64_t t0 = -1, t1 = -1;
-		};
-		struct Segment
-		{
-			int64_t t0 = 0, t1 = 0;	   // 10 ms units
-			std::string text;
-			std::vector<TokenData> tokens;
-		};
 
 		// ---- iTranscribeResult ------------------------------------------------------------------------------------
 		struct ResultData
@@ -110,6 +98,7 @@ namespace Whisper
 			// timings, the blocks of ProfileCollection (Whisper/Utils/ProfileCollection.h)
 			double msSpectrogram = 0, msEncode = 0, msDecode = 0, msRun = 0;
 			int nEncode = 0, nDecodeSteps = 0, nRuns = 0, nSpectrogram = 0, nDecodeWindows = 0;
+			TokenTimestamper stamper;	  // TokenTimestamps flag: token-level times + max_len wrapping (host-only post-processing)
 			bool gpuProfile = false;	  // WHISPER_PROFILE=1: per-kernel hipEvent timing, printed as the "Compute Shaders" table
 
 			using Clock = std::chrono::steady_clock;
@@ -265,6 +254,7 @@ namespace Whisper
 				msSpectrogram += msSince( t );
 				nSpectrogram++;
 			}
+			if( params.flag( eFullParamsFlags::TokenTimestamps ) ) stamper.begin( pcm, n );
 			const HRESULT hr = runFullImpl( params, melLen );
 			msRun += msSince( tRun );
 			nRuns++;
@@ -329,8 +319,6 @@ namespace Whisper
 				logError( "audio_ctx override is not supported by this build" );
 				return E_NOTIMPL;
 			}
-			if( params.flag( eFullParamsFlags::TokenTimestamps ) )
-				logWarning( "TokenTimestamps is not implemented: token times are left unset" );
 
 			const int seekStart = params.offset_ms / 10;
 			const int seekEnd = seekStart + ( params.duration_ms == 0 ? (int)melLen : params.duration_ms / 10 );
@@ -480,9 +468,16 @@ namespace Whisper
 						s.tokens.assign( tokensCur.begin() + i0, tokensCur.begin() + last + 1 );
 						if( params.flag( eFullParamsFlags::PrintRealtime ) ) logDebug( "[%d --> %d]  %s", t0, t1, text.c_str() );
 						resultAll.push_back( std::move( s ) );
+						uint32_t nNew = 1;
+						if( params.flag( eFullParamsFlags::TokenTimestamps ) && stamper.ready() )
+						{
+							// whisper.cpp:3063-3069 / ContextImpl.cpp:741-749
+							stamper.compute( resultAll.back(), vocab, params.thold_pt, params.thold_ptsum );
+							if( params.max_len > 0 ) nNew = (uint32_t)TokenTimestamper::wrapLast( resultAll, vocab, params.max_len );
+						}
 						if( params.new_segment_callback )
 						{
-							const HRESULT hr = params.new_segment_callback( this, 1, params.new_segment_callback_user_data );
+							const HRESULT hr = params.new_segment_callback( this, nNew, params.new_segment_callback_user_data );
 							if( FAILED( hr ) ) return hr;
 						}
 						return S_OK;
@@ -780,6 +775,29 @@ WHISPER_EXPORT int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t 
 	buf->Release();
 	return hr;
 }
+// The same with the token-timestamp parameters of sFullParams (thold_pt, thold_ptsum, max_len; sFullParams.h:79-86)
+WHISPER_EXPORT int32_t whisperc_run_full_tt( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, float tholdPt, float tholdPtsum, int maxLen )
+{
+	if( !ctx || ( !pcm && nSamples ) ) return E_POINTER;
+	iContext* c = (iContext*)ctx;
+	sFullParams p;
+	CHECK( c->fullDefaultParams( eSamplingStrategy::Greedy, &p ) );
+	p.flags = (eFullParamsFlags)flags;
+	p.language = makeLanguageKey( language ? language : "en" );
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	p.thold_pt = tholdPt;
+	p.thold_ptsum = tholdPtsum;
+	p.max_len = maxLen;
+	iAudioBuffer* buf = nullptr;
+	CHECK( createAudioBuffer( std::vector<float>( pcm, pcm + nSamples ), {}, &buf ) );
+	const HRESULT hr = c->runFull( p, buf );
+	buf->Release();
+	return hr;
+}
 // Copies the results out: segment times in 10 ms units are returned as 100 ns ticks like the COM API.
 WHISPER_EXPORT int32_t whisperc_result_counts( void* ctx, uint32_t* segments, uint32_t* tokens )
 {
@@ -815,6 +833,17 @@ WHISPER_EXPORT int32_t whisperc_result_token( void* ctx, uint32_t index, int32_t
 	*id = t.id; *p = t.probability; *pt = t.probabilityTimestamp; *ptsum = t.ptsum;
 	return S_OK;
 }
+WHISPER_EXPORT int32_t whisperc_result_token_times( void* ctx, uint32_t index, uint64_t* t0, uint64_t* t1, float* vlen )
+{
+	iTranscribeResult* r = nullptr;
+	CHECK( ( (iContext*)ctx )->getResults( eResultFlags::Tokens | eResultFlags::Timestamps, &r ) );
+	sTranscribeLength len;
+	r->getSize( len );
+	if( index >= len.countTokens ) return E_BOUNDS;
+	const sToken& t = r->getTokens()[ index ];
+	*t0 = t.time.begin.ticks; *t1 = t.time.end.ticks; *vlen = t.vlen;
+	return S_OK;
+}
 WHISPER_EXPORT int32_t whisperc_tokenize( void* model, const char* text, int32_t* out, int cap )
 {
 	struct Sink { int32_t* out; int cap; int n; } sink{ out, cap, 0 };
@@ -826,6 +855,59 @@ WHISPER_EXPORT int32_t whisperc_tokenize( void* model, const char* text, int32_t
 	return FAILED( hr ) ? hr : sink.n;
 }
 WHISPER_EXPORT int32_t whisperc_timings_print( void* ctx ) { return ( (iContext*)ctx )->timingsPrint(); }
+// Host-only post-processing of token data into token times, on its own (no device): what runFull does per segment under the
+// TokenTimestamps flag. Segments are processed in order (the anchors carry state from one to the next).
+WHISPER_EXPORT int32_t whisperc_debug_token_timestamps( const char* modelPath, const float* pcm, uint64_t nSamples, int32_t nSegments,
+	const int64_t* segTimes, const int32_t* segTokenCounts, const int32_t* ids, const int32_t* tids, const float* p, const float* pt,
+	const float* ptsum, float tholdPt, float tholdPtsum, int32_t maxLen, int32_t segCap, int32_t tokCap, int32_t* outSegCount,
+	int64_t* outSegTimes, int32_t* outSegTokenCounts, char* outTexts, uint32_t textCap, int64_t* outTokTimes, float* outVlen )
+{
+	using namespace Whisper;
+	if( !modelPath || !pcm || !segTimes || !segTokenCounts || !ids || !tids || !p || !pt || !ptsum || !outSegCount ) return E_POINTER;
+	Vocabulary vocab;
+	const HRESULT hr = loadVocabulary( modelPath, vocab );
+	if( FAILED( hr ) ) return hr;
+	TokenTimestamper stamper;
+	stamper.begin( pcm, (size_t)nSamples );
+	std::vector<Segment> all;
+	size_t at = 0;
+	for( int i = 0; i < nSegments; i++ )
+	{
+		Segment s;
+		s.t0 = segTimes[ 2 * i ]; s.t1 = segTimes[ 2 * i + 1 ];
+		for( int j = 0; j < segTokenCounts[ i ]; j++, at++ )
+		{
+			TokenData t;
+			t.id = ids[ at ]; t.tid = tids[ at ]; t.p = p[ at ]; t.pt = pt[ at ]; t.ptsum = ptsum[ at ];
+			s.tokens.push_back( t );
+			if( t.id < vocab.token_eot && vocab.string( t.id ) ) s.text += vocab.string( t.id );
+		}
+		all.push_back( std::move( s ) );
+		stamper.compute( all.back(), vocab, tholdPt, tholdPtsum );
+		if( maxLen > 0 ) TokenTimestamper::wrapLast( all, vocab, maxLen );
+	}
+	size_t nTok = 0, textAt = 0;
+	for( const Segment& s : all ) nTok += s.tokens.size();
+	if( (int)all.size() > segCap || (int)nTok > tokCap ) return E_BOUNDS;
+	*outSegCount = (int32_t)all.size();
+	size_t k = 0;
+	for( size_t i = 0; i < all.size(); i++ )
+	{
+		const Segment& s = all[ i ];
+		outSegTimes[ 2 * i ] = s.t0; outSegTimes[ 2 * i + 1 ] = s.t1;
+		outSegTokenCounts[ i ] = (int32_t)s.tokens.size();
+		if( textAt + s.text.size() + 1 > textCap ) return E_BOUNDS;
+		memcpy( outTexts + textAt, s.text.c_str(), s.text.size() + 1 );	   // NUL-separated
+		textAt += s.text.size() + 1;
+		for( const TokenData& t : s.tokens )
+		{
+			outTokTimes[ 2 * k ] = t.t0; outTokTimes[ 2 * k + 1 ] = t.t1;
+			outVlen[ k ] = t.vlen;
+			k++;
+		}
+	}
+	return S_OK;
+}
 WHISPER_EXPORT int32_t whisperc_format_measure( const char* name, double ticks, uint64_t count, char* out, uint32_t outCap )
 {
 	if( !name || !out || outCap == 0 ) return -1;
