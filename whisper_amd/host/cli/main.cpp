@@ -6,7 +6,8 @@
 //
 // Differences from the reference, all due to features this build does not have: the audio is
 // always loaded whole (runStreamed answers E_NOTIMPL and the tool falls back to runFull, as the reference itself does
-// for token timestamps), and -di / -su / -owts / -ml report what the library reports for them.
+// for token timestamps); -di and -su report what the library reports for them; -owts turns token timestamps on but
+// writes no karaoke script (the reference's tool does not either: params.h declares the option, main.cpp never reads it).
 #include <stdio.h>
 #include <string.h>
 #include <unistd.h>
