@@ -52,3 +52,31 @@ def test_no_silent_cpu_fallback():
         pytest.skip("a GPU is visible")
     with pytest.raises(binding.WhisperHipError):
         binding.HipModel(gf.hparams_for("test-d128"))
+
+
+def test_product_never_touches_the_oracle():
+    """oracle/ is the checker: nothing under whisper_amd/ (Python, C++ host, HIP) may import, include, link or execute it, and
+    the bench uses it only in the cpu_baseline leg."""
+    import re
+    pkg = os.path.join(ROOT, "whisper_amd")
+    offenders = []
+    for base, _, files in os.walk(pkg):
+        if os.sep + "lib" in base or "__pycache__" in base:
+            continue
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".h", ".hip")):
+                continue
+            text = open(os.path.join(base, f), errors="ignore").read()
+            if f == "build.py":
+                # the build script may BUILD the checker (make -C oracle); it must not import it
+                text = re.sub(r'os\.path\.join\(ROOT, "oracle"\)|"oracle"', "", text)
+            for m in re.finditer(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<][^\">]*oracle|dlopen\([^)]*oracle|CDLL\([^)]*oracle", text, re.M):
+                offenders.append((f, m.group(0)))
+    assert not offenders, offenders
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle import|import oracle", bench)]
+    assert uses, "bench.py times the reference CPU path in its cpu_baseline leg"
+    for u in uses:
+        # every import sits inside cpu_baseline_worker / cpu_baseline
+        head = bench[:u]
+        assert head.rfind("def cpu_baseline") > head.rfind("def main") and head.rfind("def cpu_baseline") > head.rfind("def run_passes")
