@@ -49,6 +49,11 @@ int32_t whisperc_debug_token_timestamps( const char* modelPath, const float* pcm
 	const int64_t* segTimes, const int32_t* segTokenCounts, const int32_t* ids, const int32_t* tids, const float* p, const float* pt,
 	const float* ptsum, float tholdPt, float tholdPtsum, int32_t maxLen, int32_t segCap, int32_t tokCap, int32_t* outSegCount,
 	int64_t* outSegTimes, int32_t* outSegTokenCounts, char* outTexts, uint32_t textCap, int64_t* outTokTimes, float* outVlen );
+/* Vocabulary and tokenizer of a model file on their own (host only, no device). whisperc_debug_tokenize returns the token count
+ * (or a negative HRESULT); whisperc_debug_token_string writes the token's text and, optionally, the special ids in the order
+ * eot, sot, prev, solm, not, beg, translate, transcribe (S_FALSE when the id has no string). */
+int32_t whisperc_debug_tokenize( const char* modelPath, const char* text, int32_t* out, int cap );
+int32_t whisperc_debug_token_string( const char* modelPath, int32_t token, char* out, uint32_t outCap, int32_t* specials8 );
 /* Process-wide choice between the two host loops the reference ships: 0 (default) = its CPU model's whisper_full
  * (Whisper/source/whisper.cpp:2765-3120: drops the past prompt when < 5 s remain, retries a failed window once without it),
  * 1 = its GPU model's ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:452-793: neither rule). */

@@ -908,6 +908,36 @@ WHISPER_EXPORT int32_t whisperc_debug_token_timestamps( const char* modelPath, c
 	}
 	return S_OK;
 }
+// Vocabulary + tokenizer of a model file on their own (host only): what iModel::tokenize / stringFromToken / getSpecialTokens answer
+WHISPER_EXPORT int32_t whisperc_debug_tokenize( const char* modelPath, const char* text, int32_t* out, int cap )
+{
+	if( !modelPath || !text || ( !out && cap > 0 ) ) return E_POINTER;
+	Whisper::Vocabulary vocab;
+	const HRESULT hr = Whisper::loadVocabulary( modelPath, vocab );
+	if( FAILED( hr ) ) return hr;
+	std::vector<int> toks;
+	const HRESULT hr2 = vocab.tokenize( text, toks );
+	if( FAILED( hr2 ) ) return hr2;
+	if( (int)toks.size() > cap ) return E_BOUNDS;
+	for( size_t i = 0; i < toks.size(); i++ ) out[ i ] = toks[ i ];
+	return (int32_t)toks.size();
+}
+WHISPER_EXPORT int32_t whisperc_debug_token_string( const char* modelPath, int32_t token, char* out, uint32_t outCap, int32_t* specials8 )
+{
+	if( !modelPath || !out || outCap == 0 ) return E_POINTER;
+	Whisper::Vocabulary vocab;
+	const HRESULT hr = Whisper::loadVocabulary( modelPath, vocab );
+	if( FAILED( hr ) ) return hr;
+	const char* const str = vocab.string( token );
+	snprintf( out, outCap, "%s", str ? str : "" );
+	if( specials8 )
+	{
+		const int v[ 8 ] = { vocab.token_eot, vocab.token_sot, vocab.token_prev, vocab.token_solm, vocab.token_not, vocab.token_beg,
+			Whisper::Vocabulary::token_translate, Whisper::Vocabulary::token_transcribe };
+		for( int i = 0; i < 8; i++ ) specials8[ i ] = v[ i ];
+	}
+	return str ? S_OK : S_FALSE;
+}
 WHISPER_EXPORT int32_t whisperc_format_measure( const char* name, double ticks, uint64_t count, char* out, uint32_t outCap )
 {
 	if( !name || !out || outCap == 0 ) return -1;
