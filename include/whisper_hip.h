@@ -2,7 +2,7 @@
  *
  * This is the drop-in boundary below the reference's host code: everything the reference implements in
  * Whisper/Whisper/WhisperContext.{h,cpp} (encode/decode graphs), Whisper/ML/MlContext.{h,cpp} (one method per
- * tensor op, each a D3D11 compute-shader dispatch) and ComputeShaders/*.hlsl is replaced by the entry points
+ * tensor op, each a D3D11 compute-shader dispatch) and the .hlsl files of ComputeShaders/ is replaced by the entry points
  * below.  Plain pointers and sizes only; no C++ types, no torch types.  All device pointers are HIP device
  * pointers; `stream` is a hipStream_t passed as void* (0 = the null stream).  Every function returns 0 on
  * success or a negative wh_status; wh_last_error() gives the text.  Nothing here ever falls back to the CPU.

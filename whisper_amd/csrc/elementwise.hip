@@ -285,7 +285,7 @@ namespace wh
 				// remove the winner from its owner's registers for the next round
 #pragma unroll
 				for( int j = 0; j < SS_PER; j++ )
-					if( threadIdx.x + j * 1024 == best.i ) v[ j ] = -INFINITY;
+					if( (int)threadIdx.x + j * 1024 == best.i ) v[ j ] = -INFINITY;
 				const bool special = best.i == tokenSot || best.i == tokenSolm || best.i == tokenNot;
 				if( !special ) break;
 			}

@@ -679,9 +679,8 @@ namespace wh
 		__global__ void __launch_bounds__( NW * 64 ) gemvFused( const GemmArgs a )
 		{
 			constexpr bool LN = PRO == 1;
-			constexpr int MROWS = 16 * MT;	  // activation rows held by the workgroup: MT column tiles of the 16x16x32 MFMA
 			__shared__ float red[ NW - 1 ][ MT * 4 ][ 64 ];
-			extern __shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[];	 // [MROWS][GV_XS_STRIDE] when there is a prologue
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[];	 // [16 * MT][GV_XS_STRIDE] when there is a prologue
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
