@@ -35,6 +35,8 @@ CLIP_SECONDS = 198.762
 WINDOW_SAMPLES = 480000
 N_PROMPT = 3
 N_GREEDY = 51
+# the reference's own published audio-s/s for this clip (its D3D11 backend on a GTX 1080Ti, SampleClips/summary.tsv:10, :14)
+PUBLISHED_AUDIO_S_PER_S = {"medium": 13.30, "large-v2": 7.22, "large": 7.22}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
 
@@ -342,12 +344,14 @@ def main():
         line = {
             "metric": "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU",
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": (round(value / PUBLISHED_AUDIO_S_PER_S[args.model], 2) if args.model in PUBLISHED_AUDIO_S_PER_S and B == 7 else None),
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, "
                                    "%d clip pass(es) per lock-step batch, %d batches in flight on separate HIP streams; GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
                                    "device-side sampling (captured hipGraph per token)" % (args.model, audio_seconds, B, C, len(slots), N_PROMPT, N_GREEDY),
-                       "model": "ggml-" + args.model, "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": len(slots), "decode_steps_per_window": N_GREEDY + 1,
+                       "model": "ggml-" + args.model, "baseline": "BASELINE.md section 1: reference D3D11 backend, GTX 1080Ti, same clip length (whole job, 1 GPU)",
+                       "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": len(slots), "decode_steps_per_window": N_GREEDY + 1,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,
