@@ -86,11 +86,25 @@ typedef enum wh_flags
 	 * (Whisper/source/ggml.c:4689-4735, 4615-4644) with `parityThreads` virtual threads. Slow; for parity runs. */
 	WH_FLAG_PARITY_PV = 1,
 	/* Launch the greedy loop's kernels one by one instead of replaying the captured hipGraph (debugging aid). */
-	WH_FLAG_NO_GRAPH = 2
+	WH_FLAG_NO_GRAPH = 2,
+	/* Keep copies of the intermediates at the reference's Tracing probe points (Whisper/Whisper/WhisperContext.cpp:142-638,
+	 * source/whisper.cpp:1121-1869) for wh_debug_read: "enc.temp1", "enc.layer0.in", "enc-KQV", "dec-KQV", "dec-KQV#2". */
+	WH_FLAG_DEBUG_CAPTURE = 4
 } wh_flags;
 
 WH_API int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out );
+/* The same with `hypotheses` decoder sequences per window (1, 2, 3, 4, 5 or 8): the sequences b*hypotheses .. b*hypotheses +
+ * hypotheses-1 decode window b and share ONE pass over its cross-attention K/V per step (each has its own self-attention
+ * cache). The reference declares beam search without implementing it (Whisper/API/sFullParams.h:12-13, `beam_width`,
+ * `n_best`): this is the data path a beam / best-of-n decoder needs, an extension with no reference oracle beyond
+ * "every hypothesis computes what a lone sequence fed the same tokens computes". In every decode entry point `batch`
+ * then counts SEQUENCES (a multiple of `hypotheses`); wh_encode's `batch` keeps counting windows. */
+WH_API int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stream, wh_context** out );
 WH_API void wh_context_destroy( wh_context* c );
+/* Binds the model's device to the calling thread (every wh_* call on a model or context does it as well): the
+ * counterpart of Device::setForCurrentThread (Whisper/ML/Device.cpp:163-177). Call it before wh_buffer_alloc /
+ * wh_buffer_free, which take no context. */
+WH_API int wh_context_bind( wh_context* c );
 WH_API int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads );
 /* Blocks until everything queued on the context's stream has finished. When `stream` was NULL at creation the context
  * owns a non-blocking stream (the legacy null stream cannot be captured into a hipGraph), so callers that produce
@@ -173,7 +187,12 @@ WH_API int wh_profile_read( wh_context* c, wh_profile_entry* out, int cap, int* 
  * Whisper/Whisper/WhisperContext.cpp:142-638). All outputs HOST FP32.
  *   what = "encode-out"  [batch][n_ctx][d]           (only valid right after wh_encode)
  *          "cross-k" / "cross-v"   layer, [batch][n_ctx][d] token-major like the reference's kvCross
- *          "self-k" / "self-v"     layer, [batch][rows][d]
+ *          "self-k" / "self-v"     layer, [sequences][rows][d]
+ * and, captured under WH_FLAG_DEBUG_CAPTURE by the wh_encode / wh_decode call that follows the flag:
+ *          "enc.temp1"      conv1 + bias + GELU, [batch][2*n_ctx][d] (time-major; the reference's tensor is [d][2*n_ctx])
+ *          "enc.layer0.in"  conv2 + GELU + positional embedding = input of encoder layer 0, [batch][n_ctx][d]
+ *          "enc-KQV"        encoder layer 0 attention output, [batch][n_ctx][d] (heads side by side)
+ *          "dec-KQV" / "dec-KQV#2"   decoder layer 0 self / cross attention output of the last wh_decode, [rows][d]
  */
 WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* dstHost, int64_t dstCapFloats );
 
@@ -201,6 +220,17 @@ WH_API int wh_op_layer_norm( void* stream, const float* x, const float* w, const
  *   index(key, dd) = (((key>>4)*2 + (dd>>5))*64 + ((key>>2)&1)*32 + (dd&31))*8 + ((key>>3)&1)*4 + (key&3)
  * out: FP16 [batch][nCtx][heads*64]. */
 WH_API int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vFrag, void* out, int batch, int heads, int nCtx );
+/* Decoder attention of WhisperContext::decodeLayer (Whisper/Whisper/WhisperContext.cpp:455-470, 505-519: mulMat(K,Q) ->
+ * diagMaskInf -> softMax -> mulMat(V,.)) on caches laid out [block][head][keyStride][64] FP16. q, out: FP16
+ * [sequences*nTok][heads*64], q already scaled. causal: query i of a sequence sees keys <= nPast + i. `group` consecutive
+ * sequences share one cache block (cross-attention of a window's hypotheses); parityThreads > 0 emulates the CPU path's
+ * FP16 thread-partitioned P.V (ggml.c:4689-4735). */
+WH_API int wh_op_decoder_attention( void* stream, const void* qF16, const void* kCache, const void* vCache, void* outF16, int sequences, int heads,
+	int nTok, int nKeys, int keyStride, int causal, int nPast, int group, int parityThreads );
+/* The cross-attention half of a decode step in one launch (WhisperContext.cpp:489-519): q = fp16( ( Wq . fp16( LayerNorm(x)
+ * * lnW + lnB ) + qB ) * qScale ) per head inside the attention kernel; x: FP32 [sequences][heads*64]. */
+WH_API int wh_op_decoder_cross_attention( void* stream, const float* x, const float* lnW, const float* lnB, const void* qW, const float* qB,
+	float qScale, const void* kCache, const void* vCache, void* outF16, int sequences, int heads, int nKeys, int keyStride, int group );
 /* softMax over rows with the reference's FP16 exp table semantics (softMax.hlsl / ggml.c:5030-5090): in place, FP32 */
 WH_API int wh_op_soft_max( void* stream, float* x, int rows, int cols );
 

@@ -318,6 +318,120 @@ class WhisperNP:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# "truth": the same graph in float64 with NO intermediate rounding
+# ----------------------------------------------------------------------------------------------------------------------
+class WhisperTruth:
+    """What the reference's graph computes in exact arithmetic, as close as float64 gets: the stored weights (FP16 / FP32
+    values as they are in the file) but no FP16 rounding of activations, no GELU / exp tables, no FP16 K/V caches, no FP16
+    accumulation. It restates whisper_encode / whisper_decode (whisper.cpp:1084-1496, :1508-1872) op for op; it is NOT the
+    reference's numerics -- it is the yardstick both the reference (any thread count) and the HIP path are measured
+    against: an implementation is "as good as the reference" when |impl - truth| <= |reference - truth|."""
+
+    def __init__(self, model):
+        self.hp = model.hparams
+        self.t = {k: np.asarray(v, np.float64) for k, v in model.tensors.items()}
+        self.cross_k, self.cross_v, self.self_k, self.self_v = [], [], [], []
+
+    @staticmethod
+    def _gelu(x):
+        return 0.5 * x * (1.0 + np.tanh(0.79788456080286535587989211986876 * x * (1.0 + 0.044715 * x * x)))
+
+    @staticmethod
+    def _ln(x, w, b):
+        mean = x.mean(axis=-1, keepdims=True)
+        v = x - mean
+        return v / np.sqrt((v * v).mean(axis=-1, keepdims=True) + np.float64(F32(1e-5))) * w + b
+
+    @staticmethod
+    def _softmax(s):
+        m = s.max(axis=-1, keepdims=True)
+        with np.errstate(invalid="ignore"):
+            e = np.where(np.isneginf(s), 0.0, np.exp(s - m))
+        return e / e.sum(axis=-1, keepdims=True)
+
+    def _conv(self, w, x, stride):
+        ic, T = x.shape
+        xp = np.zeros((ic, T + 2))
+        xp[:, 1:T + 1] = x
+        n_out = T // stride
+        out = np.zeros((w.shape[0], n_out))
+        for k in range(3):
+            out += w[:, :, k] @ xp[:, k:k + T:stride][:, :n_out]
+        return out
+
+    def encode(self, mel, mel_offset=0):
+        hp, t = self.hp, self.t
+        n_ctx, d, H = hp.n_audio_ctx, hp.n_audio_state, hp.n_audio_head
+        D = d // H
+        inp = np.zeros((hp.n_mels, 2 * n_ctx))
+        i0, i1 = min(mel_offset, mel.shape[1]), min(mel_offset + 2 * n_ctx, mel.shape[1])
+        inp[:, :i1 - i0] = mel[:, i0:i1]
+        cur = self._gelu(self._conv(t["encoder.conv1.weight"], inp, 1) + t["encoder.conv1.bias"].reshape(-1, 1))
+        cur = self._gelu(self._conv(t["encoder.conv2.weight"], cur, 2) + t["encoder.conv2.bias"].reshape(-1, 1))
+        x = t["encoder.positional_embedding"][:n_ctx] + cur.T
+        for il in range(hp.n_audio_layer):
+            p = f"encoder.blocks.{il}"
+            cur = self._ln(x, t[p + ".attn_ln.weight"], t[p + ".attn_ln.bias"])
+            q = (cur @ t[p + ".attn.query.weight"].T + t[p + ".attn.query.bias"]).reshape(n_ctx, H, D).transpose(1, 0, 2)
+            k = (cur @ t[p + ".attn.key.weight"].T).reshape(n_ctx, H, D).transpose(1, 0, 2)
+            v = (cur @ t[p + ".attn.value.weight"].T + t[p + ".attn.value.bias"]).reshape(n_ctx, H, D).transpose(1, 0, 2)
+            kqv = np.stack([self._softmax((q[h] @ k[h].T) / np.sqrt(np.float64(D))) @ v[h] for h in range(H)])
+            cur = kqv.transpose(1, 0, 2).reshape(n_ctx, d)
+            x = x + cur @ t[p + ".attn.out.weight"].T + t[p + ".attn.out.bias"]
+            cur = self._ln(x, t[p + ".mlp_ln.weight"], t[p + ".mlp_ln.bias"])
+            cur = self._gelu(cur @ t[p + ".mlp.0.weight"].T + t[p + ".mlp.0.bias"])
+            x = x + cur @ t[p + ".mlp.2.weight"].T + t[p + ".mlp.2.bias"]
+        out = self._ln(x, t["encoder.ln_post.weight"], t["encoder.ln_post.bias"])
+        ks = np.power(np.float64(d) / np.float64(H), -0.25)
+        self.cross_k, self.cross_v = [], []
+        for il in range(hp.n_text_layer):
+            p = f"decoder.blocks.{il}.cross_attn"
+            self.cross_k.append(out @ t[p + ".key.weight"].T * ks)
+            self.cross_v.append(out @ t[p + ".value.weight"].T + t[p + ".value.bias"])
+        self.self_k = [np.zeros((hp.n_text_ctx, d)) for _ in range(hp.n_text_layer)]
+        self.self_v = [np.zeros((hp.n_text_ctx, d)) for _ in range(hp.n_text_layer)]
+        return out
+
+    def _attn(self, q, K, V, n_keys, mask_past):
+        H = self.hp.n_text_head
+        D = self.hp.n_text_state // H
+        N = q.shape[0]
+        out = np.zeros((N, H * D))
+        for h in range(H):
+            sl = slice(h * D, (h + 1) * D)
+            S = q[:, sl] @ K[:n_keys, sl].T
+            if mask_past is not None:
+                S = np.where(np.arange(n_keys)[None, :] > mask_past + np.arange(N)[:, None], -np.inf, S)
+            out[:, sl] = self._softmax(S) @ V[:n_keys, sl]
+        return out
+
+    def decode(self, tokens, n_past):
+        """Returns the logits [N][n_vocab] in float64."""
+        hp, t = self.hp, self.t
+        d, H = hp.n_text_state, hp.n_text_head
+        N = len(tokens)
+        x = t["decoder.token_embedding.weight"][np.asarray(tokens, np.int64)] + t["decoder.positional_embedding"][n_past:n_past + N]
+        s = np.power(np.float64(d) / np.float64(H), -0.25)
+        for il in range(hp.n_text_layer):
+            p = f"decoder.blocks.{il}"
+            cur = self._ln(x, t[p + ".attn_ln.weight"], t[p + ".attn_ln.bias"])
+            q = (cur @ t[p + ".attn.query.weight"].T + t[p + ".attn.query.bias"]) * s
+            self.self_k[il][n_past:n_past + N] = cur @ t[p + ".attn.key.weight"].T * s
+            self.self_v[il][n_past:n_past + N] = cur @ t[p + ".attn.value.weight"].T + t[p + ".attn.value.bias"]
+            a = self._attn(q, self.self_k[il], self.self_v[il], n_past + N, n_past)
+            x = x + a @ t[p + ".attn.out.weight"].T + t[p + ".attn.out.bias"]
+            cur = self._ln(x, t[p + ".cross_attn_ln.weight"], t[p + ".cross_attn_ln.bias"])
+            q = (cur @ t[p + ".cross_attn.query.weight"].T + t[p + ".cross_attn.query.bias"]) * s
+            a = self._attn(q, self.cross_k[il], self.cross_v[il], hp.n_audio_ctx, None)
+            x = x + a @ t[p + ".cross_attn.out.weight"].T + t[p + ".cross_attn.out.bias"]
+            cur = self._ln(x, t[p + ".mlp_ln.weight"], t[p + ".mlp_ln.bias"])
+            cur = self._gelu(cur @ t[p + ".mlp.0.weight"].T + t[p + ".mlp.0.bias"])
+            x = x + cur @ t[p + ".mlp.2.weight"].T + t[p + ".mlp.2.bias"]
+        cur = self._ln(x, t["decoder.ln.weight"], t["decoder.ln.bias"])
+        return cur @ t["decoder.token_embedding.weight"].T
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # sampling (host logic; restates ContextImpl::sampleBest, Whisper/Whisper/ContextImpl.cpp:71-157 == whisper.cpp:1875-1960)
 # ----------------------------------------------------------------------------------------------------------------------
 def sample_best(probs, token_beg, token_sot, token_solm, token_not, force_timestamp=False, is_initial=False):

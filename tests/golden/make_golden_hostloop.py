@@ -36,6 +36,9 @@ def cases():
         dict(name="no_timestamp", script=script_c, prompt_len=4, seconds=6.0, flags=dict(no_context=True), **common),
         dict(name="translate_de", script=script_a, prompt_len=4, seconds=12.0, flags=dict(no_context=True, translate=True), lang="de", **common),
         dict(name="too_short", script=script_a, prompt_len=4, seconds=0.9, flags=dict(no_context=True), **common),
+        # the reference's own sample clip (SampleClips/jfk.wav, 11 s; its PCM is stored in ref_test_d128.npz) with the default
+        # parameters of the CLI: two windows, the second one seeks to the last timestamp of the first
+        dict(name="jfk_wav", script=script_a, prompt_len=3, seconds=11.0, pcm="jfk", flags=dict(no_context=True), prompt=None, n_max_text_ctx=-1),
     ]
 
 
@@ -44,15 +47,19 @@ def main():
     rng = np.random.default_rng(11)
     for c in cases():
         model = gf.scripted_model(c["script"], c["prompt_len"])
-        n = int(16000 * c["seconds"])
-        pcm = (0.05 * rng.standard_normal(n)).astype(np.float32)
+        if c.get("pcm") == "jfk":
+            pcm = np.load(os.path.join(HERE, "ref_test_d128.npz"))["pcm16"].astype(np.float32) / 32768.0
+            n = len(pcm)
+        else:
+            n = int(16000 * c["seconds"])
+            pcm = (0.05 * rng.standard_normal(n)).astype(np.float32)
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "m.bin")
             gf.write_model(path, model)
             w = ref.RefWhisper(path, n_threads=4, log_level=0)
             segs = w.full(pcm, lang=c.get("lang", "en"), prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"], **c["flags"])
             w.close()
-        rec = dict(name=c["name"], script=c["script"], prompt_len=c["prompt_len"], n_samples=n, pcm_seed=11, lang=c.get("lang", "en"),
+        rec = dict(name=c["name"], script=c["script"], prompt_len=c["prompt_len"], n_samples=n, pcm_seed=11, pcm=c.get("pcm", "noise"), lang=c.get("lang", "en"),
                    prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"], flags=c["flags"],
                    segments=[dict(t0=s["t0"], t1=s["t1"], text=s["text"].decode(), tokens=s["tokens"]) for s in segs])
         print(c["name"], "->", len(segs), "segments", [(s["t0"], s["t1"]) for s in segs][:8])

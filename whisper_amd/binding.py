@@ -18,16 +18,17 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwhisper_hip.so")
 
 WH_FLAG_PARITY_PV = 1
 WH_FLAG_NO_GRAPH = 2
+WH_FLAG_DEBUG_CAPTURE = 4
 
 # every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "wh_last_error", "wh_device_count", "wh_device_info", "wh_device_set",
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
-    "wh_context_create", "wh_context_destroy", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
+    "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
     "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
-    "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max",
+    "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
 
@@ -75,6 +76,8 @@ def lib():
         L.wh_model_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.wh_model_hparams.argtypes = [vp, C.POINTER(HParamsC)]
         L.wh_context_create.argtypes = [vp, i32, vp, C.POINTER(vp)]
+        L.wh_context_create_hyp.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+        L.wh_context_bind.argtypes = [vp]
         L.wh_context_destroy.argtypes = [vp]
         L.wh_context_destroy.restype = None
         L.wh_context_set_flags.argtypes = [vp, C.c_uint32, i32]
@@ -96,6 +99,8 @@ def lib():
         L.wh_op_layer_norm.argtypes = [vp, vp, vp, vp, vp, i32, i32]
         L.wh_op_flash_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32]
         L.wh_op_soft_max.argtypes = [vp, vp, i32, i32]
+        L.wh_op_decoder_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32]
+        L.wh_op_decoder_cross_attention.argtypes = [vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, i32]
         _lib = L
     return _lib
 
@@ -176,12 +181,15 @@ class HipModel:
 class HipContext:
     """Activations + KV caches for up to max_batch 30 s windows processed in lock step (WhisperContext of the reference)."""
 
-    def __init__(self, model: HipModel, max_batch: int = 1, stream: int = 0):
+    def __init__(self, model: HipModel, max_batch: int = 1, stream: int = 0, hypotheses: int = 1):
+        """max_batch windows; `hypotheses` decoder sequences per window share the window's cross-attention K/V (then every
+        decode entry point counts sequences = windows * hypotheses, window-major)."""
         self.model = model
         self.hp = model.hp
         self.max_batch = max_batch
+        self.hypotheses = hypotheses
         self.handle = C.c_void_p()
-        check(lib().wh_context_create(model.handle, max_batch, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
+        check(lib().wh_context_create_hyp(model.handle, max_batch, hypotheses, C.c_void_p(stream) if stream else None, C.byref(self.handle)))
         self.batch = 0
 
     def close(self):
@@ -312,10 +320,14 @@ class HipContext:
     def debug_read(self, what: str, layer: int = 0, rows: int = 0) -> np.ndarray:
         d = self.hp.n_audio_state
         b = self.batch
-        if what == "encode-out" or what.startswith("cross"):
+        if what == "enc.temp1":
+            shape = (b, 2 * self.hp.n_audio_ctx, d)
+        elif what.startswith("dec-KQV"):
+            shape = (rows, d)
+        elif what in ("encode-out", "enc.layer0.in", "enc-KQV") or what.startswith("cross"):
             shape = (b, self.hp.n_audio_ctx, d)
         else:
-            shape = (b, rows, d)
+            shape = (b * self.hypotheses, rows, d)
         out = np.empty(shape, np.float32)
         check(lib().wh_debug_read(self.handle, what.encode(), layer, rows, out.ctypes.data_as(C.c_void_p), out.size))
         return out

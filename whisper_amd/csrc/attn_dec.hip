@@ -239,6 +239,397 @@ namespace wh
 			if( tid < HEAD_DIM )
 				a.out[ rowQ * d + h * HEAD_DIM + tid ] = (f16)result;
 		}
+
+		// ---------------------------------------------------------------------------------------------------------------
+		// attentionDecG: the same arithmetic, laid out for the memory system.
+		//   * K rows are read the way V rows are: 8 consecutive lanes own one 128-byte row (16 bytes each), a wave instruction
+		//     covers 8 whole rows = 1 KiB contiguous. The 8 partial dot products are combined with three xor-shuffles. (The
+		//     first kernel gave every thread a whole row: each load instruction then touched 64 different lines for 16 bytes
+		//     apiece, eight times the tag look-ups and an L1 that cannot hold the lines until their last use.)
+		//   * NQ query rows share ONE pass over K and V: the hypotheses of a window in cross-attention (rows b*NQ .. b*NQ+NQ-1
+		//     all attend to window b's encoder keys) -- the crossKV/b term of SURVEY.md 8(d).
+		//   * FUSEQ: the cross-attention query of this head is produced here: LayerNorm of the residual row (norm.hlsl +
+		//     fmaRepeat1.hlsl), product with the head's 64 rows of the query weight (L2-resident, shared by every window),
+		//     bias, scale, FP16 rounding -- WhisperContext.cpp:489-501 -- instead of a LayerNorm launch and a gemv launch.
+		//     The K loads of the first batch are already in flight while this runs.
+		// Grid (head, window, token); 512 threads. Results differ from attentionDec only by FP32 summation order.
+		constexpr int G_ROWS = NT / 8;		  // K/V rows one load instruction of the workgroup covers (64)
+		constexpr int G_ITERS = MAX_KEYS / G_ROWS;	  // 24
+		constexpr int G_BATCH = 8;			  // rows per thread in flight per batch
+		constexpr int G_MAXD = 1280;
+
+		template<int NQ>
+		struct DecGLds
+		{
+			float sc[ NQ ][ MAX_KEYS ];
+			float qs[ NQ ][ HEAD_DIM ];
+			float red[ NQ ][ NW ][ HEAD_DIM ];
+			float shf[ NQ ][ NW ];
+			double shd[ NQ ][ NW ];
+			f16 xn[ NQ ][ G_MAXD ];
+		};
+
+		__device__ __forceinline__ float xorReduce8( float v )
+		{
+			v += __shfl_xor( v, 1, 64 );
+			v += __shfl_xor( v, 2, 64 );
+			v += __shfl_xor( v, 4, 64 );
+			return v;
+		}
+
+		template<int NQ, bool FUSEQ>
+		__global__ void __launch_bounds__( NT, 2 ) attentionDecG( const DecAttnArgs a )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemG[];
+			DecGLds<NQ>& L = *(DecGLds<NQ>*)smemG;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int g = tid >> 3, c = tid & 7;
+			const int h = blockIdx.x, bw = blockIdx.y, i = blockIdx.z;
+			const int d = a.H * HEAD_DIM;
+			const f16* const K = a.kc + ( (long long)bw * a.H + h ) * a.keyStride * HEAD_DIM;
+			const f16* const V = a.vc + ( (long long)bw * a.H + h ) * a.keyStride * HEAD_DIM;
+			int nPast = a.nPast, nKeys = a.nKeys;
+			if( a.causal && a.nPastDev )
+			{
+				nPast = *a.nPastDev;
+				nKeys = nPast + a.nTok;
+			}
+			const int nk = a.causal ? min( nPast + i + 1, nKeys ) : nKeys;
+			const int lastRow = a.keyStride - 1;
+			// query row q of this workgroup
+			auto rowOf = [ & ]( int q ) -> long long { return ( (long long)bw * NQ + q ) * a.nTok + i; };
+
+			// ---- K batch 0 goes out before anything else (rows beyond nk are clamped: the position may not be known yet) ----
+			f16x8 kA[ G_BATCH ], kB[ G_BATCH ];
+			auto loadK = [ & ]( f16x8 ( &dst )[ G_BATCH ], int it0, int limit )
+			{
+	#pragma unroll
+				for( int u = 0; u < G_BATCH; u++ )
+				{
+					int key = ( it0 + u ) * G_ROWS + g;
+					key = key < limit ? key : limit;
+					dst[ u ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + c * 8 );
+				}
+			};
+			loadK( kA, 0, lastRow );
+
+			// ---- query ----
+			if constexpr( FUSEQ )
+			{
+				// LayerNorm of the NQ residual rows, FP32 two-pass like layerNormRows (ggml.c:4098-4156 sums in double)
+				const int nv = d >> 2;	  // float4 per row
+				f32x4 xv[ NQ ];
+				f32x4 wv = { 0, 0, 0, 0 }, bv = { 0, 0, 0, 0 };
+				const bool own = tid < nv;
+				if( own )
+				{
+					wv = *(const f32x4*)( a.lnW + tid * 4 );
+					bv = *(const f32x4*)( a.lnB + tid * 4 );
+				}
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+					xv[ q ] = own ? *(const f32x4*)( a.lnX + rowOf( q ) * d + tid * 4 ) : f32x4{ 0, 0, 0, 0 };
+				const float invD = 1.0f / (float)d;
+				float s[ NQ ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) s[ q ] = waveReduceSum( ( xv[ q ][ 0 ] + xv[ q ][ 1 ] ) + ( xv[ q ][ 2 ] + xv[ q ][ 3 ] ) );
+				if( lane == 0 )
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ ) L.shf[ q ][ wave ] = s[ q ];
+				__syncthreads();
+				float mean[ NQ ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					float t = L.shf[ q ][ 0 ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) t += L.shf[ q ][ w ];
+					mean[ q ] = t * invD;
+				}
+				__syncthreads();
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					float t = 0.0f;
+					if( own )
+					{
+	#pragma unroll
+						for( int e = 0; e < 4; e++ )
+						{
+							xv[ q ][ e ] -= mean[ q ];
+							t = fmaf( xv[ q ][ e ], xv[ q ][ e ], t );
+						}
+					}
+					s[ q ] = waveReduceSum( t );
+				}
+				if( lane == 0 )
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ ) L.shf[ q ][ wave ] = s[ q ];
+				__syncthreads();
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					float t = L.shf[ q ][ 0 ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) t += L.shf[ q ][ w ];
+					const float rstd = 1.0f / sqrtf( t * invD + 1e-5f );
+					if( own )
+					{
+						f16x4 hv;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) hv[ e ] = (f16)__fadd_rn( __fmul_rn( __fmul_rn( xv[ q ][ e ], rstd ), wv[ e ] ), bv[ e ] );
+						*(f16x4*)( &L.xn[ q ][ tid * 4 ] ) = hv;
+					}
+				}
+				__syncthreads();
+				// q[j] = fp16( ( W[h*64 + j] . xn + bias ) * scale ): 8 lanes per weight row, 128 contiguous bytes per row and step
+				const f16* const wr = a.qW + ( (long long)h * HEAD_DIM + g ) * d + c * 8;
+				float acc[ NQ ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) acc[ q ] = 0.0f;
+				const int steps = d >> 6;
+				for( int s0 = 0; s0 < steps; s0 += 8 )
+				{
+					f16x8 wq[ 8 ];
+	#pragma unroll
+					for( int u = 0; u < 8; u++ )
+						if( s0 + u < steps ) wq[ u ] = *(const f16x8*)( wr + ( s0 + u ) * 64 );
+	#pragma unroll
+					for( int u = 0; u < 8; u++ )
+						if( s0 + u < steps )
+						{
+	#pragma unroll
+							for( int q = 0; q < NQ; q++ )
+							{
+								const f16x8 xq = *(const f16x8*)( &L.xn[ q ][ ( s0 + u ) * 64 + c * 8 ] );
+	#pragma unroll
+								for( int e = 0; e < 8; e++ ) acc[ q ] = fmaf( (float)wq[ u ][ e ], (float)xq[ e ], acc[ q ] );
+							}
+						}
+				}
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					const float t = xorReduce8( acc[ q ] );
+					if( c == 0 ) L.qs[ q ][ g ] = round16( ( t + a.qB[ h * HEAD_DIM + g ] ) * a.qScale );
+				}
+			}
+			else
+			{
+				if( tid < HEAD_DIM * NQ )
+				{
+					const int q = tid / HEAD_DIM, j = tid - q * HEAD_DIM;
+					L.qs[ q ][ j ] = (float)a.q[ rowOf( q ) * d + h * HEAD_DIM + j ];
+				}
+			}
+			__syncthreads();
+			float qf[ NQ ][ 8 ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+				for( int e = 0; e < 8; e++ ) qf[ q ][ e ] = L.qs[ q ][ c * 8 + e ];
+
+			// ---- scores: batches of 8 row groups, the next batch in flight while this one is reduced ----
+			float mx[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ ) mx[ q ] = -INFINITY;
+			const int nIt = ( nk + G_ROWS - 1 ) / G_ROWS;
+			auto scoreBatch = [ & ]( const f16x8 ( &kv )[ G_BATCH ], int it0 )
+			{
+	#pragma unroll
+				for( int u = 0; u < G_BATCH; u++ )
+				{
+					if( it0 + u >= nIt ) break;
+					const int key = ( it0 + u ) * G_ROWS + g;
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ )
+					{
+						float sacc = 0.0f;
+	#pragma unroll
+						for( int e = 0; e < 8; e++ ) sacc = fmaf( (float)kv[ u ][ e ], qf[ q ][ e ], sacc );
+						sacc = xorReduce8( sacc );
+						if( key < nk )
+						{
+							mx[ q ] = fmaxf( mx[ q ], sacc );
+							if( c == ( q & 7 ) ) L.sc[ q ][ key ] = sacc;
+						}
+					}
+				}
+			};
+			// the prefetched batch 0 was clamped against the buffer, not against nk: fine, rows >= nk are ignored above
+			if( nIt > G_BATCH ) loadK( kB, G_BATCH, nk - 1 );
+			scoreBatch( kA, 0 );
+			if( nIt > 2 * G_BATCH ) loadK( kA, 2 * G_BATCH, nk - 1 );
+			if( nIt > G_BATCH ) scoreBatch( kB, G_BATCH );
+			if( nIt > 2 * G_BATCH ) scoreBatch( kA, 2 * G_BATCH );
+
+			// first V batch goes out now: it does not depend on the softmax
+			f16x8 vA[ G_BATCH ], vB[ G_BATCH ];
+			auto loadV = [ & ]( f16x8 ( &dst )[ G_BATCH ], int it0 )
+			{
+	#pragma unroll
+				for( int u = 0; u < G_BATCH; u++ )
+				{
+					int key = ( it0 + u ) * G_ROWS + g;
+					key = key < nk ? key : nk - 1;
+					dst[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + c * 8 );
+				}
+			};
+			const bool fast = a.parityThreads <= 0;
+			if( fast ) loadV( vA, 0 );
+
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ ) mx[ q ] = waveReduceMax( mx[ q ] );
+			if( lane == 0 )
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) L.shf[ q ][ wave ] = mx[ q ];
+			__syncthreads();	// also publishes sc
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				float m = L.shf[ q ][ 0 ];
+	#pragma unroll
+				for( int w = 1; w < NW; w++ ) m = fmaxf( m, L.shf[ q ][ w ] );
+				mx[ q ] = m;
+			}
+
+			// ---- table softmax (ggml.c:5030-5090): e = exp16( s - max ), double sum, p = e * float( 1 / sum ) ----
+			double sum[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				sum[ q ] = 0.0;
+				for( int key = tid; key < nk; key += NT )
+				{
+					const float e = exp16( L.sc[ q ][ key ] - mx[ q ] );
+					L.sc[ q ][ key ] = e;
+					sum[ q ] += (double)e;
+				}
+				sum[ q ] = waveReduceSumD( sum[ q ] );
+			}
+			if( lane == 0 )
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) L.shd[ q ][ wave ] = sum[ q ];
+			__syncthreads();
+			float inv[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				double tot = L.shd[ q ][ 0 ];
+	#pragma unroll
+				for( int w = 1; w < NW; w++ ) tot += L.shd[ q ][ w ];
+				inv[ q ] = (float)( 1.0 / tot );
+			}
+
+			if( fast )
+			{
+				// ---- P.V, FP32: slot g owns keys g, g + 64, ...; lane c owns dims c*8 .. c*8+7 ----
+				float acc[ NQ ][ 8 ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+					for( int e = 0; e < 8; e++ ) acc[ q ][ e ] = 0.0f;
+				auto pvBatch = [ & ]( const f16x8 ( &vv )[ G_BATCH ], int it0 )
+				{
+	#pragma unroll
+					for( int u = 0; u < G_BATCH; u++ )
+					{
+						const int key = ( it0 + u ) * G_ROWS + g;
+						if( ( it0 + u ) >= nIt ) break;
+	#pragma unroll
+						for( int q = 0; q < NQ; q++ )
+						{
+							const float p = key < nk ? L.sc[ q ][ key ] * inv[ q ] : 0.0f;
+	#pragma unroll
+							for( int e = 0; e < 8; e++ ) acc[ q ][ e ] = fmaf( (float)vv[ u ][ e ], p, acc[ q ][ e ] );
+						}
+					}
+				};
+				if( nIt > G_BATCH ) loadV( vB, G_BATCH );
+				pvBatch( vA, 0 );
+				if( nIt > 2 * G_BATCH ) loadV( vA, 2 * G_BATCH );
+				if( nIt > G_BATCH ) pvBatch( vB, G_BATCH );
+				if( nIt > 2 * G_BATCH ) pvBatch( vA, 2 * G_BATCH );
+				// the 8 slots of a wave first (lanes with equal c), then the 8 waves through LDS in a fixed order
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+					for( int e = 0; e < 8; e++ )
+					{
+						float t = acc[ q ][ e ];
+						t += __shfl_xor( t, 8, 64 );
+						t += __shfl_xor( t, 16, 64 );
+						t += __shfl_xor( t, 32, 64 );
+						acc[ q ][ e ] = t;
+					}
+				if( lane < 8 )
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+						for( int e = 0; e < 8; e++ ) L.red[ q ][ wave ][ lane * 8 + e ] = acc[ q ][ e ];
+				__syncthreads();
+				if( tid < HEAD_DIM * NQ )
+				{
+					const int q = tid / HEAD_DIM, j = tid - q * HEAD_DIM;
+					float t = L.red[ q ][ 0 ][ j ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) t += L.red[ q ][ w ][ j ];
+					a.out[ rowOf( q ) * d + h * HEAD_DIM + j ] = (f16)t;
+				}
+			}
+			else
+			{
+				// ---- P.V exactly as ggml's transposed-src0 branch (ggml.c:4689-4735 + :4615-4644), see attentionDec ----
+				const int nth = min( a.parityThreads, NW );
+				const int nc = nKeys;
+				const int dc = ( nc + nth - 1 ) / nth;
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					__syncthreads();
+					if( wave < nth )
+					{
+						float y = 0.0f;
+						const int k1 = min( dc * ( wave + 1 ), nc );
+						for( int key = dc * wave; key < k1; key++ )
+						{
+							const float p = key < nk ? L.sc[ q ][ key ] * inv[ q ] : 0.0f;
+							const float v = (float)V[ (long long)key * HEAD_DIM + lane ];
+							y = round16( fmaf( v, p, y ) );
+						}
+						L.red[ q ][ wave ][ lane ] = y;
+					}
+					__syncthreads();
+					if( tid < HEAD_DIM )
+					{
+						float t = L.red[ q ][ 0 ][ tid ];
+						for( int vt = 1; vt < nth; vt++ ) t += L.red[ q ][ vt ][ tid ];
+						a.out[ rowOf( q ) * d + h * HEAD_DIM + tid ] = (f16)t;
+					}
+				}
+			}
+		}
+
+		template<int NQ, bool FUSEQ>
+		int launchDecG( const DecAttnArgs& a, hipStream_t stream )
+		{
+			constexpr int lds = (int)sizeof( DecGLds<NQ> );
+			if( lds > 64 * 1024 )
+			{
+				static PerDeviceOnce once;
+				if( once.needed() )
+				{
+					WH_HIP( hipFuncSetAttribute( (const void*)attentionDecG<NQ, FUSEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+					once.mark();
+				}
+			}
+			hipLaunchKernelGGL( ( attentionDecG<NQ, FUSEQ> ), dim3( a.H, a.batch / NQ, a.nTok ), dim3( NT ), lds, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
 	}	// namespace
 
 	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream )
@@ -248,8 +639,38 @@ namespace wh
 			setError( "attentionDec: key count out of range" );
 			return -1;
 		}
-		hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
-		WH_HIP( hipGetLastError() );
-		return 0;
+		const int group = a.group > 0 ? a.group : 1;
+		const bool fuse = a.lnX != nullptr;
+		if( ( a.batch % group ) != 0 || ( fuse && ( a.H * HEAD_DIM > G_MAXD || ( a.H * HEAD_DIM ) % 64 != 0 ) ) || ( a.parityThreads > NW && ( group > 1 || fuse ) ) )
+		{
+			setError( "attentionDec: unsupported group / fused-query configuration" );
+			return -1;
+		}
+		if( !( g_tuning & TUNE_ATTN_DEC_G ) && group == 1 && !fuse )
+		{
+			hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+		// more than 8 virtual threads of the parity emulation only exist in the first kernel
+		if( a.parityThreads > NW )
+		{
+			hipLaunchKernelGGL( attentionDec, dim3( a.H, a.batch, a.nTok ), dim3( NT ), 0, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+	#define WH_DECG( N ) case N: return fuse ? launchDecG<N, true>( a, stream ) : launchDecG<N, false>( a, stream );
+		switch( group )
+		{
+			WH_DECG( 1 )
+			WH_DECG( 2 )
+			WH_DECG( 3 )
+			WH_DECG( 4 )
+			WH_DECG( 5 )
+			WH_DECG( 8 )
+		}
+	#undef WH_DECG
+		setError( "attentionDec: hypothesis groups of 1, 2, 3, 4, 5 or 8 rows are supported" );
+		return -1;
 	}
 }

@@ -294,11 +294,11 @@ namespace wh
 		template<int KT>
 		int launchEncT( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
 		{
-			static bool attrSet = false;
-			if( !attrSet )
+			static PerDeviceOnce once;
+			if( once.needed() )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)attentionEnc<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES ) );
-				attrSet = true;
+				once.mark();
 			}
 			const int nQ = ( T + AQ - 1 ) / AQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;

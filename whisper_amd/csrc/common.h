@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 namespace wh
@@ -164,6 +165,20 @@ namespace wh
 	}
 
 	// ---- host side ----
+	// hipFuncSetAttribute is a per-DEVICE setting: one bit per device ordinal remembers where it has been applied, so a
+	// model on adapter N > 0 gets its dynamic-LDS limit too (the reference binds one D3D device per model,
+	// Whisper/ML/Device.cpp:163-177). Setting it twice from racing threads is harmless.
+	struct PerDeviceOnce
+	{
+		std::atomic<unsigned long long> done{ 0 };
+		int device = 0;
+		bool needed()
+		{
+			if( hipGetDevice( &device ) != hipSuccess ) device = 0;
+			return ( ( done.load( std::memory_order_acquire ) >> ( device & 63 ) ) & 1ull ) == 0;
+		}
+		void mark() { done.fetch_or( 1ull << ( device & 63 ), std::memory_order_release ); }
+	};
 	void setError( const std::string& s );
 	int hipFail( hipError_t e, const char* what, const char* file, int line );
 }

@@ -379,8 +379,28 @@ namespace wh
 				const int xcd = bid & 7, idx = bid >> 3;
 				lin = ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + idx;
 			}
-			const int tm = lin / tilesN;
-			const int tn = lin - tm * tilesN;
+			// Walk order inside an XCD's range. Row-major (tm = lin / tilesN) makes the ~32 (256x256) or ~96 (128x128) tiles an
+			// XCD has in flight share ONE A tile and sweep that many different W tiles through a 4 MiB L2, so W is re-read from
+			// the fabric once per M tile row (measured 8.3 GB for 0.12 GB of operands on the cross-KV product,
+			// profiles/r01_pmc_hbm_traffic.csv). Bands of groupM M tiles, walked column by column, keep the band's A rows
+			// (groupM x BM x K halves) resident while every W tile is fetched once per band and shared by groupM tiles.
+			int tm, tn;
+			if( a.groupM > 1 )
+			{
+				const int tilesM = ( a.M + BM - 1 ) / BM;
+				const int perBand = a.groupM * tilesN;
+				const int band = lin / perBand;
+				const int first = band * a.groupM;
+				const int rows = min( tilesM - first, a.groupM );
+				const int r = lin - band * perBand;
+				tm = first + r % rows;
+				tn = r / rows;
+			}
+			else
+			{
+				tm = lin / tilesN;
+				tn = lin - tm * tilesN;
+			}
 
 			if constexpr( C::GL )
 			{
@@ -686,6 +706,10 @@ namespace wh
 			const int lane = tid & 63;
 			const int wave = tid >> 6;
 			const int n0 = blockIdx.x * ROWS;
+			// more than 16 * MT activation rows: blockIdx.y selects the group of 16 * MT rows (the weight rows are streamed once
+			// per group; these launches are latency-bound, the second copy comes from L2 or overlaps the first)
+			const int m0 = blockIdx.y * 16 * MT;
+			const int mEnd = a.M;
 
 			int n = n0 + ( lane & 15 ) % ROWS;
 			n = n < a.N ? n : a.N - 1;
@@ -712,7 +736,7 @@ namespace wh
 				if( a.bias ) biasv = *(const f32x4*)( a.bias + nEp );
 #pragma unroll
 				for( int t = 0; t < MT; t++ )
-					if( a.res && t * 16 + ( lane & 15 ) < a.M ) resv[ t ] = *(const f32x4*)( a.res + (long long)( t * 16 + ( lane & 15 ) ) * a.ldc + nEp );
+					if( a.res && m0 + t * 16 + ( lane & 15 ) < mEnd ) resv[ t ] = *(const f32x4*)( a.res + (long long)( m0 + t * 16 + ( lane & 15 ) ) * a.ldc + nEp );
 			}
 
 			const f16* px[ MT ];
@@ -735,8 +759,8 @@ namespace wh
 					px[ t ] = xs + ( t * 16 + ( lane & 15 ) ) * GV_XS_STRIDE + kBeg;
 				else
 				{
-					int m = t * 16 + ( lane & 15 );
-					m = m < a.M ? m : a.M - 1;
+					int m = m0 + t * 16 + ( lane & 15 );
+					m = m < mEnd ? m : mEnd - 1;
 					px[ t ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
 				}
 			}
@@ -798,8 +822,8 @@ namespace wh
 #pragma unroll
 			for( int t = 0; t < MT; t++ )
 			{
-				const int mm = t * 16 + ( lane & 15 );
-				if( mm >= a.M ) continue;
+				const int mm = m0 + t * 16 + ( lane & 15 );
+				if( mm >= mEnd ) continue;
 				if( fastEp )
 				{
 					// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
@@ -826,14 +850,15 @@ namespace wh
 		const size_t lds = PRO != 0 ? (size_t)16 * MT * GV_XS_STRIDE * sizeof( f16 ) : 0;
 		if( lds > 64 * 1024 )
 		{
-			static bool attrSet = false;
-			if( !attrSet )
+			static PerDeviceOnce once;
+			if( once.needed() )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)gemvFused<EPI, PRO, ROWS, NW, UNROLL, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds ) );
-				attrSet = true;
+				once.mark();
 			}
 		}
-		hipLaunchKernelGGL( ( gemvFused<EPI, PRO, ROWS, NW, UNROLL, MT> ), dim3( ( a.N + ROWS - 1 ) / ROWS ), dim3( NW * 64 ), lds, stream, a );
+		const int groups = ( a.M + 16 * MT - 1 ) / ( 16 * MT );
+		hipLaunchKernelGGL( ( gemvFused<EPI, PRO, ROWS, NW, UNROLL, MT> ), dim3( ( a.N + ROWS - 1 ) / ROWS, groups ), dim3( NW * 64 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -845,6 +870,12 @@ namespace wh
 		// half the registers, which lets kernels of concurrent decode chains share a CU. More than 16 activation rows
 		// (up to 32) take a second MFMA column tile per weight fragment.
 		const bool small = a.K / NW / 32 <= 8 && ( g_tuning & TUNE_GEMV_SMALLREG );
+		if constexpr( PRO == 0 )
+		{
+			// 33 .. 128 rows: four MFMA column tiles per weight fragment (64 rows per workgroup, two row groups beyond that);
+			// always the 8-slot instance -- 4 x 8 activation fragments in flight are 128 registers
+			if( a.M > 32 ) return launchGemvK<EPI, PRO, ROWS, NW, 8, 4>( a, stream );
+		}
 		if( a.M > 16 )
 			return small ? launchGemvK<EPI, PRO, ROWS, NW, 8, 2>( a, stream ) : launchGemvK<EPI, PRO, ROWS, NW, GV_UNROLL_MAX, 2>( a, stream );
 		return small ? launchGemvK<EPI, PRO, ROWS, NW, 8, 1>( a, stream ) : launchGemvK<EPI, PRO, ROWS, NW, GV_UNROLL_MAX, 1>( a, stream );
@@ -852,15 +883,15 @@ namespace wh
 
 	int launchGemv( const GemmArgs& a, hipStream_t stream )
 	{
-		if( a.M <= 0 || a.M > 32 || a.N <= 0 || a.K <= 0 || ( a.K % 128 ) != 0 )
+		if( a.M <= 0 || a.M > GEMV_MAX_ROWS || a.N <= 0 || a.K <= 0 || ( a.K % 128 ) != 0 )
 		{
-			setError( "gemv: need 0 < M <= 32 and K a multiple of 128" );
+			setError( "gemv: need 0 < M <= 128 and K a multiple of 128" );
 			return -1;
 		}
 		const bool ln = a.lnX != nullptr;
-		if( ln && a.K > GV_MAXK_LN )
+		if( ln && ( a.K > GV_MAXK_LN || a.M > 32 ) )
 		{
-			setError( "gemv: the fused LayerNorm prologue supports rows up to 1280" );
+			setError( "gemv: the fused LayerNorm prologue supports up to 32 rows of up to 1280 columns" );
 			return -1;
 		}
 		// small N, large K (the MLP down projection): 4 weight rows per workgroup so that every CU streams
@@ -885,14 +916,16 @@ namespace wh
 	template<int EPI, class C = CfgDefault>
 	static int launchTiledT( const GemmArgs& a, hipStream_t stream )
 	{
-		static bool attrSet = false;
-		if( !attrSet )
+		static PerDeviceOnce once;
+		if( once.needed() )
 		{
 			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES ) );
-			attrSet = true;
+			once.mark();
 		}
 		const int tilesM = ( a.M + C::BM - 1 ) / C::BM, tilesN = ( a.N + C::BN - 1 ) / C::BN;
-		hipLaunchKernelGGL( ( gemmTiled<EPI, C> ), dim3( tilesM * tilesN ), dim3( C::NT ), C::LDS_BYTES, stream, a );
+		GemmArgs b = a;
+		if( b.groupM == 0 ) b.groupM = ( g_tuning & TUNE_GEMM_GROUP_M ) ? ( C::BM >= 256 ? 4 : 8 ) : 1;
+		hipLaunchKernelGGL( ( gemmTiled<EPI, C> ), dim3( tilesM * tilesN ), dim3( C::NT ), C::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

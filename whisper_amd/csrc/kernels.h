@@ -13,11 +13,14 @@ namespace wh
 		TUNE_GEMM_GL = 64,		 // tiled GEMM stages its tiles global -> LDS directly (128x128x64, swizzled source)
 		TUNE_LN_SEPARATE_BIGM = 128,	 // more than 16 decode rows: LayerNorm as its own launch instead of 192-256 redundant prologues
 		TUNE_ATTN_XCD = 256,		 // encoder attention: the query blocks of one (sequence, head) run on one XCD
+		TUNE_ATTN_DEC_G = 512,		 // decoder attention: 8 lanes per K row (coalesced) instead of a row per thread
+		TUNE_FUSE_CROSS_Q = 1024,	 // decode steps: LayerNorm + cross-attention query projection inside the attention kernel
+		TUNE_GEMM_GROUP_M = 2048,	 // tiled GEMM: blocks walk bands of 4 M tiles (A band stays in the XCD's L2) instead of rows of tiles
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M
 	};
 	extern unsigned g_tuning;
 
@@ -67,6 +70,7 @@ namespace wh
 		const float* lnX;	  // when non-null: A is produced on the fly as fp16( LayerNorm(lnX[m]) * lnW + lnB ), row length K
 		const float* lnW;
 		const float* lnB;
+		int groupM;			  // tiled kernel: M tiles per band of the block walk (0 = default for the tile shape, 1 = rows of tiles)
 	};
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
@@ -74,6 +78,7 @@ namespace wh
 	// M <= 32 rows, K % 128 == 0: 16 (or 4) weight rows per workgroup, every load of a wave in flight at once, optional
 	// fused LayerNorm prologue; the decode-step kernel
 	int launchGemv( const GemmArgs& a, hipStream_t stream );
+	constexpr int GEMV_MAX_ROWS = 128;
 	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream );	// tile-shape experiments, EPI_F32 only
 	int gemmInit();													// one-time function attributes
 
@@ -111,6 +116,17 @@ namespace wh
 		int nPast;
 		int parityThreads;	   // 0 = FP32 P.V; >0 = emulate ggml's FP16 thread-partitioned accumulation
 		const int* nPastDev;   // causal only: when non-null nPast (and nKeys = nPast + nTok) come from device memory
+		// `group` consecutive sequences share one K/V block (the hypotheses of a window in cross-attention): kc / vc hold
+		// batch / group blocks and the rows b*group .. b*group + group - 1 are served by one pass over block b. 0 or 1 = none.
+		int group;
+		// fused query (cross-attention, decode steps): when lnX is non-null, q is ignored and the query of row m is
+		// fp16( ( qW[h*64 + j] . fp16( LayerNorm( lnX[m] ) * lnW + lnB ) + qB[h*64 + j] ) * qScale )
+		const float* lnX;	   // [batch*nTok][d] residual stream
+		const float* lnW;
+		const float* lnB;
+		const f16* qW;		   // [d][d]
+		const float* qB;	   // [d]
+		float qScale;
 	};
 	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream );
 

@@ -38,9 +38,22 @@ using namespace wh;
 
 namespace
 {
-	constexpr int CONV1_KPAD = 256;	   // 3 * 80 = 240 taps*channels, zero-padded to a multiple of 64
 	inline int64_t align256( int64_t x ) { return ( x + 255 ) & ~(int64_t)255; }
 	inline int roundUp( int x, int m ) { return ( x + m - 1 ) / m * m; }
+	// conv1 as an implicit GEMM: K = 3 taps * n_mels channels, zero-padded to a multiple of 64 (80 mels: 240 -> 256;
+	// the 128 mels of the large-v3 shape: 384 exactly)
+	constexpr int CONV1_KPAD_MAX = 512;
+	inline int conv1Kpad( const wh_hparams& hp ) { return roundUp( 3 * hp.n_mels, 64 ); }
+
+	// Special token ids follow from the vocabulary size (Whisper/Whisper/Vocabulary.h:27-41 hard-codes 51864 / 51865):
+	// every language token added to the multilingual vocabulary moves the ids behind the language block up by one.
+	// 51864 (.en) -> extra 0, 51865 (multilingual, 99 languages) -> 1, 51866 (the large-v3 shape, 100 languages) -> 2.
+	struct SpecialIds { int sot, solm, tnot, beg; };
+	inline SpecialIds specialIds( const wh_hparams& hp )
+	{
+		const int extra = hp.n_vocab > 51864 ? hp.n_vocab - 51864 : 0;
+		return SpecialIds{ 50257 + ( extra > 0 ? 1 : 0 ), 50361 + extra, 50362 + extra, 50363 + extra };
+	}
 
 	struct EncLayer
 	{
@@ -68,7 +81,7 @@ namespace
 		L.filters = take( 4ll * hp.n_mels * 201 );
 		L.dft = take( 8ll * 800 );
 		L.encPe = take( 4ll * hp.n_audio_ctx * d );
-		L.conv1w = take( 2ll * d * CONV1_KPAD );
+		L.conv1w = take( 2ll * d * conv1Kpad( hp ) );
 		L.conv1b = take( 4 * d );
 		L.conv2w = take( 2ll * d * 3 * d );
 		L.conv2b = take( 4 * d );
@@ -116,7 +129,7 @@ namespace
 			return WH_E_INVALIDARG;
 		}
 		if( hp->n_audio_ctx <= 0 || hp->n_audio_ctx > 1536 || hp->n_text_ctx <= 0 || hp->n_text_ctx > 1536 || hp->n_mels <= 0 ||
-			3 * hp->n_mels > CONV1_KPAD || ( hp->n_mels % 8 ) != 0 || hp->n_vocab <= 0 || hp->n_audio_layer <= 0 || hp->n_text_layer <= 0 )
+			3 * hp->n_mels > CONV1_KPAD_MAX || ( hp->n_mels % 8 ) != 0 || hp->n_vocab <= 0 || hp->n_audio_layer <= 0 || hp->n_text_layer <= 0 )
 		{
 			setError( "unsupported model dimensions" );
 			return WH_E_INVALIDARG;
@@ -134,9 +147,22 @@ struct wh_model
 	bool finalized = false;
 	std::set<std::string> loaded;
 	bool filtersSet = false;
+	int device = 0;	   // the HIP device the arena lives on; every entry point binds the calling thread to it
 	template<class T> T* at( int64_t off ) const { return (T*)( arena + off ); }
 	size_t expectedTensors() const { return 11 + 15 * (size_t)hp.n_audio_layer + 24 * (size_t)hp.n_text_layer; }
 };
+
+// HIP's current device is per host thread. The reference binds the model's device to the calling thread at the top of
+// every call (Device::setForCurrentThread, Whisper/ML/Device.cpp:163-177); so do we, which is what lets a context be
+// created or run from a thread other than the one that loaded the model (iModel::clone, sModelSetup.adapter).
+static int bindDevice( const wh_model* m )
+{
+	int cur = -1;
+	if( hipGetDevice( &cur ) == hipSuccess && cur == m->device ) return 0;
+	WH_HIP( hipSetDevice( m->device ) );
+	return 0;
+}
+#define WH_BIND( model ) WH_CHECK( bindDevice( model ) )
 
 // Per-kernel-class GPU timing, the counterpart of the reference's GpuProfiler (Whisper/Utils/GpuProfiler.h:21-188: a
 // timestamp query per shader dispatch, aggregated per eComputeShader). hipEvent pairs on the context's stream; only
@@ -190,14 +216,17 @@ struct wh_context
 {
 	wh_model* m = nullptr;
 	Profiler prof;
-	int maxBatch = 0;
+	int maxBatch = 0;	   // 30 s windows (encoder batch, cross-attention caches)
+	int hyp = 1;		   // decoder hypotheses per window: rows b*hyp .. b*hyp+hyp-1 share window b's cross-attention K/V
+	int maxSeq = 0;		   // decoder sequences = maxBatch * hyp (self-attention caches, logits, sampler state)
 	hipStream_t stream = nullptr;
 	uint32_t flags = 0;
 	int parityThreads = 1;
 	int T = 0, Tpad = 0, maxRows = 0;
 	int64_t vram = 0;
 	bool encoded = false;
-	int lastBatch = 0;
+	int lastBatch = 0;	   // decoder sequences of the last decode call
+	int lastEncBatch = 0;  // windows of the last wh_encode
 	// encoder activations
 	f16 *convIn = nullptr, *conv1Out = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *attn = nullptr, *h = nullptr;
 	float *x = nullptr, *encOut = nullptr;
@@ -218,6 +247,11 @@ struct wh_context
 	int graphBatch = 0;
 	uint32_t graphKey = 0;
 	int windowSamples = 0;
+	// WH_FLAG_DEBUG_CAPTURE: copies of intermediates at the reference's Tracing probe points (WhisperContext.cpp:142-638)
+	f16 *capTemp1 = nullptr, *capEncKqv = nullptr, *capDecKqvSelf = nullptr, *capDecKqvCross = nullptr;
+	float* capLayer0In = nullptr;
+	int capDecRows = 0;
+	int profKeysHint = 1;	   // profiler only: keys a device-positioned self-attention launch sees (host mirror of DecodeState::nPast + 1)
 	bool ownsStream = false;
 	// pinned host staging for fully asynchronous enqueues (offsets, tokens, state)
 	int32_t* pinned = nullptr;
@@ -237,6 +271,16 @@ struct wh_context
 	}
 };
 
+
+// Debug capture: device-to-device copy of an intermediate into a lazily allocated side buffer (stream-ordered).
+template<class T>
+static int capture( wh_context* c, T*& dst, const T* src, int64_t count, int64_t capacity )
+{
+	if( !( c->flags & WH_FLAG_DEBUG_CAPTURE ) ) return 0;
+	if( !dst ) WH_CHECK( c->alloc( dst, capacity ) );
+	WH_HIP( hipMemcpyAsync( dst, src, (size_t)count * sizeof( T ), hipMemcpyDeviceToDevice, c->stream ) );
+	return 0;
+}
 
 // Runs one launch, optionally bracketed by events. flops / bytes are the ALGORITHMIC work of the launch.
 template<class F>
@@ -267,11 +311,21 @@ static int lnP( wh_context* c, const float* x, const float* w, const float* b, f
 {
 	return profiled( c, KC_LAYER_NORM, 8.0 * rows * d, 6.0 * rows * d, [ & ]() { return launchLayerNorm( x, w, b, out, rows, d, c->stream ); } );
 }
-static int attnDecP( wh_context* c, const DecAttnArgs& a )
+static int attnDecP( wh_context* c, const DecAttnArgs& a, int keysHint = -1 )
 {
-	const double keys = (double)a.nKeys;
-	const double bytes = 2.0 * 2.0 * a.batch * a.H * keys * HEAD_DIM * a.nTok;	// K and V rows, once per query row
-	const double flops = 4.0 * a.batch * a.H * keys * HEAD_DIM * a.nTok;
+	// ALGORITHMIC work of one launch: every K and V row the queries can see, once per (K/V block, head) -- the rows of a
+	// prompt step and the hypotheses of a window share them -- with the real key count (keysHint when the position lives
+	// in device memory), plus q in and the attention rows out. With a fused query also the residual rows and the query weight once.
+	const int group = a.group > 0 ? a.group : 1;
+	const double keys = (double)( keysHint > 0 ? keysHint : a.nKeys );
+	const double d = (double)a.H * HEAD_DIM;
+	double bytes = 2.0 * 2.0 * ( a.batch / group ) * a.H * keys * HEAD_DIM + 2.0 * 2.0 * a.batch * a.nTok * d;
+	double flops = 4.0 * a.batch * a.H * keys * HEAD_DIM * a.nTok;
+	if( a.lnX )
+	{
+		bytes += 4.0 * a.batch * a.nTok * d + 2.0 * d * d;
+		flops += 2.0 * a.batch * a.nTok * d * d;
+	}
 	return profiled( c, KC_ATTN_DEC, flops, bytes, [ & ]() { return launchAttentionDec( a, c->stream ); } );
 }
 
@@ -327,6 +381,7 @@ int wh_model_create( const wh_hparams* hp, void* arenaDev, int alreadyFilled, wh
 	wh_model* m = new wh_model();
 	m->hp = *hp;
 	m->L = makeLayout( *hp );
+	if( hipGetDevice( &m->device ) != hipSuccess ) m->device = 0;
 	if( arenaDev )
 	{
 		m->arena = (uint8_t*)arenaDev;
@@ -354,12 +409,14 @@ int wh_model_create( const wh_hparams* hp, void* arenaDev, int alreadyFilled, wh
 void wh_model_destroy( wh_model* m )
 {
 	if( !m ) return;
+	(void)bindDevice( m );
 	if( m->ownsArena && m->arena ) (void)hipFree( m->arena );
 	delete m;
 }
 
 static int upload( wh_model* m, int64_t off, const void* src, int64_t bytes )
 {
+	WH_BIND( m );
 	WH_HIP( hipMemcpy( m->arena + off, src, (size_t)bytes, hipMemcpyHostToDevice ) );
 	return 0;
 }
@@ -517,7 +574,7 @@ int wh_model_set_tensor( wh_model* m, const char* name, int nDims, const int32_t
 	{
 		// file: [out][in][3] (tap contiguous) -> ours: [out][tap * in + c], row padded with zeros (conv as an implicit GEMM)
 		const int64_t ic = s.convIc, oc = s.rows;
-		const int64_t kpad = ( s.off == m->L.conv1w ) ? CONV1_KPAD : 3 * ic;
+		const int64_t kpad = ( s.off == m->L.conv1w ) ? conv1Kpad( m->hp ) : 3 * ic;
 		std::vector<uint16_t> tmp( (size_t)( oc * kpad ), 0 );
 		for( int64_t o = 0; o < oc; o++ )
 			for( int64_t c = 0; c < ic; c++ )
@@ -568,6 +625,13 @@ int wh_model_finalize( wh_model* m )
 {
 	if( !m ) return WH_E_INVALIDARG;
 	if( m->finalized ) return 0;
+	if( !m->filtersSet )
+	{
+		// the reference's loader fails on a file without the filterbank (WhisperModel.cpp:446-456); an all-zero one would turn
+		// every spectrogram into log10(1e-10) without an error
+		setError( "mel filterbank has not been set (wh_model_set_filters)" );
+		return WH_E_NOT_READY;
+	}
 	if( m->loaded.size() != m->expectedTensors() )
 	{
 		char buf[ 160 ];
@@ -607,11 +671,23 @@ int wh_model_hparams( const wh_model* m, wh_hparams* out )
 // ==================================================================================================================
 int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out )
 {
-	if( !m || !out || maxBatch <= 0 ) { setError( "context_create: bad argument" ); return WH_E_INVALIDARG; }
+	return wh_context_create_hyp( m, maxBatch, 1, stream, out );
+}
+
+int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stream, wh_context** out )
+{
+	if( !m || !out || maxBatch <= 0 || hypotheses <= 0 || hypotheses > 8 || hypotheses == 6 || hypotheses == 7 )
+	{
+		setError( "context_create: bad argument (hypotheses per window: 1, 2, 3, 4, 5 or 8)" );
+		return WH_E_INVALIDARG;
+	}
 	if( !m->finalized ) { setError( "context_create: model is not finalized" ); return WH_E_NOT_READY; }
+	WH_BIND( m );
 	wh_context* c = new wh_context();
 	c->m = m;
 	c->maxBatch = maxBatch;
+	c->hyp = hypotheses;
+	c->maxSeq = maxBatch * hypotheses;
 	c->stream = (hipStream_t)stream;
 	if( !c->stream )
 	{
@@ -621,11 +697,11 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 		c->ownsStream = true;
 	}
 	const wh_hparams& hp = m->hp;
-	const int64_t d = hp.n_audio_state, B = maxBatch, H = hp.n_audio_head;
+	const int64_t d = hp.n_audio_state, B = maxBatch, H = hp.n_audio_head, S = c->maxSeq;
 	const int T = hp.n_audio_ctx;
 	c->T = T;
 	c->Tpad = roundUp( T, 256 );
-	c->maxRows = maxBatch * hp.n_text_ctx;
+	c->maxRows = c->maxSeq * hp.n_text_ctx;
 	const int64_t rowsE = B * T;
 	c->convInStride = ( 2ll * T + 2 ) * hp.n_mels;
 	c->conv1Stride = ( 2ll * T + 2 ) * d;
@@ -642,19 +718,19 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 	rc = rc ? rc : c->alloc( c->h, rowsE * 4 * d );
 	rc = rc ? rc : c->alloc( c->crossK, (int64_t)hp.n_text_layer * rowsE * d, true );
 	rc = rc ? rc : c->alloc( c->crossV, (int64_t)hp.n_text_layer * rowsE * d, true );
-	rc = rc ? rc : c->alloc( c->selfK, (int64_t)hp.n_text_layer * B * hp.n_text_ctx * d, true );
-	rc = rc ? rc : c->alloc( c->selfV, (int64_t)hp.n_text_layer * B * hp.n_text_ctx * d, true );
+	rc = rc ? rc : c->alloc( c->selfK, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, true );
+	rc = rc ? rc : c->alloc( c->selfV, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, true );
 	const int64_t rowsD = c->maxRows;
 	rc = rc ? rc : c->alloc( c->dx, rowsD * d );
 	rc = rc ? rc : c->alloc( c->dxn, rowsD * d );
 	rc = rc ? rc : c->alloc( c->dq, rowsD * d );
 	rc = rc ? rc : c->alloc( c->dattn, rowsD * d );
 	rc = rc ? rc : c->alloc( c->dh, rowsD * 4 * d );
-	rc = rc ? rc : c->alloc( c->logits, B * (int64_t)hp.n_vocab );
-	rc = rc ? rc : c->alloc( c->probs, B * (int64_t)hp.n_vocab );
+	rc = rc ? rc : c->alloc( c->logits, S * (int64_t)hp.n_vocab );
+	rc = rc ? rc : c->alloc( c->probs, S * (int64_t)hp.n_vocab );
 	rc = rc ? rc : c->alloc( c->tokensDev, rowsD );
 	rc = rc ? rc : c->alloc( c->melOffsetsDev, B );
-	rc = rc ? rc : c->alloc( c->tokDataDev, B );
+	rc = rc ? rc : c->alloc( c->tokDataDev, S );
 	rc = rc ? rc : c->alloc( c->melScratch, 64 );
 	rc = rc ? rc : c->alloc( c->state, 1, true );
 	if( rc == 0 )
@@ -662,7 +738,7 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * wh_context::PINNED_INTS, hipHostMallocDefault );
 		if( e != hipSuccess ) rc = hipFail( e, "hipHostMalloc", __FILE__, __LINE__ );
 	}
-	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * B );
+	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * S );
 	if( rc == 0 )
 	{
 		const hipError_t e = hipStreamSynchronize( c->stream );
@@ -680,12 +756,20 @@ int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out
 void wh_context_destroy( wh_context* c )
 {
 	if( !c ) return;
+	(void)bindDevice( c->m );
 	if( c->stream ) (void)hipStreamSynchronize( c->stream );
 	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
 	for( void* p : c->allocations ) (void)hipFree( p );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
 	if( c->ownsStream ) (void)hipStreamDestroy( c->stream );
 	delete c;
+}
+
+int wh_context_bind( wh_context* c )
+{
+	if( !c ) return WH_E_INVALIDARG;
+	WH_BIND( c->m );
+	return 0;
 }
 
 int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
@@ -716,6 +800,7 @@ int wh_buffer_free( void* dev )
 int wh_buffer_upload( wh_context* c, void* dev, const void* host, int64_t bytes )
 {
 	if( !c || !dev || !host || bytes < 0 ) { setError( "buffer_upload: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
 	WH_HIP( hipMemcpyAsync( dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream ) );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
 	return 0;
@@ -724,6 +809,7 @@ int wh_buffer_upload( wh_context* c, void* dev, const void* host, int64_t bytes 
 int wh_buffer_download( wh_context* c, void* host, const void* dev, int64_t bytes )
 {
 	if( !c || !dev || !host || bytes < 0 ) { setError( "buffer_download: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
 	WH_HIP( hipMemcpyAsync( host, dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream ) );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
 	return 0;
@@ -732,6 +818,7 @@ int wh_buffer_download( wh_context* c, void* host, const void* dev, int64_t byte
 int wh_context_synchronize( wh_context* c )
 {
 	if( !c ) return WH_E_INVALIDARG;
+	WH_BIND( c->m );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
 	return 0;
 }
@@ -746,6 +833,7 @@ int wh_context_memory( const wh_context* c, int64_t* vramBytes )
 int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, float* melDev, int64_t* nLenOut )
 {
 	if( !c || nSamples < 0 ) { setError( "mel: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
 	const int64_t nLen = nSamples / 160;
 	if( nLenOut ) *nLenOut = nLen;
 	if( nLen == 0 ) return 0;	// less than one hop of audio: an empty spectrogram, like the reference (whisper.cpp:2080)
@@ -772,6 +860,7 @@ static GemmArgs plainGemm( const f16* A, const f16* W, int M, int N, int K )
 int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets )
 {
 	if( !c || !melDev || batch <= 0 || batch > c->maxBatch || melLen <= 0 ) { setError( "encode: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
 	const wh_model* m = c->m;
 	const wh_hparams& hp = m->hp;
 	const Layout& L = m->L;
@@ -791,7 +880,7 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 	// conv1 (k=3, stride 1, pad 1) + bias + GELU as an implicit GEMM over the padded time-major input:
 	// row t of the im2col matrix is the contiguous slice starting at padded row t (whisper.cpp:1127-1136; ggml.c:5199-5318)
 	{
-		GemmArgs g = plainGemm( c->convIn, m->at<f16>( L.conv1w ), batch * 2 * T, d, CONV1_KPAD );
+		GemmArgs g = plainGemm( c->convIn, m->at<f16>( L.conv1w ), batch * 2 * T, d, conv1Kpad( hp ) );
 		g.lda = hp.n_mels; g.Mb = 2 * T; g.aBatchStride = c->convInStride;
 		g.epi = EPI_F16_GELU;
 		g.bias = m->at<float>( L.conv1b );
@@ -799,6 +888,7 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		g.ldc = d; g.cBatchStride = c->conv1Stride;
 		WH_CHECK( gemmP( c, g, false ) );
 	}
+	WH_CHECK( capture( c, c->capTemp1, c->conv1Out, (int64_t)batch * c->conv1Stride, (int64_t)c->maxBatch * c->conv1Stride + 1024 ) );	// "enc.temp1"
 	// conv2 (stride 2) + bias + GELU + positional embedding -> residual stream x [batch*T][d] (whisper.cpp:1138-1167)
 	{
 		GemmArgs g = plainGemm( c->conv1Out, m->at<f16>( L.conv2w ), M, d, 3 * d );
@@ -809,6 +899,7 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		g.out32 = c->x; g.ldc = d;
 		WH_CHECK( gemmP( c, g, false ) );
 	}
+	WH_CHECK( capture( c, c->capLayer0In, c->x, (int64_t)M * d, (int64_t)c->maxBatch * T * d ) );	// "enc.layer[ 0 ].in"
 	for( int il = 0; il < hp.n_audio_layer; il++ )
 	{
 		const EncLayer& e = L.enc[ il ];
@@ -823,6 +914,7 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		}
 		WH_CHECK( profiled( c, KC_ATTN_ENC, 4.0 * batch * H * (double)T * T * HEAD_DIM, 2.0 * 4.0 * batch * H * (double)T * HEAD_DIM,
 			[ & ]() { return launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, st ); } ) );
+		if( il == 0 ) WH_CHECK( capture( c, c->capEncKqv, c->attn, (int64_t)M * d, (int64_t)c->maxBatch * T * d ) );	// "enc-KQV"
 		{
 			GemmArgs g = plainGemm( c->attn, m->at<f16>( e.wo ), M, d, d );
 			g.epi = EPI_F32;
@@ -858,7 +950,8 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 		WH_CHECK( gemmP( c, g, false ) );
 	}
 	c->encoded = true;
-	c->lastBatch = batch;
+	c->lastEncBatch = batch;
+	c->lastBatch = batch * c->hyp;
 	return 0;
 }
 
@@ -881,8 +974,10 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const float kqScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
 	const int* const nPastDev = devState ? &c->state->nPast : nullptr;
-	const bool gemv = M <= 32 && ( d % 128 ) == 0;
-	const bool fuseLn = gemv && d <= 1280 && !( M > 16 && ( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
+	const bool gemv = M <= GEMV_MAX_ROWS && ( d % 128 ) == 0;
+	const bool fuseLn = gemv && d <= 1280 && M <= 32 && !( M > 16 && ( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
+	// decode steps: the cross-attention kernel normalises the residual row and projects its own head's query
+	const bool fuseCrossQ = nTokens == 1 && d <= 1280 && parity <= 8 && ( g_tuning & TUNE_FUSE_CROSS_Q );
 
 	auto product = [ & ]( GemmArgs& g, const float* lnW, const float* lnB ) -> int
 	{
@@ -903,7 +998,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	for( int il = 0; il < hp.n_text_layer; il++ )
 	{
 		const DecLayer& e = L.dec[ il ];
-		const int64_t selfLayer = (int64_t)il * c->maxBatch * hp.n_text_ctx * d;
+		const int64_t selfLayer = (int64_t)il * c->maxSeq * hp.n_text_ctx * d;
 		const int64_t crossLayer = (int64_t)il * c->maxBatch * c->T * d;
 		// self-attention
 		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d ) );
@@ -917,12 +1012,17 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 			WH_CHECK( product( g, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ) ) );
 		}
 		{
-			DecAttnArgs a;
+			DecAttnArgs a = {};
 			a.q = c->dq; a.kc = c->selfK + selfLayer; a.vc = c->selfV + selfLayer; a.out = c->dattn;
 			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = nPast + nTokens; a.keyStride = hp.n_text_ctx;
 			a.causal = 1; a.nPast = nPast; a.parityThreads = parity; a.nPastDev = nPastDev;
 			if( devState ) a.nKeys = hp.n_text_ctx;	  // upper bound for the argument check; the kernel reads the real value
-			WH_CHECK( attnDecP( c, a ) );
+			WH_CHECK( attnDecP( c, a, devState ? c->profKeysHint : -1 ) );
+			if( il == 0 && !devState )
+			{
+				WH_CHECK( capture( c, c->capDecKqvSelf, c->dattn, (int64_t)M * d, (int64_t)c->maxRows * d ) );	 // "dec-KQV" (self)
+				c->capDecRows = M;
+			}
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wo ), M, d, d );
@@ -930,18 +1030,26 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 			WH_CHECK( product( g, nullptr, nullptr ) );
 		}
 		// cross-attention
-		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d ) );
+		if( !fuseCrossQ )
 		{
+			if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d ) );
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wcq ), M, d, d );
 			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
 			WH_CHECK( product( g, m->at<float>( e.lncw ), m->at<float>( e.lncb ) ) );
 		}
 		{
-			DecAttnArgs a;
+			DecAttnArgs a = {};
 			a.q = c->dq; a.kc = c->crossK + crossLayer; a.vc = c->crossV + crossLayer; a.out = c->dattn;
 			a.batch = batch; a.H = H; a.nTok = nTokens; a.nKeys = c->T; a.keyStride = c->T;
 			a.causal = 0; a.nPast = 0; a.parityThreads = parity; a.nPastDev = nullptr;
+			a.group = c->hyp;
+			if( fuseCrossQ )
+			{
+				a.lnX = c->dx; a.lnW = m->at<float>( e.lncw ); a.lnB = m->at<float>( e.lncb );
+				a.qW = m->at<f16>( e.wcq ); a.qB = m->at<float>( e.bcq ); a.qScale = kqScale;
+			}
 			WH_CHECK( attnDecP( c, a ) );
+			if( il == 0 && !devState ) WH_CHECK( capture( c, c->capDecKqvCross, c->dattn, (int64_t)M * d, (int64_t)c->maxRows * d ) );	  // "dec-KQV" (cross)
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wco ), M, d, d );
@@ -976,8 +1084,9 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 
 int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int nPast, float* logitsHost, float* probsHost )
 {
-	if( !c || !tokens || batch <= 0 || batch > c->maxBatch || nTokens <= 0 || nPast < 0 ) { setError( "decode: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c || !tokens || batch <= 0 || batch > c->maxSeq || ( batch % c->hyp ) != 0 || nTokens <= 0 || nPast < 0 ) { setError( "decode: bad argument" ); return WH_E_INVALIDARG; }
 	if( !c->encoded ) { setError( "decode: wh_encode has not run" ); return WH_E_NOT_READY; }
+	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
 	if( nPast + nTokens > hp.n_text_ctx ) { setError( "decode: n_past + n_tokens exceeds n_text_ctx" ); return WH_E_BOUNDS; }
 	hipStream_t st = c->stream;
@@ -997,8 +1106,8 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 static int greedyStep( wh_context* c, int batch )
 {
 	const wh_hparams& hp = c->m->hp;
-	const int ml = hp.n_vocab == 51865 ? 1 : 0;
-	const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
+	const SpecialIds sp = specialIds( hp );
+	const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
 	WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
 		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->stream ); } ) );
@@ -1008,8 +1117,9 @@ static int greedyStep( wh_context* c, int batch )
 int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int nPast, int nSteps, int forceFirstTimestamp, int firstIsInitial,
 	wh_token_data* out )
 {
-	if( !c || !firstTokens || !out || batch <= 0 || batch > c->maxBatch || nSteps <= 0 || nPast < 0 ) { setError( "decode_greedy: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c || !firstTokens || !out || batch <= 0 || batch > c->maxSeq || ( batch % c->hyp ) != 0 || nSteps <= 0 || nPast < 0 ) { setError( "decode_greedy: bad argument" ); return WH_E_INVALIDARG; }
 	if( !c->encoded ) { setError( "decode_greedy: wh_encode has not run" ); return WH_E_NOT_READY; }
+	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
 	if( nPast + nSteps > hp.n_text_ctx ) { setError( "decode_greedy: n_past + n_steps exceeds n_text_ctx" ); return WH_E_BOUNDS; }
 	hipStream_t st = c->stream;
@@ -1051,7 +1161,11 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	}
 	else
 	{
-		for( int s = 0; s < nSteps; s++ ) WH_CHECK( greedyStep( c, batch ) );
+		for( int s = 0; s < nSteps; s++ )
+		{
+			c->profKeysHint = nPast + s + 1;
+			WH_CHECK( greedyStep( c, batch ) );
+		}
 	}
 	c->lastBatch = batch;
 	static_assert( sizeof( wh_token_data ) == sizeof( TokenData ), "token data layout" );
@@ -1066,8 +1180,9 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 // steps are latency-bound and use a fraction of the chip, so independent windows fill it concurrently.
 int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp, int firstIsInitial )
 {
-	if( !c || !promptTokens || batch <= 0 || batch > c->maxBatch || nPrompt <= 0 || nSteps < 0 ) { setError( "decode_window_start: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c || !promptTokens || batch <= 0 || batch > c->maxSeq || ( batch % c->hyp ) != 0 || nPrompt <= 0 || nSteps < 0 ) { setError( "decode_window_start: bad argument" ); return WH_E_INVALIDARG; }
 	if( !c->encoded ) { setError( "decode_window_start: wh_encode has not run" ); return WH_E_NOT_READY; }
+	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
 	if( nPrompt + nSteps > hp.n_text_ctx || batch * nPrompt + 8 > wh_context::PINNED_INTS - 1024 ) { setError( "decode_window_start: too many tokens" ); return WH_E_BOUNDS; }
 	hipStream_t st = c->stream;
@@ -1112,8 +1227,8 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	WH_HIP( hipMemcpyAsync( c->state, stState, sizeof( DecodeState ), hipMemcpyHostToDevice, st ) );
 	WH_CHECK( decodeGraph( c, batch, nPrompt, 0, false ) );
 	{
-		const int ml = hp.n_vocab == 51865 ? 1 : 0;
-		const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
+		const SpecialIds sp = specialIds( hp );
+		const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 		WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
 			[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, st ); } ) );
 		WH_CHECK( launchAdvanceState( c->state, st ) );
@@ -1121,7 +1236,11 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	if( useGraph )
 		for( int s = 0; s < nSteps; s++ ) WH_HIP( hipGraphLaunch( c->graphExec, st ) );
 	else
-		for( int s = 0; s < nSteps; s++ ) WH_CHECK( greedyStep( c, batch ) );
+		for( int s = 0; s < nSteps; s++ )
+		{
+			c->profKeysHint = nPrompt + s + 1;
+			WH_CHECK( greedyStep( c, batch ) );
+		}
 	c->lastBatch = batch;
 	c->windowSamples = 1 + nSteps;
 	return 0;
@@ -1130,6 +1249,7 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 int wh_decode_window_finish( wh_context* c, wh_token_data* out )
 {
 	if( !c || !out || c->windowSamples <= 0 ) { setError( "decode_window_finish: nothing was started" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
 	WH_HIP( hipMemcpyAsync( out, c->greedyOut, sizeof( TokenData ) * (size_t)c->lastBatch * c->windowSamples, hipMemcpyDeviceToHost, c->stream ) );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
 	c->windowSamples = 0;
@@ -1138,11 +1258,11 @@ int wh_decode_window_finish( wh_context* c, wh_token_data* out )
 
 int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial, wh_token_data* out )
 {
-	if( !c || !out || batch <= 0 || batch > c->maxBatch ) { setError( "sample_best: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c || !out || batch <= 0 || batch > c->maxSeq ) { setError( "sample_best: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
-	// hard-coded special token ids (Whisper/Whisper/Vocabulary.h:27-41)
-	const int ml = hp.n_vocab == 51865 ? 1 : 0;
-	const int sot = 50257 + ml, solm = 50361 + ml, tnot = 50362 + ml, beg = 50363 + ml;
+	const SpecialIds sp = specialIds( hp );
+	const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, 5.0 * 4.0 * batch * hp.n_vocab,
 		[ & ]() { return launchSampleBest( c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, forceTimestamp, isInitial, c->tokDataDev, c->stream ); } ) );
 	static_assert( sizeof( wh_token_data ) == sizeof( TokenData ), "token data layout" );
@@ -1162,6 +1282,7 @@ int wh_profile_enable( wh_context* c, int on )
 int wh_profile_read( wh_context* c, wh_profile_entry* out, int cap, int* count )
 {
 	if( !c || !count ) return WH_E_INVALIDARG;
+	WH_BIND( c->m );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
 	c->prof.resolve();
 	int n = 0;
@@ -1205,9 +1326,11 @@ static int readHeadMajor( wh_context* c, const f16* src, int batch, int rows, in
 int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* dstHost, int64_t dstCapFloats )
 {
 	if( !c || !what || !dstHost ) return WH_E_INVALIDARG;
+	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
 	const int d = hp.n_audio_state;
-	const int batch = c->lastBatch;
+	const int batch = c->lastEncBatch;
+	const int seqs = c->lastBatch;
 	const std::string w = what;
 	if( w == "encode-out" )
 	{
@@ -1220,6 +1343,41 @@ int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* 
 		for( int64_t i = 0; i < n; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
 		return 0;
 	}
+	auto readF16 = [ & ]( const f16* src, int64_t n ) -> int
+	{
+		if( !src ) { setError( "debug_read: nothing captured (set WH_FLAG_DEBUG_CAPTURE before the call that produces it)" ); return WH_E_NOT_READY; }
+		if( dstCapFloats < n ) return WH_E_BOUNDS;
+		std::vector<uint16_t> tmp( (size_t)n );
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		WH_HIP( hipMemcpy( tmp.data(), src, (size_t)n * 2, hipMemcpyDeviceToHost ) );
+		for( int64_t i = 0; i < n; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
+		return 0;
+	};
+	if( w == "enc.temp1" )
+	{
+		// conv1 + bias + GELU, time-major [batch][2*n_ctx][d] (the reference's tensor is [d][2*n_ctx]); padding rows dropped
+		if( !c->capTemp1 ) return readF16( nullptr, 0 );
+		const int64_t rowsT = 2ll * c->T;
+		if( dstCapFloats < batch * rowsT * d ) return WH_E_BOUNDS;
+		std::vector<uint16_t> tmp( (size_t)( batch * c->conv1Stride ) );
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		WH_HIP( hipMemcpy( tmp.data(), c->capTemp1, tmp.size() * 2, hipMemcpyDeviceToHost ) );
+		for( int b = 0; b < batch; b++ )
+			for( int64_t i = 0; i < rowsT * d; i++ ) dstHost[ b * rowsT * d + i ] = f16BitsToF32( tmp[ (size_t)( b * c->conv1Stride + d + i ) ] );
+		return 0;
+	}
+	if( w == "enc.layer0.in" )
+	{
+		const int64_t n = (int64_t)batch * c->T * d;
+		if( !c->capLayer0In ) return readF16( nullptr, 0 );
+		if( dstCapFloats < n ) return WH_E_BOUNDS;
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		WH_HIP( hipMemcpy( dstHost, c->capLayer0In, (size_t)n * 4, hipMemcpyDeviceToHost ) );
+		return 0;
+	}
+	if( w == "enc-KQV" ) return readF16( c->capEncKqv, (int64_t)batch * c->T * d );	   // layer 0, [batch][n_ctx][d] (heads side by side)
+	if( w == "dec-KQV" ) return readF16( c->capDecKqvSelf, (int64_t)c->capDecRows * d );   // layer 0 self-attention output, rows of the last wh_decode
+	if( w == "dec-KQV#2" ) return readF16( c->capDecKqvCross, (int64_t)c->capDecRows * d );
 	if( layer < 0 || layer >= hp.n_text_layer ) return WH_E_BOUNDS;
 	if( w == "cross-k" || w == "cross-v" )
 	{
@@ -1229,9 +1387,9 @@ int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* 
 	}
 	if( w == "self-k" || w == "self-v" )
 	{
-		if( rows <= 0 || rows > hp.n_text_ctx || dstCapFloats < (int64_t)batch * rows * d ) return WH_E_BOUNDS;
-		const f16* base = ( w == "self-k" ? c->selfK : c->selfV ) + (int64_t)layer * c->maxBatch * hp.n_text_ctx * d;
-		return readHeadMajor( c, base, batch, rows, hp.n_text_ctx, dstHost );
+		if( rows <= 0 || rows > hp.n_text_ctx || dstCapFloats < (int64_t)seqs * rows * d ) return WH_E_BOUNDS;
+		const f16* base = ( w == "self-k" ? c->selfK : c->selfV ) + (int64_t)layer * c->maxSeq * hp.n_text_ctx * d;
+		return readHeadMajor( c, base, seqs, rows, hp.n_text_ctx, dstHost );
 	}
 	setError( "debug_read: unknown item" );
 	return WH_E_INVALIDARG;
@@ -1245,7 +1403,7 @@ int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F32; g.bias = bias; g.res = residual; g.out32 = out;
 	// the same choice the decoder makes: up to 32 rows go to the gemv when K allows it
-	if( M <= 32 && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
+	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -1254,7 +1412,7 @@ int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16, const 
 	if( !bias ) { setError( "mul_mat_gelu: bias is required" ); return WH_E_INVALIDARG; }
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F16_GELU; g.bias = bias; g.out16 = (f16*)outF16;
-	if( M <= 32 && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
+	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -1266,6 +1424,28 @@ int wh_op_layer_norm( void* stream, const float* x, const float* w, const float*
 int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vT, void* out, int batch, int heads, int nCtx )
 {
 	return launchAttentionEnc( (const f16*)q, (const f16*)k, (const f16*)vT, (f16*)out, batch, heads, nCtx, roundUp( nCtx, 256 ), (hipStream_t)stream );
+}
+
+int wh_op_decoder_attention( void* stream, const void* qF16, const void* kCache, const void* vCache, void* outF16, int sequences, int heads,
+	int nTok, int nKeys, int keyStride, int causal, int nPast, int group, int parityThreads )
+{
+	DecAttnArgs a = {};
+	a.q = (const f16*)qF16; a.kc = (const f16*)kCache; a.vc = (const f16*)vCache; a.out = (f16*)outF16;
+	a.batch = sequences; a.H = heads; a.nTok = nTok; a.nKeys = nKeys; a.keyStride = keyStride;
+	a.causal = causal; a.nPast = nPast; a.group = group; a.parityThreads = parityThreads;
+	return launchAttentionDec( a, (hipStream_t)stream );
+}
+
+int wh_op_decoder_cross_attention( void* stream, const float* x, const float* lnW, const float* lnB, const void* qW, const float* qB, float qScale,
+	const void* kCache, const void* vCache, void* outF16, int sequences, int heads, int nKeys, int keyStride, int group )
+{
+	if( !x || !lnW || !lnB || !qW || !qB ) { setError( "decoder_cross_attention: null argument" ); return WH_E_INVALIDARG; }
+	DecAttnArgs a = {};
+	a.kc = (const f16*)kCache; a.vc = (const f16*)vCache; a.out = (f16*)outF16;
+	a.batch = sequences; a.H = heads; a.nTok = 1; a.nKeys = nKeys; a.keyStride = keyStride;
+	a.group = group;
+	a.lnX = x; a.lnW = lnW; a.lnB = lnB; a.qW = (const f16*)qW; a.qB = qB; a.qScale = qScale;
+	return launchAttentionDec( a, (hipStream_t)stream );
 }
 
 int wh_op_soft_max( void* stream, float* x, int rows, int cols )
@@ -1351,6 +1531,7 @@ int wh_debug_set_tuning( uint32_t mask )
 int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter )
 {
 	if( !c || !msPerIter || iters <= 0 ) return WH_E_INVALIDARG;
+	WH_BIND( c->m );
 	hipStream_t st = c->stream;
 	hipEvent_t e0, e1;
 	WH_HIP( hipEventCreate( &e0 ) );
@@ -1396,6 +1577,8 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)W, (long long)N * K, 2u );
 		GemmArgs g = plainGemm( (const f16*)A, (const f16*)W, M, N, K );
 		g.epi = EPI_F32; g.out32 = (float*)out;
+		g.groupM = variant / 100;	   // variant = tile variant + 100 * M tiles per band of the block walk (0 = default)
+		variant %= 100;
 		for( int i = 0; i < 2 && rc == 0; i++ ) rc = launchGemmVariant( g, variant, st );
 		if( rc == 0 )
 		{

@@ -42,12 +42,14 @@ def gather_window_tokens(local_tokens: np.ndarray, n_windows_total: int, max_len
     rank = dist.get_rank() if dist.is_initialized() else 0
     b, e = shard_range(n_windows_total, rank, world)
     pad = np.full((e - b, max_len), -1, np.int32)
-    lt = np.asarray(local_tokens, np.int32).reshape(e - b, -1)
-    pad[:, :lt.shape[1]] = lt[:, :max_len]
+    if e > b:           # a rank with an empty shard (world > n_windows) still has to enter the collective below
+        lt = np.asarray(local_tokens, np.int32).reshape(e - b, -1)
+        pad[:, :lt.shape[1]] = lt[:, :max_len]
     if world == 1:
         return pad
-    # equal-sized buffers for all_gather: pad each rank's block to the largest shard
-    biggest = shard_range(n_windows_total, 0, world)[1]
+    # equal-sized buffers for all_gather: pad each rank's block to the largest shard (at least one row, so that no rank
+    # contributes a zero-sized tensor)
+    biggest = max(1, shard_range(n_windows_total, 0, world)[1])
     buf = np.full((biggest, max_len), -1, np.int32)
     buf[:e - b] = pad
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -61,3 +63,15 @@ def gather_window_tokens(local_tokens: np.ndarray, n_windows_total: int, max_len
         rb, re_ = shard_range(n_windows_total, r, world)
         out[rb:re_] = p.cpu().numpy()[:re_ - rb]
     return out
+
+
+def transcribe_sharded(n_windows_total: int, transcribe_local, max_len: int):
+    """The whole data-parallel step: this rank's contiguous range of window indices -> transcribe_local(begin, end) ->
+    [end - begin][<= max_len] token ids -> gathered on rank 0 in window order (None elsewhere). No collective runs between
+    the two ends: windows are independent (ContextImpl.cpp:476-477, NoContext)."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    b, e = shard_range(n_windows_total, rank, world)
+    local = transcribe_local(b, e) if e > b else np.zeros((0, max_len), np.int32)
+    return gather_window_tokens(local, n_windows_total, max_len)

@@ -46,7 +46,7 @@ class HParams:
 
     @property
     def is_multilingual(self) -> bool:
-        return self.n_vocab == 51865
+        return self.n_vocab >= 51865
 
 
 # name -> (n_vocab, d, heads, layers); encoder and decoder widths/depths are equal for every released size.
@@ -57,17 +57,23 @@ MODEL_SHAPES = {
     "small": (51865, 768, 12, 12),
     "medium": (51865, 1024, 16, 24),
     "large-v2": (51865, 1280, 20, 32),
+    "large": (51865, 1280, 20, 32),
+    # large-v3 shape: 128 mel bins and one more language token. NOT loadable by the reference (N_MEL is a constexpr 80,
+    # Whisper/Whisper/audioConstants.h:13; special ids keyed on 51865, Vocabulary.h:38-41): an extension without an oracle.
+    "large-v3": (51866, 1280, 20, 32),
     # test-size models; layer counts must be one of {4,6,12,24,32} for the CPU reference (whisper.cpp:491-509)
     "test-d128": (51864, 128, 2, 4),
     "test-d128-ml": (51865, 128, 2, 4),
     "test-d192": (51865, 192, 3, 4),
+    "test-d128-v3": (51866, 128, 2, 4),
 }
+N_MELS = {"large-v3": 128, "test-d128-v3": 128}
 
 
 def hparams_for(kind: str, n_audio_ctx: int = 1500, n_text_ctx: int = 448) -> HParams:
     v, d, h, l = MODEL_SHAPES[kind]
     return HParams(n_vocab=v, n_audio_ctx=n_audio_ctx, n_audio_state=d, n_audio_head=h, n_audio_layer=l,
-                   n_text_ctx=n_text_ctx, n_text_state=d, n_text_head=h, n_text_layer=l, n_mels=80, f16=1)
+                   n_text_ctx=n_text_ctx, n_text_state=d, n_text_head=h, n_text_layer=l, n_mels=N_MELS.get(kind, 80), f16=1)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -165,7 +171,7 @@ class GgmlModel:
 
 def default_vocab_words(hp: HParams) -> List[bytes]:
     """Stand-in vocabulary: the file stores 50257 (multilingual) or 50256 (.en) byte strings (appendix A)."""
-    n_words = 50257 if hp.is_multilingual else 50256
+    n_words = 50257 if hp.is_multilingual else 50256      # eot is the last stored word
     words = []
     for i in range(n_words):
         if i < 256:
@@ -268,12 +274,13 @@ def read_model(path: str, load_tensors: bool = True) -> GgmlModel:
 
 
 def special_tokens(hp: HParams) -> Dict[str, int]:
-    """Hard-coded ids (Whisper/Whisper/Vocabulary.h:27-41; whisper.cpp:198-221)."""
-    t = dict(eot=50256, sot=50257, prev=50360, solm=50361, not_=50362, beg=50363)
-    if hp.is_multilingual:
-        t = {k: v + 1 for k, v in t.items()}
-    t["translate"] = 50358
-    t["transcribe"] = 50359
+    """Hard-coded ids (Whisper/Whisper/Vocabulary.h:27-41; whisper.cpp:198-221) for 51864 / 51865; for larger
+    vocabularies (the large-v3 shape, 51866) every extra language token moves the ids behind the language block up by one."""
+    extra = max(0, hp.n_vocab - 51864)
+    ml = 1 if extra > 0 else 0
+    t = dict(eot=50256 + ml, sot=50257 + ml, prev=50360 + extra, solm=50361 + extra, not_=50362 + extra, beg=50363 + extra)
+    t["translate"] = 50358 + max(0, extra - 1)
+    t["transcribe"] = 50359 + max(0, extra - 1)
     return t
 
 

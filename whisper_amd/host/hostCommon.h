@@ -75,10 +75,10 @@ namespace Whisper
 	{
 		int n_vocab = 0;
 		int token_eot = 50256, token_sot = 50257, token_prev = 50360, token_solm = 50361, token_not = 50362, token_beg = 50363;
-		static constexpr int token_translate = 50358, token_transcribe = 50359;
+		int token_translate = 50358, token_transcribe = 50359;
 		std::vector<std::string> idToToken;
 		std::map<std::string, int> tokenToId;
-		bool isMultilingual() const { return n_vocab == 51865; }
+		bool isMultilingual() const { return n_vocab >= 51865; }
 		const char* string( int id ) const { return ( id >= 0 && id < (int)idToToken.size() ) ? idToToken[ id ].c_str() : nullptr; }
 		// fills the special ids and synthesises the tokens the file does not store
 		void finalize( int nVocabModel );

@@ -201,6 +201,11 @@ namespace Whisper
 		if( isMultilingual() )
 		{
 			token_eot++; token_sot++; token_prev++; token_solm++; token_not++; token_beg++;
+			// vocabularies beyond the reference's 51865 (the large-v3 shape has one more language token): everything behind
+			// the language block moves up with it, the task tokens included
+			const int more = n_vocab - 51865;
+			token_prev += more; token_solm += more; token_not += more; token_beg += more;
+			token_translate += more; token_transcribe += more;
 		}
 		// the file stores the byte-pair vocabulary only; the special tokens get printable stand-ins
 		idToToken.resize( std::max( nWords, nVocabModel ) );
@@ -216,6 +221,9 @@ namespace Whisper
 			else w = "[_extra_token_" + std::to_string( i ) + "]";
 			idToToken[ i ] = w;
 		}
+		// Every token, the synthesised names included, is findable by the tokenizer: the reference does the same in both of
+		// its loaders (Whisper/Whisper/Vocabulary.cpp:36-40 completeBuild() maps ALL `tokens`; Whisper/source/whisper.cpp:601
+		// `vocab.token_to_id[word] = i` inside the extra-token loop), so "[_EOT_]" in a prompt tokenizes to the control id there too.
 		tokenToId.clear();
 		for( int i = 0; i < (int)idToToken.size(); i++ ) tokenToId[ idToToken[ i ] ] = i;
 	}

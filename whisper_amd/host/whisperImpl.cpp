@@ -342,7 +342,7 @@ namespace Whisper
 					return E_INVALIDARG;
 				}
 				promptInit.push_back( vocab.token_sot + 1 + langId );
-				promptInit.push_back( params.flag( eFullParamsFlags::Translate ) ? Vocabulary::token_translate : Vocabulary::token_transcribe );
+				promptInit.push_back( params.flag( eFullParamsFlags::Translate ) ? vocab.token_translate : vocab.token_transcribe );
 			}
 
 			const int nMax = hp.n_text_ctx / 2 - 4;
@@ -580,7 +580,7 @@ namespace Whisper
 				const Vocabulary& v = model->vocab;
 				r.TranscriptionEnd = v.token_eot; r.TranscriptionStart = v.token_sot; r.PreviousWord = v.token_prev;
 				r.SentenceStart = v.token_solm; r.Not = v.token_not; r.TranscriptionBegin = v.token_beg;
-				r.TaskTranslate = Vocabulary::token_translate; r.TaskTranscribe = Vocabulary::token_transcribe;
+				r.TaskTranslate = v.token_translate; r.TaskTranscribe = v.token_transcribe;
 				return S_OK;
 			}
 			const char* stringFromToken( whisper_token token ) override { return model->vocab.string( token ); }
@@ -933,7 +933,7 @@ WHISPER_EXPORT int32_t whisperc_debug_token_string( const char* modelPath, int32
 	if( specials8 )
 	{
 		const int v[ 8 ] = { vocab.token_eot, vocab.token_sot, vocab.token_prev, vocab.token_solm, vocab.token_not, vocab.token_beg,
-			Whisper::Vocabulary::token_translate, Whisper::Vocabulary::token_transcribe };
+			vocab.token_translate, vocab.token_transcribe };
 		for( int i = 0; i < 8; i++ ) specials8[ i ] = v[ i ];
 	}
 	return str ? S_OK : S_FALSE;
