@@ -26,6 +26,11 @@ int32_t whisperc_tokenize( void* model, const char* text, int32_t* out, int cap 
  * flags = eFullParamsFlags bits (Translate 1, NoContext 2, SingleSegment 4, PrintSpecial 8 ...). */
 int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx /* < 0 keeps the default 16384 */ );
+/* iMediaFoundation::loadAudioFileData( WAV bytes: 16 kHz, mono/stereo, PCM16/float32 ) + iContext::runStreamed( params,
+ * { progress callback }, reader ): the streaming entry the reference's CLI uses by default (Examples/main/main.cpp:305-311).
+ * The values the progress sink received are copied to progressOut (first progressCap of them), their count to *progressCount. */
+int32_t whisperc_run_streamed( void* ctx, const void* wavBytes, uint64_t wavSize, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, double* progressOut, int progressCap, int* progressCount );
 /* whisperc_run_full + the token-timestamp fields of sFullParams (set TokenTimestamps = 0x100 in flags): thold_pt, thold_ptsum, max_len */
 int32_t whisperc_run_full_tt( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, float tholdPt, float tholdPtsum, int maxLen );

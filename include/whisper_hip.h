@@ -127,6 +127,16 @@ WH_API int wh_buffer_download( wh_context* c, void* host, const void* dev, int64
  * The normalisation maximum is over the whole buffer, as in runFull. */
 WH_API int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, float* melDev, int64_t* nLenOut );
 
+/* One window of a STREAMED spectrogram. Replaces MelStreamer::makeBuffer + makeTransposedBuffer
+ * (Whisper/Whisper/MelStreamer.cpp:189-245, :125-187), what iContext::runStreamed feeds the encoder with: frames
+ * [frame0, frame0 + nFrames) of the stream (frame f = 400 samples from f*160, zero past nSamples; frames >= nChunks, the
+ * number of 160-sample chunks the reader delivered, are 0 BEFORE normalisation), clamped to (the WINDOW's maximum - 8) with
+ * the maximum floored at 1e-20, then (x+4)/4 in FP32. reusePreviousMax != 0 normalises with the maximum the previous
+ * call stored instead (the streamer does that when a shorter request ends at the same frame as the last one, :158-166).
+ * melDev: FP32 [n_mel][nFrames]. */
+WH_API int wh_mel_spectrogram_window( wh_context* c, const float* pcmDev, int64_t nSamples, int64_t frame0, int64_t nFrames, int64_t nChunks,
+	int reusePreviousMax, float* melDev );
+
 /* Encoder. Replaces WhisperContext::encode (WhisperContext.cpp:310-399) == whisper_encode (whisper.cpp:1084-1496).
  * melDev: FP32 device, `batch` spectrograms each [n_mel][melLen] (melStride floats apart); for each the window
  * [melOffset, melOffset + 2*n_audio_ctx) is taken and zero-padded (MelInputTensor.cpp:8-63).  Fills the
@@ -170,6 +180,12 @@ WH_API int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstToken
 WH_API int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp,
 	int firstIsInitial );
 WH_API int wh_decode_window_finish( wh_context* c, wh_token_data* out );
+/* nSteps more greedy steps of the window in progress (no host round trip: position, last token and sampler flags are in
+ * device memory), and a blocking read of samples [first, first + count) -> HOST [count][batch] that waits for those
+ * samples only. The reference's loop looks at every token before it decodes the next one (ContextImpl.cpp:597-673); a
+ * caller that keeps one chunk queued behind the one it is scanning loses at most that chunk when a stop token shows up. */
+WH_API int wh_decode_window_continue( wh_context* c, int nSteps );
+WH_API int wh_decode_window_fetch( wh_context* c, int first, int count, wh_token_data* out );
 
 /* Per-kernel-class GPU timings, the counterpart of the reference's GpuProfiler / iContext::timingsPrint
  * (Whisper/Utils/GpuProfiler.h:21-188, Whisper/Whisper/ContextImpl.misc.cpp:170-182). hipEvent pairs around every launch

@@ -87,19 +87,16 @@ def mul_mat_w(w16, x):
 # ----------------------------------------------------------------------------------------------------------------------
 # mel spectrogram
 # ----------------------------------------------------------------------------------------------------------------------
-def log_mel_spectrogram(pcm, filters, n_fft=400, hop=160):
-    """log_mel_spectrogram (whisper.cpp:2060-2180), mirrored by Spectrogram::pcmToMel (Whisper/Whisper/Spectrogram.cpp:64-122).
-
-    n_len = n_samples // hop frames, no centre padding, frames past the end are zero-filled; periodic Hann(400);
-    power spectrum with the reference's fold p[j] += p[400-j] for j = 1..199 (which doubles those bins,
-    whisper.cpp:2121-2123); 80x201 filterbank; log10(max(., 1e-10)); clamp to (global max - 8); (x + 4) / 4.
-    The DFT here is evaluated in float64 (the reference uses a float32 recursive FFT, so it carries ~1e-6 relative
-    noise of its own; tests compare with a stated tolerance). Returns [n_mel][n_len] float32.
-    """
+def log_mel_raw(pcm, filters, n_fft=400, hop=160, n_len=None):
+    """The spectrogram before its normalisation: log10(max(mel power, 1e-10)) per frame, [n_mel][n_len] float32.
+    SpectrogramContext::fft / log_mel_spectrogram's per-frame part (melSpectrogram.cpp:318-391, whisper.cpp:2080-2150):
+    n_len = n_samples // hop frames (or as given), no centre padding, samples past the end are zero; periodic Hann(400)
+    multiplied in float; power spectrum with the reference's fold p[j] += p[400-j], j = 1..199; filterbank with a double sum."""
     pcm = np.asarray(pcm, F32)
-    n_len = len(pcm) // hop
+    if n_len is None:
+        n_len = len(pcm) // hop
     hann = (0.5 * (1.0 - np.cos((2.0 * np.pi * np.arange(n_fft)) / n_fft))).astype(F32)
-    padded = np.concatenate([pcm, np.zeros(n_fft, F32)])
+    padded = np.concatenate([pcm, np.zeros(n_len * hop + n_fft, F32)])
     idx = (np.arange(n_len) * hop)[:, None] + np.arange(n_fft)[None, :]
     frames = (padded[idx] * hann[None, :]).astype(F32)          # the reference multiplies in float
     spec = np.fft.fft(frames.astype(np.float64), axis=1)
@@ -109,8 +106,42 @@ def log_mel_spectrogram(pcm, filters, n_fft=400, hop=160):
     folded[:, 1:half] += p[:, n_fft - 1:half:-1]
     mel = folded @ filters.astype(np.float64).T                 # [n_len][n_mel], double sum as the reference
     mel = np.log10(np.maximum(mel, 1e-10))
-    mel = mel.T.astype(F32)                                     # stored into a float vector before the clamp
-    return normalize_mel(mel)
+    return mel.T.astype(F32)                                    # stored into a float vector before the clamp
+
+
+def log_mel_spectrogram(pcm, filters, n_fft=400, hop=160):
+    """log_mel_spectrogram (whisper.cpp:2060-2180), mirrored by Spectrogram::pcmToMel (Whisper/Whisper/Spectrogram.cpp:64-122):
+    log_mel_raw, then clamp to (global max - 8) and (x + 4) / 4. The DFT here is evaluated in float64 (the reference uses a
+    float32 recursive FFT, so it carries ~1e-6 relative noise of its own; tests compare with a stated tolerance).
+    Returns [n_mel][n_len] float32."""
+    return normalize_mel(log_mel_raw(pcm, filters, n_fft, hop))
+
+
+class MelStreamerNP:
+    """MelStreamer::makeBuffer + makeTransposedBuffer (Whisper/Whisper/MelStreamer.cpp:189-245, :125-187), what
+    iContext::runStreamed feeds the encoder with. The reference's CPU model has no streamer, so this restatement (not a
+    reference run) is the pin for that row: frames [off, off + len) of the stream; frames the reader has no 160-sample chunk for
+    are 0 BEFORE normalisation; maximum over the window with a floor of 1e-20; when a request ends at the frame the previous
+    one ended at, the previous maximum is re-used; clamp and (x + 4) * 0.25 in FP32."""
+
+    def __init__(self, pcm, filters):
+        self.pcm = np.asarray(pcm, F32)
+        self.filters = filters
+        self.length = len(self.pcm) // 160                 # PcmReader::getLength
+        self.n_chunks = (len(self.pcm) + 159) // 160       # readChunk pads the last chunk
+        self.last_end, self.last_max = None, F32(0)
+
+    def make_buffer(self, off, length):
+        raw = log_mel_raw(self.pcm[off * 160:], self.filters, n_len=length)
+        valid = max(0, min(length, self.n_chunks - off))
+        raw[:, valid:] = 0.0
+        mmax = max(F32(1e-20), raw.max())
+        if self.last_end == off + length:
+            mmax = self.last_max
+        else:
+            self.last_end, self.last_max = off + length, mmax
+        lo = F32(mmax) - F32(8.0)
+        return ((np.maximum(raw, lo) + F32(4.0)) * F32(0.25)).astype(F32)
 
 
 def normalize_mel(mel):

@@ -22,6 +22,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_e2e():
+    """Exact-arithmetic and 8-thread reference logits + the reference's greedy ids on jfk.wav; tests/golden/make_golden_e2e.py."""
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_e2e_d128.npz")))
+
+
+@pytest.fixture(scope="session")
 def tiny_model():
     """The synthetic model the golden fixtures were produced with (regenerated from its seed)."""
     from whisper_amd import ggml_format as gf

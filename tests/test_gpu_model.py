@@ -161,8 +161,14 @@ def test_decoder_parity_mode(hip_tiny, golden, np_tiny, tiny_model):
     ctx.close()
 
 
-def test_decoder_fast_path(hip_tiny, golden, np_tiny):
-    """FP32 P.V (what the reference's own GPU shaders do) against the restatement with the same choice."""
+def test_decoder_fast_path(hip_tiny, golden, golden_e2e, np_tiny):
+    """The MEASURED path (FP32 P.V, what bench.py times and what the reference's own GPU shaders do, mulMatByRowTiled.hlsl).
+    The reference's CPU decoder accumulates P.V in FP16, key by key, per thread (ggml.c:4689-4735): its logits move by 3-5e-2
+    between 1 and 8 threads on this model, so "the reference" is a band, not a point. The yardstick is the exact-arithmetic
+    result (oracle/whisper_np.py WhisperTruth, float64, no intermediate rounding; fixtures from tests/golden/make_golden_e2e.py):
+        |HIP - truth| must not exceed |reference(1 thread) - truth|, must stay within 1.25x of |reference(8 threads) - truth|
+        (measured: 1.3-1.7e-3 vs 1.7-2.0e-3 max, 2.4e-4 vs 3.3e-4 mean), and the distance to the 8-thread reference itself is
+        bounded by the sum of the two (asserted at 4e-3 max / 6e-4 mean; north_star's 1e-3 holds in the mean)."""
     ctx = binding.HipContext(hip_tiny, 1)
     ctx.encode(torch.from_numpy(golden["mel"]).cuda())
     ctx.set_parity(0)
@@ -173,10 +179,228 @@ def test_decoder_fast_path(hip_tiny, golden, np_tiny):
         nl, _ = np_tiny.decode(golden["steps"][pos:pos + ln], n_past, exact_pv=False)
         d = report("fast logits step %d vs restatement(fp32 PV)" % i, logits[0], nl[-1])
         assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
-        d = report("fast logits step %d vs reference (1 thread)" % i, logits[0], golden["logits%d" % i])
+        truth, ref1, ref8 = golden_e2e["truth_logits%d" % i], golden["logits%d" % i], golden_e2e["ref8_logits%d" % i]
+        dt = report("fast logits step %d vs truth (float64)" % i, logits[0], truth)
+        d1 = report("   reference, 1 thread, vs truth", ref1, truth)
+        d8 = report("   reference, 8 threads, vs truth", ref8, truth)
+        report("   reference, 1 vs 8 threads", ref1, ref8)
+        assert dt.max() < 2.5e-3 and dt.mean() < 4e-4
+        assert dt.max() <= d1.max() and dt.mean() <= d1.mean()
+        assert dt.max() <= 1.25 * d8.max() and dt.mean() <= 1.25 * d8.mean()
+        dr = report("fast logits step %d vs reference (8 threads)" % i, logits[0], ref8)
+        assert dr.max() < 4e-3 and dr.mean() < 6e-4
+        assert int(np.argmax(logits[0])) == int(np.argmax(ref8)) or abs(np.sort(ref8)[-1] - np.sort(ref8)[-2]) < 4e-3
         pos += ln
         n_past += ln
     ctx.close()
+
+
+def test_greedy_token_ids_on_jfk_wav(golden, golden_e2e):
+    """north_star's end-to-end criterion on the measured path: SampleClips/jfk.wav -> GPU mel -> encoder -> prompt -> 32 greedy
+    steps (device-side sampler, captured hipGraph) must give the token ids the reference gives when IT chooses its own tokens
+    (whisper_decode + whisper_sample_timestamp / whisper_sample_best, fixture greedy_ids; identical at 1 and 8 reference
+    threads). Model: test-d128 with the tied token embedding scaled by 4 (peaked distributions; plain random weights make
+    every sample a timestamp by the sum rule)."""
+    model = gf.synth_model("test-d128", seed=1234, attn_sharpness=2.0)
+    te = model.tensors["decoder.token_embedding.weight"].astype(np.float32) * float(golden_e2e["greedy_gain"][0])
+    model.tensors["decoder.token_embedding.weight"] = te.astype(np.float16)
+    sp = gf.special_tokens(model.hparams)
+    want = [int(x) for x in golden_e2e["greedy_ids"]]
+    m = binding.HipModel.from_ggml(model)
+    pcm = torch.from_numpy(golden["pcm16"].astype(np.float32) / 32768.0).cuda()
+    for batch in (1, 3):
+        ctx = binding.HipContext(m, batch)
+        mel = ctx.mel_spectrogram(pcm)
+        ctx.encode(torch.stack([mel] * batch))
+        ctx.decode_window_start(np.array([[sp["sot"]]] * batch, np.int32), len(want) - 1, force_first_timestamp=True, first_is_initial=True)
+        ids, ps = ctx.decode_window_finish()
+        print("greedy ids (batch %d):" % batch, [int(x) for x in ids[:, 0]][:12], "reference:", want[:12], "min margin", float(golden_e2e["greedy_min_margin"][0]))
+        for b in range(batch):
+            assert [int(x) for x in ids[:, b]] == want
+        assert np.abs(ps[:, 0] - golden_e2e["greedy_p"]).max() < 5e-3
+        ctx.close()
+    m.close()
+
+
+def test_stage_level_probe_points(hip_tiny, golden, np_tiny, tiny_model):
+    """The intermediates at the reference's Tracing probe points (WhisperContext.cpp:142-638 / whisper.cpp:1121-1869),
+    read back under WH_FLAG_DEBUG_CAPTURE: localises a parity failure to conv front-end / first attention / decoder attention."""
+    ctx = binding.HipContext(hip_tiny, 1)
+    ctx.set_flags(binding.WH_FLAG_DEBUG_CAPTURE | binding.WH_FLAG_PARITY_PV, 1)
+    ctx.encode(torch.from_numpy(golden["mel"]).cuda())
+    n = wn.WhisperNP(tiny_model)
+    tr = {}
+    n.encode(golden["mel"], 0, trace=tr)
+    got = ctx.debug_read("enc.temp1")[0]                     # [2*n_ctx][d]
+    d = report("enc.temp1 (conv1 + GELU) vs restatement", got, wn.r16(tr["enc.temp1"].T))
+    assert d.max() < 2e-3 and (d > 0).mean() < 0.02          # FP16 flips of the GELU argument only
+    got = ctx.debug_read("enc.layer0.in")[0]
+    d = report("enc.layer[0].in (conv2 + GELU + pos) vs restatement", got, tr["enc.layer[ 0 ].in"])
+    assert d.max() < 4e-3 and d.mean() < 1e-4
+    got = ctx.debug_read("enc-KQV")[0]                       # [n_ctx][H*64]
+    want = golden["enc_kqv0"].astype(np.float32).transpose(1, 0, 2).reshape(got.shape)      # reference: [H][n_ctx][64]
+    d = report("enc-KQV (layer 0 attention) vs reference", got, wn.r16(want))
+    assert d.max() < 4e-3 and d.mean() < 1e-4
+    ln = int(golden["step_lens"][0])
+    ctx.decode(golden["steps"][:ln][None, :], 0)
+    for nm, key in (("dec-KQV", "dec_kqv_self0"), ("dec-KQV#2", "dec_kqv_cross0")):
+        got = ctx.debug_read(nm, rows=ln)                    # [rows][H*64]
+        want = golden[key].astype(np.float32).transpose(1, 0, 2).reshape(got.shape)
+        d = report("%s (decoder layer 0) vs reference" % nm, got, wn.r16(want))
+        assert d.max() < 4e-3 and d.mean() < 3e-4
+    ctx.close()
+
+
+def test_hypotheses_share_cross_attention(hip_tiny, golden):
+    """5 decoder sequences per window on ONE pass over the window's cross-attention K/V (wh_context_create_hyp): every
+    hypothesis computes exactly what a lone sequence fed the same tokens computes -- the greedy-equivalence at b = 1 that
+    SURVEY.md 8(d) config 3 asks for, since the reference declares beam search without implementing it (sFullParams.h:12-13)."""
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    rng = np.random.default_rng(3)
+    mel2 = torch.from_numpy(rng.uniform(-1, 1, (80, 3000)).astype(np.float32)).cuda()
+    toks = [[50257, 1000 + 7 * j, 2000 + j] for j in range(5)]
+    lone = {}
+    for wi, mm in enumerate((mel, mel2)):
+        c1 = binding.HipContext(hip_tiny, 1)
+        c1.encode(mm)
+        for j in range(5):
+            c1.encode(mm)
+            la, _ = c1.decode(np.array([toks[j]], np.int32), 0)
+            lb, _ = c1.decode(np.array([[300 + j]], np.int32), 3)
+            lone[(wi, j)] = (la[0], lb[0])
+        c1.close()
+    ch = binding.HipContext(hip_tiny, 2, hypotheses=5)
+    ch.encode(torch.stack([mel, mel2]))
+    la, _ = ch.decode(np.array(toks + toks, np.int32), 0)                       # rows window-major: w0h0..w0h4, w1h0..w1h4
+    lb, _ = ch.decode(np.array([[300 + j] for j in range(5)] * 2, np.int32), 3)
+    for wi in range(2):
+        for j in range(5):
+            d1 = report("hyp prompt step w%d h%d vs lone" % (wi, j), la[wi * 5 + j], lone[(wi, j)][0])
+            d2 = report("hyp token step  w%d h%d vs lone" % (wi, j), lb[wi * 5 + j], lone[(wi, j)][1])
+            # the 15-row prompt step of the lone run and the 30-row one here take different kernels (FP32 summation order)
+            assert d1.max() < E2E_MAX and d2.max() < E2E_MAX and d1.mean() < E2E_MEAN
+    # device-side greedy loop with hypotheses: identical first tokens -> identical streams within a window
+    ch.encode(torch.stack([mel, mel2]))
+    ch.decode_window_start(np.array([[50257, 50362, 50363]] * 10, np.int32), 6)
+    ids, _ = ch.decode_window_finish()
+    for wi in range(2):
+        assert all(np.array_equal(ids[:, wi * 5], ids[:, wi * 5 + j]) for j in range(5))
+    ch.close()
+
+
+def test_fused_cross_query_matches_separate_launches(hip_tiny, golden):
+    """Decode steps with LayerNorm + cross-attention query projection inside the attention kernel against the same steps
+    with the separate LayerNorm and gemv launches (tuning bit off)."""
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    L = binding.lib()
+    res = {}
+    for name, mask in (("fused", binding.TUNE_DEFAULT), ("separate", binding.TUNE_DEFAULT & ~binding.TUNE_FUSE_CROSS_Q)):
+        L.wh_debug_set_tuning(mask)
+        try:
+            ctx = binding.HipContext(hip_tiny, 2)
+            ctx.encode(torch.stack([mel, mel]))
+            ctx.decode(np.array([[50257, 50362, 50363]] * 2, np.int32), 0)
+            res[name] = ctx.decode(np.array([[1234], [1234]], np.int32), 3)[0]
+            ctx.close()
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+    d = report("fused vs separate cross-attention query", res["fused"][0], res["separate"][0])
+    assert d.max() < 3e-3 and d.mean() < 4e-4
+    assert np.array_equal(res["fused"][0], res["fused"][1])
+
+
+def test_large_v3_shape(tmp_path):
+    """128 mel bins, vocabulary 51866 (BASELINE config 5). The reference cannot load this shape (N_MEL is a constexpr 80,
+    audioConstants.h:13; special ids keyed on 51865): an extension whose only oracle is the numpy restatement, which is
+    pinned on the 80-mel shapes. Checks conv1 with K = 384, the special ids the sampler uses, and parity with the restatement."""
+    model = gf.synth_model("test-d128-v3", seed=77, attn_sharpness=2.0)
+    hp = model.hparams
+    assert hp.n_mels == 128 and hp.n_vocab == 51866
+    sp = gf.special_tokens(hp)
+    assert (sp["eot"], sp["sot"], sp["translate"], sp["transcribe"], sp["prev"], sp["solm"], sp["not_"], sp["beg"]) == \
+        (50257, 50258, 50359, 50360, 50362, 50363, 50364, 50365)
+    m = binding.HipModel.from_ggml(model)
+    ctx = binding.HipContext(m, 1)
+    rng = np.random.default_rng(8)
+    pcm = (0.1 * rng.standard_normal(16000 * 4)).astype(np.float32)
+    mel = ctx.mel_spectrogram(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    assert mel.shape == (128, 400)
+    want = wn.log_mel_spectrogram(pcm, model.filters)
+    assert np.abs(mel - want).max() < 2e-5
+    n = wn.WhisperNP(model)
+    n.encode(want, 0)
+    ctx.encode(torch.from_numpy(want).cuda())
+    d = report("v3-shape encode-out vs restatement", ctx.debug_read("encode-out")[0], n.encode(want, 0))
+    assert d.max() < E2E_MAX + 2e-3 and d.mean() < E2E_MEAN
+    ctx.set_parity(1)
+    toks = [sp["sot"], sp["sot"] + 1, sp["transcribe"]]
+    logits, probs = ctx.decode(np.array([toks], np.int32), 0)
+    nl, npr = n.decode(toks, 0, n_threads=1)
+    d = report("v3-shape logits vs restatement", logits[0], nl[-1])
+    assert logits.shape[1] == 51866 and d.max() < E2E_MAX and d.mean() < E2E_MEAN
+    sb = ctx.sample_best(1, True, True)[0]
+    hb = wn.sample_best(probs[0], sp["beg"], sp["sot"], sp["solm"], sp["not_"], True, True)
+    assert (sb["id"], sb["tid"]) == (hb["id"], hb["tid"]) and sp["beg"] <= sb["id"] <= sp["beg"] + 100
+    ctx.close()
+    m.close()
+
+
+def test_medium_shape_against_the_reference(ref_lib_available, tmp_path):
+    """Parity at the shape and through the kernel instances BASELINE measures: ggml-medium shape (the bench's model), an 11-window
+    lock-step batch -- M = 16500 rows, so the encoder GEMMs take the 256x256x64 direct-to-LDS tiles with the banded block
+    walk (EPI_QKV_ENC, EPI_F32, EPI_F16_GELU, EPI_CROSS_KV) -- and the measured FP32-P.V decoder, against the reference's own
+    CPU path (oracle/_ref, 16 threads) on window 0: cross-attention caches of the first and last decoder layer, then the
+    logits of the 3-token prompt and of 6 teacher-forced greedy steps (the GPU's own ids). ~25 s of host CPU."""
+    if not ref_lib_available:
+        pytest.skip("oracle/_ref/libwhisper_ref.so not present")
+    from oracle import ref
+    import bench
+    model = gf.synth_model("medium", seed=1)
+    hp = model.hparams
+    sp = gf.special_tokens(hp)
+    path = str(tmp_path / "medium.bin")
+    gf.write_model(path, model)
+    m = binding.HipModel.from_ggml(model)
+    n_win = 11
+    ctx = binding.HipContext(m, n_win)
+    pcm = bench.synth_pcm(n_win, seed=100)
+    pcm_dev = torch.from_numpy(pcm).cuda()
+    mels = torch.stack([ctx.mel_spectrogram(pcm_dev[b]) for b in range(n_win)])
+    ctx.encode(mels)
+    w = ref.RefWhisper(path, n_threads=16, log_level=0)
+    w.set_mel(mels[0].cpu().numpy())
+    w.encode(0)
+    for il in (0, hp.n_text_layer - 1):
+        k, v = w.cross_kv(il)
+        dk = report("medium cross-k[%d] vs reference" % il, ctx.debug_read("cross-k", il)[0], k)
+        dv = report("medium cross-v[%d] vs reference" % il, ctx.debug_read("cross-v", il)[0], v)
+        scale_k, scale_v = float(np.abs(k).max()), float(np.abs(v).max())
+        assert dk.max() < 1e-2 * max(1.0, scale_k) and dk.mean() < 1e-3 * max(1.0, scale_k)
+        assert dv.max() < 1e-2 * max(1.0, scale_v) and dv.mean() < 1e-3 * max(1.0, scale_v)
+    prompt = [sp["sot"], sp["sot"] + 1, sp["transcribe"]]
+    toks = np.array([prompt] * n_win, np.int32)
+    n_past = 0
+    agree = 0
+    worst = 0.0
+    for step in range(7):
+        gl, _ = ctx.decode(toks, n_past)
+        rl, _ = w.decode([int(t) for t in toks[0]], n_past)
+        rl = rl[-1]
+        d = report("medium logits step %d vs reference (16 threads)" % step, gl[0], rl)
+        span = float(rl.max() - rl.min())
+        print("    logit span %.3f, top-1 gpu %d ref %d" % (span, int(np.argmax(gl[0])), int(np.argmax(rl))))
+        worst = max(worst, d.max() / max(span, 1e-6))
+        assert np.isfinite(gl).all()
+        # random weights at 24 layers: |logit| is O(1-10); the bound is relative to the logit span of the row
+        assert d.max() < 2e-2 * max(1.0, span) and d.mean() < 2e-3 * max(1.0, span)
+        agree += int(np.argmax(gl[0]) == np.argmax(rl))
+        n_past += toks.shape[1]
+        nxt = ctx.sample_best(n_win, step == 0, step == 0)
+        toks = np.array([[t["id"]] for t in nxt], np.int32)
+    print("medium shape: top-1 agreement %d / 7 steps, worst max-diff / span %.2e" % (agree, worst))
+    w.close()
+    ctx.close()
+    m.close()
 
 
 def test_decoder_batch_invariance_and_kv_consistency(hip_tiny, golden):
@@ -388,3 +612,33 @@ def test_pipelined_passes_in_flight(hip_tiny, golden, tiny_model):
         assert ids == want[j]
     for c in ctxs:
         c.close()
+
+
+def test_streamed_mel_window(hip_tiny, golden, tiny_model):
+    """wh_mel_spectrogram_window against the restatement of MelStreamer::makeBuffer (oracle/whisper_np.py MelStreamerNP): per-window
+    maximum, the re-used maximum when a request ends where the last one ended, zero frames past the reader's chunks; and the
+    invariant that ties it to the pinned path: on a clip of one window the streamed spectrogram is the whole-buffer one."""
+    ctx = binding.HipContext(hip_tiny, 1)
+    pcm = golden["pcm16"].astype(np.float32) / 32768.0
+    loud = pcm.copy()
+    loud[16000 * 6:] *= 0.02                        # quiet tail: window-local and global maxima differ
+    dev = torch.from_numpy(loud).cuda()
+    st = wn.MelStreamerNP(loud, tiny_model.filters)
+    assert st.length == 1100
+    for off, ln, reuse in ((0, 1100, False), (600, 500, True), (700, 300, False), (900, 200, False), (950, 150, True)):
+        want = st.make_buffer(off, ln)
+        got = ctx.mel_spectrogram_window(dev, off, ln, reuse_previous_max=reuse).cpu().numpy()
+        d = report("streamed mel window off=%d len=%d reuse=%d" % (off, ln, reuse), got, want)
+        assert got.shape == (80, ln) and d.max() < 2e-5
+    whole = ctx.mel_spectrogram(dev).cpu().numpy()
+    one = ctx.mel_spectrogram_window(dev, 0, 1100).cpu().numpy()
+    assert np.abs(whole - one).max() < 1e-6
+    # the window normalised by its own maximum is NOT the slice of the whole-buffer spectrogram when the maxima differ
+    tail = ctx.mel_spectrogram_window(dev, 700, 300).cpu().numpy()
+    assert np.abs(tail - whole[:, 700:1000]).max() > 1e-2
+    # a reader that over-estimated its length: frames beyond its chunks are zero before normalisation -> (max(0, mmax-8)+4)/4
+    short = ctx.mel_spectrogram_window(dev, 1000, 150, n_chunks=1100).cpu().numpy()
+    ref_short = wn.MelStreamerNP(loud, tiny_model.filters)
+    ref_short.n_chunks = 1100
+    assert np.abs(short - ref_short.make_buffer(1000, 150)).max() < 2e-5
+    ctx.close()

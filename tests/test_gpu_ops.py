@@ -198,3 +198,178 @@ def test_exp_table_exhaustive(golden):
     # a differing entry is one FP16 ulp of e (<= 2^-10 relative); the sum (hence inv) may move by one FP32 ulp with it
     assert len(bad) <= 0.002 * len(x) or rel.max() < 2e-7
     assert rel.max() < 1.1e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 2: the tile configurations the bench actually runs, the 128-row decode kernel, decoder attention on its own
+# ----------------------------------------------------------------------------------------------------------------------
+def _torch_ref_mul_mat(a16, w16, bias=None, res=None):
+    """float64 reference computed on the GPU (numpy would take minutes at these sizes); test plumbing only."""
+    r = a16.double() @ w16.double().T
+    if bias is not None:
+        r = r + bias.double()
+    if res is not None:
+        r = r + res.double()
+    return r
+
+
+@pytest.mark.parametrize("M,N,K", [(16500, 4608, 1024), (16400, 4096, 1024), (17000, 5120, 192), (16384 + 77, 4672, 256)])
+def test_mul_mat_big_tiles(M, N, K):
+    """M >= 16384 rows and >= 300 256x256 tiles: the 256x256x64 direct-to-LDS instance with the banded block walk
+    (gemm.hip CfgGlBig, launchGemm) that the encoder of a 28-window batch runs -- plain FP32 epilogue with bias + residual,
+    ragged M and N (clamped edge tiles) included."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randn((M, K), generator=g, device="cuda").half()
+    w = (0.05 * torch.randn((N, K), generator=g, device="cuda")).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    res = torch.randn((M, N), generator=g, device="cuda")
+    want = _torch_ref_mul_mat(a, w, bias, res)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    binding.check(binding.lib().wh_op_mul_mat(None, ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), M, N, K))
+    torch.cuda.synchronize()
+    d = (out.double() - want).abs()
+    print("mul_mat big %dx%dx%d maxdiff %.3e meandiff %.3e" % (M, N, K, float(d.max()), float(d.mean())))
+    assert bool(torch.isfinite(out).all())
+    assert float(d.max()) < 2e-5 * max(1.0, np.sqrt(K / 128))
+
+
+def test_mul_mat_gelu_big_tiles(golden):
+    """The same instance with the FP16 GELU epilogue (EPI_F16_GELU, the encoder's MLP up-projection)."""
+    M, N, K = 16390, 4608, 512
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn((M, K), generator=g, device="cuda").half()
+    w = (0.1 * torch.randn((N, K), generator=g, device="cuda")).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    pre = (_torch_ref_mul_mat(a, w, bias)).float()
+    table = torch.from_numpy(golden["table_gelu"].astype(np.int32)).cuda()
+    idx = pre.half().view(torch.int16).to(torch.int32) & 0xFFFF
+    want = table[idx.long()].to(torch.int16).view(torch.float16).float()
+    out = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    binding.check(binding.lib().wh_op_mul_mat_gelu(None, ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K))
+    torch.cuda.synchronize()
+    d = (out.float() - want).abs()
+    frac = float((d > 0).float().mean())
+    print("mul_mat_gelu big: %.4f %% of entries differ, max %.3e" % (100 * frac, float(d.max())))
+    assert frac < 0.02 and bool((d <= torch.maximum(torch.tensor(4e-3, device="cuda"), want.abs() * 2.0 ** -10)).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(33, 1024, 1024), (40, 3840, 1280), (64, 1024, 4096), (65, 4096, 1024), (84, 1024, 1024),
+                                   (112, 5120, 1280), (128, 1024, 1024), (100, 51865, 1024)])
+def test_mul_mat_decode_rows(M, N, K):
+    """33 .. 128 activation rows through the decode kernel (gemvFused, four MFMA column tiles per weight fragment, two
+    row groups beyond 64 rows): what a lock-step batch of up to 128 sequences runs every token."""
+    rng = np.random.default_rng(M * 3 + N)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    w = (0.05 * rng.standard_normal((N, K))).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    want = (a.astype(np.float64) @ w.astype(np.float64).T + bias + res).astype(np.float32)
+    ad, wd, bd, rd = dev(a), dev(w), dev(bias), dev(res)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    binding.check(binding.lib().wh_op_mul_mat(None, ptr(ad), ptr(wd), ptr(bd), ptr(rd), ptr(out), M, N, K))
+    torch.cuda.synchronize()
+    d = report("mul_mat decode rows %dx%dx%d" % (M, N, K), out.cpu().numpy(), want)
+    assert d.max() < 2e-5 * max(1.0, np.sqrt(K / 128))
+
+
+def _np_decoder_attention(q, K, V, n_tok, n_keys, causal, n_past, group, n_threads):
+    """WhisperNP._attention_dec semantics on explicit caches: q [seq*n_tok][H*64] (already scaled, FP16 values),
+    K, V [blocks][H][stride][64]. n_threads = 0: FP32 P.V, else the reference's FP16 thread-partitioned accumulation."""
+    S_, d = q.shape
+    H = d // 64
+    seqs = S_ // n_tok
+    out = np.zeros((S_, d), np.float32)
+    for s in range(seqs):
+        blk = s // group
+        for h in range(H):
+            sl = slice(h * 64, (h + 1) * 64)
+            qq = q[s * n_tok:(s + 1) * n_tok, sl].astype(np.float32)
+            Kh = K[blk, h, :n_keys].astype(np.float32)
+            Vh = V[blk, h, :n_keys].astype(np.float32)
+            sc = (qq @ Kh.T).astype(np.float32)
+            if causal:
+                j = np.arange(n_keys)[None, :]
+                i = np.arange(n_tok)[:, None]
+                sc = np.where(j > n_past + i, np.float32(-np.inf), sc)
+            P = wn.softmax_table(sc)
+            if n_threads > 0:
+                out[s * n_tok:(s + 1) * n_tok, sl] = wn.WhisperNP.pv_f16_accumulate(P, Vh, n_threads)
+            else:
+                out[s * n_tok:(s + 1) * n_tok, sl] = (P.astype(np.float64) @ Vh.astype(np.float64)).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("seqs,heads,n_tok,n_keys,stride,causal,n_past,group,par", [
+    (3, 2, 1, 1500, 1500, 0, 0, 1, 0),        # cross-attention, one query row per window
+    (2, 2, 1, 1500, 1500, 0, 0, 1, 1),        # the reference's FP16 P.V, one thread
+    (2, 2, 1, 1500, 1500, 0, 0, 1, 8),        # ... eight threads
+    (10, 2, 1, 1500, 1500, 0, 0, 5, 0),       # 5 hypotheses per window share one pass over K/V
+    (8, 1, 1, 777, 1500, 0, 0, 8, 0),
+    (6, 3, 1, 130, 448, 0, 0, 2, 1),
+    (4, 2, 1, 37, 448, 1, 36, 1, 0),          # self-attention at position 36
+    (2, 2, 3, 3, 448, 1, 0, 1, 0),            # 3-token prompt step, causal
+    (2, 2, 5, 70, 448, 1, 65, 1, 1),          # crosses the 64-row group boundary
+    (1, 2, 1, 1, 448, 1, 0, 1, 0),            # a single key
+])
+def test_decoder_attention(seqs, heads, n_tok, n_keys, stride, causal, n_past, group, par):
+    """attentionDecG (8 lanes per K/V row, hypothesis groups) and the first kernel (tuning bit off) against the restatement
+    of the decoder's mulMat(K,Q) -> diagMaskInf -> softMax -> mulMat(V,.) chain (whisper.cpp:1618-1660, 1715-1748)."""
+    rng = np.random.default_rng(seqs * 100 + n_keys)
+    d = heads * 64
+    q = (rng.standard_normal((seqs * n_tok, d)) * 0.8).astype(np.float16)
+    blocks = seqs // group
+    K = (rng.standard_normal((blocks, heads, stride, 64)) * 0.8).astype(np.float16)
+    V = rng.standard_normal((blocks, heads, stride, 64)).astype(np.float16)
+    want = _np_decoder_attention(q, K, V, n_tok, n_keys, causal, n_past, group, par)
+    qd, kd, vd = dev(q), dev(K), dev(V)
+    L = binding.lib()
+    results = {}
+    for name, mask in (("grouped", None), ("first", 0)):
+        if mask == 0 and group > 1:
+            continue
+        if mask is not None:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_DEC_G)
+        try:
+            out = torch.full((seqs * n_tok, d), float("nan"), dtype=torch.float16, device="cuda")
+            binding.check(L.wh_op_decoder_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), seqs, heads, n_tok, n_keys, stride, causal, n_past,
+                                                    group, par))
+            torch.cuda.synchronize()
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+        got = out.cpu().numpy().astype(np.float32)
+        assert np.isfinite(got).all()
+        dd = report("decoder_attention %s keys=%d group=%d par=%d" % (name, n_keys, group, par), got, wn.r16(want))
+        # scores differ by FP32 summation order only: a flipped FP16 rounding of (s - max) moves one key's probability by
+        # <= 1.6 %; with the FP16 P.V emulation a flip can also move a partial sum by one FP16 ulp
+        assert dd.max() < (4e-3 if par else 2e-3) and dd.mean() < 2e-4
+        results[name] = got
+
+
+@pytest.mark.parametrize("seqs,heads,group", [(3, 2, 1), (10, 16, 5), (4, 20, 1)])
+def test_decoder_cross_attention_fused_query(seqs, heads, group):
+    """LayerNorm + query projection inside the attention kernel == the three separate steps of WhisperContext.cpp:489-519."""
+    rng = np.random.default_rng(seqs + heads)
+    d = heads * 64
+    n_keys = 1500
+    x = (rng.standard_normal((seqs, d)) * 2 + 0.3).astype(np.float32)
+    lnw = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    lnb = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    wq = (rng.standard_normal((d, d)) * (1.0 / np.sqrt(d))).astype(np.float16)
+    bq = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    scale = np.float32(64.0 ** -0.25)
+    blocks = seqs // group
+    K = (rng.standard_normal((blocks, heads, n_keys, 64)) * 0.8).astype(np.float16)
+    V = rng.standard_normal((blocks, heads, n_keys, 64)).astype(np.float16)
+    xn = wn.layer_norm(x, lnw, lnb)
+    q = wn.r16(((wn.mul_mat_w(wq, xn) + bq).astype(np.float32) * scale).astype(np.float32))
+    want = _np_decoder_attention(q.astype(np.float16), K, V, 1, n_keys, 0, 0, group, 0)
+    xd, lw, lb, wd, bd, kd, vd = dev(x), dev(lnw), dev(lnb), dev(wq), dev(bq), dev(K), dev(V)
+    out = torch.full((seqs, d), float("nan"), dtype=torch.float16, device="cuda")
+    binding.check(binding.lib().wh_op_decoder_cross_attention(None, ptr(xd), ptr(lw), ptr(lb), ptr(wd), ptr(bd), C.c_float(float(scale)), ptr(kd), ptr(vd),
+                                                              ptr(out), seqs, heads, n_keys, n_keys, group))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().astype(np.float32)
+    assert np.isfinite(got).all()
+    dd = report("fused cross attention seqs=%d heads=%d group=%d" % (seqs, heads, group), got, wn.r16(want))
+    # one more rounding point than the plain attention test: an FP16 flip of a LayerNorm output or of q moves a score by ~1e-3
+    assert dd.max() < 4e-3 and dd.mean() < 3e-4

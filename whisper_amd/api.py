@@ -53,6 +53,8 @@ def lib():
         L.whisperc_result_token_times.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         L.whisperc_result_token.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.whisperc_timings_print.argtypes = [vp]
+        L.whisperc_run_streamed.argtypes = [vp, vp, C.c_uint64, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int,
+                                            C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -140,6 +142,19 @@ class Context:
         return _check(lib().whisperc_run_full(self.h, pcm.ctypes.data_as(C.c_void_p), len(pcm), language.encode(), flags, max_tokens,
                                               pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx), "runFull")
 
+    def run_streamed(self, pcm: np.ndarray, language: str = "en", flags: int = 0, max_tokens: int = 0,
+                     prompt: Optional[Sequence[int]] = None, n_max_text_ctx: int = -1):
+        """iMediaFoundation::loadAudioFileData (the PCM wrapped as a float32 WAV image) + iContext::runStreamed.
+        Returns (HRESULT, [progress values the sink received])."""
+        wav = wav_bytes(pcm)
+        pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        prog = (C.c_double * 4096)()
+        n = C.c_int()
+        hr = _check(lib().whisperc_run_streamed(self.h, wav, len(wav), language.encode(), flags, max_tokens,
+                                                pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx,
+                                                prog, 4096, C.byref(n)), "runStreamed")
+        return hr, list(prog[:min(n.value, 4096)])
+
     def results(self):
         """getResults(Tokens | Timestamps): list of segments {t0, t1 (100 ns ticks), text, tokens[{id, p, pt, ptsum}]}."""
         ns, nt = C.c_uint32(), C.c_uint32()
@@ -161,3 +176,12 @@ class Context:
 
     def timings_print(self):
         _check(lib().whisperc_timings_print(self.h), "timingsPrint")
+
+
+def wav_bytes(pcm: np.ndarray, rate: int = 16000) -> bytes:
+    """Mono float32 PCM -> the bytes of a RIFF/WAVE file (format 3 = IEEE float), what loadAudioFileData / openAudioFile read."""
+    import struct
+    data = np.ascontiguousarray(pcm, "<f4").tobytes()
+    fmt = struct.pack("<HHIIHH", 3, 1, rate, rate * 4, 4, 32)
+    return b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + \
+        b"data" + struct.pack("<I", len(data)) + data

@@ -19,6 +19,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwhisper_hip.so")
 WH_FLAG_PARITY_PV = 1
 WH_FLAG_NO_GRAPH = 2
 WH_FLAG_DEBUG_CAPTURE = 4
+# kernel-variant switches (whisper_amd/csrc/kernels.h eTuning); TUNE_DEFAULT is what the library starts with
+TUNE_GEMV_ROWS4, TUNE_GEMM_BIG, TUNE_GEMV_SMALLREG, TUNE_GEMM_GL, TUNE_LN_SEPARATE_BIGM, TUNE_ATTN_XCD = 2, 8, 32, 64, 128, 256
+TUNE_ATTN_DEC_G, TUNE_FUSE_CROSS_Q, TUNE_GEMM_GROUP_M = 512, 1024, 2048
+TUNE_DEFAULT = (TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD |
+                TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M)
 
 # every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -27,7 +32,7 @@ EXPORTS = [
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
+    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -91,6 +96,9 @@ def lib():
         L.wh_decode_greedy.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_decode_window_start.argtypes = [vp, i32, vp, i32, i32, i32, i32]
         L.wh_decode_window_finish.argtypes = [vp, C.POINTER(TokenDataC)]
+        L.wh_decode_window_continue.argtypes = [vp, i32]
+        L.wh_decode_window_fetch.argtypes = [vp, i32, i32, C.POINTER(TokenDataC)]
+        L.wh_mel_spectrogram_window.argtypes = [vp, vp, i64, i64, i64, i64, i32, vp]
         L.wh_debug_probe.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
         L.wh_profile_enable.argtypes = [vp, i32]
         L.wh_profile_read.argtypes = [vp, C.POINTER(ProfileEntryC), i32, C.POINTER(i32)]
@@ -297,6 +305,29 @@ class HipContext:
         ids = np.array([o.id for o in out], np.int32).reshape(n, b)
         ps = np.array([o.p for o in out], np.float32).reshape(n, b)
         return ids, ps
+
+    def decode_window_continue(self, n_steps: int):
+        b, n = self._win
+        check(lib().wh_decode_window_continue(self.handle, n_steps))
+        self._win = (b, n + n_steps)
+
+    def decode_window_fetch(self, first: int, count: int):
+        """Blocks until samples [first, first + count) exist; returns their ids [count][batch]."""
+        b, _ = self._win
+        out = (TokenDataC * (b * count))()
+        check(lib().wh_decode_window_fetch(self.handle, first, count, out))
+        return np.array([o.id for o in out], np.int32).reshape(count, b)
+
+    def mel_spectrogram_window(self, pcm_dev, frame0: int, n_frames: int, n_chunks: Optional[int] = None, reuse_previous_max: bool = False):
+        """One window of a streamed spectrogram (MelStreamer semantics): torch float32 [n_mel][n_frames] on the device."""
+        import torch
+        self._wait_for_torch()
+        n = pcm_dev.numel()
+        out = torch.empty((self.hp.n_mels, n_frames), dtype=torch.float32, device=pcm_dev.device)
+        check(lib().wh_mel_spectrogram_window(self.handle, C.c_void_p(pcm_dev.data_ptr()), n, frame0, n_frames,
+                                              (n + 159) // 160 if n_chunks is None else n_chunks, int(reuse_previous_max), C.c_void_p(out.data_ptr())))
+        self.synchronize()
+        return out
 
     def set_flags(self, flags: int, parity_threads: int = 1):
         check(lib().wh_context_set_flags(self.handle, flags, parity_threads))

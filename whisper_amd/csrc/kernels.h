@@ -165,4 +165,7 @@ namespace wh
 	// raw log-mel (before clamp/normalise) [nMel][nLen] + running maximum; then normalise in place
 	int launchMel( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
 		int nMel, float* maxScratch, hipStream_t stream );
+	// one window of a streamed spectrogram, normalised by its own maximum (MelStreamer semantics); maxScratch holds 2 ints
+	int launchMelWindow( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
+		long long nValidFrames, int nMel, int reusePreviousMax, float* maxScratch, hipStream_t stream );
 }

@@ -28,7 +28,7 @@ namespace wh
 
 		__global__ void __launch_bounds__( 256 ) melKernel( const float* __restrict__ pcm, long long nSamples,
 			const float* __restrict__ filters, const double* __restrict__ dft, float* __restrict__ mel, long long nLen, int nMel,
-			int* __restrict__ maxOrdered )
+			int* __restrict__ maxOrdered, long long nValidFrames )
 		{
 			__shared__ double tw[ 2 ][ N_FFT ];		  // cos, sin of 2 pi n / 400
 			__shared__ double fr[ FR ][ N_FFT ];		  // windowed frames
@@ -86,7 +86,8 @@ namespace wh
 				double sum = 0.0;
 				for( int kk = 0; kk < N_BINS; kk++ ) sum = fma( pw[ f ][ kk ], (double)w[ kk ], sum );
 				sum = sum < 1e-10 ? 1e-10 : sum;
-				const float v = (float)log10( sum );
+				// streaming: a frame the reader has no PCM chunk for is zero BEFORE normalisation (MelStreamer.cpp:229-234 memset)
+				const float v = ( f0 + f < nValidFrames ) ? (float)log10( sum ) : 0.0f;
 				mel[ (long long)j * nLen + f0 + f ] = v;
 				localMax = fmaxf( localMax, v );
 			}
@@ -108,6 +109,22 @@ namespace wh
 		}
 
 		__global__ void melInitMax( int* maxOrdered ) { *maxOrdered = (int)0x80000000; }
+		__global__ void melInitMaxFloor( int* maxOrdered, float floorValue ) { *maxOrdered = orderedInt( floorValue ); }
+
+		// MelStreamer::makeTransposedBuffer's second pass (Whisper/Whisper/MelStreamer.cpp:148-187), all in FP32 like its SSE
+		// code: mmax = max - 8; v = (max(v, mmax) + 4) * 0.25. maxOrdered[0] is this window's maximum (floor 1e-20), [1] the
+		// one the previous request stored; reusePrev selects the stored one (a shorter request ending at the same frame).
+		__global__ void __launch_bounds__( 256 ) melNormalizeWindow( float* __restrict__ mel, long long count, int* __restrict__ maxOrdered, int reusePrev )
+		{
+			const float mmax = fromOrderedInt( maxOrdered[ reusePrev ? 1 : 0 ] ) - 8.0f;
+			for( long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256 )
+			{
+				float v = mel[ i ];
+				v = v < mmax ? mmax : v;
+				mel[ i ] = __fmul_rn( __fadd_rn( v, 4.0f ), 0.25f );
+			}
+		}
+		__global__ void melKeepMax( int* maxOrdered ) { maxOrdered[ 1 ] = maxOrdered[ 0 ]; }
 	}	// namespace
 
 	int launchMel( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
@@ -117,10 +134,28 @@ namespace wh
 		int* const mx = (int*)maxScratch;
 		hipLaunchKernelGGL( melInitMax, dim3( 1 ), dim3( 1 ), 0, stream, mx );
 		const int blocks = (int)( ( nLen + FR - 1 ) / FR );
-		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx );
+		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nLen );
 		const long long count = nLen * nMel;
 		const int nb = (int)( ( count + 255 ) / 256 < 2048 ? ( count + 255 ) / 256 : 2048 );
 		hipLaunchKernelGGL( melNormalize, dim3( nb ), dim3( 256 ), 0, stream, mel, count, mx );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	// One window of a STREAMED spectrogram: frames [0, nLen) of `pcm` (the caller offsets the pointer to the window's first
+	// frame), normalised by the window's own maximum -- MelStreamer::makeBuffer + makeTransposedBuffer.
+	int launchMelWindow( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
+		long long nValidFrames, int nMel, int reusePreviousMax, float* maxScratch, hipStream_t stream )
+	{
+		if( nLen <= 0 ) return 0;
+		int* const mx = (int*)maxScratch;
+		hipLaunchKernelGGL( melInitMaxFloor, dim3( 1 ), dim3( 1 ), 0, stream, mx, 1e-20f );
+		const int blocks = (int)( ( nLen + FR - 1 ) / FR );
+		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nValidFrames );
+		const long long count = nLen * nMel;
+		const int nb = (int)( ( count + 255 ) / 256 < 2048 ? ( count + 255 ) / 256 : 2048 );
+		hipLaunchKernelGGL( melNormalizeWindow, dim3( nb ), dim3( 256 ), 0, stream, mel, count, mx, reusePreviousMax ? 1 : 0 );
+		if( !reusePreviousMax ) hipLaunchKernelGGL( melKeepMax, dim3( 1 ), dim3( 1 ), 0, stream, mx );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

@@ -247,6 +247,11 @@ struct wh_context
 	int graphBatch = 0;
 	uint32_t graphKey = 0;
 	int windowSamples = 0;
+	int windowPos = 0;		   // position the next greedy step feeds (prompt length + steps enqueued so far)
+	hipStream_t copyStream = nullptr;
+	struct Mark { int endSample; hipEvent_t ev; };
+	std::vector<Mark> marks;   // after each enqueued chunk of samples: an event wh_decode_window_fetch can wait for
+	std::vector<hipEvent_t> markPool;
 	// WH_FLAG_DEBUG_CAPTURE: copies of intermediates at the reference's Tracing probe points (WhisperContext.cpp:142-638)
 	f16 *capTemp1 = nullptr, *capEncKqv = nullptr, *capDecKqvSelf = nullptr, *capDecKqvCross = nullptr;
 	float* capLayer0In = nullptr;
@@ -759,6 +764,9 @@ void wh_context_destroy( wh_context* c )
 	(void)bindDevice( c->m );
 	if( c->stream ) (void)hipStreamSynchronize( c->stream );
 	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
+	for( auto& mk : c->marks ) (void)hipEventDestroy( mk.ev );
+	for( hipEvent_t e : c->markPool ) (void)hipEventDestroy( e );
+	if( c->copyStream ) (void)hipStreamDestroy( c->copyStream );
 	for( void* p : c->allocations ) (void)hipFree( p );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
 	if( c->ownsStream ) (void)hipStreamDestroy( c->stream );
@@ -841,6 +849,24 @@ int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, fl
 	const wh_model* m = c->m;
 	return profiled( c, KC_MEL, 2.0 * 2.0 * 400.0 * 201.0 * nLen, 4.0 * nSamples + 4.0 * 2.0 * nLen * m->hp.n_mels,
 		[ & ]() { return launchMel( pcmDev, nSamples, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), melDev, nLen, m->hp.n_mels, c->melScratch, c->stream ); } );
+}
+
+int wh_mel_spectrogram_window( wh_context* c, const float* pcmDev, int64_t nSamples, int64_t frame0, int64_t nFrames, int64_t nChunks,
+	int reusePreviousMax, float* melDev )
+{
+	if( !c || nSamples < 0 || frame0 < 0 || nFrames < 0 ) { setError( "mel_window: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	if( nFrames == 0 ) return 0;
+	if( !pcmDev || !melDev ) { setError( "mel_window: null buffer" ); return WH_E_INVALIDARG; }
+	const wh_model* m = c->m;
+	// frame f of the stream starts at sample f * 160; frames at or beyond the reader's chunk count are zero before normalisation
+	const int64_t first = frame0 * 160;
+	const int64_t remaining = nSamples > first ? nSamples - first : 0;
+	int64_t valid = nChunks - frame0;
+	valid = valid < 0 ? 0 : ( valid > nFrames ? nFrames : valid );
+	return profiled( c, KC_MEL, 2.0 * 2.0 * 400.0 * 201.0 * nFrames, 4.0 * 160.0 * nFrames + 4.0 * 2.0 * nFrames * m->hp.n_mels,
+		[ & ]() { return launchMelWindow( pcmDev + ( remaining > 0 ? first : 0 ), remaining, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), melDev,
+			nFrames, valid, m->hp.n_mels, reusePreviousMax, c->melScratch, c->stream ); } );
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1174,6 +1200,17 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	return 0;
 }
 
+// Records an event behind everything enqueued for the window so far
+static int markWindow( wh_context* c )
+{
+	hipEvent_t e = nullptr;
+	if( !c->markPool.empty() ) { e = c->markPool.back(); c->markPool.pop_back(); }
+	else WH_HIP( hipEventCreateWithFlags( &e, hipEventDisableTiming ) );
+	WH_HIP( hipEventRecord( e, c->stream ) );
+	c->marks.push_back( { c->windowSamples, e } );
+	return 0;
+}
+
 // Enqueues, without ever blocking the host: prompt step -> first sample (sampleTimestamp rules when requested) -> nSteps
 // captured greedy steps. Token data of the 1 + nSteps samples stay on the device until wh_decode_window_finish.
 // Several contexts driven this way from one host thread overlap on the GPU (each owns a stream): single-token decode
@@ -1186,6 +1223,8 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	const wh_hparams& hp = c->m->hp;
 	if( nPrompt + nSteps > hp.n_text_ctx || batch * nPrompt + 8 > wh_context::PINNED_INTS - 1024 ) { setError( "decode_window_start: too many tokens" ); return WH_E_BOUNDS; }
 	hipStream_t st = c->stream;
+	for( auto& mk : c->marks ) c->markPool.push_back( mk.ev );
+	c->marks.clear();
 	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && nSteps > 0;
 	const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
 	if( useGraph && c->graphExec && ( c->graphBatch != batch || c->graphKey != key ) )
@@ -1243,6 +1282,75 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 		}
 	c->lastBatch = batch;
 	c->windowSamples = 1 + nSteps;
+	c->windowPos = nPrompt + nSteps;
+	return markWindow( c );
+}
+
+// More greedy steps of the window wh_decode_window_start began, still without blocking the host: the position, the last
+// token and the sampler flags live in device memory, so nothing has to come back first. A host loop that looks for a
+// stop token keeps one chunk queued behind the one it is reading (wh_decode_window_fetch) and the GPU never idles.
+int wh_decode_window_continue( wh_context* c, int nSteps )
+{
+	if( !c || nSteps <= 0 || c->windowSamples <= 0 ) { setError( "decode_window_continue: no window in progress" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	const wh_hparams& hp = c->m->hp;
+	if( c->windowPos + nSteps > hp.n_text_ctx ) { setError( "decode_window_continue: n_text_ctx exceeded" ); return WH_E_BOUNDS; }
+	const int batch = c->lastBatch;
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH );
+	const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
+	if( useGraph && ( !c->graphExec || c->graphBatch != batch || c->graphKey != key ) )
+	{
+		// the window was started with nSteps == 0 (no graph yet): capture now. The eager warm-up step must not disturb
+		// the window's device state, so the state and the pending token are saved around it.
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		DecodeState saved;
+		std::vector<int32_t> tok( (size_t)batch );
+		WH_HIP( hipMemcpy( &saved, c->state, sizeof( saved ), hipMemcpyDeviceToHost ) );
+		WH_HIP( hipMemcpy( tok.data(), c->tokensDev, sizeof( int32_t ) * batch, hipMemcpyDeviceToHost ) );
+		if( c->graphExec ) { (void)hipGraphExecDestroy( c->graphExec ); c->graphExec = nullptr; }
+		WH_CHECK( greedyStep( c, batch ) );
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		hipGraph_t graph = nullptr;
+		WH_HIP( hipStreamBeginCapture( c->stream, hipStreamCaptureModeThreadLocal ) );
+		const int rc = greedyStep( c, batch );
+		const hipError_t e = hipStreamEndCapture( c->stream, &graph );
+		if( rc != 0 ) { if( graph ) (void)hipGraphDestroy( graph ); return rc; }
+		if( e != hipSuccess ) return hipFail( e, "hipStreamEndCapture", __FILE__, __LINE__ );
+		const hipError_t e2 = hipGraphInstantiate( &c->graphExec, graph, nullptr, nullptr, 0 );
+		(void)hipGraphDestroy( graph );
+		if( e2 != hipSuccess ) { c->graphExec = nullptr; return hipFail( e2, "hipGraphInstantiate", __FILE__, __LINE__ ); }
+		c->graphBatch = batch;
+		c->graphKey = key;
+		WH_HIP( hipMemcpy( c->state, &saved, sizeof( saved ), hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->tokensDev, tok.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
+	}
+	if( useGraph )
+		for( int s = 0; s < nSteps; s++ ) WH_HIP( hipGraphLaunch( c->graphExec, c->stream ) );
+	else
+		for( int s = 0; s < nSteps; s++ )
+		{
+			c->profKeysHint = c->windowPos + s + 1;
+			WH_CHECK( greedyStep( c, batch ) );
+		}
+	c->windowSamples += nSteps;
+	c->windowPos += nSteps;
+	return markWindow( c );
+}
+
+// Samples [first, first + count) of the window in progress, HOST [count][batch]; blocks only until THOSE samples exist
+// (chunks enqueued behind them keep running).
+int wh_decode_window_fetch( wh_context* c, int first, int count, wh_token_data* out )
+{
+	if( !c || !out || first < 0 || count <= 0 || first + count > c->windowSamples ) { setError( "decode_window_fetch: range not enqueued" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	const wh_context::Mark* mk = nullptr;
+	for( const auto& x : c->marks )
+		if( x.endSample >= first + count ) { mk = &x; break; }
+	if( !mk ) { setError( "decode_window_fetch: no completion mark for that range" ); return WH_E_INVALIDARG; }
+	if( !c->copyStream ) WH_HIP( hipStreamCreateWithFlags( &c->copyStream, hipStreamNonBlocking ) );
+	WH_HIP( hipStreamWaitEvent( c->copyStream, mk->ev, 0 ) );
+	WH_HIP( hipMemcpyAsync( out, c->greedyOut + (size_t)first * c->lastBatch, sizeof( TokenData ) * (size_t)count * c->lastBatch, hipMemcpyDeviceToHost, c->copyStream ) );
+	WH_HIP( hipStreamSynchronize( c->copyStream ) );
 	return 0;
 }
 

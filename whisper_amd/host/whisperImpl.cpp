@@ -25,7 +25,7 @@ namespace Whisper
 		eHostLoopRules g_hostLoopRules = eHostLoopRules::ReferenceCpu;
 
 		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
-		constexpr int GREEDY_CHUNK = 8;		   // tokens fetched per device-side greedy call
+		constexpr int GREEDY_CHUNK = 16;	   // greedy steps enqueued per chunk; one chunk always runs behind the one being scanned
 
 
 		// ---- iTranscribeResult ------------------------------------------------------------------------------------
@@ -81,6 +81,46 @@ namespace Whisper
 			HRESULT getTime( int64_t& rdi ) const override { rdi = 0; return S_OK; }
 		};
 
+		// ---- iAudioReader -----------------------------------------------------------------------------------------
+		// The reference's readers wrap an IMFSourceReader that iContext::runStreamed pulls 10 ms chunks from
+		// (Whisper/MF/PcmReader.cpp:393-430). Media Foundation does not exist here; the reader holds the decoded 16 kHz PCM
+		// of a WAV file and hands it to runStreamed through a private interface (getReader keeps its slot: E_NOTIMPL).
+		// {5d6b0c1e-7f0a-4f53-9f6e-3c1d2a7b9e41}
+		struct iPcmSource : public ComLight::IUnknown
+		{
+			static constexpr ComLight::GUID iid() { return { 0x5d6b0c1e, 0x7f0a, 0x4f53, { 0x9f, 0x6e, 0x3c, 0x1d, 0x2a, 0x7b, 0x9e, 0x41 } }; }
+			virtual const std::vector<float>& pcmMono() const = 0;
+		};
+		class WavReader : public iAudioReader, public iPcmSource
+		{
+			std::atomic<uint32_t> rc{ 1 };
+			std::vector<float> mono;
+			bool stereo;
+		public:
+			WavReader( std::vector<float>&& m, bool wantStereo ) : mono( std::move( m ) ), stereo( wantStereo ) {}
+			virtual ~WavReader() = default;
+			HRESULT QueryInterface( const ComLight::GUID& riid, void** ppv ) override
+			{
+				if( !ppv ) return E_POINTER;
+				if( riid == iAudioReader::iid() || riid == ComLight::IID_IUnknown ) { *ppv = static_cast<iAudioReader*>( this ); AddRef(); return S_OK; }
+				if( riid == iPcmSource::iid() ) { *ppv = static_cast<iPcmSource*>( this ); AddRef(); return S_OK; }
+				*ppv = nullptr;
+				return E_NOINTERFACE;
+			}
+			uint32_t AddRef() override { return ++rc; }
+			uint32_t Release() override
+			{
+				const uint32_t r = --rc;
+				if( r == 0 ) delete this;
+				return r;
+			}
+			// 100 ns ticks, like MF_PD_DURATION (PcmReader.cpp getDuration)
+			HRESULT getDuration( int64_t& rdi ) const override { rdi = (int64_t)mono.size() * 10000000ll / 16000; return S_OK; }
+			HRESULT getReader( IMFSourceReader** pp ) const override { if( pp ) *pp = nullptr; return E_NOTIMPL; }
+			HRESULT requestedStereo() const override { return stereo ? S_OK : S_FALSE; }
+			const std::vector<float>& pcmMono() const override { return mono; }
+		};
+
 		// ---- iContext ---------------------------------------------------------------------------------------------
 		class ContextImpl : public ComObject<iContext>
 		{
@@ -104,8 +144,20 @@ namespace Whisper
 			using Clock = std::chrono::steady_clock;
 			static double msSince( Clock::time_point t ) { return std::chrono::duration<double, std::milli>( Clock::now() - t ).count(); }
 
+			// iSpectrogram of the reference: runFull hands the loop a whole-buffer spectrogram (global maximum), runStreamed a
+			// MelStreamer that makes each window on demand with the window's own maximum (MelStreamer.cpp:125-245)
+			struct MelSource
+			{
+				bool streamed = false;
+				int64_t length = 0;			  // iSpectrogram::getLength(): 10 ms frames
+				int64_t nSamples = 0, nChunks = 0;
+				int64_t lastBufferEnd = -1;	  // MelStreamer::lastBufferEnd
+			};
+			MelSource mel;
+
 			HRESULT ensureBuffer( void*& dev, int64_t& cap, int64_t bytes )
 			{
+				CHECK_WH( wh_context_bind( gpu ) );
 				if( bytes <= cap ) return S_OK;
 				if( dev ) { wh_buffer_free( dev ); dev = nullptr; cap = 0; }
 				CHECK_WH( wh_buffer_alloc( bytes, &dev ) );
@@ -113,7 +165,8 @@ namespace Whisper
 				return S_OK;
 			}
 			HRESULT fillResults( eResultFlags flags, ResultData& res ) const;
-			HRESULT runFullImpl( const sFullParams& params, int64_t melLen );
+			HRESULT runFullImpl( const sFullParams& params, const sProgressSink& progress );
+			HRESULT encodeWindow( int seek );
 
 		public:
 			ContextImpl( const std::shared_ptr<LoadedModel>& m, iModel* o ) : model( m ), owner( o )
@@ -122,6 +175,7 @@ namespace Whisper
 			}
 			~ContextImpl() override
 			{
+				if( gpu ) wh_context_bind( gpu );
 				if( melDev ) wh_buffer_free( melDev );
 				if( pcmDev ) wh_buffer_free( pcmDev );
 				if( gpu ) wh_context_destroy( gpu );
@@ -139,11 +193,7 @@ namespace Whisper
 			}
 
 			HRESULT runFull( const sFullParams& params, const iAudioBuffer* buffer ) override;
-			HRESULT runStreamed( const sFullParams&, const sProgressSink&, const iAudioReader* ) override
-			{
-				logError( "runStreamed: Media Foundation readers do not exist on this platform; load the audio and call runFull" );
-				return E_NOTIMPL;
-			}
+			HRESULT runStreamed( const sFullParams& params, const sProgressSink& progress, const iAudioReader* reader ) override;
 			HRESULT runCapture( const sFullParams&, const sCaptureCallbacks&, const iAudioCapture* ) override { return E_NOTIMPL; }
 			HRESULT getResults( eResultFlags flags, iTranscribeResult** pp ) const override;
 			HRESULT detectSpeaker( const sTimeInterval&, eSpeakerChannel& result ) const override
@@ -242,6 +292,8 @@ namespace Whisper
 			const uint32_t n = buffer->countSamples();
 			const float* pcm = buffer->getPcmMono();
 			const int64_t melLen = n / 160;
+			mel = MelSource{};
+			mel.length = melLen;
 			if( melLen > 0 )
 			{
 				const auto t = Clock::now();
@@ -255,57 +307,142 @@ namespace Whisper
 				nSpectrogram++;
 			}
 			if( params.flag( eFullParamsFlags::TokenTimestamps ) ) stamper.begin( pcm, n );
-			const HRESULT hr = runFullImpl( params, melLen );
+			const sProgressSink noProgress{ nullptr, nullptr };
+			const HRESULT hr = runFullImpl( params, noProgress );
 			msRun += msSince( tRun );
 			nRuns++;
 			return hr;
 		}
 
-		// The token stream of one window: first token from sampleTimestamp(true) on the prompt's probabilities, the rest
-		// from the device-side greedy loop, fetched GREEDY_CHUNK tokens at a time.
+		// ContextImpl::runStreamed (Whisper/Whisper/ContextImpl.misc.cpp:391-419): the same loop over a spectrogram that is
+		// made window by window. What differs from runFull in the RESULTS is the normalisation: every window is clamped
+		// against its own maximum (floor 1e-20, FP32 arithmetic) instead of the whole recording's, and a request that ends
+		// where the previous one ended re-uses the previous maximum (MelStreamer.cpp:148-166). The PCM of the reader is
+		// resident in HBM (a 3 h recording is 690 MB of 288 GB); only the window's frames are ever transformed.
+		HRESULT ContextImpl::runStreamed( const sFullParams& params, const sProgressSink& progress, const iAudioReader* reader )
+		{
+			if( !reader ) return E_POINTER;
+			if( params.flag( eFullParamsFlags::TokenTimestamps ) )
+			{
+				logError( "eFullParamsFlags.TokenTimestamps flag is not supported in streaming mode" );
+				return E_NOTIMPL;
+			}
+			iPcmSource* src = nullptr;
+			if( FAILED( const_cast<iAudioReader*>( reader )->QueryInterface( iPcmSource::iid(), (void**)&src ) ) || !src )
+			{
+				logError( "runStreamed: this reader was not created by iMediaFoundation::openAudioFile / loadAudioFileData of this library" );
+				return E_INVALIDARG;
+			}
+			const auto tRun = Clock::now();
+			mediaTimeOffset = 0;
+			const std::vector<float>& pcm = src->pcmMono();
+			mel = MelSource{};
+			mel.streamed = true;
+			mel.nSamples = (int64_t)pcm.size();
+			mel.length = mel.nSamples / 160;			   // PcmReader::getLength(): whole 10 ms chunks (PcmReader.h:50-55)
+			mel.nChunks = ( mel.nSamples + 159 ) / 160;	   // readChunk pads the last incomplete chunk with zeros (PcmReader.cpp:416-424)
+			HRESULT hr = S_OK;
+			if( mel.nSamples > 0 )
+			{
+				hr = ensureBuffer( pcmDev, pcmCapacity, mel.nSamples * 4 );
+				if( SUCCEEDED( hr ) ) hr = ensureBuffer( melDev, melCapacity, (int64_t)CHUNK_FRAMES * model->hp.n_mels * 4 );
+				if( SUCCEEDED( hr ) && 0 != wh_buffer_upload( gpu, pcmDev, pcm.data(), mel.nSamples * 4 ) ) hr = E_FAIL;
+			}
+			if( SUCCEEDED( hr ) ) hr = runFullImpl( params, progress );
+			src->Release();
+			msRun += msSince( tRun );
+			nRuns++;
+			return hr;
+		}
+
+		// ContextImpl::encode( iSpectrogram&, seek ) + MelInputTensor::create (MelInputTensor.cpp:8-63)
+		HRESULT ContextImpl::encodeWindow( int seek )
+		{
+			const wh_hparams& hp = model->hp;
+			if( !mel.streamed )
+			{
+				const int32_t off = seek;
+				CHECK_WH( wh_encode( gpu, (const float*)melDev, 1, mel.length, mel.length * hp.n_mels, &off ) );
+				return S_OK;
+			}
+			const int64_t i0 = std::min( (int64_t)seek, mel.length );
+			const int64_t i1 = std::min( (int64_t)seek + 2 * hp.n_audio_ctx, mel.length );
+			if( i1 <= i0 ) return E_BOUNDS;
+			const auto t = Clock::now();
+			const bool reuse = mel.lastBufferEnd == i1;
+			CHECK_WH( wh_mel_spectrogram_window( gpu, (const float*)pcmDev, mel.nSamples, i0, i1 - i0, mel.nChunks, reuse ? 1 : 0, (float*)melDev ) );
+			if( !reuse ) mel.lastBufferEnd = i1;
+			msSpectrogram += msSince( t );	   // enqueue time only: the transform overlaps nothing else and is < 1 % of a window
+			nSpectrogram++;
+			const int32_t zero = 0;
+			CHECK_WH( wh_encode( gpu, (const float*)melDev, 1, i1 - i0, ( i1 - i0 ) * hp.n_mels, &zero ) );
+			return S_OK;
+		}
+
+		// The token stream of one window. The prompt step, the first sample (sampleTimestamp(true) of the reference) and the
+		// first two chunks of greedy steps are enqueued at once; the host then reads chunk k while chunk k+1 runs and, if no
+		// stop rule fired, enqueues chunk k+2 before it looks at k+1 -- the device never waits for the host, and at most
+		// one chunk (GREEDY_CHUNK steps) is decoded in vain when a window ends.
 		class WindowDecoder
 		{
 			wh_context* gpu;
-			int nPast, nTextCtx;
-			std::vector<wh_token_data> chunk;
+			int nTextCtx, nPrompt = 0;
+			int enqueued = 0;	  // samples enqueued so far (1 + greedy steps)
+			int fetched = 0;	  // samples copied to `buf`
+			std::vector<wh_token_data> buf;
 			size_t cursor = 0;
-			int lastId = 0;
+			int room() const { return nTextCtx - ( nPrompt + enqueued - 1 ); }	// positions left for further greedy steps
+			HRESULT enqueueChunk()
+			{
+				const int n = std::min( GREEDY_CHUNK, room() );
+				if( n <= 0 ) return S_FALSE;
+				CHECK_WH( wh_decode_window_continue( gpu, n ) );
+				enqueued += n;
+				return S_OK;
+			}
 		public:
 			int steps = 0;
-			WindowDecoder( wh_context* c, int nTextCtx_ ) : gpu( c ), nPast( 0 ), nTextCtx( nTextCtx_ ) {}
+			WindowDecoder( wh_context* c, int nTextCtx_ ) : gpu( c ), nTextCtx( nTextCtx_ ) {}
 			HRESULT start( const std::vector<int>& prompt, TokenData& first )
 			{
-				CHECK_WH( wh_decode( gpu, prompt.data(), 1, (int)prompt.size(), 0, nullptr, nullptr ) );
-				nPast = (int)prompt.size();
-				wh_token_data t;
-				CHECK_WH( wh_sample_best( gpu, 1, 1, 1, &t ) );
+				nPrompt = (int)prompt.size();
+				const int n0 = std::max( 0, std::min( GREEDY_CHUNK, nTextCtx - nPrompt ) );
+				CHECK_WH( wh_decode_window_start( gpu, 1, prompt.data(), nPrompt, n0, 1, 1 ) );
+				enqueued = 1 + n0;
+				CHECK( enqueueChunk() );
+				buf.resize( 1 );
+				CHECK_WH( wh_decode_window_fetch( gpu, 0, 1, buf.data() ) );
+				fetched = 1;
+				cursor = 1;
+				const wh_token_data& t = buf[ 0 ];
 				first.id = t.id; first.tid = t.tid; first.p = t.p; first.pt = t.pt; first.ptsum = t.ptsum;
-				lastId = t.id;
 				steps = 1;
 				return S_OK;
 			}
 			HRESULT next( TokenData& out )
 			{
-				if( cursor >= chunk.size() )
+				if( cursor >= buf.size() )
 				{
-					const int room = nTextCtx - nPast;
-					if( room <= 0 ) return E_BOUNDS;
-					const int n = std::min( GREEDY_CHUNK, room );
-					chunk.resize( n );
+					if( fetched >= enqueued ) return E_BOUNDS;
+					// the chunk that follows what has been read: everything up to the next chunk boundary
+					const int n = std::min( GREEDY_CHUNK, enqueued - fetched );
+					buf.resize( (size_t)n );
+					CHECK_WH( wh_decode_window_fetch( gpu, fetched, n, buf.data() ) );
+					fetched += n;
 					cursor = 0;
-					CHECK_WH( wh_decode_greedy( gpu, 1, &lastId, nPast, n, 0, 0, chunk.data() ) );
-					nPast += n;
-					lastId = chunk.back().id;
-					steps += n;
+					CHECK( enqueueChunk() );	  // keeps one chunk in flight behind the one about to be scanned
 				}
-				const wh_token_data& t = chunk[ cursor++ ];
+				const wh_token_data& t = buf[ cursor++ ];
 				out.id = t.id; out.tid = t.tid; out.p = t.p; out.pt = t.pt; out.ptsum = t.ptsum;
+				steps++;
 				return S_OK;
 			}
 		};
 
-		HRESULT ContextImpl::runFullImpl( const sFullParams& params, int64_t melLen )
+		HRESULT ContextImpl::runFullImpl( const sFullParams& params, const sProgressSink& progress )
 		{
+			const int64_t melLen = mel.length;
+			bool stoppedPrematurely = false;
 			const Vocabulary& vocab = model->vocab;
 			const wh_hparams& hp = model->hp;
 			resultAll.clear();
@@ -349,8 +486,15 @@ namespace Whisper
 			std::vector<TokenData> tokensCur;
 			std::vector<int> prompt;
 			int seek = seekStart;
-			while( seek + 100 < seekEnd )
+			while( true )
 			{
+				if( progress.pfn )
+				{
+					// ContextImpl.cpp:533-540
+					const double percentage = (double)( seek - seekStart ) / (double)( seekEnd - seekStart );
+					CHECK( progress.pfn( percentage, this, progress.pv ) );
+				}
+				if( seek + 100 >= seekEnd ) break;
 				// whisper.cpp only: with less than 5 s left the past prompt is dropped, "since it tends to confuse the decoder"
 				// (Whisper/source/whisper.cpp:2874-2878; absent from ContextImpl.cpp)
 				if( g_hostLoopRules == eHostLoopRules::ReferenceCpu && seek > seekStart && seek + 500 >= seekEnd ) promptPast.clear();
@@ -359,13 +503,18 @@ namespace Whisper
 				{
 					const HRESULT hr = params.encoder_begin_callback( this, params.encoder_begin_callback_user_data );
 					if( FAILED( hr ) ) return hr;
-					if( hr != S_OK ) break;
+					if( hr != S_OK )
+					{
+						stoppedPrematurely = true;
+						break;
+					}
 				}
 				{
+					// enqueued without a host sync: the decoder's launches line up behind the encoder's on the context's stream.
+					// With WHISPER_PROFILE=1 the two are separated so that the "Encode" block means what it means in the reference.
 					const auto t = Clock::now();
-					const int32_t off = seek;
-					CHECK_WH( wh_encode( gpu, (const float*)melDev, 1, melLen, melLen * hp.n_mels, &off ) );
-					CHECK_WH( wh_context_synchronize( gpu ) );
+					CHECK( encodeWindow( seek ) );
+					if( gpuProfile ) CHECK_WH( wh_context_synchronize( gpu ) );
 					msEncode += msSince( t );
 					nEncode++;
 				}
@@ -434,7 +583,7 @@ namespace Whisper
 					}
 				}
 				msDecode += msSince( tDec );
-				nDecodeSteps += dec.steps;
+				nDecodeSteps += dec.steps;	   // tokens the loop consumed (the reference counts one DecodeStep per token)
 				nDecodeWindows++;
 				if( failed )
 				{
@@ -501,6 +650,7 @@ namespace Whisper
 				}
 				seek += seekDelta;
 			}
+			if( progress.pfn && !stoppedPrematurely ) CHECK( progress.pfn( 1.0, this, progress.pv ) );	   // ContextImpl.cpp:788-792
 			return S_OK;
 		}
 
@@ -594,53 +744,50 @@ namespace Whisper
 		{
 		public:
 			HRESULT loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const override;
-			HRESULT openAudioFile( const wchar_t*, bool, iAudioReader** ) override { return E_NOTIMPL; }
-			HRESULT loadAudioFileData( const void*, uint64_t, bool, iAudioReader** ) override { return E_NOTIMPL; }
+			HRESULT openAudioFile( const wchar_t* path, bool stereo, iAudioReader** pp ) override;
+			HRESULT loadAudioFileData( const void* data, uint64_t size, bool stereo, iAudioReader** pp ) override;
 			HRESULT listCaptureDevices( pfnFoundCaptureDevices, void* ) override { return E_NOTIMPL; }
 			HRESULT openCaptureDevice( const wchar_t*, const sCaptureParams&, iAudioCapture** ) override { return E_NOTIMPL; }
 		};
 
-		HRESULT WavLoader::loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const
+		// RIFF/WAVE, 16 kHz, mono or stereo, PCM16 or float32 -> mono (and interleaved stereo when asked for)
+		static HRESULT decodeWav( const char* bytes, size_t size, const std::string& what, bool wantStereo, std::vector<float>& mono, std::vector<float>& st )
 		{
-			if( !pp || !path ) return E_POINTER;
-			const std::string p = utf8( path );
-			std::ifstream f( p, std::ios::binary );
-			if( !f ) { logError( "failed to open audio file '%s'", p.c_str() ); return (HRESULT)0x80070002; }
-			std::vector<char> data( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
-			if( data.size() < 44 || memcmp( data.data(), "RIFF", 4 ) || memcmp( data.data() + 8, "WAVE", 4 ) )
+			if( size < 44 || memcmp( bytes, "RIFF", 4 ) || memcmp( bytes + 8, "WAVE", 4 ) )
 			{
-				logError( "'%s' is not a RIFF/WAVE file (only WAV is supported on this platform)", p.c_str() );
+				logError( "'%s' is not a RIFF/WAVE file (only WAV is supported on this platform)", what.c_str() );
 				return E_INVALIDARG;
 			}
 			uint16_t fmt = 0, channels = 0, bits = 0;
 			uint32_t rate = 0;
 			const char* pcm = nullptr;
 			size_t pcmBytes = 0;
-			for( size_t o = 12; o + 8 <= data.size(); )
+			for( size_t o = 12; o + 8 <= size; )
 			{
 				uint32_t len;
-				memcpy( &len, data.data() + o + 4, 4 );
-				const char* body = data.data() + o + 8;
-				if( !memcmp( data.data() + o, "fmt ", 4 ) && len >= 16 )
+				memcpy( &len, bytes + o + 4, 4 );
+				const char* body = bytes + o + 8;
+				if( !memcmp( bytes + o, "fmt ", 4 ) && len >= 16 )
 				{
 					memcpy( &fmt, body, 2 ); memcpy( &channels, body + 2, 2 ); memcpy( &rate, body + 4, 4 ); memcpy( &bits, body + 14, 2 );
 				}
-				else if( !memcmp( data.data() + o, "data", 4 ) )
+				else if( !memcmp( bytes + o, "data", 4 ) )
 				{
 					pcm = body;
-					pcmBytes = std::min( (size_t)len, data.size() - ( o + 8 ) );
+					pcmBytes = std::min( (size_t)len, size - ( o + 8 ) );
 				}
 				o += 8 + (size_t)len + ( len & 1 );
 			}
 			const bool isFloat = fmt == 3 && bits == 32, isPcm16 = fmt == 1 && bits == 16;
 			if( !pcm || !( isFloat || isPcm16 ) || channels < 1 || channels > 2 || rate != 16000 )
 			{
-				logError( "'%s': need 16 kHz mono/stereo PCM16 or float32 WAV (got format %u, %u bit, %u ch, %u Hz)", p.c_str(), fmt, bits, channels, rate );
+				logError( "'%s': need 16 kHz mono/stereo PCM16 or float32 WAV (got format %u, %u bit, %u ch, %u Hz)", what.c_str(), fmt, bits, channels, rate );
 				return E_INVALIDARG;
 			}
 			const size_t frames = pcmBytes / ( ( bits / 8 ) * channels );
-			std::vector<float> mono( frames ), st;
-			if( stereo ) st.resize( frames * 2 );
+			mono.resize( frames );
+			st.clear();
+			if( wantStereo ) st.resize( frames * 2 );
 			auto sample = [ & ]( size_t i ) -> float
 			{
 				if( isFloat ) { float v; memcpy( &v, pcm + i * 4, 4 ); return v; }
@@ -650,9 +797,41 @@ namespace Whisper
 			{
 				const float l = sample( i * channels ), r = channels == 2 ? sample( i * 2 + 1 ) : l;
 				mono[ i ] = channels == 2 ? 0.5f * ( l + r ) : l;
-				if( stereo ) { st[ 2 * i ] = l; st[ 2 * i + 1 ] = r; }
+				if( wantStereo ) { st[ 2 * i ] = l; st[ 2 * i + 1 ] = r; }
 			}
+			return S_OK;
+		}
+		static HRESULT readWavFile( const wchar_t* path, bool stereo, std::vector<float>& mono, std::vector<float>& st )
+		{
+			const std::string p = utf8( path );
+			std::ifstream f( p, std::ios::binary );
+			if( !f ) { logError( "failed to open audio file '%s'", p.c_str() ); return (HRESULT)0x80070002; }
+			std::vector<char> data( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
+			return decodeWav( data.data(), data.size(), p, stereo, mono, st );
+		}
+
+		HRESULT WavLoader::loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const
+		{
+			if( !pp || !path ) return E_POINTER;
+			std::vector<float> mono, st;
+			CHECK( readWavFile( path, stereo, mono, st ) );
 			return createAudioBuffer( std::move( mono ), std::move( st ), pp );
+		}
+		HRESULT WavLoader::openAudioFile( const wchar_t* path, bool stereo, iAudioReader** pp )
+		{
+			if( !pp || !path ) return E_POINTER;
+			std::vector<float> mono, st;
+			CHECK( readWavFile( path, false, mono, st ) );
+			*pp = new WavReader( std::move( mono ), stereo );
+			return S_OK;
+		}
+		HRESULT WavLoader::loadAudioFileData( const void* data, uint64_t size, bool stereo, iAudioReader** pp )
+		{
+			if( !pp || !data ) return E_POINTER;
+			std::vector<float> mono, st;
+			CHECK( decodeWav( (const char*)data, (size_t)size, "<memory>", false, mono, st ) );
+			*pp = new WavReader( std::move( mono ), stereo );
+			return S_OK;
 		}
 	}	// namespace
 
@@ -695,12 +874,25 @@ namespace Whisper
 		int device = 0;
 		if( setup.adapter && *setup.adapter )
 		{
-			// adapter names come from listGPUs: "<index>: <name>"
+			// What listGPUs hands out is "<index>: <name>"; the reference matches the adapter by its listed name
+			// (Whisper/D3D/createDevice.cpp). Accepted: the full listed string, the name alone, or the bare index ("2" / "2:").
 			const std::string a = utf8( setup.adapter );
-			device = atoi( a.c_str() );
-			if( device < 0 || device >= wh_device_count() )
+			const int nDev = wh_device_count();
+			device = -1;
+			size_t digits = 0;
+			while( digits < a.size() && isdigit( (unsigned char)a[ digits ] ) ) digits++;
+			if( digits > 0 && ( digits == a.size() || ( digits + 1 == a.size() && a[ digits ] == ':' ) ) )
+				device = atoi( a.c_str() );
+			else
+				for( int i = 0; i < nDev && device < 0; i++ )
+				{
+					char name[ 256 ];
+					if( 0 != wh_device_info( i, name, sizeof( name ), nullptr, nullptr ) ) continue;
+					if( a == std::to_string( i ) + ": " + name || a == name ) device = i;
+				}
+			if( device < 0 || device >= nDev )
 			{
-				logError( "loadModel: adapter '%s' not found", a.c_str() );
+				logError( "loadModel: adapter '%s' not found (see listGPUs)", a.c_str() );
 				return E_INVALIDARG;
 			}
 		}
@@ -773,6 +965,42 @@ WHISPER_EXPORT int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t 
 	CHECK( createAudioBuffer( std::vector<float>( pcm, pcm + nSamples ), {}, &buf ) );
 	const HRESULT hr = c->runFull( p, buf );
 	buf->Release();
+	return hr;
+}
+// initMediaFoundation -> loadAudioFileData( WAV bytes ) -> iContext::runStreamed; progress values are appended to
+// progressOut (up to progressCap), their count is returned through progressCount
+WHISPER_EXPORT int32_t whisperc_run_streamed( void* ctx, const void* wavBytes, uint64_t wavSize, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, double* progressOut, int progressCap, int* progressCount )
+{
+	if( !ctx || !wavBytes ) return E_POINTER;
+	iContext* c = (iContext*)ctx;
+	sFullParams p;
+	CHECK( c->fullDefaultParams( eSamplingStrategy::Greedy, &p ) );
+	p.flags = (eFullParamsFlags)flags;
+	p.language = makeLanguageKey( language ? language : "en" );
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	iMediaFoundation* mf = nullptr;
+	CHECK( initMediaFoundation( &mf ) );
+	iAudioReader* reader = nullptr;
+	HRESULT hr = mf->loadAudioFileData( wavBytes, wavSize, false, &reader );
+	mf->Release();
+	if( FAILED( hr ) ) return hr;
+	struct Sink { double* out; int cap, n; } sink{ progressOut, progressCap, 0 };
+	sProgressSink ps;
+	ps.pfn = []( double v, iContext*, void* pv ) noexcept -> HRESULT
+	{
+		Sink* s = (Sink*)pv;
+		if( s->out && s->n < s->cap ) s->out[ s->n ] = v;
+		s->n++;
+		return S_OK;
+	};
+	ps.pv = &sink;
+	hr = c->runStreamed( p, ps, reader );
+	reader->Release();
+	if( progressCount ) *progressCount = sink.n;
 	return hr;
 }
 // The same with the token-timestamp parameters of sFullParams (thold_pt, thold_ptsum, max_len; sFullParams.h:79-86)
