@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- audio-seconds/sec of the Whisper hot path (mel -> encoder -> KV-cached greedy decoder -> token ids).
+"""bench.py -- audio-seconds/sec of the Whisper hot path (PCM -> mel -> encoder -> KV-cached greedy decoder -> token ids).
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
 torch.distributed.run with one rank per GPU. Prints ONE JSON line on rank 0.
 
-Workload at N = 1 = BASELINE.json configs[1]: a ggml-medium-shaped model (random FP16 weights of the exact real
+Default workload at N = 1 = BASELINE.json configs[1]: a ggml-medium-shaped model (random FP16 weights of the exact real
 shapes -- no real weights exist offline) on a clip of the length of the reference's columbia sample (198.762 s,
 Tools/PerfSummary/Summary.cs:50) = 7 windows of 30 s, processed as one lock-step batch of independent windows
-(NoContext semantics, ContextImpl.cpp:476-477): PCM resident in HBM -> GPU mel -> encoder -> 3-token prompt step +
+(NoContext semantics, ContextImpl.cpp:476-477): pinned host PCM -> H2D -> GPU mel -> encoder -> 3-token prompt step +
 51 greedy steps per window (the reference's observed 511 steps / 10 windows, columbia-medium-1080ti.txt:8-10; random
 weights never emit EOT sensibly, so the step count is forced while the sampled token IS fed back). One "step" of the
-bench = one pass over the whole clip. value = audio seconds / wall seconds; weak scaling for N > 1 (every rank
-transcribes its own clip; the weight arena is broadcast once over RCCL before the timed region).
+bench = one pass over the whole clip; the span is first H2D byte to last token id on the host. value = audio seconds /
+wall seconds; weak scaling for N > 1 (every rank transcribes its own clip; the weight arena is broadcast once over RCCL
+before the timed region).
 
-Extra objects: `roofline` for the dominant kernel class (per-launch durations from hipEvent pairs on the launch stream,
-collected in a separate, identical pass because two event records per launch would perturb the launch-bound decode
-loop), and `cpu_baseline` = the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample.
+Objects next to the contract fields:
+  roofline      dominant kernel class: algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on
+                the launch stream minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per launch from the
+                committed PMC pass (profiles/r02_pmc.json); `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured
+  cpu_baseline  the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample, same run
+  parity        ggml-medium shape, window 0: the measured (FP32 P.V) GPU path against the reference CPU path -- cross-KV,
+                logits of the prompt and of teacher-forced greedy steps, top-1 agreement
+  single_stream the SAME clip through the drop-in boundary, sequentially: libWhisper.so iContext::runFull with prompt
+                carry-over on a scripted medium-shape model (7 windows x 52 steps) -- the like-for-like figure against the
+                reference's published single-clip number (`vs_baseline` lives here), plus T host threads x their own iContext
+  large_v2      the batched pipeline once more on the ggml-large-v2 shape (BASELINE names both models)
+
+Other workloads (BASELINE configs 3-5): --workload shard256 | beam5 | v3stream, see --help.
 """
 from __future__ import annotations
 
@@ -39,6 +50,9 @@ N_GREEDY = 51
 PUBLISHED_AUDIO_S_PER_S = {"medium": 13.30, "large-v2": 7.22, "large": 7.22}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
+MFMA_CLASSES = ("gemmTiled", "attentionEnc")
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc.json")
+METRIC = "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU"
 
 
 def synth_pcm(n_windows: int, seed: int) -> np.ndarray:
@@ -52,29 +66,13 @@ def synth_pcm(n_windows: int, seed: int) -> np.ndarray:
     return (x * env * 3).astype(np.float32).reshape(n_windows, WINDOW_SAMPLES)
 
 
-def transcribe_clip(groups, prompt, n_greedy):
-    """One pass of the hot path over the clip. `groups` = [(ctx, pcm_dev [k][480000], mel_dev [k][80][3000])]: every group is a
-    lock-step batch of windows on its own context (= its own HIP stream and captured decode graph). Everything is enqueued
-    without a host sync -- GPU mel, encoder, prompt step, first sample, n_greedy device-side greedy steps -- group after
-    group, so the latency-bound decode steps of one group overlap the encoder GEMMs and decode steps of the others; then
-    the sampled token ids are collected. Returns [n_windows][n_greedy + 1] token ids."""
-    for ctx, pcm_dev, mel_dev in groups:
-        k = pcm_dev.shape[0]
-        for b in range(k):
-            ctx.mel_spectrogram(pcm_dev[b], mel_dev[b], sync=False)
-        ctx.encode(mel_dev, sync=False)
-        ctx.decode_window_start(np.tile(np.asarray(prompt, np.int32), (k, 1)), n_greedy, force_first_timestamp=True, first_is_initial=True)
-    outs = []
-    for ctx, _, _ in groups:
-        ids, _ = ctx.decode_window_finish()
-        outs.append(ids.T)
-    return np.concatenate(outs, axis=0)
-
-
 def clip_start(group, prompt, n_greedy):
-    """Enqueue one whole clip pass on the group's context (mel, encoder, prompt step, greedy steps); no host sync."""
-    ctx, pcm_dev, mel_dev = group
+    """Enqueue one whole pass on the group's context: H2D of the PCM, mel, encoder, prompt step, greedy steps; no host sync.
+    group = (ctx, pcm_host_pinned [k][480000] or None, pcm_dev [k][480000], mel_dev [k][n_mels][3000])."""
+    ctx, pcm_host, pcm_dev, mel_dev = group
     k = pcm_dev.shape[0]
+    if pcm_host is not None:
+        ctx.upload_async(pcm_dev, pcm_host)
     for b in range(k):
         ctx.mel_spectrogram(pcm_dev[b], mel_dev[b], sync=False)
     ctx.encode(mel_dev, sync=False)
@@ -107,11 +105,14 @@ def log(msg):
 
 
 CPU_BASELINE_THREADS_MAX = 16      # ggml's spin-wait thread pool stops scaling (and can collapse) far below a big host's core count
-CPU_BASELINE_TIMEOUT_S = 240
+CPU_BASELINE_TIMEOUT_S = 300
+PARITY_STEPS = 8
 
 
-def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, out_path):
-    """Runs in a child process (so a slow host cannot stall the bench): the reference's own CPU path, one 30 s window."""
+def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, parity_path, out_path):
+    """Runs in a child process (so a slow host cannot stall the bench): the reference's own CPU path.
+    1. cpu_baseline: three times the same 30 s window end to end, timed. 2. parity: the GPU's spectrogram of that window and
+    the GPU's own greedy ids are fed to the reference; its cross-KV and logits are compared with what the GPU computed."""
     from oracle import ref
     w = ref.RefWhisper(model_path, n_threads=n_threads, log_level=0)
     pcm = np.load(pcm_path)
@@ -130,45 +131,350 @@ def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, out
         t4 = time.time()
         t_mel += t1 - t0; t_enc += t2 - t1; t_prompt += t3 - t2; t_dec += t4 - t3
     total = t_mel + t_enc + t_prompt + t_dec
-    res = {"value": round(30.0 * n_win / total, 4), "unit": "audio-seconds/sec", "cores": n_threads, "kind": "reference",
-           "sample": "%s-shape model, %d x the same 30 s window end to end on the reference's CPU path (Whisper/source compiled into "
-                     "oracle/_ref): %.1f s of CPU time = mel %.2f s + encode %.2f s + %d-token prompt %.2f s + %d greedy steps %.2f s "
-                     "(%.1f ms/token); n_threads=%d of %d host cpus" % (model_kind, n_win, total, t_mel, t_enc, len(prompt), t_prompt,
-                                                                       N_GREEDY * n_win, t_dec, 1e3 * t_dec / (N_GREEDY * n_win),
-                                                                       n_threads, os.cpu_count() or 1)}
+    res = {"cpu_baseline": {
+        "value": round(30.0 * n_win / total, 4), "unit": "audio-seconds/sec", "cores": n_threads, "kind": "reference",
+        "sample": "%s-shape model, %d x the same 30 s window end to end on the reference's CPU path (Whisper/source compiled into "
+                  "oracle/_ref): %.1f s of CPU time = mel %.2f s + encode %.2f s + %d-token prompt %.2f s + %d greedy steps %.2f s "
+                  "(%.1f ms/token); n_threads=%d of %d host cpus" % (model_kind, n_win, total, t_mel, t_enc, len(prompt), t_prompt,
+                                                                    N_GREEDY * n_win, t_dec, 1e3 * t_dec / (N_GREEDY * n_win),
+                                                                    n_threads, os.cpu_count() or 1)}}
+    if parity_path:
+        g = np.load(parity_path)
+        w.set_mel(g["mel"])
+        w.encode(0)
+        par = {"model": "ggml-%s shape, window 0 of the bench clip" % model_kind, "reference_threads": n_threads, "gpu_path": "FP32 P.V (the timed path)"}
+        for il, name in ((0, "first"), (w.n_text_layer - 1, "last")):
+            k, v = w.cross_kv(il)
+            par["cross_k_%s_layer_max" % name] = float(np.abs(k - g["cross_k_%s" % name]).max())
+            par["cross_v_%s_layer_max" % name] = float(np.abs(v - g["cross_v_%s" % name]).max())
+        ids = [int(x) for x in g["ids"]]
+        worst_max = worst_mean = 0.0
+        agree = 0
+        spans = []
+        n_past = 0
+        toks = list(prompt)
+        for s in range(len(ids)):
+            rl = w.decode(toks, n_past)[0][-1]
+            gl = g["logits"][s]
+            d = np.abs(rl.astype(np.float64) - gl)
+            worst_max, worst_mean = max(worst_max, float(d.max())), max(worst_mean, float(d.mean()))
+            spans.append(float(rl.max() - rl.min()))
+            agree += int(np.argmax(rl) == np.argmax(gl))
+            n_past += len(toks)
+            toks = [ids[s]]
+        par.update({"steps": len(ids), "logits_max_abs_diff": worst_max, "logits_mean_abs_diff": worst_mean,
+                    "logit_span_min": min(spans), "top1_agreement": "%d/%d" % (agree, len(ids)),
+                    "note": "teacher-forced by the GPU's own greedy ids; the reference's decoder result itself moves by ~5e-2 between 1 and "
+                            "8 threads on random weights (FP16 P.V accumulation, ggml.c:4689-4735): see tests/test_gpu_model.py::test_decoder_fast_path "
+                            "for the exact-arithmetic yardstick"})
+        res["parity"] = par
     with open(out_path, "w") as f:
         json.dump(res, f)
 
 
-def cpu_baseline(model, model_kind, pcm_one_window, prompt):
+def gpu_parity_record(hip_model, hp, pcm_window, prompt, path):
+    """Window 0 through a lone 1-window context on the measured path; what the reference is compared with."""
+    import torch
+    from whisper_amd import binding
+    ctx = binding.HipContext(hip_model, 1)
+    mel = ctx.mel_spectrogram(torch.from_numpy(pcm_window).cuda())
+    ctx.encode(mel)
+    rec = {"mel": mel.cpu().numpy()}
+    for il, name in ((0, "first"), (hp.n_text_layer - 1, "last")):
+        rec["cross_k_%s" % name] = ctx.debug_read("cross-k", il)[0]
+        rec["cross_v_%s" % name] = ctx.debug_read("cross-v", il)[0]
+    logits, ids = [], []
+    toks = np.asarray([prompt], np.int32)
+    n_past = 0
+    for s in range(PARITY_STEPS + 1):
+        gl, _ = ctx.decode(toks, n_past)
+        logits.append(gl[0])
+        n_past += toks.shape[1]
+        t = ctx.sample_best(1, s == 0, s == 0)[0]["id"]
+        ids.append(t)
+        toks = np.asarray([[t]], np.int32)
+    rec["logits"] = np.stack(logits)
+    rec["ids"] = np.asarray(ids, np.int32)
+    np.savez(path, **rec)
+    ctx.close()
+
+
+def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want_parity=True):
     """The reference's own CPU path (compiled unmodified into oracle/_ref) timed on this host, bounded by a timeout."""
     null = {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference"}
     try:
         from oracle import ref
         if not ref.available():
-            return dict(null, sample="oracle/_ref/libwhisper_ref.so not present")
+            return dict(null, sample="oracle/_ref/libwhisper_ref.so not present"), None
     except Exception as e:      # pragma: no cover
-        return dict(null, sample="oracle unavailable: %s" % e)
+        return dict(null, sample="oracle unavailable: %s" % e), None
     import subprocess
     import tempfile
     from whisper_amd import ggml_format as gf
     n_threads = max(1, min(os.cpu_count() or 1, CPU_BASELINE_THREADS_MAX))
     with tempfile.TemporaryDirectory() as td:
         mp, pp, op = os.path.join(td, "m.bin"), os.path.join(td, "pcm.npy"), os.path.join(td, "out.json")
+        gp = os.path.join(td, "gpu.npz") if (want_parity and hip_model is not None) else ""
         gf.write_model(mp, model)
         np.save(pp, pcm_one_window)
-        code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%r, %r, %r, %r, %d, %r)"
-                % (ROOT, mp, model_kind, pp, list(map(int, prompt)), n_threads, op))
+        if gp:
+            gpu_parity_record(hip_model, model.hparams, pcm_one_window, prompt, gp)
+        code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%r, %r, %r, %r, %d, %r, %r)"
+                % (ROOT, mp, model_kind, pp, list(map(int, prompt)), n_threads, gp, op))
         try:
             subprocess.run([sys.executable, "-c", code], timeout=CPU_BASELINE_TIMEOUT_S, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             with open(op) as f:
-                return json.load(f)
+                r = json.load(f)
+            return r["cpu_baseline"], r.get("parity")
         except subprocess.TimeoutExpired:
-            return dict(null, cores=n_threads, sample="reference CPU path did not finish one 30 s window of the %s-shape model within "
-                                                      "%d s on %d threads" % (model_kind, CPU_BASELINE_TIMEOUT_S, n_threads))
+            return dict(null, cores=n_threads, sample="reference CPU path did not finish within %d s on %d threads" % (CPU_BASELINE_TIMEOUT_S, n_threads)), None
         except Exception as e:
-            return dict(null, cores=n_threads, sample="reference CPU run failed: %s" % str(e)[:200])
+            return dict(null, cores=n_threads, sample="reference CPU run failed: %s" % str(e)[:200]), None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the batched pipeline (default workload; also the large_v2 sub-object)
+# ----------------------------------------------------------------------------------------------------------------------
+def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True):
+    import torch
+    from whisper_amd import binding
+    n_frames = WINDOW_SAMPLES // 160
+
+    def make_slot(n_clips):
+        """A context for n_clips clip passes in lock step + its inputs; clip j of every slot is the same seeded clip."""
+        host = torch.from_numpy(np.concatenate([synth_pcm(B, seed=100 + rank + 1000 * j) for j in range(n_clips)])).pin_memory()
+        dev = host.cuda()
+        mel = torch.empty((B * n_clips, hp.n_mels, n_frames), dtype=torch.float32, device="cuda")
+        return (binding.HipContext(hip_model, B * n_clips), host if h2d else None, dev, mel)
+
+    slots = [make_slot(C) for _ in range(max(1, inflight))]
+    n_full, rem = divmod(steps, C)
+    rem_slot = make_slot(rem) if rem else None
+    sequence = [slots[i % len(slots)] for i in range(n_full)] + ([rem_slot] if rem_slot else [])
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        run_passes(slots + ([rem_slot] if rem_slot else []), prompt, N_GREEDY, len(slots))
+    barrier()
+    t0 = time.perf_counter()
+    toks = run_passes(sequence, prompt, N_GREEDY, len(slots))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = {"elapsed": elapsed, "toks": toks, "slots": slots, "single_clip_ms": None, "kernels": {}, "lone_batch_ms": None}
+    if want_kernels and rank == 0:
+        grp = slots[0]
+        # (a) one lone batch pass from the captured graph: latency of a batch with nothing else on the GPU
+        lone = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_passes([grp], prompt, N_GREEDY, 1)
+            lone = min(lone, 1e3 * (time.perf_counter() - t0))
+        out["lone_batch_ms"] = lone
+        # (b) a lone SINGLE clip (7 windows): the latency a caller with one recording sees from this path
+        one = make_slot(1)
+        run_passes([one], prompt, N_GREEDY, 1)
+        sc = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_passes([one], prompt, N_GREEDY, 1)
+            sc = min(sc, 1e3 * (time.perf_counter() - t0))
+        out["single_clip_ms"] = sc
+        one[0].close()
+        # (c) the same lone batch pass with hipEvent pairs around every launch (eager: a captured graph cannot hold them)
+        grp[0].profile(True)
+        run_passes([grp], prompt, N_GREEDY, 1)
+        out["kernels"] = grp[0].profile_read()
+        grp[0].profile(False)
+    return out
+
+
+def roofline_from(kernels, batch_ms_timed, lone_ms):
+    """Per-launch figures of the dominant kernel class + the whole-path floor. The event bracket's own cost (class
+    "eventPair": an empty kernel between the same two records) is subtracted from every launch -- a per-launch constant,
+    not a proportional rescale."""
+    pair = kernels.get("eventPair")
+    calib_us = 1e3 * pair["ms"] / pair["calls"] if pair and pair["calls"] else 0.0
+    classes = {}
+    for k, v in kernels.items():
+        if k == "eventPair" or not v["calls"]:
+            continue
+        ms = max(v["ms"] - v["calls"] * calib_us * 1e-3, 0.05 * v["ms"])
+        classes[k] = dict(v, ms_net=ms)
+    total = sum(c["ms_net"] for c in classes.values())
+    name, dom = max(classes.items(), key=lambda kv: kv[1]["ms_net"])
+    avg_us = 1e3 * dom["ms_net"] / dom["calls"]
+    if name in MFMA_CLASSES:
+        ach = dom["flops"] / (dom["ms_net"] * 1e-3) / 1e12
+        r = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+    else:
+        ach = dom["bytes"] / (dom["ms_net"] * 1e-3) / 1e9
+        r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+    r["traffic"] = None
+    try:
+        with open(PMC_JSON) as f:
+            pmc = json.load(f)
+        if name in pmc.get("kernels", {}):
+            e = pmc["kernels"][name]
+            r["traffic"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+            r["traffic_source"] = "%s: %s" % (os.path.relpath(PMC_JSON, ROOT), pmc.get("note", ""))
+            r["traffic_over_algorithmic"] = round(r["traffic"] / max(e.get("algorithmic_bytes_per_launch", dom["bytes"] / dom["calls"]), 1.0), 3)
+    except (OSError, ValueError, KeyError):
+        pass
+    floor_ms = sum(1e3 * (c["flops"] / (MFMA_PEAK_TFLOPS * 1e12) if k in MFMA_CLASSES else c["bytes"] / (HBM_PEAK_GBS * 1e9)) for k, c in classes.items())
+    r.update({
+        "avg_launch_us": round(avg_us, 2), "launches_per_batch_pass": dom["calls"], "share_of_kernel_time": round(dom["ms_net"] / total, 3),
+        "algorithmic_per_launch": round((dom["flops"] if r["bound"] == "mfma" else dom["bytes"]) / dom["calls"], 1),
+        "event_pair_us": round(calib_us, 2),
+        "timing": "hipEvent pairs around every launch of one lone batch pass on the launch stream (eager), minus %.2f us per launch "
+                  "= the same bracket around an empty kernel" % calib_us,
+        "end_to_end": {"floor_ms_per_batch": round(floor_ms, 2), "measured_ms_per_batch": round(batch_ms_timed, 2),
+                       "frac": round(floor_ms / batch_ms_timed, 4), "lone_batch_ms": round(lone_ms, 2) if lone_ms else None,
+                       "definition": "sum over kernel classes of algorithmic flops / 2.5 PFLOP/s (gemmTiled, attentionEnc) or "
+                                     "algorithmic bytes / 8 TB/s (all others), per lock-step batch, over the measured time per batch in the timed region"}})
+    table = {k: {"calls": c["calls"], "ms": round(c["ms_net"], 3), "avg_us": round(1e3 * c["ms_net"] / c["calls"], 2),
+                 "tflops": round(c["flops"] / c["ms_net"] / 1e9, 2), "gbs": round(c["bytes"] / c["ms_net"] / 1e6, 1)} for k, c in classes.items()}
+    return r, table
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the same clip through the drop-in boundary (libWhisper.so, iContext::runFull), sequentially
+# ----------------------------------------------------------------------------------------------------------------------
+def single_stream(model_kind, n_threads_multi=4):
+    import tempfile
+    import threading
+    from whisper_amd import api, ggml_format as gf
+    hp = gf.hparams_for(model_kind)
+    cap = 102
+    positions, kept = gf.carry_over_script(hp, 7, 49, cap)
+    model = gf.scripted_model_at(positions, kind=model_kind, seed=7)
+    pcm = synth_pcm(7, seed=100).reshape(-1)[:int(CLIP_SECONDS * 16000)]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "scripted.bin")
+        gf.write_model(path, model)
+        del model
+        m = api.Model(path)
+        ctx = m.create_context()
+        hr = ctx.run_full(pcm, n_max_text_ctx=cap)            # warm-up: graph capture, buffers
+        segs = ctx.results()
+        n_tok = sum(len(s["tokens"]) for s in segs)
+        best = 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ctx.run_full(pcm, n_max_text_ctx=cap)
+            best = min(best, time.perf_counter() - t0)
+        res = {"value": round(CLIP_SECONDS / best, 2), "unit": "audio-seconds/sec", "seconds": round(best, 4), "hr": hr,
+               "windows": 7, "tokens_transcribed": n_tok, "decode_steps": 7 * (kept + 1),
+               "workload": "libWhisper.so loadModel -> createContext -> runFull (COM-style iContext, batch 1, sequential windows with prompt "
+                           "carry-over capped at %d tokens) on a scripted ggml-%s-shape model that transcribes 51 tokens + EOT per window "
+                           "(the reference's run: 10 windows, 511 steps, SampleClips/columbia-medium-1080ti.txt)" % (cap, model_kind),
+               "vs_baseline": round(CLIP_SECONDS / best / PUBLISHED_AUDIO_S_PER_S[model_kind], 2) if model_kind in PUBLISHED_AUDIO_S_PER_S else None}
+        # T host threads, each with its own iContext on the shared model (what iModel::clone is for in the reference)
+        ctxs = [m.create_context() for _ in range(n_threads_multi)]
+        for c in ctxs:
+            c.run_full(pcm[:WINDOW_SAMPLES * 2], n_max_text_ctx=cap)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=lambda c=c: c.run_full(pcm, n_max_text_ctx=cap)) for c in ctxs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        res["multi_stream"] = {"streams": n_threads_multi, "value": round(n_threads_multi * CLIP_SECONDS / dt, 2), "seconds": round(dt, 4)}
+        for c in ctxs + [ctx]:
+            c.close()
+        m.close()
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 3 / 4: N x 30 s synthetic-mel chunks, sharded over the ranks (strong scaling), optional hypotheses
+# ----------------------------------------------------------------------------------------------------------------------
+def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_steps, t_bcast):
+    import torch
+    from whisper_amd import binding, distributed as wd
+    per = args.batch
+    b, e = wd.shard_range(n_chunks, rank, world)
+
+    def synth_mel(idx):
+        g = torch.Generator(device="cuda").manual_seed(1000 + idx)          # seed = chunk index (SURVEY.md 8(d) config 4)
+        return torch.rand((hp.n_mels, 3000), generator=g, device="cuda") * 2.0 - 1.0
+
+    mels = torch.stack([synth_mel(i) for i in range(b, e)]) if e > b else torch.empty((0, hp.n_mels, 3000), device="cuda")
+    ctxs = [binding.HipContext(hip_model, per, hypotheses=hyp) for _ in range(max(1, args.inflight))]
+    # hypothesis j of a window starts from its own third prompt token, so the sequences of a window differ
+    base = np.asarray(prompt, np.int32)
+
+    def prompts(k):
+        p = np.tile(base, (k * hyp, 1))
+        for j in range(hyp):
+            p[j::hyp, -1] = base[-1] + j
+        return p
+
+    def transcribe(lb, le):
+        outs, pending = [], []
+        idx = list(range(lb - b, le - b, per))
+        for n, i0 in enumerate(idx):
+            c = ctxs[n % len(ctxs)]
+            while len(pending) >= len(ctxs):
+                pc, _ = pending.pop(0)
+                outs.append(pc.decode_window_finish()[0].T)
+            k = min(per, le - b - i0)
+            c.encode(mels[i0:i0 + k], sync=False)
+            c.decode_window_start(prompts(k), n_steps, force_first_timestamp=True, first_is_initial=True)
+            pending.append((c, k))
+        for pc, _ in pending:
+            outs.append(pc.decode_window_finish()[0].T)
+        ids = np.concatenate(outs, axis=0) if outs else np.zeros((0, n_steps + 1), np.int32)
+        return ids.reshape(le - lb, hyp * (n_steps + 1))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        transcribe(b, min(e, b + per * len(ctxs)))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        toks = wd.transcribe_sharded(n_chunks, transcribe, hyp * (n_steps + 1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    value = n_chunks * 30.0 * args.steps / elapsed
+    return {
+        "metric": METRIC, "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "ggml-%s shape (random weights), %d x 30 s synthetic mel chunks (U(-1,1), seed = chunk index) resident in HBM, contiguous "
+                               "shards over %d rank(s), lock-step batches of %d windows x %d hypotheses sharing one pass over the cross-attention K/V, "
+                               "%d contexts in flight, %d-token prompt + %d greedy steps per sequence; token ids gathered on rank 0"
+                               % (args.model, n_chunks, world, per, hyp, len(ctxs), N_PROMPT, n_steps),
+                   "model": "ggml-" + args.model, "chunks": n_chunks, "hypotheses": hyp, "windows_per_batch": per,
+                   "parallelism": "dp%d (independent windows; RCCL weight broadcast %.3f s outside the timed region; no collective in the step)" % (world, t_bcast)},
+        "rtf": round(elapsed / (args.steps * n_chunks * 30.0), 6), "roofline": None, "cpu_baseline": None,
+        "sequences_per_second": round(n_chunks * hyp * args.steps / elapsed, 2),
+        "tokens_checksum": int(np.asarray(toks, np.int64).clip(min=0).sum() % 1000003),
+    }
 
 
 def main():
@@ -176,19 +482,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="medium")
+    ap.add_argument("--model", default=None, help="medium (default), large-v2, large-v3")
+    ap.add_argument("--workload", default="clip", choices=["clip", "shard256", "beam5", "v3stream"],
+                    help="clip = BASELINE configs[1] (default, the driver's line); shard256 = configs[3]: 256 x 30 s chunks sharded over the ranks "
+                         "(large-v2, strong scaling); beam5 = configs[2]: 8 x 30 s chunks x 5 hypotheses per chunk (large-v2, 50 steps); "
+                         "v3stream = configs[4]: the clip workload on the large-v3 shape (128 mels, vocabulary 51866), translate task")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--clips-per-batch", type=int, default=4, help="clip passes decoded as ONE lock-step batch (7 windows each, at most 4: the decode "
-                    "gemv holds 32 rows); a step stays one clip pass, K steps run as K // C batches plus one batch with the remainder")
-    ap.add_argument("--inflight", type=int, default=3, help="clip passes in flight, each on its own context and HIP stream: the decode chain of one "
-                    "pass is latency-bound, so the encoder GEMMs and the decode chains of its neighbours run underneath it "
-                    "(measured on MI355X, one clip per batch: 107 / 74 / 66 / 65 ms per pass with 1 / 2 / 3 / 6 in flight; four clips "
-                    "per batch: 62.6 / 48.8 / 45.6 with 1 / 2 / 3)")
+    ap.add_argument("--clips-per-batch", type=int, default=4, help="clip passes decoded as ONE lock-step batch (7 windows each); a step stays one clip "
+                    "pass, K steps run as K // C batches plus one batch with the remainder")
+    ap.add_argument("--inflight", type=int, default=3, help="batches in flight, each on its own context and HIP stream")
+    ap.add_argument("--batch", type=int, default=16, help="shard256 / beam5: windows per lock-step batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-single-stream", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the large_v2 sub-object of the default line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in a dry run)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device for this rank (default LOCAL_RANK)")
-    ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if args.model is None:
+        args.model = {"clip": "medium", "shard256": "large-v2", "beam5": "large-v2", "v3stream": "large-v3"}[args.workload]
 
     import torch
     import torch.distributed as dist
@@ -209,156 +521,127 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    hp = gf.hparams_for(args.model)
+    def load(kind):
+        """Rank 0 builds the model and fills its arena; the others receive one RCCL broadcast over xGMI."""
+        hp = gf.hparams_for(kind)
+        arena = torch.empty(binding.arena_bytes(hp), dtype=torch.uint8, device="cuda")
+        model, hm = None, None
+        t0 = time.time()
+        if rank == 0:
+            log("building %s-shape random model ..." % kind)
+            model = gf.synth_model(kind, seed=1)
+            log("uploading weights ...")
+            hm = binding.HipModel.from_ggml(model, arena_ptr=arena.data_ptr(), keepalive=arena)
+        t_load = time.time() - t0
+        t_bcast = 0.0
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.time()
+            dist.broadcast(arena, src=0)
+            torch.cuda.synchronize()
+            t_bcast = time.time() - t0
+            if rank != 0:
+                hm = binding.HipModel(hp, arena_ptr=arena.data_ptr(), already_filled=True, keepalive=arena)
+        return hp, model, hm, t_load, t_bcast
+
+    hp, model, hip_model, t_load, t_bcast = load(args.model)
     sp = gf.special_tokens(hp)
-    prompt = [sp["sot"], sp["sot"] + 1, sp["transcribe"]] if hp.is_multilingual else [sp["sot"], sp["not_"], sp["beg"]]
+    task = sp["translate"] if args.workload == "v3stream" else sp["transcribe"]
+    prompt = [sp["sot"], sp["sot"] + 1, task] if hp.is_multilingual else [sp["sot"], sp["not_"], sp["beg"]]
     prompt = prompt[:N_PROMPT]
 
-    # ---- weights: rank 0 builds the model and fills its arena; the others receive one RCCL broadcast over xGMI ----
-    arena = torch.empty(binding.arena_bytes(hp), dtype=torch.uint8, device="cuda")
-    model = None
-    t0 = time.time()
-    if rank == 0:
-        log("building %s-shape random model ..." % args.model)
-        model = gf.synth_model(args.model, seed=1)
-        log("uploading weights ...")
-        hip_model = binding.HipModel.from_ggml(model, arena_ptr=arena.data_ptr(), keepalive=arena)
-    t_load = time.time() - t0
-    t_bcast = 0.0
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.time()
-        dist.broadcast(arena, src=0)
-        torch.cuda.synchronize()
-        t_bcast = time.time() - t0
-        if rank != 0:
-            hip_model = binding.HipModel(hp, arena_ptr=arena.data_ptr(), already_filled=True, keepalive=arena)
+    if args.workload in ("shard256", "beam5"):
+        n_chunks, hyp, n_steps = (256, 1, N_GREEDY) if args.workload == "shard256" else (8, 5, 50)
+        if args.workload == "beam5":
+            args.batch = min(args.batch, 8)
+        line = run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_steps, t_bcast)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     B = args.windows
     C = max(1, args.clips_per_batch)
-    if B * C > 32:
-        raise SystemExit("windows x clips-per-batch must not exceed 32 (rows of the decode gemv)")
-    n_frames = WINDOW_SAMPLES // 160
-
-    def make_slot(n_clips):
-        """A context for n_clips clip passes in lock step + its inputs; clip j of every slot is the same seeded clip."""
-        pcm = torch.from_numpy(np.concatenate([synth_pcm(B, seed=100 + rank + 1000 * j) for j in range(n_clips)])).cuda()
-        mel = torch.empty((B * n_clips, hp.n_mels, n_frames), dtype=torch.float32, device="cuda")
-        return (binding.HipContext(hip_model, B * n_clips), pcm, mel)
-
-    slots = [make_slot(C) for _ in range(max(1, args.inflight))]
-    n_full, rem = divmod(args.steps, C)
-    rem_slot = make_slot(rem) if rem else None
-    sequence = [slots[i % len(slots)] for i in range(n_full)] + ([rem_slot] if rem_slot else [])
-    groups = [slots[0]]
-    torch.cuda.synchronize()
+    if B * C > 128:
+        raise SystemExit("windows x clips-per-batch must not exceed 128 (rows of the decode kernel)")
     audio_seconds = CLIP_SECONDS * B / 7.0
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     if rank == 0:
-        log("warmup ...")
-    for _ in range(args.warmup):
-        run_passes(slots + ([rem_slot] if rem_slot else []), prompt, N_GREEDY, len(slots))
-    barrier()
-    if rank == 0:
-        log("timed region: %d steps ..." % args.steps)
-    t0 = time.perf_counter()
-    toks = run_passes(sequence, prompt, N_GREEDY, len(slots))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- per-kernel pass (rank 0): identical work with hipEvent pairs around every launch ----
-    roofline, kernels = None, {}
+        log("warmup + timed region: %d steps ..." % args.steps)
+    m = measure_batched(hip_model, hp, prompt, args.steps, args.warmup, B, C, args.inflight, rank, world, dist,
+                        want_kernels=not args.no_roofline)
+    elapsed, toks = m["elapsed"], m["toks"]
     if rank == 0:
         log("timed region done: %.3f s" % elapsed)
-    if rank == 0 and not args.no_roofline:
-        # one group at a time (events on concurrent streams would time each other's kernels), summed over the groups
-        kernels = {}
-        for grp in groups:
-            grp[0].profile(True)
-            transcribe_clip([grp], prompt, N_GREEDY)
-            for k, v in grp[0].profile_read().items():
-                acc = kernels.setdefault(k, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-                for f in acc:
-                    acc[f] += v[f]
-            grp[0].profile(False)
-        total_ms = sum(k["ms"] for k in kernels.values())
-        # The event pairs need eager launches, which cost ~0.6 us more per dispatch than the captured graph the timed region
-        # replays. One lone pass from the graph is timed as a whole (wall clock between syncs) and the per-kernel times are
-        # rescaled so that they sum to it: that is the per-launch duration inside the graph, the one rocprofv3 reports.
-        graph_ms = 1e9
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            transcribe_clip(groups, prompt, N_GREEDY)
-            graph_ms = min(graph_ms, 1e3 * (time.perf_counter() - t0))
-        scale = min(1.0, graph_ms / total_ms)
-        name, dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])
-        dom_ms = dom["ms"] * scale
-        avg_us = 1e3 * dom_ms / dom["calls"]
-        if name in ("gemmTiled", "attentionEnc"):
-            ach = dom["flops"] / (dom_ms * 1e-3) / 1e12
-            roofline = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
-        else:
-            ach = dom["bytes"] / (dom_ms * 1e-3) / 1e9
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-        # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 cannot run inside this process):
-        # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of the eager single-token decode steps, tools/pmc_probe.py
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_gemv.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("kernel") == name:
-                roofline["traffic"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
-                roofline["traffic_source"] = pmc["source"] + " (" + pmc["note"] + ")"
-        except (OSError, ValueError, KeyError):
-            pass
-        roofline.update({"avg_launch_us": round(avg_us, 2), "launches_per_batch_pass": dom["calls"],
-                         "share_of_gpu_time": round(dom["ms"] / total_ms, 3),
-                         "algorithmic_per_launch": round((dom["flops"] if roofline["bound"] == "mfma" else dom["bytes"]) / dom["calls"], 1),
-                         "timing": "hipEvent pairs around every launch of one lone pass (eager, sum %.1f ms), rescaled by %.3f to the "
-                                   "%.1f ms the same pass takes from the captured graph" % (total_ms, scale, graph_ms)})
 
-    cpu = None
+    roofline, kernels = None, {}
+    if rank == 0 and m["kernels"]:
+        roofline, kernels = roofline_from(m["kernels"], 1e3 * elapsed / args.steps * C, m["lone_batch_ms"])
+        roofline["single_clip"] = {"ms": round(m["single_clip_ms"], 2), "audio_seconds_per_sec": round(audio_seconds / (m["single_clip_ms"] * 1e-3), 1),
+                                   "what": "ONE %.0f s clip (7 windows as one lock-step batch) alone on the GPU, H2D to token ids" % audio_seconds}
+
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        if model is None:
-            model = gf.synth_model(args.model, seed=1)
-        log("cpu baseline (reference CPU path, bounded) ...")
-        cpu = cpu_baseline(model, args.model, slots[0][1][0].cpu().numpy(), prompt)
+        log("cpu baseline + parity (reference CPU path, bounded) ...")
+        cpu, parity = cpu_baseline(model, args.model, m["slots"][0][2][0].cpu().numpy(), prompt, hip_model)
         log("cpu baseline done: %s" % cpu.get("value"))
+    for s in m["slots"]:
+        s[0].close()
+    del m
+
+    single = large = None
+    if rank == 0 and world == 1 and args.workload == "clip":
+        if not args.no_single_stream and args.model in ("medium", "large-v2"):
+            log("single stream through libWhisper.so ...")
+            try:
+                single = single_stream(args.model)
+                log("single stream: %s audio-s/s" % single["value"])
+            except Exception as e:       # the sub-object must not take the line down
+                single = {"error": str(e)[:300]}
+        if not args.no_large and args.model == "medium":
+            log("large-v2 shape ...")
+            try:
+                hip_model.close()
+                hp2, model2, hm2, _, _ = load("large-v2")
+                sp2 = gf.special_tokens(hp2)
+                p2 = [sp2["sot"], sp2["sot"] + 1, sp2["transcribe"]]
+                m2 = measure_batched(hm2, hp2, p2, 8, 1, B, C, args.inflight, 0, 1, dist, want_kernels=False)
+                large = {"model": "ggml-large-v2", "value": round(audio_seconds * 8 / m2["elapsed"], 2), "unit": "audio-seconds/sec", "steps": 8,
+                         "ms_per_step": round(1e3 * m2["elapsed"] / 8, 3), "same_pipeline": True}
+                for s in m2["slots"]:
+                    s[0].close()
+                log("large-v2: %s audio-s/s" % large["value"])
+            except Exception as e:
+                large = {"error": str(e)[:300]}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * audio_seconds * args.steps / elapsed
         line = {
-            "metric": "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU",
+            "metric": METRIC,
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": (round(value / PUBLISHED_AUDIO_S_PER_S[args.model], 2) if args.model in PUBLISHED_AUDIO_S_PER_S and B == 7 else None),
+            # the published number (13.30 audio-s/s, one clip, sequential, GTX 1080Ti) is not this batched workload:
+            # the like-for-like ratio is single_stream.vs_baseline
+            "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, "
-                                   "%d clip pass(es) per lock-step batch, %d batches in flight on separate HIP streams; GPU mel + encoder + %d-token prompt + %d greedy steps per window, "
-                                   "device-side sampling (captured hipGraph per token)" % (args.model, audio_seconds, B, C, len(slots), N_PROMPT, N_GREEDY),
-                       "model": "ggml-" + args.model, "baseline": "BASELINE.md section 1: reference D3D11 backend, GTX 1080Ti, same clip length (whole job, 1 GPU)",
-                       "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": len(slots), "decode_steps_per_window": N_GREEDY + 1,
+                                   "%d clip pass(es) per lock-step batch, %d batches in flight on separate HIP streams; pinned host PCM -> H2D -> GPU mel + encoder + "
+                                   "%d-token prompt + %d greedy steps per window, device-side sampling (captured hipGraph per token); span = first H2D byte to "
+                                   "last token id on the host" % (args.model, audio_seconds, B, C, args.inflight, N_PROMPT, N_GREEDY),
+                       "model": "ggml-" + args.model, "task": "translate" if args.workload == "v3stream" else "transcribe",
+                       "baseline": "BASELINE.md section 1 publishes one sequential clip on a GTX 1080Ti (13.30 audio-s/s medium): compared in single_stream, not here",
+                       "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": args.inflight, "decode_steps_per_window": N_GREEDY + 1,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "kernels": {k: {"calls": v["calls"], "ms": round(v["ms"], 3),
-                            "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
-                        for k, v in kernels.items()},
+            "parity": parity,
+            "single_stream": single,
+            "large_v2": large,
+            "kernels": kernels,
             "model_build_s": round(t_load, 1),
             "tokens_checksum": int(np.asarray(toks, np.int64)[:B].sum() % 1000003),
         }

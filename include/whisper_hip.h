@@ -119,6 +119,9 @@ WH_API int wh_buffer_alloc( int64_t bytes, void** dev );
 WH_API int wh_buffer_free( void* dev );
 WH_API int wh_buffer_upload( wh_context* c, void* dev, const void* host, int64_t bytes );
 WH_API int wh_buffer_download( wh_context* c, void* host, const void* dev, int64_t bytes );
+/* Enqueues the copy on the context's stream and returns; `host` must stay valid (and should be pinned) until the stream
+ * passes it. This is how a caller puts the PCM upload inside the pipeline instead of in front of it. */
+WH_API int wh_buffer_upload_async( wh_context* c, void* dev, const void* host, int64_t bytes );
 
 /* PCM -> log-mel on the GPU. Replaces Spectrogram::pcmToMel (Whisper/Whisper/Spectrogram.cpp:64-122) ==
  * log_mel_spectrogram (Whisper/source/whisper.cpp:2060-2180): hop 160, Hann 400, |DFT|^2 with the reference's

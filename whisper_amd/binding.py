@@ -31,7 +31,7 @@ EXPORTS = [
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
-    "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_download",
+    "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
     "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
@@ -88,6 +88,7 @@ def lib():
         L.wh_context_set_flags.argtypes = [vp, C.c_uint32, i32]
         L.wh_context_memory.argtypes = [vp, C.POINTER(i64)]
         L.wh_context_synchronize.argtypes = [vp]
+        L.wh_buffer_upload_async.argtypes = [vp, vp, vp, i64]
         L.wh_mel_spectrogram.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
         L.wh_encode.argtypes = [vp, vp, i32, i64, i64, vp]
         L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
@@ -214,6 +215,12 @@ class HipContext:
     def set_parity(self, n_threads: int):
         """n_threads > 0: emulate the CPU reference's FP16 thread-partitioned P.V accumulation; 0: FP32 fast path."""
         check(lib().wh_context_set_flags(self.handle, WH_FLAG_PARITY_PV if n_threads > 0 else 0, max(n_threads, 1)))
+
+    def upload_async(self, dst_dev, src_host_pinned):
+        """Enqueue a host -> device copy on the context's stream (torch tensors; the host one should be pinned)."""
+        assert dst_dev.numel() * dst_dev.element_size() == src_host_pinned.numel() * src_host_pinned.element_size()
+        check(lib().wh_buffer_upload_async(self.handle, C.c_void_p(dst_dev.data_ptr()), C.c_void_p(src_host_pinned.data_ptr()),
+                                           dst_dev.numel() * dst_dev.element_size()))
 
     def vram_bytes(self) -> int:
         n = C.c_int64()

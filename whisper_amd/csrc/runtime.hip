@@ -38,6 +38,7 @@ using namespace wh;
 
 namespace
 {
+	__global__ void probeEmpty( int* p ) { if( p && threadIdx.x == 0xFFFF ) *p = 1; }
 	inline int64_t align256( int64_t x ) { return ( x + 255 ) & ~(int64_t)255; }
 	inline int roundUp( int x, int m ) { return ( x + m - 1 ) / m * m; }
 	// conv1 as an implicit GEMM: K = 3 taps * n_mels channels, zero-padded to a multiple of 64 (80 mels: 240 -> 256;
@@ -169,10 +170,14 @@ static int bindDevice( const wh_model* m )
 // active between wh_profile_enable(1) and wh_profile_read, because two event records per launch perturb launch-bound code.
 enum eKernelClass : int
 {
-	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX, KC_SAMPLE, KC_COUNT
+	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_ATTN_DEC_CROSS, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX,
+	KC_SAMPLE, KC_EVENT_PAIR, KC_COUNT
 };
-static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "layerNorm", "mel",
-	"melToConvInput", "embed", "vocabSoftMax", "softMaxSample" };
+// "attentionDecCross" = cross-attention launches (attentionDecG<NQ, true> / <NQ, false> with group or nKeys = n_audio_ctx),
+// "attentionDec" = causal self-attention; "eventPair" = the calibration launches of wh_profile_enable (an empty kernel
+// between the same two event records: what the bracket itself costs, to be subtracted from every per-launch average).
+static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "attentionDecCross",
+	"layerNorm", "mel", "melToConvInput", "embed", "vocabSoftMax", "softMaxSample", "eventPair" };
 
 struct Profiler
 {
@@ -331,7 +336,7 @@ static int attnDecP( wh_context* c, const DecAttnArgs& a, int keysHint = -1 )
 		bytes += 4.0 * a.batch * a.nTok * d + 2.0 * d * d;
 		flops += 2.0 * a.batch * a.nTok * d * d;
 	}
-	return profiled( c, KC_ATTN_DEC, flops, bytes, [ & ]() { return launchAttentionDec( a, c->stream ); } );
+	return profiled( c, a.causal ? KC_ATTN_DEC : KC_ATTN_DEC_CROSS, flops, bytes, [ & ]() { return launchAttentionDec( a, c->stream ); } );
 }
 
 // ==================================================================================================================
@@ -811,6 +816,14 @@ int wh_buffer_upload( wh_context* c, void* dev, const void* host, int64_t bytes 
 	WH_BIND( c->m );
 	WH_HIP( hipMemcpyAsync( dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream ) );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int wh_buffer_upload_async( wh_context* c, void* dev, const void* host, int64_t bytes )
+{
+	if( !c || !dev || !host || bytes < 0 ) { setError( "buffer_upload_async: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	WH_HIP( hipMemcpyAsync( dev, host, (size_t)bytes, hipMemcpyHostToDevice, c->stream ) );
 	return 0;
 }
 
@@ -1382,8 +1395,15 @@ int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial,
 int wh_profile_enable( wh_context* c, int on )
 {
 	if( !c ) return WH_E_INVALIDARG;
+	WH_BIND( c->m );
 	c->prof.reset();
 	c->prof.on = on != 0;
+	if( c->prof.on )
+	{
+		// calibration: what an event pair around a launch measures when the kernel does nothing
+		for( int i = 0; i < 64; i++ )
+			WH_CHECK( profiled( c, KC_EVENT_PAIR, 0.0, 0.0, [ & ]() { hipLaunchKernelGGL( probeEmpty, dim3( 1 ), dim3( 64 ), 0, c->stream, (int*)nullptr ); return 0; } ) );
+	}
 	return 0;
 }
 
@@ -1567,8 +1587,6 @@ int wh_op_soft_max( void* stream, float* x, int rows, int cols )
 // ------------------------------------------------------------------------------------------------------------------
 namespace
 {
-	__global__ void probeEmpty( int* p ) { if( p && threadIdx.x == 0xFFFF ) *p = 1; }
-
 	// Grid-wide barrier cost probe: `n` rounds of { every workgroup publishes 64 bytes, barrier, reads another workgroup's
 	// line and checks it }. One monotonic counter, agent-scope release on arrival, acquire polling, bounded spin.
 	// mode 0: every workgroup polls the one counter; mode 1: arrivals are counted per XCD (workgroup id % 8) and the last

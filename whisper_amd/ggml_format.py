@@ -293,6 +293,12 @@ def scripted_model(script: List[int], prompt_len: int, kind: str = "test-d128-ml
     window is predicted at position prompt_len - 1 + i. The audio plays no role (cross-attention output is zeroed too),
     so every window of a NoContext run produces the same script, the way a real model repeats on repetitive audio.
     """
+    return scripted_model_at({prompt_len - 1 + i: tok for i, tok in enumerate(script)}, kind, seed, gain)
+
+
+def scripted_model_at(position_tokens: Dict[int, int], kind: str = "test-d128-ml", seed: int = 5, gain: float = 0.12) -> GgmlModel:
+    """scripted_model with the script given per decoder position (position -> the token predicted there), which is what a run
+    WITH prompt carry-over needs: the prompt, hence the position of a window's first token, grows from window to window."""
     m = synth_model(kind, seed=seed, w_std=0.02)
     hp = m.hparams
     d = hp.n_text_state
@@ -300,8 +306,8 @@ def scripted_model(script: List[int], prompt_len: int, kind: str = "test-d128-ml
     codes = rng.choice(np.array([-1.0, 1.0], np.float32), size=(hp.n_text_ctx, d))
     m.tensors["decoder.positional_embedding"] = codes.astype(np.float32)
     te = (0.02 * rng.standard_normal((hp.n_vocab, d))).astype(np.float32)
-    for i, tok in enumerate(script):
-        te[tok] += gain * codes[prompt_len - 1 + i]
+    for pos, tok in position_tokens.items():
+        te[tok] += gain * codes[pos]
     m.tensors["decoder.token_embedding.weight"] = te.astype(np.float16)
     m.tensors["decoder.ln.weight"] = np.ones(d, np.float32)
     m.tensors["decoder.ln.bias"] = np.zeros(d, np.float32)
@@ -311,3 +317,28 @@ def scripted_model(script: List[int], prompt_len: int, kind: str = "test-d128-ml
             m.tensors[p + nm + ".weight"] = np.zeros_like(m.tensors[p + nm + ".weight"])
             m.tensors[p + nm + ".bias"] = np.zeros_like(m.tensors[p + nm + ".bias"])
     return m
+
+
+def carry_over_script(hp: HParams, n_windows: int, text_per_window: int, n_max_text_ctx: int):
+    """Positions -> tokens for a sequential run with prompt carry-over in which EVERY window transcribes as
+    [timestamp <= 1 s (forced by the sampler), text_per_window text tokens, the 30.00 s timestamp, EOT]:
+    window w's prompt is [prev] + the last min(n_max_text_ctx, n_text_ctx/2, past) tokens + the task tokens
+    (ContextImpl.cpp:565-576), so its token i sits at position len(prompt) - 1 + i. Returns (positions, tokens kept per window)."""
+    sp = special_tokens(hp)
+    n_init = 3 if hp.is_multilingual else 1
+    kept = 1 + text_per_window + 1            # first timestamp, text, closing timestamp (EOT is dropped by result_len)
+    positions: Dict[int, int] = {}
+    past = 0
+    for w in range(n_windows):
+        take = min(n_max_text_ctx, hp.n_text_ctx // 2, past)
+        plen = (1 + take if past else 0) + n_init
+        for i in range(text_per_window + 3):
+            if i == 0 and w > 0:
+                continue                      # the sampler forces SOME timestamp <= 1 s there; scripting it would collide with the previous EOT's position
+            pos = plen - 1 + i
+            # text tokens are keyed by position: once the carried prompt has reached its cap every window sits at the same positions
+            t = sp["beg"] if i == 0 else (1000 + pos if i <= text_per_window else (sp["beg"] + 1500 if i == text_per_window + 1 else sp["eot"]))
+            assert pos < hp.n_text_ctx and positions.get(pos, t) == t, "script positions collide: change n_max_text_ctx"
+            positions[pos] = t
+        past += kept
+    return positions, kept

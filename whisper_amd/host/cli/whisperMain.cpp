@@ -4,9 +4,10 @@
 //
 //   whisper-main -m ggml-medium.bin -f clip.wav -osrt
 //
-// Differences from the reference, all due to features this build does not have: the audio is
-// always loaded whole (runStreamed answers E_NOTIMPL and the tool falls back to runFull, as the reference itself does
-// for token timestamps); -di and -su report what the library reports for them; -owts turns token timestamps on but
+// Like the reference's tool the audio goes through iMediaFoundation::openAudioFile + iContext::runStreamed (per-window
+// spectrogram normalisation) unless token timestamps are requested, which need the whole buffer (main.cpp:305-321).
+// Differences from the reference, all due to features this build does not have: -di and -su report
+// what the library reports for them; -owts turns token timestamps on but
 // writes no karaoke script (the reference's tool does not either: params.h declares the option, main.cpp never reads it).
 #include <stdio.h>
 #include <string.h>
