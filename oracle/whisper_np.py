@@ -106,7 +106,7 @@ def log_mel_raw(pcm, filters, n_fft=400, hop=160, n_len=None):
     folded[:, 1:half] += p[:, n_fft - 1:half:-1]
     mel = folded @ filters.astype(np.float64).T                 # [n_len][n_mel], double sum as the reference
     mel = np.log10(np.maximum(mel, 1e-10))
-    return mel.T.astype(F32)                                    # stored into a float vector before the clamp
+    return np.ascontiguousarray(mel.T.astype(F32))              # stored into a float vector before the clamp
 
 
 def log_mel_spectrogram(pcm, filters, n_fft=400, hop=160):

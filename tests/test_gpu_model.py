@@ -255,7 +255,9 @@ def test_hypotheses_share_cross_attention(hip_tiny, golden):
     """5 decoder sequences per window on ONE pass over the window's cross-attention K/V (wh_context_create_hyp): every
     hypothesis computes exactly what a lone sequence fed the same tokens computes -- the greedy-equivalence at b = 1 that
     SURVEY.md 8(d) config 3 asks for, since the reference declares beam search without implementing it (sFullParams.h:12-13)."""
-    mel = torch.from_numpy(golden["mel"]).cuda()
+    pad = np.zeros((80, 3000), np.float32)
+    pad[:, :1100] = golden["mel"]
+    mel = torch.from_numpy(pad).cuda()
     rng = np.random.default_rng(3)
     mel2 = torch.from_numpy(rng.uniform(-1, 1, (80, 3000)).astype(np.float32)).cuda()
     toks = [[50257, 1000 + 7 * j, 2000 + j] for j in range(5)]
@@ -288,25 +290,37 @@ def test_hypotheses_share_cross_attention(hip_tiny, golden):
     ch.close()
 
 
-def test_fused_cross_query_matches_separate_launches(hip_tiny, golden):
-    """Decode steps with LayerNorm + cross-attention query projection inside the attention kernel against the same steps
-    with the separate LayerNorm and gemv launches (tuning bit off)."""
-    mel = torch.from_numpy(golden["mel"]).cuda()
+@pytest.mark.parametrize("bit,batch", [("TUNE_FUSE_CROSS_Q", 2), ("TUNE_FUSE_SELF_BLOCK", 2), ("TUNE_FUSE_SELF_BLOCK", 25), ("TUNE_GEMV_LN_BLOCK", 20),
+                                       ("TUNE_GEMV_K8", 3)])
+def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
+    """Decode steps with a fusion switched on against the same steps with the separate launches (tuning bit off):
+    LayerNorm + cross-attention query inside the attention kernel; LayerNorm + per-head QKV + cache append + self-attention
+    as one kernel (1, 2 or 4 sequences per workgroup); the workgroup-wide LayerNorm prologue of the 17..32-row gemv; 8 waves
+    splitting K in the MLP down-projection. Only FP32 summation order may differ."""
+    pad = np.zeros((80, 3000), np.float32)
+    pad[:, :1100] = golden["mel"]
+    mel = torch.from_numpy(pad).cuda()
     L = binding.lib()
     res = {}
-    for name, mask in (("fused", binding.TUNE_DEFAULT), ("separate", binding.TUNE_DEFAULT & ~binding.TUNE_FUSE_CROSS_Q)):
+    for name, mask in (("fused", binding.TUNE_DEFAULT), ("separate", binding.TUNE_DEFAULT & ~getattr(binding, bit))):
         L.wh_debug_set_tuning(mask)
         try:
-            ctx = binding.HipContext(hip_tiny, 2)
-            ctx.encode(torch.stack([mel, mel]))
-            ctx.decode(np.array([[50257, 50362, 50363]] * 2, np.int32), 0)
-            res[name] = ctx.decode(np.array([[1234], [1234]], np.int32), 3)[0]
+            ctx = binding.HipContext(hip_tiny, batch)
+            ctx.encode(torch.stack([mel] * batch))
+            ctx.decode(np.array([[50257, 50362, 50363]] * batch, np.int32), 0)
+            a = ctx.decode(np.array([[1234]] * batch, np.int32), 3)[0]
+            b = ctx.decode(np.array([[777]] * batch, np.int32), 4)[0]
+            res[name] = (a, b, ctx.debug_read("self-k", 3, 5), ctx.debug_read("self-v", 0, 5))
             ctx.close()
         finally:
             L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
-    d = report("fused vs separate cross-attention query", res["fused"][0], res["separate"][0])
-    assert d.max() < 3e-3 and d.mean() < 4e-4
-    assert np.array_equal(res["fused"][0], res["fused"][1])
+    for i in range(2):
+        d = report("%s on vs off, step %d" % (bit, i), res["fused"][i][0], res["separate"][i][0])
+        assert d.max() < 3e-3 and d.mean() < 4e-4
+        assert all(np.array_equal(res["fused"][i][0], res["fused"][i][k]) for k in range(batch))
+    for i in (2, 3):
+        d = report("%s on vs off, self cache" % bit, res["fused"][i][0], res["separate"][i][0])
+        assert d.max() < 4e-3 and d.mean() < 2e-4
 
 
 def test_large_v3_shape(tmp_path):
@@ -329,7 +343,7 @@ def test_large_v3_shape(tmp_path):
     assert np.abs(mel - want).max() < 2e-5
     n = wn.WhisperNP(model)
     n.encode(want, 0)
-    ctx.encode(torch.from_numpy(want).cuda())
+    ctx.encode(torch.from_numpy(np.ascontiguousarray(want)).cuda())
     d = report("v3-shape encode-out vs restatement", ctx.debug_read("encode-out")[0], n.encode(want, 0))
     assert d.max() < E2E_MAX + 2e-3 and d.mean() < E2E_MEAN
     ctx.set_parity(1)

@@ -613,6 +613,315 @@ namespace wh
 			}
 		}
 
+		// ---------------------------------------------------------------------------------------------------------------
+		// selfBlockDec: the self-attention half of a single-token decode step in ONE launch (WhisperContext.cpp:412-470):
+		//   LayerNorm of the residual row -> this head's 64 rows of Wq, Wk, Wv (the QKV product restricted to one head)
+		//   -> q = fp16((.+bq)*s), k = fp16(.*s), v = fp16(.+bv) -> k, v appended to the self-attention cache at the current
+		//   position -> causal attention over the cached keys plus the new one (taken from LDS, not re-read) -> out.
+		// It replaces a LayerNorm launch, a gemv launch and an attention launch. NQ sequences share one pass over the head's
+		// 384 KB weight slice (L2-resident: every sequence group reads the same slice); grid (head, sequences / NQ).
+		// Rounding points are those of the separate launches; only FP32 summation order differs.
+		template<int NQ>
+		struct SelfBlockLds
+		{
+			float sc[ NQ ][ MAX_KEYS / 3 ];	  // n_text_ctx <= 512 keys
+			float qs[ NQ ][ HEAD_DIM ], kn[ NQ ][ HEAD_DIM ], vn[ NQ ][ HEAD_DIM ];
+			float red[ NQ ][ NW ][ HEAD_DIM ];
+			float shf[ NQ ][ NW ];
+			double shd[ NQ ][ NW ];
+			f16 xn[ NQ ][ G_MAXD ];
+		};
+
+		template<int NQ>
+		__global__ void __launch_bounds__( NT, 2 ) selfBlockDec( const DecSelfArgs a )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemS[];
+			SelfBlockLds<NQ>& L = *(SelfBlockLds<NQ>*)smemS;
+			const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+			const int g = tid >> 3, c = tid & 7;
+			const int h = blockIdx.x, sg = blockIdx.y;
+			const int d = a.H * HEAD_DIM;
+			const int pos = a.nPastDev ? *a.nPastDev : a.nPast;	  // position of the token being fed = number of cached keys
+			const int nk = pos + 1;
+			const int nSeq = min( NQ, a.batch - sg * NQ );
+			auto seqOf = [ & ]( int q ) { return sg * NQ + ( q < nSeq ? q : nSeq - 1 ); };
+			auto cacheOf = [ & ]( const f16* base, int q ) { return base + ( (long long)seqOf( q ) * a.H + h ) * a.keyStride * HEAD_DIM; };
+
+			// cached K rows 0..63 of every sequence go out first (clamped against the buffer: rows >= pos are ignored later)
+			f16x8 k0[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+				k0[ q ] = *(const f16x8*)( cacheOf( a.kc, q ) + (long long)min( g, a.keyStride - 1 ) * HEAD_DIM + c * 8 );
+
+			// ---- LayerNorm of the NQ residual rows (same arithmetic as attentionDecG's fused query) ----
+			{
+				const int nv = d >> 2;
+				f32x4 xv[ NQ ];
+				f32x4 wv = { 0, 0, 0, 0 }, bv = { 0, 0, 0, 0 };
+				const bool own = tid < nv;
+				if( own )
+				{
+					wv = *(const f32x4*)( a.lnW + tid * 4 );
+					bv = *(const f32x4*)( a.lnB + tid * 4 );
+				}
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+					xv[ q ] = own ? *(const f32x4*)( a.x + (long long)seqOf( q ) * d + tid * 4 ) : f32x4{ 0, 0, 0, 0 };
+				const float invD = 1.0f / (float)d;
+				float s[ NQ ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) s[ q ] = waveReduceSum( ( xv[ q ][ 0 ] + xv[ q ][ 1 ] ) + ( xv[ q ][ 2 ] + xv[ q ][ 3 ] ) );
+				if( lane == 0 )
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ ) L.shf[ q ][ wave ] = s[ q ];
+				__syncthreads();
+				float mean[ NQ ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					float t = L.shf[ q ][ 0 ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) t += L.shf[ q ][ w ];
+					mean[ q ] = t * invD;
+				}
+				__syncthreads();
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					float t = 0.0f;
+					if( own )
+					{
+	#pragma unroll
+						for( int e = 0; e < 4; e++ )
+						{
+							xv[ q ][ e ] -= mean[ q ];
+							t = fmaf( xv[ q ][ e ], xv[ q ][ e ], t );
+						}
+					}
+					s[ q ] = waveReduceSum( t );
+				}
+				if( lane == 0 )
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ ) L.shf[ q ][ wave ] = s[ q ];
+				__syncthreads();
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					float t = L.shf[ q ][ 0 ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) t += L.shf[ q ][ w ];
+					const float rstd = 1.0f / sqrtf( t * invD + 1e-5f );
+					if( own )
+					{
+						f16x4 hv;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) hv[ e ] = (f16)__fadd_rn( __fmul_rn( __fmul_rn( xv[ q ][ e ], rstd ), wv[ e ] ), bv[ e ] );
+						*(f16x4*)( &L.xn[ q ][ tid * 4 ] ) = hv;
+					}
+				}
+				__syncthreads();
+			}
+
+			// ---- this head's rows of Wq, Wk, Wv: 8 lanes per weight row, 128 contiguous bytes per row and step ----
+			{
+				float acc[ 3 ][ NQ ];
+	#pragma unroll
+				for( int m = 0; m < 3; m++ )
+	#pragma unroll
+					for( int q = 0; q < NQ; q++ ) acc[ m ][ q ] = 0.0f;
+				const f16* wr[ 3 ];
+	#pragma unroll
+				for( int m = 0; m < 3; m++ ) wr[ m ] = a.wqkv + ( (long long)m * d + h * HEAD_DIM + g ) * d + c * 8;
+				const int steps = d >> 6;
+				for( int s0 = 0; s0 < steps; s0 += 8 )
+				{
+					f16x8 wq[ 3 ][ 8 ];
+	#pragma unroll
+					for( int m = 0; m < 3; m++ )
+	#pragma unroll
+						for( int u = 0; u < 8; u++ )
+							if( s0 + u < steps ) wq[ m ][ u ] = *(const f16x8*)( wr[ m ] + ( s0 + u ) * 64 );
+	#pragma unroll
+					for( int u = 0; u < 8; u++ )
+						if( s0 + u < steps )
+						{
+	#pragma unroll
+							for( int q = 0; q < NQ; q++ )
+							{
+								const f16x8 xq = *(const f16x8*)( &L.xn[ q ][ ( s0 + u ) * 64 + c * 8 ] );
+	#pragma unroll
+								for( int m = 0; m < 3; m++ )
+	#pragma unroll
+									for( int e = 0; e < 8; e++ ) acc[ m ][ q ] = fmaf( (float)wq[ m ][ u ][ e ], (float)xq[ e ], acc[ m ][ q ] );
+							}
+						}
+				}
+				const int col = h * HEAD_DIM + g;
+				const float bq = a.bqkv[ col ], bv = a.bqkv[ 2 * d + col ];
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					const float tq = xorReduce8( acc[ 0 ][ q ] ), tk = xorReduce8( acc[ 1 ][ q ] ), tv = xorReduce8( acc[ 2 ][ q ] );
+					if( c == 0 )
+					{
+						const f16 hq = (f16)( ( tq + bq ) * a.scale ), hk = (f16)( tk * a.scale ), hv = (f16)( tv + bv );
+						L.qs[ q ][ g ] = (float)hq;
+						L.kn[ q ][ g ] = (float)hk;
+						L.vn[ q ][ g ] = (float)hv;
+						if( q < nSeq )
+						{
+							const long long o = ( ( (long long)seqOf( q ) * a.H + h ) * a.keyStride + pos ) * HEAD_DIM + g;
+							a.kc[ o ] = hk;
+							a.vc[ o ] = hv;
+						}
+					}
+				}
+			}
+			__syncthreads();
+
+			// ---- scores: cached keys (8 lanes per row) + the new key from LDS ----
+			float qf[ NQ ][ 8 ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+				for( int e = 0; e < 8; e++ ) qf[ q ][ e ] = L.qs[ q ][ c * 8 + e ];
+			float mx[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ ) mx[ q ] = -INFINITY;
+			const int nIt = ( pos + G_ROWS - 1 ) / G_ROWS;
+			for( int it = 0; it < nIt; it++ )
+			{
+				const int key = it * G_ROWS + g;
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					const f16x8 kv = it == 0 ? k0[ q ] : *(const f16x8*)( cacheOf( a.kc, q ) + (long long)min( key, pos - 1 ) * HEAD_DIM + c * 8 );
+					float sacc = 0.0f;
+	#pragma unroll
+					for( int e = 0; e < 8; e++ ) sacc = fmaf( (float)kv[ e ], qf[ q ][ e ], sacc );
+					sacc = xorReduce8( sacc );
+					if( key < pos )
+					{
+						mx[ q ] = fmaxf( mx[ q ], sacc );
+						if( c == ( q & 7 ) ) L.sc[ q ][ key ] = sacc;
+					}
+				}
+			}
+			// first V group of the cache goes out before the softmax
+			f16x8 v0[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+				v0[ q ] = *(const f16x8*)( cacheOf( a.vc, q ) + (long long)min( g, max( pos - 1, 0 ) ) * HEAD_DIM + c * 8 );
+			if( wave == 0 )
+			{
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					const float sNew = waveReduceSum( L.qs[ q ][ lane ] * L.kn[ q ][ lane ] );
+					mx[ q ] = fmaxf( mx[ q ], sNew );
+					if( lane == 0 ) L.sc[ q ][ pos ] = sNew;
+				}
+			}
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ ) mx[ q ] = waveReduceMax( mx[ q ] );
+			if( lane == 0 )
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) L.shf[ q ][ wave ] = mx[ q ];
+			__syncthreads();
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				float m = L.shf[ q ][ 0 ];
+	#pragma unroll
+				for( int w = 1; w < NW; w++ ) m = fmaxf( m, L.shf[ q ][ w ] );
+				mx[ q ] = m;
+			}
+			double sum[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				sum[ q ] = 0.0;
+				for( int key = tid; key < nk; key += NT )
+				{
+					const float e = exp16( L.sc[ q ][ key ] - mx[ q ] );
+					L.sc[ q ][ key ] = e;
+					sum[ q ] += (double)e;
+				}
+				sum[ q ] = waveReduceSumD( sum[ q ] );
+			}
+			if( lane == 0 )
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ ) L.shd[ q ][ wave ] = sum[ q ];
+			__syncthreads();
+			float inv[ NQ ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				double tot = L.shd[ q ][ 0 ];
+	#pragma unroll
+				for( int w = 1; w < NW; w++ ) tot += L.shd[ q ][ w ];
+				inv[ q ] = (float)( 1.0 / tot );
+			}
+
+			// ---- P.V over the cached rows, FP32; the new row is added from LDS at the end ----
+			float acc[ NQ ][ 8 ];
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+				for( int e = 0; e < 8; e++ ) acc[ q ][ e ] = 0.0f;
+			for( int it = 0; it < nIt; it++ )
+			{
+				const int key = it * G_ROWS + g;
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+				{
+					const f16x8 vv = it == 0 ? v0[ q ] : *(const f16x8*)( cacheOf( a.vc, q ) + (long long)min( key, pos - 1 ) * HEAD_DIM + c * 8 );
+					const float p = key < pos ? L.sc[ q ][ key ] * inv[ q ] : 0.0f;
+	#pragma unroll
+					for( int e = 0; e < 8; e++ ) acc[ q ][ e ] = fmaf( (float)vv[ e ], p, acc[ q ][ e ] );
+				}
+			}
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+				for( int e = 0; e < 8; e++ )
+				{
+					float t = acc[ q ][ e ];
+					t += __shfl_xor( t, 8, 64 );
+					t += __shfl_xor( t, 16, 64 );
+					t += __shfl_xor( t, 32, 64 );
+					acc[ q ][ e ] = t;
+				}
+			if( lane < 8 )
+	#pragma unroll
+				for( int q = 0; q < NQ; q++ )
+	#pragma unroll
+					for( int e = 0; e < 8; e++ ) L.red[ q ][ wave ][ lane * 8 + e ] = acc[ q ][ e ];
+			__syncthreads();
+			if( tid < HEAD_DIM * NQ )
+			{
+				const int q = tid / HEAD_DIM, j = tid - q * HEAD_DIM;
+				if( q < nSeq )
+				{
+					float t = L.red[ q ][ 0 ][ j ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) t += L.red[ q ][ w ][ j ];
+					t = fmaf( L.vn[ q ][ j ], L.sc[ q ][ pos ] * inv[ q ], t );
+					a.out[ (long long)seqOf( q ) * d + h * HEAD_DIM + j ] = (f16)t;
+				}
+			}
+		}
+
+		template<int NQ>
+		int launchSelfBlockT( const DecSelfArgs& a, hipStream_t stream )
+		{
+			constexpr int lds = (int)sizeof( SelfBlockLds<NQ> );
+			static_assert( lds <= 64 * 1024, "selfBlockDec LDS" );
+			hipLaunchKernelGGL( ( selfBlockDec<NQ> ), dim3( a.H, ( a.batch + NQ - 1 ) / NQ ), dim3( NT ), lds, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+
 		template<int NQ, bool FUSEQ>
 		int launchDecG( const DecAttnArgs& a, hipStream_t stream )
 		{
@@ -672,5 +981,21 @@ namespace wh
 	#undef WH_DECG
 		setError( "attentionDec: hypothesis groups of 1, 2, 3, 4, 5 or 8 rows are supported" );
 		return -1;
+	}
+
+	int launchSelfBlockDec( const DecSelfArgs& a, hipStream_t stream )
+	{
+		const int d = a.H * HEAD_DIM;
+		if( a.batch <= 0 || d > G_MAXD || ( d % 64 ) != 0 || a.keyStride > MAX_KEYS / 3 || a.keyStride <= 0 )
+		{
+			setError( "selfBlockDec: unsupported shape (d <= 1280, n_text_ctx <= 512)" );
+			return -1;
+		}
+		// sequences per workgroup: enough to bring the grid down to about one workgroup per CU -- the 384 KB weight slice of
+		// a head is then read from L2 once per sequence group instead of once per sequence
+		const int wgs1 = a.H * a.batch;
+		if( wgs1 > 768 ) return launchSelfBlockT<4>( a, stream );
+		if( wgs1 > 320 ) return launchSelfBlockT<2>( a, stream );
+		return launchSelfBlockT<1>( a, stream );
 	}
 }

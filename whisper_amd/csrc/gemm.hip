@@ -690,7 +690,103 @@ namespace wh
 		constexpr int GV_MAXK_LN = 1280;
 		constexpr int GV_XS_STRIDE = GV_MAXK_LN + 8;
 
-		// PRO = 0: A rows are FP16 in global memory; 1: fused LayerNorm prologue.
+		// LayerNorm + affine of up to RB rows by the WHOLE workgroup (NWV waves): thread t owns the float4 columns t and
+		// t + 64 * NWV of every row, so a row is one coalesced pass and all RB rows are in flight at once; the two reductions go
+		// wave-shuffle -> LDS -> every thread. Same formula as layerNormRows (two-pass FP32, eps 1e-5, w*y + b, FP16 result);
+		// the summation tree differs, so rows are not bit-identical with the one-wave-per-row version.
+		template<int RB, int MAXC, int NWV, class Store>
+		__device__ __forceinline__ void layerNormBlock( const float* __restrict__ x, int nRows, const float* __restrict__ w, const float* __restrict__ b,
+			int d, int tid, float ( *shA )[ RB ], float ( *shB )[ RB ], Store&& store )
+		{
+			constexpr int NTH = NWV * 64;
+			const int lane = tid & 63, wave = tid >> 6;
+			const int nv = d >> 2;
+			f32x4 v[ RB ][ MAXC ], wv[ MAXC ], bv[ MAXC ];
+	#pragma unroll
+			for( int i = 0; i < MAXC; i++ )
+			{
+				const int cv = tid + i * NTH;
+				const int cc = ( cv < nv ? cv : nv - 1 ) * 4;
+				wv[ i ] = *(const f32x4*)( w + cc );
+				bv[ i ] = *(const f32x4*)( b + cc );
+	#pragma unroll
+				for( int r = 0; r < RB; r++ )
+				{
+					const int rr = r < nRows ? r : ( nRows > 0 ? nRows - 1 : 0 );
+					v[ r ][ i ] = *(const f32x4*)( x + (long long)rr * d + cc );
+				}
+			}
+			const float invD = 1.0f / (float)d;
+			float s[ RB ];
+	#pragma unroll
+			for( int r = 0; r < RB; r++ )
+			{
+				float t = 0.0f;
+	#pragma unroll
+				for( int i = 0; i < MAXC; i++ )
+					if( tid + i * NTH < nv ) t += ( v[ r ][ i ][ 0 ] + v[ r ][ i ][ 1 ] ) + ( v[ r ][ i ][ 2 ] + v[ r ][ i ][ 3 ] );
+				s[ r ] = t;
+			}
+	#pragma unroll
+			for( int o = 32; o > 0; o >>= 1 )
+	#pragma unroll
+				for( int r = 0; r < RB; r++ ) s[ r ] += __shfl_xor( s[ r ], o, 64 );
+			if( lane == 0 )
+	#pragma unroll
+				for( int r = 0; r < RB; r++ ) shA[ wave ][ r ] = s[ r ];
+			__syncthreads();
+	#pragma unroll
+			for( int r = 0; r < RB; r++ )
+			{
+				float t = shA[ 0 ][ r ];
+	#pragma unroll
+				for( int ww = 1; ww < NWV; ww++ ) t += shA[ ww ][ r ];
+				const float mean = t * invD;
+				float q = 0.0f;
+	#pragma unroll
+				for( int i = 0; i < MAXC; i++ )
+				{
+	#pragma unroll
+					for( int e = 0; e < 4; e++ ) v[ r ][ i ][ e ] -= mean;
+					if( tid + i * NTH < nv )
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) q = fmaf( v[ r ][ i ][ e ], v[ r ][ i ][ e ], q );
+				}
+				s[ r ] = q;
+			}
+	#pragma unroll
+			for( int o = 32; o > 0; o >>= 1 )
+	#pragma unroll
+				for( int r = 0; r < RB; r++ ) s[ r ] += __shfl_xor( s[ r ], o, 64 );
+			if( lane == 0 )
+	#pragma unroll
+				for( int r = 0; r < RB; r++ ) shB[ wave ][ r ] = s[ r ];
+			__syncthreads();
+	#pragma unroll
+			for( int r = 0; r < RB; r++ )
+			{
+				if( r >= nRows ) continue;
+				float t = shB[ 0 ][ r ];
+	#pragma unroll
+				for( int ww = 1; ww < NWV; ww++ ) t += shB[ ww ][ r ];
+				const float rstd = 1.0f / sqrtf( t * invD + 1e-5f );
+	#pragma unroll
+				for( int i = 0; i < MAXC; i++ )
+				{
+					const int cv = tid + i * NTH;
+					if( cv < nv )
+					{
+						f16x4 hv;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) hv[ e ] = (f16)__fadd_rn( __fmul_rn( __fmul_rn( v[ r ][ i ][ e ], rstd ), wv[ i ][ e ] ), bv[ i ][ e ] );
+						store( r, cv * 4, hv );
+					}
+				}
+			}
+		}
+
+		// PRO = 0: A rows are FP16 in global memory; 1: fused LayerNorm prologue, a wave per pair of rows (up to 16 rows);
+		// 2: fused LayerNorm prologue by the whole workgroup, 16 rows at a time (17 .. 32 rows).
 		// ROWS = weight rows per workgroup: 16 fills the MFMA; 4 (rows replicated across the operand's 16 row slots) gives 4x
 		// the workgroups when N is small and K large -- a CU streams only ~24 GB/s, so 8 MB over 64 CUs would take 5 us.
 		// NW = waves per workgroup that split K. GV_UNROLL = fragment slots per wave (8 halves the registers when K / NW / 32 <= 8).
@@ -700,6 +796,7 @@ namespace wh
 		{
 			constexpr bool LN = PRO == 1;
 			__shared__ float red[ NW - 1 ][ MT * 4 ][ 64 ];
+			__shared__ float lnA[ PRO == 2 ? NW : 1 ][ 16 ], lnB2[ PRO == 2 ? NW : 1 ][ 16 ];
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) f16 xs[];	 // [16 * MT][GV_XS_STRIDE] when there is a prologue
 
 			const int tid = threadIdx.x;
@@ -897,16 +994,25 @@ namespace wh
 		// small N, large K (the MLP down projection): 4 weight rows per workgroup so that every CU streams
 		// (up to 16 activation rows: beyond that the rows a workgroup re-reads outweigh its 4 weight rows, measured +3 % without)
 		const bool rows4 = !ln && a.epi == EPI_F32 && ( a.N % 16 ) == 0 && a.N <= 2048 && a.K >= 2048 && a.M <= 16 && ( g_tuning & TUNE_GEMV_ROWS4 );
+		// K >= 2048 (the MLP down-projection, 64 workgroups): 8 waves split K, so a wave's 16 weight fragments are ONE round of loads
+		const bool k8 = !ln && !rows4 && a.epi == EPI_F32 && a.K >= 2048 && ( a.K % 256 ) == 0 && ( g_tuning & TUNE_GEMV_K8 );
+		// more than 16 rows: the LayerNorm prologue is done by the whole workgroup, 16 rows at a time
+		const bool lnBlock = ln && a.M > 16;
 		switch( a.epi )
 		{
 		case EPI_F32:
+			if( lnBlock ) return launchGemvK<EPI_F32, 2, 16, 4, 8, 2>( a, stream );
 			if( ln ) return launchGemvT<EPI_F32, 1>( a, stream );
+			if( k8 ) return launchGemvT<EPI_F32, 0, 16, 8>( a, stream );
 			return rows4 ? launchGemvT<EPI_F32, 0, 4, 4>( a, stream ) : launchGemvT<EPI_F32, 0>( a, stream );
 		case EPI_F16_GELU:
+			if( lnBlock ) return launchGemvK<EPI_F16_GELU, 2, 16, 4, 8, 2>( a, stream );
 			return ln ? launchGemvT<EPI_F16_GELU, 1>( a, stream ) : launchGemvT<EPI_F16_GELU, 0>( a, stream );
 		case EPI_QKV_DEC:
+			if( lnBlock ) return launchGemvK<EPI_QKV_DEC, 2, 16, 4, 8, 2>( a, stream );
 			return ln ? launchGemvT<EPI_QKV_DEC, 1>( a, stream ) : launchGemvT<EPI_QKV_DEC, 0>( a, stream );
 		case EPI_Q_DEC:
+			if( lnBlock ) return launchGemvK<EPI_Q_DEC, 2, 16, 4, 8, 2>( a, stream );
 			return ln ? launchGemvT<EPI_Q_DEC, 1>( a, stream ) : launchGemvT<EPI_Q_DEC, 0>( a, stream );
 		}
 		setError( "gemv: epilogue not available" );

@@ -15,12 +15,15 @@ namespace wh
 		TUNE_ATTN_XCD = 256,		 // encoder attention: the query blocks of one (sequence, head) run on one XCD
 		TUNE_ATTN_DEC_G = 512,		 // decoder attention: 8 lanes per K row (coalesced) instead of a row per thread
 		TUNE_FUSE_CROSS_Q = 1024,	 // decode steps: LayerNorm + cross-attention query projection inside the attention kernel
+		TUNE_FUSE_SELF_BLOCK = 4096,	 // decode steps: LayerNorm + per-head QKV + cache append + self-attention in one launch
+		TUNE_GEMV_LN_BLOCK = 8192,	 // decode steps, 17..32 rows: block-wide LayerNorm prologue in the MLP up-projection instead of a launch
+		TUNE_GEMV_K8 = 16384,		 // decode steps: 8 waves split K when K >= 2048 (the MLP down-projection)
 		TUNE_GEMM_GROUP_M = 2048,	 // tiled GEMM: blocks walk bands of 4 M tiles (A band stays in the XCD's L2) instead of rows of tiles
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_LN_BLOCK | TUNE_GEMV_K8
 	};
 	extern unsigned g_tuning;
 
@@ -129,6 +132,25 @@ namespace wh
 		float qScale;
 	};
 	int launchAttentionDec( const DecAttnArgs& a, hipStream_t stream );
+
+	// The self-attention half of a single-token decode step as one launch: LayerNorm -> per-head Q/K/V rows of the fused
+	// [3d][d] weight -> cache append at the current position -> causal attention -> out (FP16 [batch][d]).
+	struct DecSelfArgs
+	{
+		const float* x;		   // [batch][d] residual stream
+		const float* lnW;
+		const float* lnB;
+		const f16* wqkv;	   // [3d][d]: query, key, value rows
+		const float* bqkv;	   // [3d] (the key third is zero)
+		float scale;		   // (d/H)^-0.25 on q and k
+		f16* kc;			   // self-attention caches of this layer [batch][H][keyStride][64]
+		f16* vc;
+		f16* out;
+		int batch, H, keyStride;
+		int nPast;
+		const int* nPastDev;   // when non-null the position comes from device memory (graph replay)
+	};
+	int launchSelfBlockDec( const DecSelfArgs& a, hipStream_t stream );
 
 
 	// ---------------------------------------------------------------------------------------------------------------

@@ -170,14 +170,14 @@ static int bindDevice( const wh_model* m )
 // active between wh_profile_enable(1) and wh_profile_read, because two event records per launch perturb launch-bound code.
 enum eKernelClass : int
 {
-	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_ATTN_DEC_CROSS, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX,
+	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_ATTN_DEC_CROSS, KC_SELF_BLOCK, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX,
 	KC_SAMPLE, KC_EVENT_PAIR, KC_COUNT
 };
 // "attentionDecCross" = cross-attention launches (attentionDecG<NQ, true> / <NQ, false> with group or nKeys = n_audio_ctx),
 // "attentionDec" = causal self-attention; "eventPair" = the calibration launches of wh_profile_enable (an empty kernel
 // between the same two event records: what the bracket itself costs, to be subtracted from every per-launch average).
 static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "attentionDecCross",
-	"layerNorm", "mel", "melToConvInput", "embed", "vocabSoftMax", "softMaxSample", "eventPair" };
+	"selfBlockDec", "layerNorm", "mel", "melToConvInput", "embed", "vocabSoftMax", "softMaxSample", "eventPair" };
 
 struct Profiler
 {
@@ -1014,7 +1014,9 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
 	const int* const nPastDev = devState ? &c->state->nPast : nullptr;
 	const bool gemv = M <= GEMV_MAX_ROWS && ( d % 128 ) == 0;
-	const bool fuseLn = gemv && d <= 1280 && M <= 32 && !( M > 16 && ( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
+	const bool fuseLn = gemv && d <= 1280 && M <= 32 && ( M <= 16 || ( g_tuning & TUNE_GEMV_LN_BLOCK ) || !( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
+	// decode steps: LayerNorm + this head's Q/K/V rows + cache append + self-attention in one launch
+	const bool fuseSelf = nTokens == 1 && d <= 1280 && hp.n_text_ctx <= 512 && parity == 0 && ( g_tuning & TUNE_FUSE_SELF_BLOCK );
 	// decode steps: the cross-attention kernel normalises the residual row and projects its own head's query
 	const bool fuseCrossQ = nTokens == 1 && d <= 1280 && parity <= 8 && ( g_tuning & TUNE_FUSE_CROSS_Q );
 
@@ -1040,6 +1042,26 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 		const int64_t selfLayer = (int64_t)il * c->maxSeq * hp.n_text_ctx * d;
 		const int64_t crossLayer = (int64_t)il * c->maxBatch * c->T * d;
 		// self-attention
+		if( fuseSelf )
+		{
+			DecSelfArgs a = {};
+			a.x = c->dx; a.lnW = m->at<float>( e.ln1w ); a.lnB = m->at<float>( e.ln1b );
+			a.wqkv = m->at<f16>( e.wqkv ); a.bqkv = m->at<float>( e.bqkv ); a.scale = kqScale;
+			a.kc = c->selfK + selfLayer; a.vc = c->selfV + selfLayer; a.out = c->dattn;
+			a.batch = batch; a.H = H; a.keyStride = hp.n_text_ctx; a.nPast = nPast; a.nPastDev = nPastDev;
+			const double keys = devState ? c->profKeysHint : nPast + 1;
+			// algorithmic: the fused [3d][d] weight once, the residual rows, the cached K and V rows, the appended rows, the output
+			const double bytes = 2.0 * 3.0 * d * d + 4.0 * M * d + 2.0 * 2.0 * M * ( keys - 1 ) * d + 2.0 * 2.0 * M * d + 2.0 * M * d;
+			const double flops = 2.0 * M * 3.0 * d * d + 4.0 * M * keys * d;
+			WH_CHECK( profiled( c, KC_SELF_BLOCK, flops, bytes, [ & ]() { return launchSelfBlockDec( a, st ); } ) );
+			if( il == 0 && !devState )
+			{
+				WH_CHECK( capture( c, c->capDecKqvSelf, c->dattn, (int64_t)M * d, (int64_t)c->maxRows * d ) );	 // "dec-KQV" (self)
+				c->capDecRows = M;
+			}
+		}
+		else
+		{
 		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wqkv ), M, 3 * d, d );
@@ -1062,6 +1084,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 				WH_CHECK( capture( c, c->capDecKqvSelf, c->dattn, (int64_t)M * d, (int64_t)c->maxRows * d ) );	 // "dec-KQV" (self)
 				c->capDecRows = M;
 			}
+		}
 		}
 		{
 			GemmArgs g = plainGemm( c->dattn, m->at<f16>( e.wo ), M, d, d );
@@ -1400,7 +1423,10 @@ int wh_profile_enable( wh_context* c, int on )
 	c->prof.on = on != 0;
 	if( c->prof.on )
 	{
-		// calibration: what an event pair around a launch measures when the kernel does nothing
+		// calibration: what an event pair around a launch measures when the kernel does nothing (the first launch of a
+		// kernel loads its code object: keep that out of the average)
+		for( int i = 0; i < 4; i++ ) hipLaunchKernelGGL( probeEmpty, dim3( 1 ), dim3( 64 ), 0, c->stream, (int*)nullptr );
+		WH_HIP( hipStreamSynchronize( c->stream ) );
 		for( int i = 0; i < 64; i++ )
 			WH_CHECK( profiled( c, KC_EVENT_PAIR, 0.0, 0.0, [ & ]() { hipLaunchKernelGGL( probeEmpty, dim3( 1 ), dim3( 64 ), 0, c->stream, (int*)nullptr ); return 0; } ) );
 	}

@@ -25,7 +25,7 @@ namespace Whisper
 		eHostLoopRules g_hostLoopRules = eHostLoopRules::ReferenceCpu;
 
 		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
-		constexpr int GREEDY_CHUNK = 16;	   // greedy steps enqueued per chunk; one chunk always runs behind the one being scanned
+		constexpr int GREEDY_CHUNK = 8; 	   // greedy steps enqueued per chunk; one chunk always runs behind the one being scanned
 
 
 		// ---- iTranscribeResult ------------------------------------------------------------------------------------
