@@ -302,7 +302,7 @@ def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
     mel = torch.from_numpy(pad).cuda()
     L = binding.lib()
     res = {}
-    for name, mask in (("fused", binding.TUNE_DEFAULT), ("separate", binding.TUNE_DEFAULT & ~getattr(binding, bit))):
+    for name, mask in (("fused", binding.TUNE_DEFAULT | getattr(binding, bit)), ("separate", binding.TUNE_DEFAULT & ~getattr(binding, bit))):
         L.wh_debug_set_tuning(mask)
         try:
             ctx = binding.HipContext(hip_tiny, batch)

@@ -144,8 +144,8 @@ def test_soft_max(rows, cols):
     assert d.max() < 1e-3 * want.max() and (d > 0).mean() < 0.01
 
 
-@pytest.mark.parametrize("batch,heads,T", [(1, 2, 1500), (2, 3, 200), (1, 1, 64), (1, 2, 777),
-                                           (2, 4, 300), (4, 6, 130)])        # batch x heads a multiple of 8: XCD-grouped block order
+@pytest.mark.parametrize("batch,heads,T", [(1, 2, 1500), (2, 3, 200), (1, 1, 64), (1, 2, 777), (1, 1, 1), (1, 2, 129), (1, 1, 1536),
+                                           (2, 4, 300), (4, 6, 130), (2, 16, 1500)])        # batch x heads a multiple of 8: XCD-grouped block order
 def test_flash_attention(batch, heads, T):
     """Unmasked encoder attention against ggml_flash_attn_f16 semantics (ggml.c:5912-6097)."""
     rng = np.random.default_rng(T)
@@ -165,16 +165,23 @@ def test_flash_attention(batch, heads, T):
         P = wn.softmax_table(S)
         o = (wn.r16(P) @ v[bh].astype(np.float32)).astype(np.float32)
         want[bh // heads, :, (bh % heads) * D:(bh % heads + 1) * D] = o
-    out = torch.full((batch, T, heads * D), float("nan"), dtype=torch.float16, device="cuda")
     qd, kd, vd = dev(q), dev(k), dev(vT)
-    binding.check(binding.lib().wh_op_flash_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), batch, heads, T))
-    torch.cuda.synchronize()
-    got = out.cpu().numpy().astype(np.float32)
-    assert np.isfinite(got).all()
-    d = report("flash_attention b%d h%d T%d" % (batch, heads, T), got, wn.r16(want))
-    # S differs by FP32 summation order only; that can flip the FP16 rounding of (S - max) for a few keys, each worth
-    # <= 1.6 % of that key's probability, plus the final FP16 rounding of the output
-    assert d.max() < 6e-3 and d.mean() < 2e-4
+    L = binding.lib()
+    # both kernels: three sweeps with recomputed scores (default) and scores kept in registers (tuning bit off)
+    for name, mask in (("three-sweep", binding.TUNE_DEFAULT), ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
+        L.wh_debug_set_tuning(mask)
+        try:
+            out = torch.full((batch, T, heads * D), float("nan"), dtype=torch.float16, device="cuda")
+            binding.check(L.wh_op_flash_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), batch, heads, T))
+            torch.cuda.synchronize()
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+        got = out.cpu().numpy().astype(np.float32)
+        assert np.isfinite(got).all()
+        d = report("flash_attention %s b%d h%d T%d" % (name, batch, heads, T), got, wn.r16(want))
+        # S differs by FP32 summation order only; that can flip the FP16 rounding of (S - max) for a few keys, each worth
+        # <= 1.6 % of that key's probability, plus the final FP16 rounding of the output
+        assert d.max() < 6e-3 and d.mean() < 2e-4
 
 
 def test_exp_table_exhaustive(golden):

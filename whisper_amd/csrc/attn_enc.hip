@@ -19,6 +19,7 @@
 //     cross-lane movement is needed.
 //   * the 8 partial O^T tiles are tree-reduced through LDS in a fixed order (deterministic).
 #include "kernels.h"
+#include <type_traits>
 
 namespace wh
 {
@@ -291,6 +292,251 @@ namespace wh
 			}
 		}
 
+		// ---------------------------------------------------------------------------------------------------------------
+		// attentionEncF: the same arithmetic (exact ggml_flash_attn_f16 semantics: P rounded to FP16 AFTER normalising by the
+		// full row sum) with the scores RECOMPUTED instead of kept: three sweeps over the keys -- row maximum, row sum of
+		// exp16(s - max), then P.V -- each forming S^T = K.Q^T again on the matrix cores. That doubles the MFMA work of the
+		// product but removes what made the first kernel slow: 192 score registers per lane (one workgroup per CU, every
+		// wave in the same phase), K/V read from L2 by each 64-query workgroup, and a three-level cross-wave reduction of O.
+		//   * a wave owns 32 query rows and ALL keys: no cross-wave exchange at all (max / sum / O are per lane + one xor-32 shuffle);
+		//   * 8 waves = 256 query rows share every K tile (128 keys x 64 dims, XOR-swizzled like the GEMM's A tile) and V tile
+		//     (fragment-major, lane-linear) through LDS, filled by global_load_lds_dwordx4, double buffered, one barrier per tile;
+		//   * ~110 registers: two workgroups per CU, so one's exp / convert VALU work runs under the other's MFMAs.
+		// S is bit-identical in the three sweeps (same instruction sequence), so max, sum and P are consistent.
+		constexpr int FQ = 256;					   // query rows per workgroup (8 waves x 32)
+		constexpr int FK = 128;					   // keys per LDS tile
+		constexpr int F_TILE = FK * HEAD_DIM;	   // halfs per tile (16 KiB)
+		constexpr int F_LDS_BYTES = 4 * F_TILE * 2;   // K and V, two buffers each
+
+		__global__ void __launch_bounds__( 512, 4 ) attentionEncF( const f16* __restrict__ q, const f16* __restrict__ k,
+			const f16* __restrict__ vT, f16* __restrict__ out, int heads, int T, int Tpad, int nQ, int xcdRemap )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemF[];
+			f16* const ldsK = (f16*)smemF;				  // [2][128][64], chunk-swizzled rows
+			f16* const ldsV = ldsK + 2 * F_TILE;		  // [2][8 key blocks][2 dd halves][64 lanes][8]
+			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+			typedef const __attribute__( ( address_space( 1 ) ) ) void* GlobalPtr;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int hi = lane >> 5;
+			const int c = lane & 31;
+			int bh, qb;
+			{
+				const int L = blockIdx.x;
+				if( xcdRemap )
+				{
+					const int kIdx = L >> 3;
+					bh = ( L & 7 ) + 8 * ( kIdx / nQ );
+					qb = kIdx % nQ;
+				}
+				else
+				{
+					bh = L / nQ;
+					qb = L - bh * nQ;
+				}
+			}
+			const f16* const Q = q + (long long)bh * T * HEAD_DIM;
+			const f16* const K = k + (long long)bh * T * HEAD_DIM;
+			const f16* const VT = vT + (long long)bh * HEAD_DIM * Tpad;
+			const int qRow = qb * FQ + wave * 32 + c;
+			const int nTiles = ( T + FK - 1 ) / FK;
+
+			// Q fragments of this lane's query row (B operand), kept for the whole kernel
+			f16x8 qf[ 4 ];
+			{
+				const int qr = qRow < T ? qRow : T - 1;
+	#pragma unroll
+				for( int kk = 0; kk < 4; kk++ ) qf[ kk ] = *(const f16x8*)( Q + (long long)qr * HEAD_DIM + kk * 16 + hi * 8 );
+			}
+
+			// K tile t -> LDS buffer: two 1 KiB wave instructions per wave (8 rows each); the XOR of the 16-byte chunk index is
+			// applied to the SOURCE address, the LDS image of an instruction is lane-linear
+			auto issueK = [ & ]( int t, int buf )
+			{
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+				{
+					const int row = ( wave * 2 + i ) * 8 + ( lane >> 3 );
+					const int cl = ( lane & 7 ) ^ ( ( row >> 1 ) & 7 );
+					int key = t * FK + row;
+					key = key < T ? key : T - 1;
+					__builtin_amdgcn_global_load_lds( (GlobalPtr)( K + (long long)key * HEAD_DIM + cl * 8 ),
+						(LdsPtr)( ldsK + buf * F_TILE + ( wave * 2 + i ) * 512 ), 16, 0, 0 );
+				}
+			};
+			auto issueV = [ & ]( int t, int buf )
+			{
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+					__builtin_amdgcn_global_load_lds( (GlobalPtr)( VT + (long long)t * F_TILE + ( wave * 2 + i ) * 512 + lane * 8 ),
+						(LdsPtr)( ldsV + buf * F_TILE + ( wave * 2 + i ) * 512 ), 16, 0, 0 );
+			};
+			// S^T of one 32-key sub-tile: keys (r & 3) + 8 (r >> 2) + 4 hi down the registers, this lane's query across
+			auto scores = [ & ]( const f16* kt, int st ) -> f32x16
+			{
+				f32x16 acc;
+	#pragma unroll
+				for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
+				const int row = st * 32 + c;
+				const int sw = ( row >> 1 ) & 7;
+	#pragma unroll
+				for( int kk = 0; kk < 4; kk++ )
+				{
+					const f16x8 kf = *(const f16x8*)( kt + row * HEAD_DIM + ( ( ( kk * 2 + hi ) ^ sw ) << 3 ) );
+					acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( kf, qf[ kk ], acc, 0, 0, 0 );
+				}
+				return acc;
+			};
+			const float scale = 0.125f;	   // 1 / sqrt(64)
+			// the four 32-key sub-tiles of tile t. Keys >= T (only the last tile has any) are selected away with a compare + select
+			// per element in every tile: two more VALU operations per score, against a second copy of every loop body (which
+			// measured 141 spilled SGPRs and 165 VGPRs)
+			auto sweepTile = [ & ]( int t, auto&& body )
+			{
+	#pragma unroll
+				for( int st = 0; st < 4; st++ ) body( std::true_type{}, st );
+			};
+
+			// ---- sweep 1: row maximum ----
+			float mx = -INFINITY;
+			issueK( 0, 0 );
+			for( int t = 0; t < nTiles; t++ )
+			{
+				const int buf = t & 1;
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				__syncthreads();
+				if( t + 1 < nTiles ) issueK( t + 1, buf ^ 1 );
+				const f16* const kt = ldsK + buf * F_TILE;
+				sweepTile( t, [ & ]( auto masked, int st )
+				{
+					const f32x16 S = scores( kt, st );
+					const int key0 = t * FK + st * 32 + 4 * hi;
+	#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const float sv = S[ r ] * scale;
+						if constexpr( decltype( masked )::value )
+							mx = fmaxf( mx, key0 + ( r & 3 ) + 8 * ( r >> 2 ) < T ? sv : -INFINITY );
+						else
+							mx = fmaxf( mx, sv );
+					}
+				} );
+			}
+			mx = fmaxf( mx, __shfl_xor( mx, 32, 64 ) );
+
+			// ---- sweep 2: row sum of exp16( s - max ), per-lane FP32 partials of a sub-tile combined in double ----
+			double sum = 0.0;
+			__syncthreads();
+			issueK( 0, 0 );
+			for( int t = 0; t < nTiles; t++ )
+			{
+				const int buf = t & 1;
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				__syncthreads();
+				if( t + 1 < nTiles ) issueK( t + 1, buf ^ 1 );
+				const f16* const kt = ldsK + buf * F_TILE;
+				sweepTile( t, [ & ]( auto masked, int st )
+				{
+					const f32x16 S = scores( kt, st );
+					const int key0 = t * FK + st * 32 + 4 * hi;
+					float part = 0.0f;
+	#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						// the exponential is evaluated unconditionally (s <= max always holds for real keys; padded keys are
+						// clamped to 0 and then selected away): a per-element branch would serialise the whole sub-tile
+						float e = exp16( fminf( S[ r ] * scale - mx, 0.0f ) );
+						if constexpr( decltype( masked )::value ) e = key0 + ( r & 3 ) + 8 * ( r >> 2 ) < T ? e : 0.0f;
+						part += e;
+					}
+					sum += (double)part;
+				} );
+			}
+			sum += __shfl_xor( sum, 32, 64 );
+			const float inv = (float)( 1.0 / sum );
+
+			// ---- sweep 3: P = fp16( e * inv ) packed straight into the B operand of O^T += V^T . P^T ----
+			f32x16 O[ 2 ];
+	#pragma unroll
+			for( int a = 0; a < 2; a++ )
+	#pragma unroll
+				for( int r = 0; r < 16; r++ ) O[ a ][ r ] = 0.0f;
+			__syncthreads();
+			issueK( 0, 0 );
+			issueV( 0, 0 );
+			for( int t = 0; t < nTiles; t++ )
+			{
+				const int buf = t & 1;
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				__syncthreads();
+				if( t + 1 < nTiles )
+				{
+					issueK( t + 1, buf ^ 1 );
+					issueV( t + 1, buf ^ 1 );
+				}
+				const f16* const kt = ldsK + buf * F_TILE;
+				const f16* const vt = ldsV + buf * F_TILE;
+				sweepTile( t, [ & ]( auto masked, int st )
+				{
+					const f32x16 S = scores( kt, st );
+					const int key0 = t * FK + st * 32 + 4 * hi;
+					f16x8 P[ 2 ];
+	#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						float e = exp16( fminf( S[ r ] * scale - mx, 0.0f ) );
+						if constexpr( decltype( masked )::value ) e = key0 + ( r & 3 ) + 8 * ( r >> 2 ) < T ? e : 0.0f;
+						P[ r >> 3 ][ r & 7 ] = (f16)( e * inv );
+					}
+	#pragma unroll
+					for( int half = 0; half < 2; half++ )
+					{
+						const int kb = st * 2 + half;	  // 16-key block inside the tile
+	#pragma unroll
+						for( int ddt = 0; ddt < 2; ddt++ )
+						{
+							const f16x8 vf = *(const f16x8*)( vt + ( ( kb * 2 + ddt ) * 64 + lane ) * 8 );
+							O[ ddt ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( vf, P[ half ], O[ ddt ], 0, 0, 0 );
+						}
+					}
+				} );
+			}
+
+			// ---- store: out[b][t][h*64 + dd] FP16; O^T rows are dd = ddt*32 + (r&3) + 8 (r>>2) + 4 hi, the column is this lane's query
+			if( qRow < T )
+			{
+				const int b = bh / heads, h = bh - b * heads;
+				f16* const o = out + ( (long long)b * T + qRow ) * ( heads * HEAD_DIM ) + h * HEAD_DIM;
+	#pragma unroll
+				for( int ddt = 0; ddt < 2; ddt++ )
+	#pragma unroll
+					for( int g4 = 0; g4 < 4; g4++ )
+					{
+						f16x4 pk;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) pk[ e ] = (f16)O[ ddt ][ 4 * g4 + e ];
+						*(f16x4*)( o + ddt * 32 + 8 * g4 + 4 * hi ) = pk;
+					}
+			}
+		}
+
+		int launchEncF( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
+		{
+			static PerDeviceOnce once;
+			if( once.needed() )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
+				once.mark();
+			}
+			const int nQ = ( T + FQ - 1 ) / FQ, BH = batch * heads;
+			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
+			hipLaunchKernelGGL( attentionEncF, dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+
 		template<int KT>
 		int launchEncT( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
 		{
@@ -317,6 +563,7 @@ namespace wh
 			setError( "attentionEnc: need 0 < T <= 1536 and Tpad >= roundup(T, 256)" );
 			return -1;
 		}
+		if( g_tuning & TUNE_ATTN_ENC_F ) return launchEncF( q, k, vT, out, batch, heads, T, Tpad, stream );
 		switch( ( T + 255 ) / 256 )
 		{
 		case 1: return launchEncT<1>( q, k, vT, out, batch, heads, T, Tpad, stream );

@@ -201,6 +201,9 @@ namespace wh
 			}
 			if( threadIdx.x == 0 )
 			{
+				// NaN logits compare false everywhere and would leave the sentinel index: never hand an out-of-range id to the
+				// embedding gather of the next step
+				if( pick.i < 0 || pick.i >= nVocab ) pick.i = 0;
 				TokenData r;
 				r.id = pick.i;
 				r.tid = ts.v > -1.0f ? ts.i : 0;
@@ -291,6 +294,9 @@ namespace wh
 			}
 			if( threadIdx.x == 0 )
 			{
+				// NaN logits compare false everywhere and would leave the sentinel index: never hand an out-of-range id to the
+				// embedding gather of the next step
+				if( pick.i < 0 || pick.i >= nVocab ) pick.i = 0;
 				TokenData r;
 				r.id = pick.i;
 				r.tid = ts.v > -1.0f ? ts.i : 0;

@@ -358,7 +358,174 @@ namespace wh
 			}
 		}
 
+		// ---------------------------------------------------------------------------------------------------------------
+		// Wide epilogue: the wave's 64x64 accumulator block goes through the (now idle) LDS tile memory and leaves as 16-byte
+		// stores along the rows of the destination. In the MFMA accumulator layout a lane holds ONE column and 16 rows of
+		// each 32x32 tile, so a direct epilogue issues 64 two- or four-byte stores per lane (and as many residual loads);
+		// per 256x256 tile that is 1024 wave-level store instructions of 64-128 useful bytes, and the tile's fixed cost
+		// (24 us against 28 us of K loop at K = 1024, profiles/r01_gemm_tile_probe.txt) was mostly their issue time.
+		// Through LDS a lane stores 8 x 16 bytes (FP16 outputs) or loads + stores 16 x 16 bytes (FP32 outputs with residual).
+		// LDS image per wave: [64 rows][64 cols] FP16 (8 KiB) or [32 rows][64 cols] FP32 (8 KiB, two halves), 16-byte chunk
+		// index XORed with the row so that both the column-wise writes and the row-wise reads are conflict free.
+		// Same arithmetic per element as the direct epilogue. Preconditions (checked by the launcher, a.wideEpi): N % 8 == 0,
+		// 16-byte aligned rows, T % 8 == 0 irrelevant (rows are independent), a wave's 64 columns inside one head.
 		template<int EPI, class C>
+		__device__ __forceinline__ void tileEpilogueWide( const GemmArgs& a, f32x16 ( &acc )[ C::TI ][ C::TJ ], int tm, int tn, int wm, int wn, int lane,
+			unsigned char* ldsWave )
+		{
+			static_assert( C::TI == 2 && C::TJ == 2, "64x64 wave tiles" );
+			constexpr int BM = C::BM, BN = C::BN;
+			const int hi = lane >> 5, c = lane & 31;
+			const int d = a.H * HEAD_DIM;
+			const int m0 = tm * BM + wm * 64, n0 = tn * BN + wn * 64;
+			float bias[ 2 ];
+	#pragma unroll
+			for( int j = 0; j < 2; j++ )
+			{
+				const int n = n0 + j * 32 + c;
+				bias[ j ] = ( a.bias && n < a.N ) ? a.bias[ n ] : 0.0f;
+			}
+			if constexpr( EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV )
+			{
+				f16* const L = (f16*)ldsWave;
+				// column block -> what it is (uniform over the wave: 64 columns never straddle a head)
+				int sel = 0, head = 0, layer = 0;
+				if constexpr( EPI == EPI_QKV_ENC )
+				{
+					sel = n0 / d;
+					head = ( n0 - sel * d ) >> 6;
+				}
+				if constexpr( EPI == EPI_CROSS_KV )
+				{
+					layer = n0 / ( 2 * d );
+					const int c2 = n0 - layer * 2 * d;
+					sel = c2 >= d ? 1 : 0;
+					head = ( sel ? c2 - d : c2 ) >> 6;
+				}
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+	#pragma unroll
+					for( int j = 0; j < 2; j++ )
+	#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							const int row = i * 32 + ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+							const int col = j * 32 + c;
+							const float v = acc[ i ][ j ][ r ];
+							f16 hv;
+							if constexpr( EPI == EPI_F16_GELU )
+								hv = gelu16( v + bias[ j ] );
+							else if constexpr( EPI == EPI_QKV_ENC )
+								hv = (f16)( v + bias[ j ] );
+							else
+								hv = sel ? (f16)( v + bias[ j ] ) : (f16)( v * a.scale );
+							L[ row * 64 + ( ( ( col >> 3 ) ^ ( row & 7 ) ) << 3 ) + ( col & 7 ) ] = hv;
+						}
+				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+				const int chunk = lane & 7;
+	#pragma unroll
+				for( int it = 0; it < 8; it++ )
+				{
+					const int row = it * 8 + ( lane >> 3 );
+					const int m = m0 + row;
+					const f16x8 v = *(const f16x8*)( L + row * 64 + ( ( chunk ^ ( row & 7 ) ) << 3 ) );
+					const int n = n0 + chunk * 8;
+					if( m >= a.M || n >= a.N ) continue;
+					if constexpr( EPI == EPI_F16_GELU )
+						*(f16x8*)( a.out16 + rowOffset( m, a.Mb, a.ldc, a.cBatchStride ) + n ) = v;
+					else
+					{
+						const int b = m / a.T;
+						const int t = m - b * a.T;
+						if constexpr( EPI == EPI_QKV_ENC )
+						{
+							f16* const dst = sel == 0 ? a.q : a.k;
+							*(f16x8*)( dst + ( ( (long long)b * a.H + head ) * a.T + t ) * HEAD_DIM + chunk * 8 ) = v;
+						}
+						else
+						{
+							f16* const dst = sel ? a.v : a.k;
+							*(f16x8*)( dst + ( ( ( (long long)layer * a.B + b ) * a.H + head ) * a.T + t ) * HEAD_DIM + chunk * 8 ) = v;
+						}
+					}
+				}
+			}
+			else
+			{
+				// FP32 outputs: 32 rows at a time
+				float* const L = (float*)ldsWave;
+				const int chunk = lane & 15;
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+				{
+					if( i == 1 )
+					{
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+						__builtin_amdgcn_wave_barrier();
+						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+					}
+	#pragma unroll
+					for( int j = 0; j < 2; j++ )
+	#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+							const int col = j * 32 + c;
+							float v = acc[ i ][ j ][ r ] + bias[ j ];
+							if constexpr( EPI == EPI_CONV2 ) v = (float)gelu16( v );
+							L[ row * 64 + ( ( ( col >> 2 ) ^ ( row & 15 ) ) << 2 ) + ( col & 3 ) ] = v;
+						}
+					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+					// everything a group of 4 chunks READS from memory first, then its stores (two groups per half: 16 + 8 registers
+					// of operands in flight instead of 32 + 16)
+	#pragma unroll
+					for( int g4 = 0; g4 < 2; g4++ )
+					{
+						f32x4 ex[ 4 ];
+						long long off[ 4 ];
+	#pragma unroll
+						for( int u = 0; u < 4; u++ )
+						{
+							const int row = ( g4 * 4 + u ) * 4 + ( lane >> 4 );
+							int m = m0 + i * 32 + row;
+							m = m < a.M ? m : a.M - 1;
+							int n = n0 + chunk * 4;
+							n = n < a.N ? n : a.N - 4;
+							if constexpr( EPI == EPI_F32 )
+							{
+								off[ u ] = rowOffset( m, a.Mb, a.ldc, a.cBatchStride ) + n;
+								ex[ u ] = a.res ? *(const f32x4*)( a.res + off[ u ] ) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+							}
+							else
+							{
+								const int b = m / a.Mb;
+								off[ u ] = (long long)m * a.ldc + n;
+								ex[ u ] = *(const f32x4*)( a.pe + (long long)( m - b * a.Mb ) * a.N + n );
+							}
+						}
+	#pragma unroll
+						for( int u = 0; u < 4; u++ )
+						{
+							const int row = ( g4 * 4 + u ) * 4 + ( lane >> 4 );
+							const int m = m0 + i * 32 + row;
+							const int n = n0 + chunk * 4;
+							if( m >= a.M || n >= a.N ) continue;
+							const f32x4 v = *(const f32x4*)( L + row * 64 + ( ( chunk ^ ( row & 15 ) ) << 2 ) );
+							f32x4 o;
+	#pragma unroll
+							for( int e = 0; e < 4; e++ ) o[ e ] = EPI == EPI_F32 ? v[ e ] + ex[ u ][ e ] : ex[ u ][ e ] + v[ e ];
+							*(f32x4*)( a.out32 + off[ u ] ) = o;
+						}
+					}
+				}
+			}
+		}
+
+		template<int EPI, class C, bool WIDE = false>
 		__global__ void __launch_bounds__( C::NT, C::MINW ) gemmTiled( const GemmArgs a )
 		{
 			constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDS_STRIDE = C::STRIDE;
@@ -475,6 +642,17 @@ namespace wh
 #pragma unroll
 							for( int j = 0; j < C::TJ; j++ )
 								acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ], fb[ j ], acc[ i ][ j ], 0, 0, 0 );
+					}
+				}
+				if constexpr( WIDE )
+				{
+					// V of the encoder (fragment-major, already 8-byte stores of 4 keys) keeps the direct path; a wave's 64 columns are one head
+					const bool vPart = EPI == EPI_QKV_ENC && ( tn * BN + wn * 64 ) >= 2 * a.H * HEAD_DIM;
+					__syncthreads();	  // every wave is done reading the operand tiles: LDS is free
+					if( !vPart )
+					{
+						tileEpilogueWide<EPI, C>( a, acc, tm, tn, wm, wn, lane, smem + wave * 8192 );
+						return;
 					}
 				}
 				tileEpilogue<EPI, C>( a, acc, tm, tn, wm, wn, lane );
@@ -849,6 +1027,13 @@ namespace wh
 				}
 				__syncthreads();
 			}
+			if constexpr( PRO == 2 )
+			{
+				for( int r0 = 0; r0 < a.M; r0 += 16 )
+					layerNormBlock<16, ( GV_MAXK_LN / 4 + NW * 64 - 1 ) / ( NW * 64 ), NW>( a.lnX + (long long)r0 * a.K, a.M - r0, a.lnW, a.lnB, a.K, tid, lnA, lnB2,
+						[ = ]( int j, int c, f16x4 v ) { *(f16x4*)( xs + ( r0 + j ) * GV_XS_STRIDE + c ) = v; } );
+				__syncthreads();
+			}
 #pragma unroll
 			for( int t = 0; t < MT; t++ )
 			{
@@ -1019,21 +1204,49 @@ namespace wh
 		return -1;
 	}
 
-	template<int EPI, class C = CfgDefault>
-	static int launchTiledT( const GemmArgs& a, hipStream_t stream )
+	template<int EPI, class C, bool WIDE>
+	static int launchTiledK( const GemmArgs& b, hipStream_t stream )
 	{
 		static PerDeviceOnce once;
 		if( once.needed() )
 		{
-			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES ) );
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI, C, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES ) );
 			once.mark();
 		}
-		const int tilesM = ( a.M + C::BM - 1 ) / C::BM, tilesN = ( a.N + C::BN - 1 ) / C::BN;
-		GemmArgs b = a;
-		if( b.groupM == 0 ) b.groupM = ( g_tuning & TUNE_GEMM_GROUP_M ) ? ( C::BM >= 256 ? 4 : 8 ) : 1;
-		hipLaunchKernelGGL( ( gemmTiled<EPI, C> ), dim3( tilesM * tilesN ), dim3( C::NT ), C::LDS_BYTES, stream, b );
+		const int tilesM = ( b.M + C::BM - 1 ) / C::BM, tilesN = ( b.N + C::BN - 1 ) / C::BN;
+		hipLaunchKernelGGL( ( gemmTiled<EPI, C, WIDE> ), dim3( tilesM * tilesN ), dim3( C::NT ), C::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );
 		return 0;
+	}
+
+	template<int EPI, class C = CfgDefault>
+	static int launchTiledT( const GemmArgs& a, hipStream_t stream )
+	{
+		GemmArgs b = a;
+		if( b.groupM == 0 ) b.groupM = ( g_tuning & TUNE_GEMM_GROUP_M ) ? ( C::BM >= 256 ? 4 : 8 ) : 1;
+		// the LDS-transposed epilogue with 16-byte stores needs whole, aligned chunks
+		bool wide = false;
+		constexpr bool canWide = C::GL && C::TI == 2 && C::TJ == 2 &&
+			( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_CONV2 || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV );
+		if( canWide && ( g_tuning & TUNE_GEMM_WIDE_EPI ) )
+		{
+			const bool al16 = ( a.N % 8 ) == 0 && ( a.ldc % 8 ) == 0 && ( a.cBatchStride % 8 ) == 0;
+			switch( EPI )
+			{
+			case EPI_F32: wide = al16 && ( ( (size_t)a.out32 | (size_t)a.res ) % 16 ) == 0; break;
+			case EPI_CONV2: wide = al16 && ( ( (size_t)a.out32 | (size_t)a.pe ) % 16 ) == 0; break;
+			case EPI_F16_GELU: wide = al16 && ( (size_t)a.out16 % 16 ) == 0; break;
+			case EPI_QKV_ENC: wide = ( a.N % 64 ) == 0 && ( ( (size_t)a.q | (size_t)a.k ) % 16 ) == 0; break;
+			case EPI_CROSS_KV: wide = ( a.N % 64 ) == 0 && ( ( (size_t)a.k | (size_t)a.v ) % 16 ) == 0; break;
+			default: break;
+			}
+		}
+		b.wideEpi = wide ? 1 : 0;
+		if constexpr( canWide )
+		{
+			if( wide ) return launchTiledK<EPI, C, true>( b, stream );
+		}
+		return launchTiledK<EPI, C, false>( b, stream );
 	}
 
 	// Tile-shape experiments on the plain FP32 epilogue (tools/gemm_probe.py): variant -> configuration

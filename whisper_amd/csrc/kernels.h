@@ -17,13 +17,17 @@ namespace wh
 		TUNE_FUSE_CROSS_Q = 1024,	 // decode steps: LayerNorm + cross-attention query projection inside the attention kernel
 		TUNE_FUSE_SELF_BLOCK = 4096,	 // decode steps: LayerNorm + per-head QKV + cache append + self-attention in one launch
 		TUNE_GEMV_LN_BLOCK = 8192,	 // decode steps, 17..32 rows: block-wide LayerNorm prologue in the MLP up-projection instead of a launch
+									 // (measured round 2, 28 rows: +11 ms per 28-window batch pass against the separate launch -- OFF)
 		TUNE_GEMV_K8 = 16384,		 // decode steps: 8 waves split K when K >= 2048 (the MLP down-projection)
+		TUNE_SPLIT_STREAMS = 32768,	 // contexts run the encoder on a second, low-priority stream and the decode chain on a high-priority one
+		TUNE_ATTN_ENC_F = 65536,		 // encoder attention: scores recomputed in three sweeps (32 queries x all keys per wave, K/V tiles through LDS)
+		TUNE_GEMM_WIDE_EPI = 131072,	 // tiled GEMM: accumulators leave through LDS as 16-byte row stores instead of 2/4-byte column stores
 		TUNE_GEMM_GROUP_M = 2048,	 // tiled GEMM: blocks walk bands of 4 M tiles (A band stays in the XCD's L2) instead of rows of tiles
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_LN_BLOCK | TUNE_GEMV_K8
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI
 	};
 	extern unsigned g_tuning;
 
@@ -73,6 +77,7 @@ namespace wh
 		const float* lnX;	  // when non-null: A is produced on the fly as fp16( LayerNorm(lnX[m]) * lnW + lnB ), row length K
 		const float* lnW;
 		const float* lnB;
+		int wideEpi;		  // tiled kernel, set by the launcher: the LDS-transposed epilogue with 16-byte stores applies
 		int groupM;			  // tiled kernel: M tiles per band of the block walk (0 = default for the tile shape, 1 = rows of tiles)
 	};
 

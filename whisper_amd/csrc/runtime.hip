@@ -254,6 +254,10 @@ struct wh_context
 	int windowSamples = 0;
 	int windowPos = 0;		   // position the next greedy step feeds (prompt length + steps enqueued so far)
 	hipStream_t copyStream = nullptr;
+	// TUNE_SPLIT_STREAMS: the MFMA-bound encoder on its own low-priority stream, so that the latency-bound decode chains of
+	// OTHER contexts (high-priority streams) get their workgroups dispatched first whenever CUs free up
+	hipStream_t encStream = nullptr;
+	hipEvent_t encReady = nullptr, encDone = nullptr;
 	struct Mark { int endSample; hipEvent_t ev; };
 	std::vector<Mark> marks;   // after each enqueued chunk of samples: an event wh_decode_window_fetch can wait for
 	std::vector<hipEvent_t> markPool;
@@ -702,8 +706,19 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	if( !c->stream )
 	{
 		// the legacy null stream cannot be captured into a hipGraph: own a non-blocking stream instead
-		const hipError_t e = hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking );
-		if( e != hipSuccess ) { delete c; return hipFail( e, "hipStreamCreateWithFlags", __FILE__, __LINE__ ); }
+		hipError_t e;
+		if( g_tuning & TUNE_SPLIT_STREAMS )
+		{
+			int lo = 0, hi = 0;
+			(void)hipDeviceGetStreamPriorityRange( &lo, &hi );	   // lo = least, hi = greatest priority (numerically lower)
+			e = hipStreamCreateWithPriority( &c->stream, hipStreamNonBlocking, hi );
+			if( e == hipSuccess ) e = hipStreamCreateWithPriority( &c->encStream, hipStreamNonBlocking, lo );
+			if( e == hipSuccess ) e = hipEventCreateWithFlags( &c->encReady, hipEventDisableTiming );
+			if( e == hipSuccess ) e = hipEventCreateWithFlags( &c->encDone, hipEventDisableTiming );
+		}
+		else
+			e = hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking );
+		if( e != hipSuccess ) { delete c; return hipFail( e, "hipStreamCreate", __FILE__, __LINE__ ); }
 		c->ownsStream = true;
 	}
 	const wh_hparams& hp = m->hp;
@@ -772,6 +787,9 @@ void wh_context_destroy( wh_context* c )
 	for( auto& mk : c->marks ) (void)hipEventDestroy( mk.ev );
 	for( hipEvent_t e : c->markPool ) (void)hipEventDestroy( e );
 	if( c->copyStream ) (void)hipStreamDestroy( c->copyStream );
+	if( c->encStream ) { (void)hipStreamSynchronize( c->encStream ); (void)hipStreamDestroy( c->encStream ); }
+	if( c->encReady ) (void)hipEventDestroy( c->encReady );
+	if( c->encDone ) (void)hipEventDestroy( c->encDone );
 	for( void* p : c->allocations ) (void)hipFree( p );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
 	if( c->ownsStream ) (void)hipStreamDestroy( c->stream );
@@ -896,7 +914,26 @@ static GemmArgs plainGemm( const f16* A, const f16* W, int M, int N, int K )
 	return g;
 }
 
+static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets );
+
 int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets )
+{
+	if( !c || !c->encStream || c->prof.on ) return encodeImpl( c, melDev, batch, melLen, melStride, melOffsets );
+	// everything queued so far (PCM upload, spectrogram) -> encoder on the low-priority stream -> the decode stream waits for it
+	WH_BIND( c->m );
+	WH_HIP( hipEventRecord( c->encReady, c->stream ) );
+	WH_HIP( hipStreamWaitEvent( c->encStream, c->encReady, 0 ) );
+	hipStream_t const main = c->stream;
+	c->stream = c->encStream;
+	const int rc = encodeImpl( c, melDev, batch, melLen, melStride, melOffsets );
+	c->stream = main;
+	WH_CHECK( rc );
+	WH_HIP( hipEventRecord( c->encDone, c->encStream ) );
+	WH_HIP( hipStreamWaitEvent( c->stream, c->encDone, 0 ) );
+	return 0;
+}
+
+static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets )
 {
 	if( !c || !melDev || batch <= 0 || batch > c->maxBatch || melLen <= 0 ) { setError( "encode: bad argument" ); return WH_E_INVALIDARG; }
 	WH_BIND( c->m );
