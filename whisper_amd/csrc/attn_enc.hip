@@ -373,12 +373,28 @@ namespace wh
 					__builtin_amdgcn_global_load_lds( (GlobalPtr)( VT + (long long)t * F_TILE + ( wave * 2 + i ) * 512 + lane * 8 ),
 						(LdsPtr)( ldsV + buf * F_TILE + ( wave * 2 + i ) * 512 ), 16, 0, 0 );
 			};
+			const float scale = 0.125f;	   // 1 / sqrt(64)
 			// S^T of one 32-key sub-tile: keys (r & 3) + 8 (r >> 2) + 4 hi down the registers, this lane's query across
-			auto scores = [ & ]( const f16* kt, int st ) -> f32x16
+			// Keys >= T (only the last tile has any) never get a per-element test: their accumulator rows START at -3e38 instead of
+			// 0, so the score comes out hugely negative, the clamp of the exponential's argument (one v_med3 that is there
+			// anyway) turns it into exp16( -64 ) = 0, and the row maximum ignores it.
+			auto scores = [ & ]( const f16* kt, int st, int t ) -> f32x16
 			{
 				f32x16 acc;
+				if( t == nTiles - 1 )
+				{
+					// opaque to the optimiser: otherwise the 4 x 16 mask values of the last tile are hoisted out of the three
+					// sweeps and live in registers for the whole kernel (608 spilled VGPRs)
+					int limit = T - ( t * FK + st * 32 + 4 * hi );
+					asm volatile( "" : "+v"( limit ) );
 	#pragma unroll
-				for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
+					for( int r = 0; r < 16; r++ ) acc[ r ] = ( r & 3 ) + 8 * ( r >> 2 ) < limit ? 0.0f : -3.0e38f;
+				}
+				else
+				{
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
+				}
 				const int row = st * 32 + c;
 				const int sw = ( row >> 1 ) & 7;
 	#pragma unroll
@@ -389,15 +405,14 @@ namespace wh
 				}
 				return acc;
 			};
-			const float scale = 0.125f;	   // 1 / sqrt(64)
-			// the four 32-key sub-tiles of tile t. Keys >= T (only the last tile has any) are selected away with a compare + select
-			// per element in every tile: two more VALU operations per score, against a second copy of every loop body (which
-			// measured 141 spilled SGPRs and 165 VGPRs)
 			auto sweepTile = [ & ]( int t, auto&& body )
 			{
 	#pragma unroll
-				for( int st = 0; st < 4; st++ ) body( std::true_type{}, st );
+				for( int st = 0; st < 4; st++ ) body( st );
 			};
+			// exp16 of a score: the argument is clamped to [-64, 0] (exp16( -64 ) == 0 == exp16 of anything below -17.4, and a real
+			// key never exceeds the row maximum), which also absorbs the padded keys' -3e38
+			auto expScore = [ & ]( float sRaw, float mxv ) -> float { return exp16( __builtin_amdgcn_fmed3f( fmaf( sRaw, scale, -mxv ), -64.0f, 0.0f ) ); };
 
 			// ---- sweep 1: row maximum ----
 			float mx = -INFINITY;
@@ -409,21 +424,16 @@ namespace wh
 				__syncthreads();
 				if( t + 1 < nTiles ) issueK( t + 1, buf ^ 1 );
 				const f16* const kt = ldsK + buf * F_TILE;
-				sweepTile( t, [ & ]( auto masked, int st )
+				sweepTile( t, [ & ]( int st )
 				{
-					const f32x16 S = scores( kt, st );
-					const int key0 = t * FK + st * 32 + 4 * hi;
+					// maximum of the RAW products; the positive scale is applied once at the end (max and scaling commute exactly:
+					// scaling by 2^-3 is exact)
+					const f32x16 S = scores( kt, st, t );
 	#pragma unroll
-					for( int r = 0; r < 16; r++ )
-					{
-						const float sv = S[ r ] * scale;
-						if constexpr( decltype( masked )::value )
-							mx = fmaxf( mx, key0 + ( r & 3 ) + 8 * ( r >> 2 ) < T ? sv : -INFINITY );
-						else
-							mx = fmaxf( mx, sv );
-					}
+					for( int r = 0; r < 16; r++ ) mx = fmaxf( mx, S[ r ] );
 				} );
 			}
+			mx *= scale;
 			mx = fmaxf( mx, __shfl_xor( mx, 32, 64 ) );
 
 			// ---- sweep 2: row sum of exp16( s - max ), per-lane FP32 partials of a sub-tile combined in double ----
@@ -437,20 +447,12 @@ namespace wh
 				__syncthreads();
 				if( t + 1 < nTiles ) issueK( t + 1, buf ^ 1 );
 				const f16* const kt = ldsK + buf * F_TILE;
-				sweepTile( t, [ & ]( auto masked, int st )
+				sweepTile( t, [ & ]( int st )
 				{
-					const f32x16 S = scores( kt, st );
-					const int key0 = t * FK + st * 32 + 4 * hi;
+					const f32x16 S = scores( kt, st, t );
 					float part = 0.0f;
 	#pragma unroll
-					for( int r = 0; r < 16; r++ )
-					{
-						// the exponential is evaluated unconditionally (s <= max always holds for real keys; padded keys are
-						// clamped to 0 and then selected away): a per-element branch would serialise the whole sub-tile
-						float e = exp16( fminf( S[ r ] * scale - mx, 0.0f ) );
-						if constexpr( decltype( masked )::value ) e = key0 + ( r & 3 ) + 8 * ( r >> 2 ) < T ? e : 0.0f;
-						part += e;
-					}
+					for( int r = 0; r < 16; r++ ) part += expScore( S[ r ], mx );
 					sum += (double)part;
 				} );
 			}
@@ -478,18 +480,12 @@ namespace wh
 				}
 				const f16* const kt = ldsK + buf * F_TILE;
 				const f16* const vt = ldsV + buf * F_TILE;
-				sweepTile( t, [ & ]( auto masked, int st )
+				sweepTile( t, [ & ]( int st )
 				{
-					const f32x16 S = scores( kt, st );
-					const int key0 = t * FK + st * 32 + 4 * hi;
+					const f32x16 S = scores( kt, st, t );
 					f16x8 P[ 2 ];
 	#pragma unroll
-					for( int r = 0; r < 16; r++ )
-					{
-						float e = exp16( fminf( S[ r ] * scale - mx, 0.0f ) );
-						if constexpr( decltype( masked )::value ) e = key0 + ( r & 3 ) + 8 * ( r >> 2 ) < T ? e : 0.0f;
-						P[ r >> 3 ][ r & 7 ] = (f16)( e * inv );
-					}
+					for( int r = 0; r < 16; r++ ) P[ r >> 3 ][ r & 7 ] = (f16)( expScore( S[ r ], mx ) * inv );
 	#pragma unroll
 					for( int half = 0; half < 2; half++ )
 					{

@@ -136,10 +136,13 @@ namespace wh
 		// an XOR of the 16-byte chunk index applied to the SOURCE address and again when the fragments are read.
 		// A wave owns TI x TJ MFMA tiles of 32x32 (default 2 x 2 = 64x64); 4 x 2 reads 6 fragments for 8 MFMAs instead of 4 for 4,
 		// which is what the LDS bandwidth of a CU asks for.
-		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2>
+		// NBUF (GL only) = LDS stages: 2 = the next tile lands while this one is multiplied (wait for everything at the top of
+		// a K step); 3 or 4 = one or two MORE tiles stay in flight across the step's barrier (counted vmcnt + raw s_barrier),
+		// which is what covers an HBM round trip that is longer than one K step.
+		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2>
 		struct TileCfg
 		{
-			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_;
+			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_, NBUF = NBUF_;
 			static constexpr bool GL = GL_;
 			static constexpr int WAVES_M = BM / ( 32 * TI ), WAVES_N = BN / ( 32 * TJ ), NT = WAVES_M * WAVES_N * 64;
 			static_assert( GL || ( TI == 2 && TJ == 2 ), "the register-staged path is written for 64x64 wave tiles" );
@@ -148,7 +151,8 @@ namespace wh
 			static constexpr int RPB = 128 / BK;				 // GL: tile rows per 256-byte bank row
 			static constexpr int IA = BM / RPI / ( NT / 64 ), IW = BN / RPI / ( NT / 64 );	 // GL: instructions per wave and tile
 			static constexpr int A_HALFS = BM * STRIDE, W_HALFS = BN * STRIDE, STAGE = A_HALFS + W_HALFS;
-			static constexpr int LDS_BYTES = 2 * STAGE * 2;
+			static constexpr int LDS_BYTES = NBUF * STAGE * 2;
+			static_assert( NBUF == 2 || GL, "more than two stages only with direct-to-LDS staging" );
 			static constexpr int CPR = BK / 8;					 // 16-byte chunks per tile row
 			static constexpr int CA = BM * CPR / NT, CW = BN * CPR / NT;
 			static_assert( CA >= 1 && CW >= 1 && BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile does not divide over the threads" );
@@ -618,28 +622,45 @@ namespace wh
 					for( int i = 0; i < C::IW; i++ )
 						__builtin_amdgcn_global_load_lds( (GlobalPtr)( gW[ i ] + ko ), (LdsPtr)( dstW + i * C::RPI * BK ), 16, 0, 0 );
 				};
-				issue( 0, 0 );
+				constexpr int NB = C::NBUF;
+				constexpr int PER_TILE = C::IA + C::IW;	  // LDS-DMA instructions of one tile per wave
+	#pragma unroll
+				for( int p = 0; p < NB - 1; p++ )
+					if( p < nk ) issue( p, p );
 				for( int kt = 0; kt < nk; kt++ )
 				{
-					const int buf = kt & 1;
-					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-					__syncthreads();
-					if( kt + 1 < nk ) issue( kt + 1, buf ^ 1 );
+					const int buf = kt % NB;
+					if constexpr( NB == 2 )
+					{
+						asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+						__syncthreads();
+					}
+					else
+					{
+						// tile kt must have landed; the NB - 2 tiles behind it may stay in flight (they were issued later and
+						// complete in order). A plain __syncthreads() would drain them: raw barrier.
+						if( kt + NB - 2 < nk )
+							asm volatile( "s_waitcnt vmcnt(%0)" ::"n"( ( NB - 2 ) * PER_TILE ) : "memory" );
+						else
+							asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+						__builtin_amdgcn_s_barrier();
+					}
+					if( kt + NB - 1 < nk ) issue( kt + NB - 1, ( kt + NB - 1 ) % NB );
 					const f16* const ldsA = lds + buf * C::STAGE;
 					const f16* const ldsW = ldsA + C::A_HALFS;
-#pragma unroll
+	#pragma unroll
 					for( int ks = 0; ks < BK / 16; ks++ )
 					{
 						f16x8 fa[ C::TI ], fb[ C::TJ ];
-#pragma unroll
+	#pragma unroll
 						for( int i = 0; i < C::TI; i++ )
 							fa[ i ] = *(const f16x8*)( ldsA + glOffset<C>( wm * 32 * C::TI + i * 32 + fragRow, ks * 2 + fragC ) );
-#pragma unroll
+	#pragma unroll
 						for( int j = 0; j < C::TJ; j++ )
 							fb[ j ] = *(const f16x8*)( ldsW + glOffset<C>( wn * 32 * C::TJ + j * 32 + fragRow, ks * 2 + fragC ) );
-#pragma unroll
+	#pragma unroll
 						for( int i = 0; i < C::TI; i++ )
-#pragma unroll
+	#pragma unroll
 							for( int j = 0; j < C::TJ; j++ )
 								acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ], fb[ j ], acc[ i ][ j ], 0, 0, 0 );
 					}
@@ -1254,6 +1275,11 @@ namespace wh
 	{
 		switch( variant )
 		{
+		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );
+		case 21: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 4>>( a, stream );
+		case 22: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1, true, 2, 2, 3>>( a, stream );
+		case 23: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 2>>( a, stream );
+		case 24: return launchTiledT<EPI_F32, TileCfg<128, 256, 64, 2, 1, true, 2, 2, 3>>( a, stream );
 		case 10: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 1, true>>( a, stream );
 		case 11: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true>>( a, stream );
 		case 12: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true>>( a, stream );
