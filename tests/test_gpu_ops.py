@@ -167,8 +167,12 @@ def test_flash_attention(batch, heads, T):
         want[bh // heads, :, (bh % heads) * D:(bh % heads + 1) * D] = o
     qd, kd, vd = dev(q), dev(k), dev(vT)
     L = binding.lib()
-    # both kernels: three sweeps with recomputed scores (default) and scores kept in registers (tuning bit off)
-    for name, mask in (("three-sweep", binding.TUNE_DEFAULT), ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
+    # every kernel variant: two sweeps (default: unnormalised e into P.V, O / sum at the end), the same with the one-multiply
+    # exponential, three sweeps (the reference's fp16(e / sum) operand), and the scores kept in registers
+    for name, mask in (("two-sweep", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP),
+                       ("two-sweep-fastexp", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_FASTEXP),
+                       ("three-sweep", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_2SWEEP),
+                       ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
         L.wh_debug_set_tuning(mask)
         try:
             out = torch.full((batch, T, heads * D), float("nan"), dtype=torch.float16, device="cuda")
@@ -238,6 +242,32 @@ def test_mul_mat_big_tiles(M, N, K):
     print("mul_mat big %dx%dx%d maxdiff %.3e meandiff %.3e" % (M, N, K, float(d.max()), float(d.mean())))
     assert bool(torch.isfinite(out).all())
     assert float(d.max()) < 2e-5 * max(1.0, np.sqrt(K / 128))
+
+
+@pytest.mark.parametrize("M,N,K", [(16500, 4608, 1024), (1500, 1024, 1024), (3000, 384, 1536), (16384 + 77, 4672, 256)])
+def test_mul_mat_fragment_prefetch_is_bit_identical(M, N, K):
+    """TUNE_GEMM_FRAGPF only changes WHEN the MFMA operands are read from LDS (two register sets, counted waits, the
+    direct-to-LDS loads issued as assembly): the products and their order are the same, so both K loops must give the same
+    bits -- on the 128x128x32 and the 256x256x64 instance, ragged edges included. A missing wait shows up here."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + 1)
+    a = torch.randn((M, K), generator=g, device="cuda").half()
+    w = (0.05 * torch.randn((N, K), generator=g, device="cuda")).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    L = binding.lib()
+    outs = []
+    try:
+        for mask in (binding.TUNE_DEFAULT | binding.TUNE_GEMM_FRAGPF, binding.TUNE_DEFAULT & ~binding.TUNE_GEMM_FRAGPF):
+            L.wh_debug_set_tuning(mask)
+            for rep in range(3):        # races are intermittent: a few launches each
+                out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+                binding.check(L.wh_op_mul_mat(None, ptr(a), ptr(w), ptr(bias), None, ptr(out), M, N, K))
+                outs.append(out)
+    finally:
+        L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0]).all())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 def test_mul_mat_gelu_big_tiles(golden):

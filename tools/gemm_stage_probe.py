@@ -12,8 +12,8 @@ def main():
     m = binding.HipModel.from_ggml(gf.synth_model("test-d128", seed=1))
     ctx = binding.HipContext(m, 1)
     shapes = [(42000, 1024, 1024), (42000, 3072, 1024), (42000, 4096, 1024), (42000, 1024, 4096), (48000, 3840, 1280), (48000, 5120, 1280)]
-    tiles = {12: "256x256x64 2 stages", 23: "256x256x32 2 stages", 20: "256x256x32 3 stages", 21: "256x256x32 4 stages",
-             22: "256x128x64 3 stages", 24: "128x256x64 3 stages", 11: "128x128x32 2 stages"}
+    tiles = {12: "256x256x64 2 stages", 25: "256x256x64 2 stages fragpf", 27: "256x256x32 3 stages fragpf", 20: "256x256x32 3 stages", 26: "128x128x32 fragpf",
+             11: "128x128x32 2 stages"}
     for (M, N, K) in shapes:
         row = []
         for v, name in tiles.items():

@@ -308,6 +308,12 @@ namespace wh
 		constexpr int F_TILE = FK * HEAD_DIM;	   // halfs per tile (16 KiB)
 		constexpr int F_LDS_BYTES = 4 * F_TILE * 2;   // K and V, two buffers each
 
+		// TWO: the second and third sweep are one -- O accumulates V^T . e^T with e = exp16( s - max ) (an FP16 number already, so
+		// the operand is exact) while the row sum is formed, and O is scaled by 1 / sum at the end in FP32. That drops the
+		// reference's rounding of e / sum to FP16 (ggml.c:6035-6046), i.e. it is closer to the exact softmax than the
+		// reference is, not bit-compatible with it; the kernel is bound by the exponentials (VALU), and this halves them.
+		// FASTEXP (with TWO): exp16Fast (common.h) instead of the table-exact exp16.
+		template<bool TWO, bool FASTEXP = false>
 		__global__ void __launch_bounds__( 512, 4 ) attentionEncF( const f16* __restrict__ q, const f16* __restrict__ k,
 			const f16* __restrict__ vT, f16* __restrict__ out, int heads, int T, int Tpad, int nQ, int xcdRemap )
 		{
@@ -412,7 +418,12 @@ namespace wh
 			};
 			// exp16 of a score: the argument is clamped to [-64, 0] (exp16( -64 ) == 0 == exp16 of anything below -17.4, and a real
 			// key never exceeds the row maximum), which also absorbs the padded keys' -3e38
-			auto expScore = [ & ]( float sRaw, float mxv ) -> float { return exp16( __builtin_amdgcn_fmed3f( fmaf( sRaw, scale, -mxv ), -64.0f, 0.0f ) ); };
+			auto expScore = [ & ]( float sRaw, float mxv ) -> float
+			{
+				const float x = __builtin_amdgcn_fmed3f( fmaf( sRaw, scale, -mxv ), -64.0f, 0.0f );
+				if constexpr( FASTEXP ) return exp16Fast( x );
+				else return exp16( x );
+			};
 
 			// ---- sweep 1: row maximum ----
 			float mx = -INFINITY;
@@ -438,6 +449,8 @@ namespace wh
 
 			// ---- sweep 2: row sum of exp16( s - max ), per-lane FP32 partials of a sub-tile combined in double ----
 			double sum = 0.0;
+			if constexpr( !TWO )
+			{
 			__syncthreads();
 			issueK( 0, 0 );
 			for( int t = 0; t < nTiles; t++ )
@@ -457,7 +470,8 @@ namespace wh
 				} );
 			}
 			sum += __shfl_xor( sum, 32, 64 );
-			const float inv = (float)( 1.0 / sum );
+			}
+			const float inv = TWO ? 1.0f : (float)( 1.0 / sum );
 
 			// ---- sweep 3: P = fp16( e * inv ) packed straight into the B operand of O^T += V^T . P^T ----
 			f32x16 O[ 2 ];
@@ -484,8 +498,23 @@ namespace wh
 				{
 					const f32x16 S = scores( kt, st, t );
 					f16x8 P[ 2 ];
+					if constexpr( TWO )
+					{
+						float part = 0.0f;
 	#pragma unroll
-					for( int r = 0; r < 16; r++ ) P[ r >> 3 ][ r & 7 ] = (f16)( expScore( S[ r ], mx ) * inv );
+						for( int r = 0; r < 16; r++ )
+						{
+							const float e = expScore( S[ r ], mx );
+							part += e;
+							P[ r >> 3 ][ r & 7 ] = (f16)e;
+						}
+						sum += (double)part;
+					}
+					else
+					{
+	#pragma unroll
+						for( int r = 0; r < 16; r++ ) P[ r >> 3 ][ r & 7 ] = (f16)( expScore( S[ r ], mx ) * inv );
+					}
 	#pragma unroll
 					for( int half = 0; half < 2; half++ )
 					{
@@ -500,6 +529,15 @@ namespace wh
 				} );
 			}
 
+			if constexpr( TWO )
+			{
+				sum += __shfl_xor( sum, 32, 64 );
+				const float invSum = (float)( 1.0 / sum );
+	#pragma unroll
+				for( int a = 0; a < 2; a++ )
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) O[ a ][ r ] *= invSum;
+			}
 			// ---- store: out[b][t][h*64 + dd] FP16; O^T rows are dd = ddt*32 + (r&3) + 8 (r>>2) + 4 hi, the column is this lane's query
 			if( qRow < T )
 			{
@@ -523,12 +561,19 @@ namespace wh
 			static PerDeviceOnce once;
 			if( once.needed() )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
 				once.mark();
 			}
 			const int nQ = ( T + FQ - 1 ) / FQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
-			hipLaunchKernelGGL( attentionEncF, dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
+			if( ( g_tuning & TUNE_ATTN_ENC_2SWEEP ) && ( g_tuning & TUNE_ATTN_ENC_FASTEXP ) )
+				hipLaunchKernelGGL( ( attentionEncF<true, true> ), dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
+			else if( g_tuning & TUNE_ATTN_ENC_2SWEEP )
+				hipLaunchKernelGGL( attentionEncF<true>, dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
+			else
+				hipLaunchKernelGGL( attentionEncF<false>, dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}

@@ -139,10 +139,13 @@ namespace wh
 		// NBUF (GL only) = LDS stages: 2 = the next tile lands while this one is multiplied (wait for everything at the top of
 		// a K step); 3 or 4 = one or two MORE tiles stay in flight across the step's barrier (counted vmcnt + raw s_barrier),
 		// which is what covers an HBM round trip that is longer than one K step.
-		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2>
+		// FRAGPF (GL only): the MFMA fragments of k-substep s+1 are read from LDS before the MFMAs of substep s are issued (two
+		// register sets). hipcc on its own re-uses one set, so every substep starts with an exposed LDS round trip.
+		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2, bool FRAGPF_ = false>
 		struct TileCfg
 		{
 			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_, NBUF = NBUF_;
+			static constexpr bool FRAGPF = FRAGPF_;
 			static constexpr bool GL = GL_;
 			static constexpr int WAVES_M = BM / ( 32 * TI ), WAVES_N = BN / ( 32 * TJ ), NT = WAVES_M * WAVES_N * 64;
 			static_assert( GL || ( TI == 2 && TJ == 2 ), "the register-staged path is written for 64x64 wave tiles" );
@@ -164,6 +167,8 @@ namespace wh
 		using CfgBig = TileCfg<256, 256, 64, 4, 1>;
 		using CfgGl = TileCfg<128, 128, 32, 3, 1, true>;
 		using CfgGlBig = TileCfg<256, 256, 64, 4, 1, true>;
+		using CfgGlPf = TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, true>;
+		using CfgGlBigPf = TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, true>;
 
 		// physical position (in halfs) of logical 16-byte chunk c of tile row `row` in a GL tile
 		template<class C>
@@ -615,6 +620,21 @@ namespace wh
 					f16* const dstA = lds + buf * C::STAGE + wave * C::IA * C::RPI * BK;
 					f16* const dstW = lds + buf * C::STAGE + C::A_HALFS + wave * C::IW * C::RPI * BK;
 					const int ko = kt * BK;
+					if constexpr( C::FRAGPF )
+					{
+						// Issued as assembly: hipcc models the builtin as a FLAT access that may touch LDS and, while one is in
+						// flight, turns every LDS wait of the wave into lgkmcnt(0) -- the fragment prefetch below needs counted
+						// waits. The loads are ordered by the explicit vmcnt waits + barriers of the K loop.
+						const unsigned baseA = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)dstA );
+						const unsigned baseW = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)dstW );
+	#pragma unroll
+						for( int i = 0; i < C::IA; i++ )
+							asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory" );
+	#pragma unroll
+						for( int i = 0; i < C::IW; i++ )
+							asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory" );
+						return;
+					}
 #pragma unroll
 					for( int i = 0; i < C::IA; i++ )
 						__builtin_amdgcn_global_load_lds( (GlobalPtr)( gA[ i ] + ko ), (LdsPtr)( dstA + i * C::RPI * BK ), 16, 0, 0 );
@@ -648,6 +668,48 @@ namespace wh
 					if( kt + NB - 1 < nk ) issue( kt + NB - 1, ( kt + NB - 1 ) % NB );
 					const f16* const ldsA = lds + buf * C::STAGE;
 					const f16* const ldsW = ldsA + C::A_HALFS;
+					if constexpr( C::FRAGPF )
+					{
+						f16x8 fa[ 2 ][ C::TI ], fb[ 2 ][ C::TJ ];
+						auto readFrags = [ & ]( auto set, int ks )
+						{
+							constexpr int S = decltype( set )::value;
+	#pragma unroll
+							for( int i = 0; i < C::TI; i++ )
+								fa[ S ][ i ] = *(const f16x8*)( ldsA + glOffset<C>( wm * 32 * C::TI + i * 32 + fragRow, ks * 2 + fragC ) );
+	#pragma unroll
+							for( int j = 0; j < C::TJ; j++ )
+								fb[ S ][ j ] = *(const f16x8*)( ldsW + glOffset<C>( wn * 32 * C::TJ + j * 32 + fragRow, ks * 2 + fragC ) );
+						};
+						auto mfmas = [ & ]( auto set )
+						{
+							constexpr int S = decltype( set )::value;
+	#pragma unroll
+							for( int i = 0; i < C::TI; i++ )
+	#pragma unroll
+								for( int j = 0; j < C::TJ; j++ )
+									acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ S ][ i ], fb[ S ][ j ], acc[ i ][ j ], 0, 0, 0 );
+						};
+						using S0 = std::integral_constant<int, 0>;
+						using S1 = std::integral_constant<int, 1>;
+						static_assert( ( BK / 16 ) % 2 == 0, "fragment prefetch walks the k-substeps in pairs" );
+						readFrags( S0{}, 0 );
+	#pragma unroll
+						for( int ks = 0; ks < BK / 16; ks += 2 )
+						{
+							// the scheduling fences keep hipcc from sinking the reads back below the MFMAs to save registers
+							readFrags( S1{}, ks + 1 );
+							__builtin_amdgcn_sched_barrier( 0 );
+							mfmas( S0{} );
+							__builtin_amdgcn_sched_barrier( 0 );
+							if( ks + 2 < BK / 16 ) readFrags( S0{}, ks + 2 );
+							__builtin_amdgcn_sched_barrier( 0 );
+							mfmas( S1{} );
+							__builtin_amdgcn_sched_barrier( 0 );
+						}
+					}
+					else
+					{
 	#pragma unroll
 					for( int ks = 0; ks < BK / 16; ks++ )
 					{
@@ -663,6 +725,7 @@ namespace wh
 	#pragma unroll
 							for( int j = 0; j < C::TJ; j++ )
 								acc[ i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ], fb[ j ], acc[ i ][ j ], 0, 0, 0 );
+					}
 					}
 				}
 				if constexpr( WIDE )
@@ -1275,6 +1338,9 @@ namespace wh
 	{
 		switch( variant )
 		{
+		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, true>>( a, stream );
+		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, true>>( a, stream );
+		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, true>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );
 		case 21: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 4>>( a, stream );
 		case 22: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1, true, 2, 2, 3>>( a, stream );
@@ -1335,7 +1401,10 @@ namespace wh
 		// big tiles only when they still give every CU a workgroup and M is several clips deep
 		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
+		const bool pf = gl && ( g_tuning & TUNE_GEMM_FRAGPF ) != 0;
 #define WH_TILED( E )                                                    \
+	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
+	if( pf ) return launchTiledT<E, CfgGlPf>( a, stream );               \
 	if( gl && big ) return launchTiledT<E, CfgGlBig>( a, stream );       \
 	if( gl ) return launchTiledT<E, CfgGl>( a, stream );                 \
 	if( big ) return launchTiledT<E, CfgBig>( a, stream );               \
@@ -1344,7 +1413,7 @@ namespace wh
 		{
 		case EPI_F32: WH_TILED( EPI_F32 )
 		case EPI_F16_GELU: WH_TILED( EPI_F16_GELU )
-		case EPI_CONV2: if( gl ) return launchTiledT<EPI_CONV2, CfgGl>( a, stream ); return launchTiledT<EPI_CONV2>( a, stream );
+		case EPI_CONV2: if( pf ) return launchTiledT<EPI_CONV2, CfgGlPf>( a, stream ); if( gl ) return launchTiledT<EPI_CONV2, CfgGl>( a, stream ); return launchTiledT<EPI_CONV2>( a, stream );
 		case EPI_QKV_ENC: WH_TILED( EPI_QKV_ENC )
 		case EPI_CROSS_KV: WH_TILED( EPI_CROSS_KV )
 		case EPI_QKV_DEC: if( gl ) return launchTiledT<EPI_QKV_DEC, CfgGl>( a, stream ); return launchTiledT<EPI_QKV_DEC>( a, stream );

@@ -1700,6 +1700,18 @@ namespace
 			}
 		}
 	}
+	// max |a - b| over n floats (non-negative floats order like their bit patterns; NaN counts as +inf)
+	__global__ void probeMaxDiff( const float* a, const float* b, long long n, int* out )
+	{
+		float m = 0.0f;
+		for( long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x )
+		{
+			const float d = fabsf( a[ i ] - b[ i ] );
+			m = ( d != d ) ? INFINITY : fmaxf( m, d );
+		}
+		for( int off = 32; off > 0; off >>= 1 ) m = fmaxf( m, __shfl_xor( m, off ) );
+		if( ( threadIdx.x & 63 ) == 0 ) atomicMax( out, __float_as_int( m ) );
+	}
 	__global__ void probeFill( _Float16* p, long long n, unsigned seed )
 	{
 		for( long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x )
@@ -1777,6 +1789,35 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 			WH_HIP( hipEventRecord( e1, st ) );
 			WH_HIP( hipEventSynchronize( e1 ) );
 			WH_HIP( hipEventElapsedTime( &ms, e0, e1 ) );
+		}
+		// every variant is checked against the production path on the same operands: a pipeline that races is fast and wrong
+		if( rc == 0 )
+		{
+			void* ref = nullptr;
+			int* diff = nullptr;
+			WH_HIP( hipMalloc( &ref, (size_t)M * N * 4 ) );
+			WH_HIP( hipMalloc( (void**)&diff, 4 ) );
+			WH_HIP( hipMemsetAsync( diff, 0, 4, st ) );
+			GemmArgs g2 = plainGemm( (const f16*)A, (const f16*)W, M, N, K );
+			g2.epi = EPI_F32; g2.out32 = (float*)ref;
+			rc = launchGemm( g2, st );
+			if( rc == 0 )
+			{
+				hipLaunchKernelGGL( probeMaxDiff, dim3( 2048 ), dim3( 256 ), 0, st, (const float*)out, (const float*)ref, (long long)M * N, diff );
+				int bits = 0;
+				WH_HIP( hipMemcpyAsync( &bits, diff, 4, hipMemcpyDeviceToHost, st ) );
+				WH_HIP( hipStreamSynchronize( st ) );
+				float md;
+				memcpy( &md, &bits, 4 );
+				if( !( md <= 1e-3f ) )
+				{
+					char buf[ 160 ];
+					snprintf( buf, sizeof( buf ), "gemm probe: variant %d differs from the production kernel by %g", variant, (double)md );
+					setError( buf );
+					rc = -1;
+				}
+			}
+			(void)hipFree( ref ); (void)hipFree( diff );
 		}
 		(void)hipFree( A ); (void)hipFree( W ); (void)hipFree( out );
 	}
