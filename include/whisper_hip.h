@@ -83,7 +83,9 @@ typedef enum wh_flags
 {
 	WH_FLAG_NONE = 0,
 	/* Emulate the reference CPU path's FP16, thread-partitioned accumulation of the decoder P.V product
-	 * (Whisper/source/ggml.c:4689-4735, 4615-4644) with `parityThreads` virtual threads. Slow; for parity runs. */
+	 * (Whisper/source/ggml.c:4689-4735, 4615-4644) with `parityThreads` virtual threads, and feed the encoder's P.V product
+	 * the reference's operand fp16( e / sum ) (ggml.c:6035-6046) instead of the exact FP16 e with the division applied to the
+	 * FP32 result. Slow; for parity runs. */
 	WH_FLAG_PARITY_PV = 1,
 	/* Launch the greedy loop's kernels one by one instead of replaying the captured hipGraph (debugging aid). */
 	WH_FLAG_NO_GRAPH = 2,

@@ -167,10 +167,9 @@ def test_flash_attention(batch, heads, T):
         want[bh // heads, :, (bh % heads) * D:(bh % heads + 1) * D] = o
     qd, kd, vd = dev(q), dev(k), dev(vT)
     L = binding.lib()
-    # every kernel variant: two sweeps (default: unnormalised e into P.V, O / sum at the end), the same with the one-multiply
-    # exponential, three sweeps (the reference's fp16(e / sum) operand), and the scores kept in registers
+    # every kernel variant: two sweeps (default: unnormalised e into P.V, O / sum at the end), three sweeps (the reference's
+    # fp16(e / sum) operand), and the scores kept in registers
     for name, mask in (("two-sweep", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP),
-                       ("two-sweep-fastexp", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_FASTEXP),
                        ("three-sweep", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_2SWEEP),
                        ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
         L.wh_debug_set_tuning(mask)

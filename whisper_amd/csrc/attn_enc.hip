@@ -312,8 +312,9 @@ namespace wh
 		// the operand is exact) while the row sum is formed, and O is scaled by 1 / sum at the end in FP32. That drops the
 		// reference's rounding of e / sum to FP16 (ggml.c:6035-6046), i.e. it is closer to the exact softmax than the
 		// reference is, not bit-compatible with it; the kernel is bound by the exponentials (VALU), and this halves them.
-		// FASTEXP (with TWO): exp16Fast (common.h) instead of the table-exact exp16.
-		template<bool TWO, bool FASTEXP = false>
+		// (A one-multiply exponential -- exp2( fp16( x ) * log2 e ) without the hi/lo split of exp16 -- measured SLOWER in this
+		// kernel, 2782 vs 2457 us per launch at 112 windows, and is not table-exact: retired.)
+		template<bool TWO>
 		__global__ void __launch_bounds__( 512, 4 ) attentionEncF( const f16* __restrict__ q, const f16* __restrict__ k,
 			const f16* __restrict__ vT, f16* __restrict__ out, int heads, int T, int Tpad, int nQ, int xcdRemap )
 		{
@@ -349,12 +350,18 @@ namespace wh
 			const int qRow = qb * FQ + wave * 32 + c;
 			const int nTiles = ( T + FK - 1 ) / FK;
 
-			// Q fragments of this lane's query row (B operand), kept for the whole kernel
+			// Q fragments of this lane's query row (B operand), kept for the whole kernel, pre-multiplied by 1 / sqrt(64) = 2^-3: exact
+			// (bar FP16 underflow of |q| < 5e-4, which moves a score by < 1e-8), and S then needs no multiply per element
 			f16x8 qf[ 4 ];
 			{
 				const int qr = qRow < T ? qRow : T - 1;
 	#pragma unroll
-				for( int kk = 0; kk < 4; kk++ ) qf[ kk ] = *(const f16x8*)( Q + (long long)qr * HEAD_DIM + kk * 16 + hi * 8 );
+				for( int kk = 0; kk < 4; kk++ )
+				{
+					qf[ kk ] = *(const f16x8*)( Q + (long long)qr * HEAD_DIM + kk * 16 + hi * 8 );
+	#pragma unroll
+					for( int j = 0; j < 8; j++ ) qf[ kk ][ j ] = qf[ kk ][ j ] * (f16)0.125f;
+				}
 			}
 
 			// K tile t -> LDS buffer: two 1 KiB wave instructions per wave (8 rows each); the XOR of the 16-byte chunk index is
@@ -379,28 +386,15 @@ namespace wh
 					__builtin_amdgcn_global_load_lds( (GlobalPtr)( VT + (long long)t * F_TILE + ( wave * 2 + i ) * 512 + lane * 8 ),
 						(LdsPtr)( ldsV + buf * F_TILE + ( wave * 2 + i ) * 512 ), 16, 0, 0 );
 			};
-			const float scale = 0.125f;	   // 1 / sqrt(64)
-			// S^T of one 32-key sub-tile: keys (r & 3) + 8 (r >> 2) + 4 hi down the registers, this lane's query across
-			// Keys >= T (only the last tile has any) never get a per-element test: their accumulator rows START at -3e38 instead of
-			// 0, so the score comes out hugely negative, the clamp of the exponential's argument (one v_med3 that is there
-			// anyway) turns it into exp16( -64 ) = 0, and the row maximum ignores it.
+			// S^T of one 32-key sub-tile (already scaled): keys (r & 3) + 8 (r >> 2) + 4 hi down the registers, this lane's query across.
+			// The accumulator starts from the constant 0 (an inline operand of the first MFMA, no register initialisation).
+			// Keys >= T (only the last tile has any) are overwritten with -3e38 afterwards: the row maximum ignores them and the
+			// clamp of the exponential's argument turns them into exp16( -64 ) = 0.
 			auto scores = [ & ]( const f16* kt, int st, int t ) -> f32x16
 			{
 				f32x16 acc;
-				if( t == nTiles - 1 )
-				{
-					// opaque to the optimiser: otherwise the 4 x 16 mask values of the last tile are hoisted out of the three
-					// sweeps and live in registers for the whole kernel (608 spilled VGPRs)
-					int limit = T - ( t * FK + st * 32 + 4 * hi );
-					asm volatile( "" : "+v"( limit ) );
 	#pragma unroll
-					for( int r = 0; r < 16; r++ ) acc[ r ] = ( r & 3 ) + 8 * ( r >> 2 ) < limit ? 0.0f : -3.0e38f;
-				}
-				else
-				{
-	#pragma unroll
-					for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
-				}
+				for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
 				const int row = st * 32 + c;
 				const int sw = ( row >> 1 ) & 7;
 	#pragma unroll
@@ -408,6 +402,15 @@ namespace wh
 				{
 					const f16x8 kf = *(const f16x8*)( kt + row * HEAD_DIM + ( ( ( kk * 2 + hi ) ^ sw ) << 3 ) );
 					acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( kf, qf[ kk ], acc, 0, 0, 0 );
+				}
+				if( t == nTiles - 1 )
+				{
+					// opaque to the optimiser: otherwise the 4 x 16 mask tests of the last tile are hoisted out of the sweeps and
+					// live in registers for the whole kernel (608 spilled VGPRs)
+					int limit = T - ( t * FK + st * 32 + 4 * hi );
+					asm volatile( "" : "+v"( limit ) );
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) acc[ r ] = ( r & 3 ) + 8 * ( r >> 2 ) < limit ? acc[ r ] : -3.0e38f;
 				}
 				return acc;
 			};
@@ -418,11 +421,20 @@ namespace wh
 			};
 			// exp16 of a score: the argument is clamped to [-64, 0] (exp16( -64 ) == 0 == exp16 of anything below -17.4, and a real
 			// key never exceeds the row maximum), which also absorbs the padded keys' -3e38
-			auto expScore = [ & ]( float sRaw, float mxv ) -> float
+			auto expScore = [ & ]( float sc, float mxv ) -> float { return exp16( __builtin_amdgcn_fmed3f( sc - mxv, -64.0f, 0.0f ) ); };
+			// sum of 16 FP16-exact numbers <= 1 (the e of one sub-tile, packed as the P operand): v_dot2_f32_f16 against ones adds two
+			// per instruction in FP32 without converting them back first
+			auto sumP = [ & ]( const f16x8 ( &P )[ 2 ] ) -> float
 			{
-				const float x = __builtin_amdgcn_fmed3f( fmaf( sRaw, scale, -mxv ), -64.0f, 0.0f );
-				if constexpr( FASTEXP ) return exp16Fast( x );
-				else return exp16( x );
+				typedef _Float16 h2 __attribute__( ( ext_vector_type( 2 ) ) );
+				const h2 ones = { (f16)1.0f, (f16)1.0f };
+				float part = 0.0f;
+	#pragma unroll
+				for( int h = 0; h < 2; h++ )
+	#pragma unroll
+					for( int j = 0; j < 8; j += 2 )
+						part = __builtin_amdgcn_fdot2( h2{ P[ h ][ j ], P[ h ][ j + 1 ] }, ones, part, false );
+				return part;
 			};
 
 			// ---- sweep 1: row maximum ----
@@ -437,14 +449,11 @@ namespace wh
 				const f16* const kt = ldsK + buf * F_TILE;
 				sweepTile( t, [ & ]( int st )
 				{
-					// maximum of the RAW products; the positive scale is applied once at the end (max and scaling commute exactly:
-					// scaling by 2^-3 is exact)
 					const f32x16 S = scores( kt, st, t );
 	#pragma unroll
 					for( int r = 0; r < 16; r++ ) mx = fmaxf( mx, S[ r ] );
 				} );
 			}
-			mx *= scale;
 			mx = fmaxf( mx, __shfl_xor( mx, 32, 64 ) );
 
 			// ---- sweep 2: row sum of exp16( s - max ), per-lane FP32 partials of a sub-tile combined in double ----
@@ -463,10 +472,10 @@ namespace wh
 				sweepTile( t, [ & ]( int st )
 				{
 					const f32x16 S = scores( kt, st, t );
-					float part = 0.0f;
+					f16x8 E[ 2 ];
 	#pragma unroll
-					for( int r = 0; r < 16; r++ ) part += expScore( S[ r ], mx );
-					sum += (double)part;
+					for( int r = 0; r < 16; r++ ) E[ r >> 3 ][ r & 7 ] = (f16)expScore( S[ r ], mx );
+					sum += (double)sumP( E );
 				} );
 			}
 			sum += __shfl_xor( sum, 32, 64 );
@@ -500,15 +509,9 @@ namespace wh
 					f16x8 P[ 2 ];
 					if constexpr( TWO )
 					{
-						float part = 0.0f;
 	#pragma unroll
-						for( int r = 0; r < 16; r++ )
-						{
-							const float e = expScore( S[ r ], mx );
-							part += e;
-							P[ r >> 3 ][ r & 7 ] = (f16)e;
-						}
-						sum += (double)part;
+						for( int r = 0; r < 16; r++ ) P[ r >> 3 ][ r & 7 ] = (f16)expScore( S[ r ], mx );
+						sum += (double)sumP( P );
 					}
 					else
 					{
@@ -556,21 +559,19 @@ namespace wh
 			}
 		}
 
-		int launchEncF( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
+		int launchEncF( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream )
 		{
 			static PerDeviceOnce once;
 			if( once.needed() )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
 				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
-				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
 				once.mark();
 			}
 			const int nQ = ( T + FQ - 1 ) / FQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
-			if( ( g_tuning & TUNE_ATTN_ENC_2SWEEP ) && ( g_tuning & TUNE_ATTN_ENC_FASTEXP ) )
-				hipLaunchKernelGGL( ( attentionEncF<true, true> ), dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
-			else if( g_tuning & TUNE_ATTN_ENC_2SWEEP )
+			const bool two = !exactP && ( g_tuning & TUNE_ATTN_ENC_2SWEEP );
+			if( two )
 				hipLaunchKernelGGL( attentionEncF<true>, dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
 			else
 				hipLaunchKernelGGL( attentionEncF<false>, dim3( nQ * BH ), dim3( 512 ), F_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
@@ -597,14 +598,14 @@ namespace wh
 
 	int attentionInit() { return 0; }
 
-	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
+	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream )
 	{
 		if( T <= 0 || T > 1536 || Tpad < ( ( T + 255 ) / 256 ) * 256 || ( Tpad & 7 ) != 0 )
 		{
 			setError( "attentionEnc: need 0 < T <= 1536 and Tpad >= roundup(T, 256)" );
 			return -1;
 		}
-		if( g_tuning & TUNE_ATTN_ENC_F ) return launchEncF( q, k, vT, out, batch, heads, T, Tpad, stream );
+		if( g_tuning & TUNE_ATTN_ENC_F ) return launchEncF( q, k, vT, out, batch, heads, T, Tpad, exactP, stream );
 		switch( ( T + 255 ) / 256 )
 		{
 		case 1: return launchEncT<1>( q, k, vT, out, batch, heads, T, Tpad, stream );

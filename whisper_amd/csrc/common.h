@@ -54,16 +54,6 @@ namespace wh
 		return (float)(f16)r;
 	}
 
-	// exp16 without the hi/lo split of the exponent: one multiply + v_exp_f32. The product x * log2(e) carries up to
-	// |x| * 2^-24 of absolute error, i.e. <= 1e-6 relative in the result for |x| <= 17.4 (beyond that the table is 0), so the
-	// FP16 rounding lands on the table's neighbour in ~0.05 % (|x| < 2) to ~0.4 % (|x| ~ 17) of the inputs -- one FP16 ulp,
-	// the size of the rounding error every table entry already carries. For the encoder's attention weights only.
-	__device__ __forceinline__ float exp16Fast( float x )
-	{
-		const float f = round16( x );
-		return (float)(f16)__builtin_amdgcn_exp2f( f * 1.44269502162933349609375f );
-	}
-
 	__device__ __forceinline__ float waveReduceMax( float v )
 	{
 #pragma unroll

@@ -154,7 +154,8 @@ namespace wh
 			static constexpr int RPB = 128 / BK;				 // GL: tile rows per 256-byte bank row
 			static constexpr int IA = BM / RPI / ( NT / 64 ), IW = BN / RPI / ( NT / 64 );	 // GL: instructions per wave and tile
 			static constexpr int A_HALFS = BM * STRIDE, W_HALFS = BN * STRIDE, STAGE = A_HALFS + W_HALFS;
-			static constexpr int LDS_BYTES = NBUF * STAGE * 2;
+			// the LDS-transposed epilogue (tileEpilogueWide) takes 8 KiB per wave once the operand tiles are dead
+			static constexpr int LDS_BYTES = ( NBUF * STAGE * 2 > ( GL ? NT / 64 * 8192 : 0 ) ) ? NBUF * STAGE * 2 : NT / 64 * 8192;
 			static_assert( NBUF == 2 || GL, "more than two stages only with direct-to-LDS staging" );
 			static constexpr int CPR = BK / 8;					 // 16-byte chunks per tile row
 			static constexpr int CA = BM * CPR / NT, CW = BN * CPR / NT;

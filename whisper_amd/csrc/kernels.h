@@ -24,7 +24,6 @@ namespace wh
 		TUNE_GEMM_WIDE_EPI = 131072,	 // tiled GEMM: accumulators leave through LDS as 16-byte row stores instead of 2/4-byte column stores
 		TUNE_GEMM_FRAGPF = 262144,	 // direct-to-LDS tiled GEMM: MFMA fragments of k-substep s+1 are read before the MFMAs of substep s (two register sets, counted LDS waits)
 		TUNE_ATTN_ENC_2SWEEP = 524288,	 // attentionEncF: row sum and P.V in one sweep with the unnormalised FP16 e, O scaled by 1 / sum at the end
-		TUNE_ATTN_ENC_FASTEXP = 1048576, // attentionEncF (two sweeps): exp16Fast, one multiply + v_exp_f32 (OFF: measured first)
 		TUNE_GEMM_GROUP_M = 2048,	 // tiled GEMM: blocks walk bands of 4 M tiles (A band stays in the XCD's L2) instead of rows of tiles
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
@@ -111,7 +110,8 @@ namespace wh
 	// attention
 	// ---------------------------------------------------------------------------------------------------------------
 	// encoder (unmasked) attention, all keys; q,k [bh][T][64], vT [bh][64][Tpad], out [b][T][H*64] FP16
-	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream );
+	// exactP: the P.V operand is the reference's fp16( e / sum ) (ggml.c:6035-6046) even when the two-sweep kernel is selected
+	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream );
 	int attentionInit();
 
 	struct DecAttnArgs

@@ -989,7 +989,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 			WH_CHECK( gemmP( c, g, false ) );
 		}
 		WH_CHECK( profiled( c, KC_ATTN_ENC, 4.0 * batch * H * (double)T * T * HEAD_DIM, 2.0 * 4.0 * batch * H * (double)T * HEAD_DIM,
-			[ & ]() { return launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, st ); } ) );
+			[ & ]() { return launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, ( c->flags & WH_FLAG_PARITY_PV ) != 0, st ); } ) );
 		if( il == 0 ) WH_CHECK( capture( c, c->capEncKqv, c->attn, (int64_t)M * d, (int64_t)c->maxBatch * T * d ) );	// "enc-KQV"
 		{
 			GemmArgs g = plainGemm( c->attn, m->at<f16>( e.wo ), M, d, d );
@@ -1614,7 +1614,7 @@ int wh_op_layer_norm( void* stream, const float* x, const float* w, const float*
 
 int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vT, void* out, int batch, int heads, int nCtx )
 {
-	return launchAttentionEnc( (const f16*)q, (const f16*)k, (const f16*)vT, (f16*)out, batch, heads, nCtx, roundUp( nCtx, 256 ), (hipStream_t)stream );
+	return launchAttentionEnc( (const f16*)q, (const f16*)k, (const f16*)vT, (f16*)out, batch, heads, nCtx, roundUp( nCtx, 256 ), false, (hipStream_t)stream );
 }
 
 int wh_op_decoder_attention( void* stream, const void* qF16, const void* kCache, const void* vCache, void* outF16, int sequences, int heads,
