@@ -290,10 +290,13 @@ def test_mul_mat_gelu_big_tiles(golden):
 
 
 @pytest.mark.parametrize("M,N,K", [(33, 1024, 1024), (40, 3840, 1280), (64, 1024, 4096), (65, 4096, 1024), (84, 1024, 1024),
-                                   (112, 5120, 1280), (128, 1024, 1024), (100, 51865, 1024)])
+                                   (112, 5120, 1280), (128, 1024, 1024), (100, 51865, 1024), (112, 1024, 4096), (112, 1280, 5120),
+                                   (49, 1000, 384), (96, 52, 2048)])
 def test_mul_mat_decode_rows(M, N, K):
-    """33 .. 128 activation rows through the decode kernel (gemvFused, four MFMA column tiles per weight fragment, two
-    row groups beyond 64 rows): what a lock-step batch of up to 128 sequences runs every token."""
+    """33 .. 128 activation rows through the decode kernels -- what a lock-step batch of up to 128 sequences runs every token:
+    gemmSplitK (default: 32 columns x all rows x one K slice per workgroup, slices combined in ticket order) and gemvFused
+    (tuning bit off: four MFMA column tiles per weight fragment, two row groups beyond 64 rows). The split-K result must
+    not depend on which workgroup arrives last: repeated launches are bit-identical."""
     rng = np.random.default_rng(M * 3 + N)
     a = rng.standard_normal((M, K)).astype(np.float16)
     w = (0.05 * rng.standard_normal((N, K))).astype(np.float16)
@@ -301,11 +304,48 @@ def test_mul_mat_decode_rows(M, N, K):
     res = rng.standard_normal((M, N)).astype(np.float32)
     want = (a.astype(np.float64) @ w.astype(np.float64).T + bias + res).astype(np.float32)
     ad, wd, bd, rd = dev(a), dev(w), dev(bias), dev(res)
-    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-    binding.check(binding.lib().wh_op_mul_mat(None, ptr(ad), ptr(wd), ptr(bd), ptr(rd), ptr(out), M, N, K))
-    torch.cuda.synchronize()
-    d = report("mul_mat decode rows %dx%dx%d" % (M, N, K), out.cpu().numpy(), want)
-    assert d.max() < 2e-5 * max(1.0, np.sqrt(K / 128))
+    L = binding.lib()
+    for name, mask in (("split-K", binding.TUNE_DEFAULT | binding.TUNE_GEMV_SPLITK), ("gemv", binding.TUNE_DEFAULT & ~binding.TUNE_GEMV_SPLITK)):
+        outs = []
+        try:
+            L.wh_debug_set_tuning(mask)
+            for rep in range(4):
+                out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+                binding.check(L.wh_op_mul_mat(None, ptr(ad), ptr(wd), ptr(bd), ptr(rd), ptr(out), M, N, K))
+                outs.append(out)
+            torch.cuda.synchronize()
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+        d = report("mul_mat decode rows %s %dx%dx%d" % (name, M, N, K), outs[0].cpu().numpy(), want)
+        assert d.max() < 2e-5 * max(1.0, np.sqrt(K / 128))
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("M,N,K", [(112, 4096, 1024), (48, 5120, 1280), (128, 2000, 512)])
+def test_mul_mat_gelu_decode_rows(M, N, K, golden):
+    """The MLP up-projection of a 33 .. 128-row decode step: split-K kernel with the FP16 GELU-table epilogue."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randn((M, K), generator=g, device="cuda").half()
+    w = (0.1 * torch.randn((N, K), generator=g, device="cuda")).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    pre = (_torch_ref_mul_mat(a, w, bias)).float()
+    table = torch.from_numpy(golden["table_gelu"].astype(np.int32)).cuda()
+    idx = pre.half().view(torch.int16).to(torch.int32) & 0xFFFF
+    want = table[idx.long()].to(torch.int16).view(torch.float16).float()
+    L = binding.lib()
+    for name, mask in (("split-K", binding.TUNE_DEFAULT | binding.TUNE_GEMV_SPLITK), ("gemv", binding.TUNE_DEFAULT & ~binding.TUNE_GEMV_SPLITK)):
+        try:
+            L.wh_debug_set_tuning(mask)
+            out = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+            binding.check(L.wh_op_mul_mat_gelu(None, ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K))
+            torch.cuda.synchronize()
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+        d = (out.float() - want).abs()
+        frac = float((d > 0).float().mean())
+        print("mul_mat_gelu decode rows %s %dx%dx%d: %.4f %% of entries differ, max %.3e" % (name, M, N, K, 100 * frac, float(d.max())))
+        assert frac < 0.02 and bool((d <= torch.maximum(torch.tensor(4e-3, device="cuda"), want.abs() * 2.0 ** -10)).all())
 
 
 def _np_decoder_attention(q, K, V, n_tok, n_keys, causal, n_past, group, n_threads):

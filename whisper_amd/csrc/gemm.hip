@@ -17,6 +17,7 @@
 //   workgroup), the few activation rows are the B operand; 4 waves split K and reduce through LDS.
 // gemvFused: the decode-step kernel, up to 32 activation rows (see below).
 #include "kernels.h"
+#include <mutex>
 #include <type_traits>
 
 namespace wh
@@ -1209,7 +1210,282 @@ namespace wh
 				}
 			}
 		}
+
+		// -----------------------------------------------------------------------------------------------------------
+		// gemmSplitK: 33 .. 128 activation rows (one decode step of a 33 .. 128-sequence lock-step batch).
+		// The product is tiny (M = 112: 0.2 .. 1 GFLOP) and the weights are 2 .. 8 MB that should cross HBM once, so the only
+		// question is how many CUs pull on them at the same time: a CU streams a few tens of GB/s, the chip needs all 256.
+		// gemvFused gets its parallelism from N alone (16 columns per workgroup: 64 workgroups for N = 1024) and re-reads the
+		// activation rows once per 16 columns. Here a workgroup owns 32 columns x ALL rows x one K slice:
+		//   * grid = column tiles x S slices, S chosen by the launcher so that 256 .. 768 workgroups exist; the S slices of a
+		//     tile are placed on one XCD (their partial sums meet in that XCD's L2);
+		//   * 4 waves split the slice; a wave keeps MT x 2 MFMA 16x16x32 tiles (all rows x 32 columns) and has two k-steps of
+		//     loads (2 weight + MT activation fragments each) in flight;
+		//   * the 4 partial tiles meet in LDS, wave w sums accumulator groups w, w + 4, ... in the fixed order 0, 1, 2, 3;
+		//   * S > 1: the workgroup's partial goes to the context's scratch (coalesced 256-byte rows), fence, one atomic ticket
+		//     per tile; the workgroup that draws the last ticket adds the S partials in the fixed order 0 .. S - 1 and runs
+		//     the epilogue, so the result does not depend on which workgroup finishes last; it also resets the ticket.
+		template<int EPI, int MT>
+		__global__ void __launch_bounds__( 256 ) gemmSplitK( const GemmArgs a, int S, int kSlice, int xcdMap )
+		{
+			constexpr int NW = 4, CT = 2, G = MT * CT;
+			constexpr int GPW = ( G + NW - 1 ) / NW;	   // accumulator groups (4 registers x 64 lanes) a wave owns after the LDS exchange
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) float redK[];	 // [NW][G * 4][64]
+			__shared__ int lastFlag;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			int tile, s;
+			{
+				const int b = blockIdx.x;
+				if( xcdMap )
+				{
+					tile = ( b & 7 ) + 8 * ( b / ( 8 * S ) );
+					s = ( b >> 3 ) % S;
+				}
+				else
+				{
+					tile = b / S;
+					s = b - tile * S;
+				}
+			}
+			const int n0 = tile * 16 * CT;
+			const int kPer = kSlice / NW;
+			const int kBeg = s * kSlice + wave * kPer + ( lane >> 4 ) * 8;
+			const int steps = kPer / 32;
+
+			const f16* pw[ CT ];
+	#pragma unroll
+			for( int c = 0; c < CT; c++ )
+			{
+				int n = n0 + c * 16 + ( lane & 15 );
+				n = n < a.N ? n : a.N - 1;
+				pw[ c ] = a.W + (long long)n * a.K + kBeg;
+			}
+			const f16* px[ MT ];
+	#pragma unroll
+			for( int t = 0; t < MT; t++ )
+			{
+				int m = t * 16 + ( lane & 15 );
+				m = m < a.M ? m : a.M - 1;
+				px[ t ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
+			}
+
+			f32x4 acc[ MT ][ CT ];
+	#pragma unroll
+			for( int t = 0; t < MT; t++ )
+	#pragma unroll
+				for( int c = 0; c < CT; c++ ) acc[ t ][ c ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+			for( int s0 = 0; s0 < steps; s0 += 2 )
+			{
+				f16x8 fw[ 2 ][ CT ], fx[ 2 ][ MT ];
+	#pragma unroll
+				for( int u = 0; u < 2; u++ )
+					if( s0 + u < steps )
+					{
+	#pragma unroll
+						for( int c = 0; c < CT; c++ ) fw[ u ][ c ] = __builtin_nontemporal_load( (const f16x8*)( pw[ c ] + ( s0 + u ) * 32 ) );
+	#pragma unroll
+						for( int t = 0; t < MT; t++ ) fx[ u ][ t ] = *(const f16x8*)( px[ t ] + ( s0 + u ) * 32 );
+					}
+	#pragma unroll
+				for( int u = 0; u < 2; u++ )
+					if( s0 + u < steps )
+					{
+	#pragma unroll
+						for( int t = 0; t < MT; t++ )
+	#pragma unroll
+							for( int c = 0; c < CT; c++ )
+								acc[ t ][ c ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ][ c ], fx[ u ][ t ], acc[ t ][ c ], 0, 0, 0 );
+					}
+			}
+
+			// ---- the 4 K-quarters of the workgroup meet in LDS ----
+	#pragma unroll
+			for( int t = 0; t < MT; t++ )
+	#pragma unroll
+				for( int c = 0; c < CT; c++ )
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) redK[ ( wave * G * 4 + ( t * CT + c ) * 4 + r ) * 64 + lane ] = acc[ t ][ c ][ r ];
+			__syncthreads();
+			f32x4 part[ GPW ];
+	#pragma unroll
+			for( int i = 0; i < GPW; i++ )
+			{
+				const int g = wave + NW * i;
+				if( g >= G ) continue;
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+				{
+					float v = redK[ ( 0 * G * 4 + g * 4 + r ) * 64 + lane ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) v += redK[ ( w * G * 4 + g * 4 + r ) * 64 + lane ];
+					part[ i ][ r ] = v;
+				}
+			}
+
+			if( S > 1 )
+			{
+				// ---- the S slices of the tile meet in the scratch buffer; the last one to arrive adds them in slice order ----
+				const long long tileFloats = (long long)G * 256;
+				float* const mine = a.splitScratch + ( (long long)tile * S + s ) * tileFloats;
+	#pragma unroll
+				for( int i = 0; i < GPW; i++ )
+				{
+					const int g = wave + NW * i;
+					if( g >= G ) continue;
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) mine[ ( g * 4 + r ) * 64 + lane ] = part[ i ][ r ];
+				}
+				__threadfence();
+				__syncthreads();
+				if( tid == 0 )
+				{
+					const unsigned ticket = atomicAdd( a.splitCounters + tile, 1u );
+					lastFlag = ticket == (unsigned)( S - 1 ) ? 1 : 0;
+				}
+				__syncthreads();
+				if( !lastFlag ) return;
+				__threadfence();
+				const float* const base = a.splitScratch + (long long)tile * S * tileFloats;
+	#pragma unroll
+				for( int i = 0; i < GPW; i++ )
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) part[ i ][ r ] = 0.0f;
+	#pragma unroll 2
+				for( int ss = 0; ss < S; ss++ )
+				{
+	#pragma unroll
+					for( int i = 0; i < GPW; i++ )
+					{
+						const int g = wave + NW * i;
+						if( g >= G ) continue;
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) part[ i ][ r ] += base[ ss * tileFloats + ( g * 4 + r ) * 64 + lane ];
+					}
+				}
+				if( tid == 0 ) a.splitCounters[ tile ] = 0;	  // the next launch on this stream starts from zero
+			}
+
+			// ---- epilogue: group g = (row tile t, column fragment c); D[row][col]: col = lane & 15 = activation row, row = weight row slot
+			const bool fastEp = EPI == EPI_F32 && ( a.N & 3 ) == 0 && a.Mb >= a.M;
+	#pragma unroll
+			for( int i = 0; i < GPW; i++ )
+			{
+				const int g = wave + NW * i;
+				if( g >= G ) continue;
+				const int t = g / CT, c = g - t * CT;
+				const int mm = t * 16 + ( lane & 15 );
+				const int nn = n0 + c * 16 + ( lane >> 4 ) * 4;
+				if( mm >= a.M || nn >= a.N ) continue;
+				if( fastEp )
+				{
+					// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
+					f32x4 o = part[ i ];
+					if( a.bias )
+					{
+						const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) o[ r ] += bv[ r ];
+					}
+					const long long off = (long long)mm * a.ldc + nn;
+					if( a.res )
+					{
+						const f32x4 rv = *(const f32x4*)( a.res + off );
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) o[ r ] += rv[ r ];
+					}
+					*(f32x4*)( a.out32 + off ) = o;
+					continue;
+				}
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+					if( nn + r < a.N ) epilogueOne<EPI>( a, mm, nn + r, part[ i ][ r ] );
+			}
+		}
 	}	// namespace
+
+	// Process-wide scratch for the standalone op entry points (no context): one stream at a time.
+	static float* g_splitScratch[ 16 ] = {};
+	static unsigned* g_splitCounters[ 16 ] = {};
+	constexpr long long SPLITK_SCRATCH_FLOATS = 4ll << 20;	  // 16 MiB: 1024 workgroup partials of 8 x 2 tiles
+	constexpr int SPLITK_COUNTERS = 4096;
+
+	template<int EPI, int MT>
+	static int launchSplitKT( const GemmArgs& a, int tiles, int S, hipStream_t stream )
+	{
+		constexpr int G = MT * 2;
+		constexpr int lds = 4 * G * 4 * 64 * 4;
+		if( lds > 48 * 1024 )
+		{
+			static PerDeviceOnce once;
+			if( once.needed() )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmSplitK<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				once.mark();
+			}
+		}
+		const int xcdMap = ( tiles % 8 ) == 0 && S > 1 ? 1 : 0;
+		hipLaunchKernelGGL( ( gemmSplitK<EPI, MT> ), dim3( tiles * S ), dim3( 256 ), lds, stream, a, S, a.K / S, xcdMap );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	// 33 .. 128 rows, EPI_F32 / EPI_F16_GELU, A in global memory. Returns 1 when the shape is not covered (the caller falls back).
+	static int launchSplitK( const GemmArgs& a0, hipStream_t stream )
+	{
+		GemmArgs a = a0;
+		if( a.lnX || ( a.epi != EPI_F32 && a.epi != EPI_F16_GELU ) || a.M <= 32 || a.M > 128 || ( a.K % 128 ) != 0 ) return 1;
+		if( !a.splitScratch || !a.splitCounters )
+		{
+			int dev = 0;
+			WH_HIP( hipGetDevice( &dev ) );
+			if( dev < 0 || dev >= 16 ) return 1;
+			static std::mutex mtx;
+			std::lock_guard<std::mutex> lock( mtx );
+			if( !g_splitScratch[ dev ] )
+			{
+				WH_HIP( hipMalloc( (void**)&g_splitScratch[ dev ], (size_t)SPLITK_SCRATCH_FLOATS * 4 ) );
+				WH_HIP( hipMalloc( (void**)&g_splitCounters[ dev ], (size_t)SPLITK_COUNTERS * 4 ) );
+				WH_HIP( hipMemset( g_splitCounters[ dev ], 0, (size_t)SPLITK_COUNTERS * 4 ) );
+			}
+			a.splitScratch = g_splitScratch[ dev ];
+			a.splitCounters = g_splitCounters[ dev ];
+			a.splitScratchFloats = SPLITK_SCRATCH_FLOATS;
+			a.splitCounterCount = SPLITK_COUNTERS;
+		}
+		const int MT = ( a.M + 15 ) / 16;
+		const int tiles = ( a.N + 31 ) / 32;
+		// S = the largest divisor of K / 128 (a wave's share of a slice is whole 32-wide k-steps) that keeps the grid <= 768
+		// workgroups and fits the scratch
+		const int kUnits = a.K / 128;
+		int S = 1;
+		for( int cand = 2; cand <= kUnits; cand++ )
+			if( ( kUnits % cand ) == 0 && (long long)tiles * cand <= 768 ) S = cand;
+		while( S > 1 && ( (long long)tiles * S * MT * 2 * 256 > a.splitScratchFloats || tiles > a.splitCounterCount ) )
+		{
+			int next = 1;
+			for( int cand = 1; cand < S; cand++ )
+				if( ( kUnits % cand ) == 0 ) next = cand;
+			S = next;
+		}
+		if( tiles > a.splitCounterCount && S > 1 ) S = 1;
+#define WH_SPLITK( E )                                                     \
+	switch( MT )                                                           \
+	{                                                                      \
+	case 3: return launchSplitKT<E, 3>( a, tiles, S, stream );             \
+	case 4: return launchSplitKT<E, 4>( a, tiles, S, stream );             \
+	case 5: return launchSplitKT<E, 5>( a, tiles, S, stream );             \
+	case 6: return launchSplitKT<E, 6>( a, tiles, S, stream );             \
+	case 7: return launchSplitKT<E, 7>( a, tiles, S, stream );             \
+	default: return launchSplitKT<E, 8>( a, tiles, S, stream );            \
+	}
+		if( a.epi == EPI_F32 ) { WH_SPLITK( EPI_F32 ) }
+		WH_SPLITK( EPI_F16_GELU )
+#undef WH_SPLITK
+	}
 
 	template<int EPI, int PRO, int ROWS, int NW, int UNROLL, int MT>
 	static int launchGemvK( const GemmArgs& a, hipStream_t stream )
@@ -1256,6 +1532,11 @@ namespace wh
 			return -1;
 		}
 		const bool ln = a.lnX != nullptr;
+		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_SPLITK ) )
+		{
+			const int rc = launchSplitK( a, stream );
+			if( rc <= 0 ) return rc;
+		}
 		if( ln && ( a.K > GV_MAXK_LN || a.M > 32 ) )
 		{
 			setError( "gemv: the fused LayerNorm prologue supports up to 32 rows of up to 1280 columns" );
