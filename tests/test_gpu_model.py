@@ -291,12 +291,19 @@ def test_hypotheses_share_cross_attention(hip_tiny, golden):
 
 
 @pytest.mark.parametrize("bit,batch", [("TUNE_FUSE_CROSS_Q", 2), ("TUNE_FUSE_SELF_BLOCK", 2), ("TUNE_FUSE_SELF_BLOCK", 25), ("TUNE_GEMV_LN_BLOCK", 20),
-                                       ("TUNE_GEMV_K8", 3)])
+                                       ("TUNE_GEMV_K8", 3),
+                                       # 2 heads x 170 / 390 sequences: 2 / 4 sequences per workgroup of the fused self-attention block
+                                       ("TUNE_FUSE_SELF_BLOCK", 170), ("TUNE_FUSE_SELF_BLOCK", 390),
+                                       # its projection on the matrix cores vs on the VALU (1 and 4 sequences per workgroup)
+                                       ("TUNE_SELF_MFMA", 3), ("TUNE_SELF_MFMA", 390),
+                                       # 40 and 100 rows: 32 instead of 64 rows per workgroup in the decode products
+                                       ("TUNE_GEMV_ROWGROUPS", 40), ("TUNE_GEMV_ROWGROUPS", 100)])
 def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
     """Decode steps with a fusion switched on against the same steps with the separate launches (tuning bit off):
     LayerNorm + cross-attention query inside the attention kernel; LayerNorm + per-head QKV + cache append + self-attention
-    as one kernel (1, 2 or 4 sequences per workgroup); the workgroup-wide LayerNorm prologue of the 17..32-row gemv; 8 waves
-    splitting K in the MLP down-projection. Only FP32 summation order may differ."""
+    as one kernel (1, 2 or 4 sequences per workgroup), its Q/K/V projection as MFMA tiles; the workgroup-wide LayerNorm
+    prologue of the 17..32-row gemv; 8 waves splitting K in the MLP down-projection; the row grouping of the 33..128-row
+    products. Only FP32 summation order may differ."""
     pad = np.zeros((80, 3000), np.float32)
     pad[:, :1100] = golden["mel"]
     mel = torch.from_numpy(pad).cuda()

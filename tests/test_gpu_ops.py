@@ -291,12 +291,12 @@ def test_mul_mat_gelu_big_tiles(golden):
 
 @pytest.mark.parametrize("M,N,K", [(33, 1024, 1024), (40, 3840, 1280), (64, 1024, 4096), (65, 4096, 1024), (84, 1024, 1024),
                                    (112, 5120, 1280), (128, 1024, 1024), (100, 51865, 1024), (112, 1024, 4096), (112, 1280, 5120),
-                                   (49, 1000, 384), (96, 52, 2048)])
+                                   (49, 1000, 384), (96, 52, 2048), (40, 20000, 256)])
 def test_mul_mat_decode_rows(M, N, K):
     """33 .. 128 activation rows through the decode kernels -- what a lock-step batch of up to 128 sequences runs every token:
-    gemmSplitK (default: 32 columns x all rows x one K slice per workgroup, slices combined in ticket order) and gemvFused
-    (tuning bit off: four MFMA column tiles per weight fragment, two row groups beyond 64 rows). The split-K result must
-    not depend on which workgroup arrives last: repeated launches are bit-identical."""
+    gemvFused with 32 or 64 rows per workgroup (whichever gives >= 256 workgroups) and, for the vocabulary-sized N,
+    gemmAllRows (32 columns x all rows per workgroup); with both tuning bits off, the 64-row gemvFused for everything.
+    Repeated launches are bit-identical (fixed summation order)."""
     rng = np.random.default_rng(M * 3 + N)
     a = rng.standard_normal((M, K)).astype(np.float16)
     w = (0.05 * rng.standard_normal((N, K))).astype(np.float16)
@@ -305,7 +305,7 @@ def test_mul_mat_decode_rows(M, N, K):
     want = (a.astype(np.float64) @ w.astype(np.float64).T + bias + res).astype(np.float32)
     ad, wd, bd, rd = dev(a), dev(w), dev(bias), dev(res)
     L = binding.lib()
-    for name, mask in (("split-K", binding.TUNE_DEFAULT | binding.TUNE_GEMV_SPLITK), ("gemv", binding.TUNE_DEFAULT & ~binding.TUNE_GEMV_SPLITK)):
+    for name, mask in (("default", binding.TUNE_DEFAULT), ("gemv64", binding.TUNE_DEFAULT & ~(binding.TUNE_GEMV_ALLROWS | binding.TUNE_GEMV_ROWGROUPS))):
         outs = []
         try:
             L.wh_debug_set_tuning(mask)
@@ -324,7 +324,7 @@ def test_mul_mat_decode_rows(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(112, 4096, 1024), (48, 5120, 1280), (128, 2000, 512)])
 def test_mul_mat_gelu_decode_rows(M, N, K, golden):
-    """The MLP up-projection of a 33 .. 128-row decode step: split-K kernel with the FP16 GELU-table epilogue."""
+    """The MLP up-projection of a 33 .. 128-row decode step: FP16 GELU-table epilogue, both row groupings."""
     g = torch.Generator(device="cuda").manual_seed(M + N)
     a = torch.randn((M, K), generator=g, device="cuda").half()
     w = (0.1 * torch.randn((N, K), generator=g, device="cuda")).half()
@@ -334,7 +334,7 @@ def test_mul_mat_gelu_decode_rows(M, N, K, golden):
     idx = pre.half().view(torch.int16).to(torch.int32) & 0xFFFF
     want = table[idx.long()].to(torch.int16).view(torch.float16).float()
     L = binding.lib()
-    for name, mask in (("split-K", binding.TUNE_DEFAULT | binding.TUNE_GEMV_SPLITK), ("gemv", binding.TUNE_DEFAULT & ~binding.TUNE_GEMV_SPLITK)):
+    for name, mask in (("default", binding.TUNE_DEFAULT), ("gemv64", binding.TUNE_DEFAULT & ~(binding.TUNE_GEMV_ALLROWS | binding.TUNE_GEMV_ROWGROUPS))):
         try:
             L.wh_debug_set_tuning(mask)
             out = torch.zeros((M, N), dtype=torch.float16, device="cuda")

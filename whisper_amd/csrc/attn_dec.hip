@@ -13,6 +13,7 @@
 // loads issued together, up to 3 rows) in the score phase and 24 x 16-byte V loads in the P.V phase; the three
 // reductions (max, sum, P.V partials) go through LDS.
 #include "kernels.h"
+#include <type_traits>
 
 namespace wh
 {
@@ -631,12 +632,23 @@ namespace wh
 			double shd[ NQ ][ NW ];
 			f16 xn[ NQ ][ G_MAXD ];
 		};
-
+		// MF: the projection runs on the matrix cores and needs the waves' partial tiles side by side
 		template<int NQ>
+		struct SelfBlockLdsMf : SelfBlockLds<NQ>
+		{
+			float mm[ NW ][ 12 ][ 16 ][ NQ ];	// [k share of a wave][row tile: 4 x q, 4 x k, 4 x v][row in tile][sequence]
+		};
+
+		// MF = the head's 192 weight rows x NQ activation rows as MFMA 16x16x32 tiles (the NQ rows occupy NQ of the 16 operand
+		// columns): wave w takes the k-steps w, w + 8, ... of all 12 row tiles, the 8 partial tiles are added in wave order.
+		// The VALU version (8 lanes per weight row, FP16 -> FP32 converts + FMAs) is bound by those converts: ~2500 VALU
+		// instructions per lane at NQ = 4, d = 1024.
+		template<int NQ, bool MF>
 		__global__ void __launch_bounds__( NT, 2 ) selfBlockDec( const DecSelfArgs a )
 		{
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemS[];
-			SelfBlockLds<NQ>& L = *(SelfBlockLds<NQ>*)smemS;
+			using Lds = std::conditional_t<MF, SelfBlockLdsMf<NQ>, SelfBlockLds<NQ>>;
+			Lds& L = *(Lds*)smemS;
 			const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 			const int g = tid >> 3, c = tid & 7;
 			const int h = blockIdx.x, sg = blockIdx.y;
@@ -722,6 +734,77 @@ namespace wh
 				__syncthreads();
 			}
 
+			if constexpr( MF )
+			{
+				// ---- this head's rows of Wq, Wk, Wv on the matrix cores ----
+				// A = 16 weight rows x 32 k (lane & 15 = row, lane >> 4 = 8-half chunk), B = the NQ normalised rows from LDS in
+				// operand columns 0 .. NQ-1 (the other columns repeat the last row; their results are never read),
+				// D[row = (lane >> 4) * 4 + r][col = lane & 15]
+				const int steps = d >> 5;
+				const int qCol = min( lane & 15, NQ - 1 );
+				const f16* const xrow = &L.xn[ qCol ][ ( lane >> 4 ) * 8 ];
+				const f16* const wbase = a.wqkv + ( (long long)h * HEAD_DIM + ( lane & 15 ) ) * d + ( lane >> 4 ) * 8;
+	#pragma unroll
+				for( int m = 0; m < 3; m++ )
+				{
+					f32x4 acc4[ 4 ];
+	#pragma unroll
+					for( int t = 0; t < 4; t++ ) acc4[ t ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					const f16* const wm = wbase + (long long)m * d * d;
+					constexpr int U = 2;	  // k-steps in flight per wave (4 keeps the kernel above 128 registers: one workgroup per CU)
+					for( int s0 = wave; s0 < steps; s0 += U * NW )
+					{
+						f16x8 wf[ U ][ 4 ], xf[ U ];
+	#pragma unroll
+						for( int u = 0; u < U; u++ )
+							if( s0 + u * NW < steps )
+							{
+	#pragma unroll
+								for( int t = 0; t < 4; t++ ) wf[ u ][ t ] = *(const f16x8*)( wm + (long long)t * 16 * d + ( s0 + u * NW ) * 32 );
+								xf[ u ] = *(const f16x8*)( xrow + ( s0 + u * NW ) * 32 );
+							}
+	#pragma unroll
+						for( int u = 0; u < U; u++ )
+							if( s0 + u * NW < steps )
+							{
+	#pragma unroll
+								for( int t = 0; t < 4; t++ ) acc4[ t ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( wf[ u ][ t ], xf[ u ], acc4[ t ], 0, 0, 0 );
+							}
+					}
+					if( ( lane & 15 ) < NQ )
+	#pragma unroll
+						for( int t = 0; t < 4; t++ )
+	#pragma unroll
+							for( int r = 0; r < 4; r++ ) L.mm[ wave ][ m * 4 + t ][ ( lane >> 4 ) * 4 + r ][ lane & 15 ] = acc4[ t ][ r ];
+				}
+				__syncthreads();
+				// lane c < NQ of weight row g finishes sequence c: the 8 k-shares in wave order, then the reference's rounding points
+				if( c < NQ )
+				{
+					const int q = c;
+					float tq = 0.0f, tk = 0.0f, tv = 0.0f;
+	#pragma unroll
+					for( int w = 0; w < NW; w++ )
+					{
+						tq += L.mm[ w ][ 0 + ( g >> 4 ) ][ g & 15 ][ q ];
+						tk += L.mm[ w ][ 4 + ( g >> 4 ) ][ g & 15 ][ q ];
+						tv += L.mm[ w ][ 8 + ( g >> 4 ) ][ g & 15 ][ q ];
+					}
+					const int col = h * HEAD_DIM + g;
+					const float bq = a.bqkv[ col ], bv = a.bqkv[ 2 * d + col ];
+					const f16 hq = (f16)( ( tq + bq ) * a.scale ), hk = (f16)( tk * a.scale ), hv = (f16)( tv + bv );
+					L.qs[ q ][ g ] = (float)hq;
+					L.kn[ q ][ g ] = (float)hk;
+					L.vn[ q ][ g ] = (float)hv;
+					if( q < nSeq )
+					{
+						const long long o = ( ( (long long)seqOf( q ) * a.H + h ) * a.keyStride + pos ) * HEAD_DIM + g;
+						a.kc[ o ] = hk;
+						a.vc[ o ] = hv;
+					}
+				}
+			}
+			else
 			// ---- this head's rows of Wq, Wk, Wv: 8 lanes per weight row, 128 contiguous bytes per row and step ----
 			{
 				float acc[ 3 ][ NQ ];
@@ -912,12 +995,12 @@ namespace wh
 			}
 		}
 
-		template<int NQ>
-		int launchSelfBlockT( const DecSelfArgs& a, hipStream_t stream )
+		template<int NQ, bool MF>
+		int launchSelfBlockK( const DecSelfArgs& a, hipStream_t stream )
 		{
-			constexpr int lds = (int)sizeof( SelfBlockLds<NQ> );
+			constexpr int lds = (int)sizeof( std::conditional_t<MF, SelfBlockLdsMf<NQ>, SelfBlockLds<NQ>> );
 			static_assert( lds <= 64 * 1024, "selfBlockDec LDS" );
-			hipLaunchKernelGGL( ( selfBlockDec<NQ> ), dim3( a.H, ( a.batch + NQ - 1 ) / NQ ), dim3( NT ), lds, stream, a );
+			hipLaunchKernelGGL( ( selfBlockDec<NQ, MF> ), dim3( a.H, ( a.batch + NQ - 1 ) / NQ ), dim3( NT ), lds, stream, a );
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}
@@ -994,8 +1077,9 @@ namespace wh
 		// sequences per workgroup: enough to bring the grid down to about one workgroup per CU -- the 384 KB weight slice of
 		// a head is then read from L2 once per sequence group instead of once per sequence
 		const int wgs1 = a.H * a.batch;
-		if( wgs1 > 768 ) return launchSelfBlockT<4>( a, stream );
-		if( wgs1 > 320 ) return launchSelfBlockT<2>( a, stream );
-		return launchSelfBlockT<1>( a, stream );
+		const bool mf = ( g_tuning & TUNE_SELF_MFMA ) != 0;
+		if( wgs1 > 768 ) return mf ? launchSelfBlockK<4, true>( a, stream ) : launchSelfBlockK<4, false>( a, stream );
+		if( wgs1 > 320 ) return mf ? launchSelfBlockK<2, true>( a, stream ) : launchSelfBlockK<2, false>( a, stream );
+		return mf ? launchSelfBlockK<1, true>( a, stream ) : launchSelfBlockK<1, false>( a, stream );
 	}
 }

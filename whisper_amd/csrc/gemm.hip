@@ -17,7 +17,6 @@
 //   workgroup), the few activation rows are the B operand; 4 waves split K and reduce through LDS.
 // gemvFused: the decode-step kernel, up to 32 activation rows (see below).
 #include "kernels.h"
-#include <mutex>
 #include <type_traits>
 
 namespace wh
@@ -1212,47 +1211,30 @@ namespace wh
 		}
 
 		// -----------------------------------------------------------------------------------------------------------
-		// gemmSplitK: 33 .. 128 activation rows (one decode step of a 33 .. 128-sequence lock-step batch).
-		// The product is tiny (M = 112: 0.2 .. 1 GFLOP) and the weights are 2 .. 8 MB that should cross HBM once, so the only
-		// question is how many CUs pull on them at the same time: a CU streams a few tens of GB/s, the chip needs all 256.
-		// gemvFused gets its parallelism from N alone (16 columns per workgroup: 64 workgroups for N = 1024) and re-reads the
-		// activation rows once per 16 columns. Here a workgroup owns 32 columns x ALL rows x one K slice:
-		//   * grid = column tiles x S slices, S chosen by the launcher so that 256 .. 768 workgroups exist; the S slices of a
-		//     tile are placed on one XCD (their partial sums meet in that XCD's L2);
-		//   * 4 waves split the slice; a wave keeps MT x 2 MFMA 16x16x32 tiles (all rows x 32 columns) and has two k-steps of
-		//     loads (2 weight + MT activation fragments each) in flight;
-		//   * the 4 partial tiles meet in LDS, wave w sums accumulator groups w, w + 4, ... in the fixed order 0, 1, 2, 3;
-		//   * S > 1: the workgroup's partial goes to the context's scratch (coalesced 256-byte rows), fence, one atomic ticket
-		//     per tile; the workgroup that draws the last ticket adds the S partials in the fixed order 0 .. S - 1 and runs
-		//     the epilogue, so the result does not depend on which workgroup finishes last; it also resets the ticket.
+		// gemmAllRows: 33 .. 128 activation rows against a WIDE weight matrix (the vocabulary projection of a decode step:
+		// N = 51865). A workgroup owns 32 columns x ALL rows: the weights are fetched once (gemvFused fetches them once per
+		// group of 64 rows) and the activation rows are re-read once per 32 columns instead of once per 16. The 4 waves split
+		// K; a wave keeps MT x 2 MFMA 16x16x32 tiles and has two k-steps of loads (2 weight + MT activation fragments each)
+		// in flight; the 4 partial tiles meet in LDS and wave w finishes accumulator groups w, w + 4, ... in the fixed order
+		// 0, 1, 2, 3. Measured at 112 rows, N = 51865, K = 1024: 112 us (950 GB/s) vs 165 us for gemvFused.
+		// It needs N / 32 >= ~500 workgroups to fill the chip. Splitting K over MORE workgroups for the narrow products
+		// (N = 1024: 32 column tiles) was built and measured -- partial sums to a scratch buffer, __threadfence, one atomic
+		// ticket per tile, last arrival adds the slices in slice order -- and retired: the agent-scope fences (an L2 write-back
+		// per workgroup on gfx950) cost 5-30 us per launch, 40-78 us against gemvFused's 8-22 us.
 		template<int EPI, int MT>
-		__global__ void __launch_bounds__( 256 ) gemmSplitK( const GemmArgs a, int S, int kSlice, int xcdMap )
+		__global__ void __launch_bounds__( 256 ) gemmAllRows( const GemmArgs a )
 		{
 			constexpr int NW = 4, CT = 2, G = MT * CT;
 			constexpr int GPW = ( G + NW - 1 ) / NW;	   // accumulator groups (4 registers x 64 lanes) a wave owns after the LDS exchange
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) float redK[];	 // [NW][G * 4][64]
-			__shared__ int lastFlag;
 
 			const int tid = threadIdx.x;
 			const int lane = tid & 63;
 			const int wave = tid >> 6;
-			int tile, s;
-			{
-				const int b = blockIdx.x;
-				if( xcdMap )
-				{
-					tile = ( b & 7 ) + 8 * ( b / ( 8 * S ) );
-					s = ( b >> 3 ) % S;
-				}
-				else
-				{
-					tile = b / S;
-					s = b - tile * S;
-				}
-			}
+			const int tile = blockIdx.x;
 			const int n0 = tile * 16 * CT;
-			const int kPer = kSlice / NW;
-			const int kBeg = s * kSlice + wave * kPer + ( lane >> 4 ) * 8;
+			const int kPer = a.K / NW;
+			const int kBeg = wave * kPer + ( lane >> 4 ) * 8;
 			const int steps = kPer / 32;
 
 			const f16* pw[ CT ];
@@ -1326,49 +1308,6 @@ namespace wh
 				}
 			}
 
-			if( S > 1 )
-			{
-				// ---- the S slices of the tile meet in the scratch buffer; the last one to arrive adds them in slice order ----
-				const long long tileFloats = (long long)G * 256;
-				float* const mine = a.splitScratch + ( (long long)tile * S + s ) * tileFloats;
-	#pragma unroll
-				for( int i = 0; i < GPW; i++ )
-				{
-					const int g = wave + NW * i;
-					if( g >= G ) continue;
-	#pragma unroll
-					for( int r = 0; r < 4; r++ ) mine[ ( g * 4 + r ) * 64 + lane ] = part[ i ][ r ];
-				}
-				__threadfence();
-				__syncthreads();
-				if( tid == 0 )
-				{
-					const unsigned ticket = atomicAdd( a.splitCounters + tile, 1u );
-					lastFlag = ticket == (unsigned)( S - 1 ) ? 1 : 0;
-				}
-				__syncthreads();
-				if( !lastFlag ) return;
-				__threadfence();
-				const float* const base = a.splitScratch + (long long)tile * S * tileFloats;
-	#pragma unroll
-				for( int i = 0; i < GPW; i++ )
-	#pragma unroll
-					for( int r = 0; r < 4; r++ ) part[ i ][ r ] = 0.0f;
-	#pragma unroll 2
-				for( int ss = 0; ss < S; ss++ )
-				{
-	#pragma unroll
-					for( int i = 0; i < GPW; i++ )
-					{
-						const int g = wave + NW * i;
-						if( g >= G ) continue;
-	#pragma unroll
-						for( int r = 0; r < 4; r++ ) part[ i ][ r ] += base[ ss * tileFloats + ( g * 4 + r ) * 64 + lane ];
-					}
-				}
-				if( tid == 0 ) a.splitCounters[ tile ] = 0;	  // the next launch on this stream starts from zero
-			}
-
 			// ---- epilogue: group g = (row tile t, column fragment c); D[row][col]: col = lane & 15 = activation row, row = weight row slot
 			const bool fastEp = EPI == EPI_F32 && ( a.N & 3 ) == 0 && a.Mb >= a.M;
 	#pragma unroll
@@ -1407,84 +1346,38 @@ namespace wh
 		}
 	}	// namespace
 
-	// Process-wide scratch for the standalone op entry points (no context): one stream at a time.
-	static float* g_splitScratch[ 16 ] = {};
-	static unsigned* g_splitCounters[ 16 ] = {};
-	constexpr long long SPLITK_SCRATCH_FLOATS = 4ll << 20;	  // 16 MiB: 1024 workgroup partials of 8 x 2 tiles
-	constexpr int SPLITK_COUNTERS = 4096;
-
 	template<int EPI, int MT>
-	static int launchSplitKT( const GemmArgs& a, int tiles, int S, hipStream_t stream )
+	static int launchAllRowsT( const GemmArgs& a, int tiles, hipStream_t stream )
 	{
-		constexpr int G = MT * 2;
-		constexpr int lds = 4 * G * 4 * 64 * 4;
+		constexpr int lds = 4 * MT * 2 * 4 * 64 * 4;
 		if( lds > 48 * 1024 )
 		{
 			static PerDeviceOnce once;
 			if( once.needed() )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)gemmSplitK<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmAllRows<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
 				once.mark();
 			}
 		}
-		const int xcdMap = ( tiles % 8 ) == 0 && S > 1 ? 1 : 0;
-		hipLaunchKernelGGL( ( gemmSplitK<EPI, MT> ), dim3( tiles * S ), dim3( 256 ), lds, stream, a, S, a.K / S, xcdMap );
+		hipLaunchKernelGGL( ( gemmAllRows<EPI, MT> ), dim3( tiles ), dim3( 256 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
 
-	// 33 .. 128 rows, EPI_F32 / EPI_F16_GELU, A in global memory. Returns 1 when the shape is not covered (the caller falls back).
-	static int launchSplitK( const GemmArgs& a0, hipStream_t stream )
+	// 33 .. 128 rows, EPI_F32, A in global memory, at least 512 column tiles. Returns 1 when the shape is not covered.
+	static int launchAllRows( const GemmArgs& a, hipStream_t stream )
 	{
-		GemmArgs a = a0;
-		if( a.lnX || ( a.epi != EPI_F32 && a.epi != EPI_F16_GELU ) || a.M <= 32 || a.M > 128 || ( a.K % 128 ) != 0 ) return 1;
-		if( !a.splitScratch || !a.splitCounters )
-		{
-			int dev = 0;
-			WH_HIP( hipGetDevice( &dev ) );
-			if( dev < 0 || dev >= 16 ) return 1;
-			static std::mutex mtx;
-			std::lock_guard<std::mutex> lock( mtx );
-			if( !g_splitScratch[ dev ] )
-			{
-				WH_HIP( hipMalloc( (void**)&g_splitScratch[ dev ], (size_t)SPLITK_SCRATCH_FLOATS * 4 ) );
-				WH_HIP( hipMalloc( (void**)&g_splitCounters[ dev ], (size_t)SPLITK_COUNTERS * 4 ) );
-				WH_HIP( hipMemset( g_splitCounters[ dev ], 0, (size_t)SPLITK_COUNTERS * 4 ) );
-			}
-			a.splitScratch = g_splitScratch[ dev ];
-			a.splitCounters = g_splitCounters[ dev ];
-			a.splitScratchFloats = SPLITK_SCRATCH_FLOATS;
-			a.splitCounterCount = SPLITK_COUNTERS;
-		}
-		const int MT = ( a.M + 15 ) / 16;
 		const int tiles = ( a.N + 31 ) / 32;
-		// S = the largest divisor of K / 128 (a wave's share of a slice is whole 32-wide k-steps) that keeps the grid <= 768
-		// workgroups and fits the scratch
-		const int kUnits = a.K / 128;
-		int S = 1;
-		for( int cand = 2; cand <= kUnits; cand++ )
-			if( ( kUnits % cand ) == 0 && (long long)tiles * cand <= 768 ) S = cand;
-		while( S > 1 && ( (long long)tiles * S * MT * 2 * 256 > a.splitScratchFloats || tiles > a.splitCounterCount ) )
+		if( a.lnX || a.epi != EPI_F32 || a.M <= 32 || a.M > 128 || ( a.K % 128 ) != 0 || tiles < 512 ) return 1;
+		switch( ( a.M + 15 ) / 16 )
 		{
-			int next = 1;
-			for( int cand = 1; cand < S; cand++ )
-				if( ( kUnits % cand ) == 0 ) next = cand;
-			S = next;
+		case 3: return launchAllRowsT<EPI_F32, 3>( a, tiles, stream );
+		case 4: return launchAllRowsT<EPI_F32, 4>( a, tiles, stream );
+		case 5: return launchAllRowsT<EPI_F32, 5>( a, tiles, stream );
+		case 6: return launchAllRowsT<EPI_F32, 6>( a, tiles, stream );
+		case 7: return launchAllRowsT<EPI_F32, 7>( a, tiles, stream );
+		default: return launchAllRowsT<EPI_F32, 8>( a, tiles, stream );
 		}
-		if( tiles > a.splitCounterCount && S > 1 ) S = 1;
-#define WH_SPLITK( E )                                                     \
-	switch( MT )                                                           \
-	{                                                                      \
-	case 3: return launchSplitKT<E, 3>( a, tiles, S, stream );             \
-	case 4: return launchSplitKT<E, 4>( a, tiles, S, stream );             \
-	case 5: return launchSplitKT<E, 5>( a, tiles, S, stream );             \
-	case 6: return launchSplitKT<E, 6>( a, tiles, S, stream );             \
-	case 7: return launchSplitKT<E, 7>( a, tiles, S, stream );             \
-	default: return launchSplitKT<E, 8>( a, tiles, S, stream );            \
-	}
-		if( a.epi == EPI_F32 ) { WH_SPLITK( EPI_F32 ) }
-		WH_SPLITK( EPI_F16_GELU )
-#undef WH_SPLITK
 	}
 
 	template<int EPI, int PRO, int ROWS, int NW, int UNROLL, int MT>
@@ -1517,7 +1410,15 @@ namespace wh
 		{
 			// 33 .. 128 rows: four MFMA column tiles per weight fragment (64 rows per workgroup, two row groups beyond that);
 			// always the 8-slot instance -- 4 x 8 activation fragments in flight are 128 registers
-			if( a.M > 32 ) return launchGemvK<EPI, PRO, ROWS, NW, 8, 4>( a, stream );
+			if( a.M > 32 )
+			{
+				// 64 rows per workgroup read each weight row once per 64 rows, but N / ROWS x ceil(M / 64) workgroups must still
+				// cover the chip: below 256 of them, 32 rows per workgroup (twice the workgroups, each with half the activation
+				// traffic) measured 5.8 vs 7.8 us (N = K = 1024) and 14.1 vs 22.0 us (N = 1024, K = 4096) at 112 rows
+				const int wgs = ( a.N + ROWS - 1 ) / ROWS * ( ( a.M + 63 ) / 64 );
+				if( wgs < 256 && ( g_tuning & TUNE_GEMV_ROWGROUPS ) ) return launchGemvK<EPI, PRO, ROWS, NW, 8, 2>( a, stream );
+				return launchGemvK<EPI, PRO, ROWS, NW, 8, 4>( a, stream );
+			}
 		}
 		if( a.M > 16 )
 			return small ? launchGemvK<EPI, PRO, ROWS, NW, 8, 2>( a, stream ) : launchGemvK<EPI, PRO, ROWS, NW, GV_UNROLL_MAX, 2>( a, stream );
@@ -1532,9 +1433,9 @@ namespace wh
 			return -1;
 		}
 		const bool ln = a.lnX != nullptr;
-		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_SPLITK ) )
+		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_ALLROWS ) )
 		{
-			const int rc = launchSplitK( a, stream );
+			const int rc = launchAllRows( a, stream );
 			if( rc <= 0 ) return rc;
 		}
 		if( ln && ( a.K > GV_MAXK_LN || a.M > 32 ) )

@@ -24,13 +24,15 @@ namespace wh
 		TUNE_GEMM_WIDE_EPI = 131072,	 // tiled GEMM: accumulators leave through LDS as 16-byte row stores instead of 2/4-byte column stores
 		TUNE_GEMM_FRAGPF = 262144,	 // direct-to-LDS tiled GEMM: MFMA fragments of k-substep s+1 are read before the MFMAs of substep s (two register sets, counted LDS waits)
 		TUNE_ATTN_ENC_2SWEEP = 524288,	 // attentionEncF: row sum and P.V in one sweep with the unnormalised FP16 e, O scaled by 1 / sum at the end
-		TUNE_GEMV_SPLITK = 1048576,		 // 33 .. 128 decode rows: 32 columns x all rows x one K slice per workgroup, slices combined in ticket order
+		TUNE_SELF_MFMA = 4194304,		 // selfBlockDec: the head's Q/K/V rows as MFMA tiles instead of 8 lanes per weight row on the VALU
+		TUNE_GEMV_ALLROWS = 1048576,	 // 33 .. 128 decode rows, N >= 16384 (vocabulary projection): 32 columns x all rows per workgroup (gemmAllRows)
+		TUNE_GEMV_ROWGROUPS = 2097152,	 // 33 .. 128 decode rows: 32 instead of 64 rows per workgroup while that leaves fewer than 256 workgroups
 		TUNE_GEMM_GROUP_M = 2048,	 // tiled GEMM: blocks walk bands of 4 M tiles (A band stays in the XCD's L2) instead of rows of tiles
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_SPLITK
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA
 	};
 	extern unsigned g_tuning;
 
@@ -82,12 +84,6 @@ namespace wh
 		const float* lnB;
 		int wideEpi;		  // tiled kernel, set by the launcher: the LDS-transposed epilogue with 16-byte stores applies
 		int groupM;			  // tiled kernel: M tiles per band of the block walk (0 = default for the tile shape, 1 = rows of tiles)
-		// split-K decode kernel (33 .. 128 rows): per-context scratch for the K slices' partial sums and one ticket per column
-		// tile (zero between launches); null = the library's process-wide pair (standalone ops, one stream at a time)
-		float* splitScratch;
-		unsigned* splitCounters;
-		long long splitScratchFloats;
-		int splitCounterCount;
 	};
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M

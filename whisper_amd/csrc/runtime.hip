@@ -265,12 +265,6 @@ struct wh_context
 	f16 *capTemp1 = nullptr, *capEncKqv = nullptr, *capDecKqvSelf = nullptr, *capDecKqvCross = nullptr;
 	float* capLayer0In = nullptr;
 	int capDecRows = 0;
-	// split-K decode products (gemm.hip gemmSplitK): partial sums of the K slices + one ticket per column tile, private to this
-	// context because contexts run concurrently on their own streams
-	float* splitScratch = nullptr;
-	unsigned* splitCounters = nullptr;
-	static constexpr int64_t SPLIT_SCRATCH_FLOATS = 4ll << 20;
-	static constexpr int SPLIT_COUNTERS = 4096;
 	int profKeysHint = 1;	   // profiler only: keys a device-positioned self-attention launch sees (host mirror of DecodeState::nPast + 1)
 	bool ownsStream = false;
 	// pinned host staging for fully asynchronous enqueues (offsets, tokens, state)
@@ -764,11 +758,6 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	rc = rc ? rc : c->alloc( c->tokDataDev, S );
 	rc = rc ? rc : c->alloc( c->melScratch, 64 );
 	rc = rc ? rc : c->alloc( c->state, 1, true );
-	if( c->maxSeq > 32 )
-	{
-		rc = rc ? rc : c->alloc( c->splitScratch, wh_context::SPLIT_SCRATCH_FLOATS );
-		rc = rc ? rc : c->alloc( c->splitCounters, wh_context::SPLIT_COUNTERS, true );
-	}
 	if( rc == 0 )
 	{
 		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * wh_context::PINNED_INTS, hipHostMallocDefault );
@@ -1072,11 +1061,6 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	{
 		g.nPastDev = nPastDev;
 		if( !gemv ) return gemmP( c, g, true );
-		if( c->splitScratch )
-		{
-			g.splitScratch = c->splitScratch; g.splitCounters = c->splitCounters;
-			g.splitScratchFloats = wh_context::SPLIT_SCRATCH_FLOATS; g.splitCounterCount = wh_context::SPLIT_COUNTERS;
-		}
 		if( lnW && fuseLn )
 		{
 			g.lnX = c->dx; g.lnW = lnW; g.lnB = lnB;
