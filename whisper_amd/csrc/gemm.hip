@@ -139,13 +139,22 @@ namespace wh
 		// NBUF (GL only) = LDS stages: 2 = the next tile lands while this one is multiplied (wait for everything at the top of
 		// a K step); 3 or 4 = one or two MORE tiles stay in flight across the step's barrier (counted vmcnt + raw s_barrier),
 		// which is what covers an HBM round trip that is longer than one K step.
-		// FRAGPF (GL only): the MFMA fragments of k-substep s+1 are read from LDS before the MFMAs of substep s are issued (two
-		// register sets). hipcc on its own re-uses one set, so every substep starts with an exposed LDS round trip.
-		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2, bool FRAGPF_ = false>
+		// PIPE: see below (fragment prefetch / loads spread behind the MFMA groups).
+		// ABL (probe only, wrong results by construction): 1 = no global -> LDS loads in the K loop, 2 = MFMA fragments read from LDS
+		// once instead of every k-substep, 3 = both, 4 = loads issued but never waited for: what the K loop costs without one of its streams.
+		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2, int PIPE_ = 0, int ABL_ = 0>
 		struct TileCfg
 		{
+			static constexpr int ABL = ABL_;
 			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_, NBUF = NBUF_;
-			static constexpr bool FRAGPF = FRAGPF_;
+			// PIPE (GL only): 1 = FRAGPF, the MFMA fragments of k-substep s+1 are read from LDS before the MFMAs of substep s are
+			// issued; 2 = SPREAD on top of it: the direct-to-LDS loads of the next tile are issued one or two at a time BEHIND
+			// the MFMA groups of the current tile instead of as a burst at the top of the K step. Right after the barrier every
+			// wave of the workgroup is at the same instruction, and a burst makes the 16 waves queue 64 one-KiB loads through the
+			// CU's single address path before any of them can issue its first fragment read: measured with the loads removed
+			// 1298 vs 776 TFLOP/s, with the loads issued but never waited for 767 (so it is the issue, not the latency).
+			static constexpr bool FRAGPF = PIPE_ >= 1;
+			static constexpr bool SPREAD = PIPE_ >= 2;
 			static constexpr bool GL = GL_;
 			static constexpr int WAVES_M = BM / ( 32 * TI ), WAVES_N = BN / ( 32 * TJ ), NT = WAVES_M * WAVES_N * 64;
 			static_assert( GL || ( TI == 2 && TJ == 2 ), "the register-staged path is written for 64x64 wave tiles" );
@@ -168,8 +177,10 @@ namespace wh
 		using CfgBig = TileCfg<256, 256, 64, 4, 1>;
 		using CfgGl = TileCfg<128, 128, 32, 3, 1, true>;
 		using CfgGlBig = TileCfg<256, 256, 64, 4, 1, true>;
-		using CfgGlPf = TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, true>;
-		using CfgGlBigPf = TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, true>;
+		using CfgGlPf = TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>;
+		using CfgGlBigPf = TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>;
+		// half a CU per workgroup (8 waves, 96 KB LDS): leaves registers and LDS for the kernels of another stream on the same CU
+		using CfgGlHalfPf = TileCfg<256, 128, 64, 2, 1, true, 2, 2, 2, 1>;
 
 		// physical position (in halfs) of logical 16-byte chunk c of tile row `row` in a GL tile
 		template<class C>
@@ -616,11 +627,16 @@ namespace wh
 				const int fragC = lane >> 5;
 				typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
 				typedef const __attribute__( ( address_space( 1 ) ) ) void* GlobalPtr;
-				auto issue = [ & ]( int kt, int buf )
+				// the LDS-DMA instructions p0 .. p1-1 of tile kt (A pieces first, then W pieces)
+				auto issuePieces = [ & ]( int kt, int buf, int p0, int p1 )
 				{
 					f16* const dstA = lds + buf * C::STAGE + wave * C::IA * C::RPI * BK;
 					f16* const dstW = lds + buf * C::STAGE + C::A_HALFS + wave * C::IW * C::RPI * BK;
 					const int ko = kt * BK;
+					if constexpr( ( C::ABL & 1 ) != 0 )
+					{
+						if( kt > 0 ) return;
+					}
 					if constexpr( C::FRAGPF )
 					{
 						// Issued as assembly: hipcc models the builtin as a FLAT access that may touch LDS and, while one is in
@@ -630,10 +646,12 @@ namespace wh
 						const unsigned baseW = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)dstW );
 	#pragma unroll
 						for( int i = 0; i < C::IA; i++ )
-							asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory" );
+							if( i >= p0 && i < p1 )
+								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory" );
 	#pragma unroll
 						for( int i = 0; i < C::IW; i++ )
-							asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory" );
+							if( C::IA + i >= p0 && C::IA + i < p1 )
+								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory" );
 						return;
 					}
 #pragma unroll
@@ -645,6 +663,8 @@ namespace wh
 				};
 				constexpr int NB = C::NBUF;
 				constexpr int PER_TILE = C::IA + C::IW;	  // LDS-DMA instructions of one tile per wave
+				auto issue = [ & ]( int kt, int buf ) { issuePieces( kt, buf, 0, PER_TILE ); };
+				static_assert( !C::SPREAD || ( NB == 2 && C::FRAGPF ), "spread loads are written for the two-stage fragment-prefetch loop" );
 	#pragma unroll
 				for( int p = 0; p < NB - 1; p++ )
 					if( p < nk ) issue( p, p );
@@ -653,7 +673,7 @@ namespace wh
 					const int buf = kt % NB;
 					if constexpr( NB == 2 )
 					{
-						asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+						if constexpr( ( C::ABL & 4 ) == 0 ) asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 						__syncthreads();
 					}
 					else
@@ -666,7 +686,11 @@ namespace wh
 							asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 						__builtin_amdgcn_s_barrier();
 					}
-					if( kt + NB - 1 < nk ) issue( kt + NB - 1, ( kt + NB - 1 ) % NB );
+					const bool more = kt + NB - 1 < nk;
+					if constexpr( !C::SPREAD )
+					{
+						if( more ) issue( kt + NB - 1, ( kt + NB - 1 ) % NB );
+					}
 					const f16* const ldsA = lds + buf * C::STAGE;
 					const f16* const ldsW = ldsA + C::A_HALFS;
 					if constexpr( C::FRAGPF )
@@ -675,6 +699,10 @@ namespace wh
 						auto readFrags = [ & ]( auto set, int ks )
 						{
 							constexpr int S = decltype( set )::value;
+							if constexpr( ( C::ABL & 2 ) != 0 )
+							{
+								if( kt > 0 ) return;
+							}
 	#pragma unroll
 							for( int i = 0; i < C::TI; i++ )
 								fa[ S ][ i ] = *(const f16x8*)( ldsA + glOffset<C>( wm * 32 * C::TI + i * 32 + fragRow, ks * 2 + fragC ) );
@@ -699,13 +727,24 @@ namespace wh
 						for( int ks = 0; ks < BK / 16; ks += 2 )
 						{
 							// the scheduling fences keep hipcc from sinking the reads back below the MFMAs to save registers
+							// load pieces behind each MFMA group of the FIRST half of the K step: the data then still has half a step
+							// plus the barrier skew to land before the wait at the top of the next step
+							constexpr int NSUB = BK / 16, HALF = NSUB / 2, PPS = ( PER_TILE + HALF - 1 ) / HALF;
 							readFrags( S1{}, ks + 1 );
 							__builtin_amdgcn_sched_barrier( 0 );
 							mfmas( S0{} );
+							if constexpr( C::SPREAD )
+							{
+								if( more ) issuePieces( kt + 1, buf ^ 1, ks * PPS, ( ks + 1 ) * PPS < PER_TILE ? ( ks + 1 ) * PPS : PER_TILE );
+							}
 							__builtin_amdgcn_sched_barrier( 0 );
 							if( ks + 2 < BK / 16 ) readFrags( S0{}, ks + 2 );
 							__builtin_amdgcn_sched_barrier( 0 );
 							mfmas( S1{} );
+							if constexpr( C::SPREAD )
+							{
+								if( more ) issuePieces( kt + 1, buf ^ 1, ( ks + 1 ) * PPS, ( ks + 2 ) * PPS < PER_TILE ? ( ks + 2 ) * PPS : PER_TILE );
+							}
 							__builtin_amdgcn_sched_barrier( 0 );
 						}
 					}
@@ -1521,9 +1560,17 @@ namespace wh
 	{
 		switch( variant )
 		{
-		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, true>>( a, stream );
-		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, true>>( a, stream );
-		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, true>>( a, stream );
+		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
+		case 28: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 2>>( a, stream );
+		case 30: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 2, 1, true, 4, 2, 2, 1>>( a, stream );
+		case 35: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 2, 1, true, 2, 4, 2, 1>>( a, stream );
+		case 29: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 2>>( a, stream );
+		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
+		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
+		case 33: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 3>>( a, stream );
+		case 34: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 4>>( a, stream );
+		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
+		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, 1>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );
 		case 21: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 4>>( a, stream );
 		case 22: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1, true, 2, 2, 3>>( a, stream );
@@ -1585,7 +1632,9 @@ namespace wh
 		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
 		const bool pf = gl && ( g_tuning & TUNE_GEMM_FRAGPF ) != 0;
+		const bool half = pf && big && ( g_tuning & TUNE_GEMM_HALF_CU );
 #define WH_TILED( E )                                                    \
+	if( half ) return launchTiledT<E, CfgGlHalfPf>( a, stream );         \
 	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
 	if( pf ) return launchTiledT<E, CfgGlPf>( a, stream );               \
 	if( gl && big ) return launchTiledT<E, CfgGlBig>( a, stream );       \
