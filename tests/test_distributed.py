@@ -69,3 +69,83 @@ def test_gloo_world_size_2_broadcast_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results == {"rank0": True, "rank1": True}
+
+
+def _transcribe_windows_cpu(model, mels, begin, end, n_steps):
+    """The oracle's numpy model as the per-rank compute stand-in (there is no GPU here): greedy token ids of windows
+    [begin, end) -- encode, the 3-token prompt, n_steps argmax steps. Same role as HipContext.decode_window_* on a GPU rank."""
+    from oracle import whisper_np as wn
+    from whisper_amd import ggml_format as gf
+    sp = gf.special_tokens(model.hparams)
+    n = wn.WhisperNP(model)
+    rows = []
+    for w in range(begin, end):
+        n.encode(mels[w], 0)
+        toks = [sp["sot"], sp["sot"] + 1, sp["transcribe"]] if model.hparams.n_vocab >= 51865 else [sp["sot"]]
+        logits, _ = n.decode(toks, 0, exact_pv=False)
+        n_past, out = len(toks), []
+        for _ in range(n_steps):
+            t = int(np.argmax(logits[-1]))
+            out.append(t)
+            logits, _ = n.decode([t], n_past, exact_pv=False)
+            n_past += 1
+        rows.append(out)
+    return np.array(rows, np.int32).reshape(end - begin, n_steps)
+
+
+def _model_worker(rank, world, port, n_windows, n_steps, path, q):
+    """Rank 0 reads the ggml file and broadcasts its BYTES (the stand-in for the packed arena); every rank parses the model
+    from what it received, transcribes its contiguous shard of windows and enters the gather."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from whisper_amd import ggml_format as gf
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        size = torch.zeros(1, dtype=torch.int64)
+        if rank == 0:
+            raw = np.fromfile(path, dtype=np.uint8)
+            size[0] = raw.size
+        dist.broadcast(size, 0)
+        arena = torch.from_numpy(raw.copy()) if rank == 0 else torch.zeros(int(size[0]), dtype=torch.uint8)
+        wd.broadcast_arena(arena, 0)
+        with tempfile.TemporaryDirectory() as td:
+            mine = os.path.join(td, "m.bin")
+            arena.numpy().tofile(mine)
+            model = gf.read_model(mine)
+        rng = np.random.default_rng(17)
+        mels = rng.uniform(-1, 1, (n_windows, model.hparams.n_mels, 3000)).astype(np.float32)      # same on every rank (seeded)
+        out = wd.transcribe_sharded(n_windows, lambda b, e: _transcribe_windows_cpu(model, mels, b, e, n_steps), n_steps)
+        q.put((rank, None if out is None else out.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_windows", [3, 1])
+def test_gloo_world_size_2_shard_transcribe_gather(tmp_path, n_windows):
+    """The whole data-parallel step on two ranks with real window tokens: broadcast of the model bytes, contiguous shards
+    (3 windows -> 2 + 1; 1 window -> 1 + 0: a rank with an empty shard still has to enter the collective), per-rank compute,
+    gather on rank 0 in window order -- equal to one process transcribing every window."""
+    import torch.multiprocessing as mp
+    from whisper_amd import ggml_format as gf
+    n_steps = 2
+    model = gf.synth_model("test-d128", seed=77, n_audio_ctx=200)
+    path = str(tmp_path / "m.bin")
+    gf.write_model(path, model)
+    rng = np.random.default_rng(17)
+    mels = rng.uniform(-1, 1, (n_windows, model.hparams.n_mels, 3000)).astype(np.float32)
+    want = _transcribe_windows_cpu(gf.read_model(path), mels, 0, n_windows, n_steps)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, 2, port, n_windows, n_steps, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] is None
+    assert np.array_equal(np.array(results[0], np.int32), want)

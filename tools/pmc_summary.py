@@ -60,6 +60,19 @@ def main():
             e["launches_algorithmic"] = a["calls"]
             e["traffic_over_algorithmic"] = round((e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]) / max(e["algorithmic_bytes_per_launch"], 1), 3)
         kernels[c] = e
+    # kernel names cannot tell the prompt step's cross-attention (attentionDecG<.., false>, query projected by a separate product)
+    # from its causal self-attention: the name class "attentionDec" holds both, so its algorithmic bytes are the library's
+    # self-attention class plus the cross-attention launches that are not in the fused-query name class
+    cross, self_, named = algo["classes"].get("attentionDecCross"), algo["classes"].get("attentionDec"), kernels.get("attentionDec")
+    if cross and self_ and named and cross["calls"]:
+        unfused = max(cross["calls"] - kernels.get("attentionDecCross", {}).get("launches", 0), 0)
+        n = self_["calls"] + unfused
+        if n:
+            named["algorithmic_bytes_per_launch"] = round((self_["bytes"] + unfused * cross["bytes"] / cross["calls"]) / n)
+            named["algorithmic_flops_per_launch"] = round((self_["flops"] + unfused * cross["flops"] / cross["calls"]) / n)
+            named["launches_algorithmic"] = n
+            named["traffic_over_algorithmic"] = round((named["hbm_read_bytes_per_launch"] + named["hbm_write_bytes_per_launch"]) / max(named["algorithmic_bytes_per_launch"], 1), 3)
+            named["holds"] = "%d causal self-attention + %d unfused cross-attention launches of the prompt step" % (self_["calls"], unfused)
     doc = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/pmc_probe.py: eager launches, %s shape, %d windows in lock "
                    "step, encoder + prompt step + %d single-token steps; read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE as reported; "
                    "per-launch averages over all launches of the class in that run" % (algo["model"], algo["windows"], algo["steps"]),

@@ -141,7 +141,7 @@ namespace wh
 		// which is what covers an HBM round trip that is longer than one K step.
 		// PIPE: see below (fragment prefetch / loads spread behind the MFMA groups).
 		// ABL (probe only, wrong results by construction): 1 = no global -> LDS loads in the K loop, 2 = MFMA fragments read from LDS
-		// once instead of every k-substep, 3 = both, 4 = loads issued but never waited for: what the K loop costs without one of its streams.
+		// once instead of every k-substep, 3 = both, 4 = loads issued but never waited for, 8 / 16 = only the A / only the W tile is loaded: what the K loop costs without one of its streams.
 		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2, int PIPE_ = 0, int ABL_ = 0>
 		struct TileCfg
 		{
@@ -646,11 +646,11 @@ namespace wh
 						const unsigned baseW = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)dstW );
 	#pragma unroll
 						for( int i = 0; i < C::IA; i++ )
-							if( i >= p0 && i < p1 )
+							if( i >= p0 && i < p1 && ( ( C::ABL & 16 ) == 0 || kt == 0 ) )
 								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory" );
 	#pragma unroll
 						for( int i = 0; i < C::IW; i++ )
-							if( C::IA + i >= p0 && C::IA + i < p1 )
+							if( C::IA + i >= p0 && C::IA + i < p1 && ( ( C::ABL & 8 ) == 0 || kt == 0 ) )
 								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory" );
 						return;
 					}
@@ -1569,6 +1569,8 @@ namespace wh
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
 		case 33: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 3>>( a, stream );
 		case 34: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 4>>( a, stream );
+		case 36: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 8>>( a, stream );	 // no W loads
+		case 37: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 16>>( a, stream );	 // no A loads
 		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, 1>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );
