@@ -290,12 +290,12 @@ def test_hypotheses_share_cross_attention(hip_tiny, golden):
     ch.close()
 
 
-@pytest.mark.parametrize("bit,batch", [("TUNE_FUSE_CROSS_Q", 2), ("TUNE_FUSE_SELF_BLOCK", 2), ("TUNE_FUSE_SELF_BLOCK", 25), ("TUNE_GEMV_LN_BLOCK", 20),
+@pytest.mark.parametrize("bit,batch", [("TUNE_FUSE_CROSS_Q", 2), ("TUNE_FUSE_SELF_BLOCK", 9), ("TUNE_FUSE_SELF_BLOCK", 25), ("TUNE_GEMV_LN_BLOCK", 20),
                                        ("TUNE_GEMV_K8", 3),
                                        # 2 heads x 170 / 390 sequences: 2 / 4 sequences per workgroup of the fused self-attention block
                                        ("TUNE_FUSE_SELF_BLOCK", 170), ("TUNE_FUSE_SELF_BLOCK", 390),
                                        # its projection on the matrix cores vs on the VALU (1 and 4 sequences per workgroup)
-                                       ("TUNE_SELF_MFMA", 3), ("TUNE_SELF_MFMA", 390),
+                                       ("TUNE_SELF_MFMA", 10), ("TUNE_SELF_MFMA", 390),
                                        # 40 and 100 rows: 32 instead of 64 rows per workgroup in the decode products
                                        ("TUNE_GEMV_ROWGROUPS", 40), ("TUNE_GEMV_ROWGROUPS", 100)])
 def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):

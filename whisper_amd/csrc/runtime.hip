@@ -1053,7 +1053,10 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const bool gemv = M <= GEMV_MAX_ROWS && ( d % 128 ) == 0;
 	const bool fuseLn = gemv && d <= 1280 && M <= 32 && ( M <= 16 || ( g_tuning & TUNE_GEMV_LN_BLOCK ) || !( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
 	// decode steps: LayerNorm + this head's Q/K/V rows + cache append + self-attention in one launch
-	const bool fuseSelf = nTokens == 1 && d <= 1280 && hp.n_text_ctx <= 512 && parity == 0 && ( g_tuning & TUNE_FUSE_SELF_BLOCK );
+	// (from 9 sequences up: with fewer, one workgroup per (head, sequence) leaves the 6 d^2 bytes of QKV weights to H CUs at
+	// ~25 GB/s each -- 15.7 us per layer at one sequence -- and the separate gemv + attention launches are faster: 74.3 vs 86.6 ms
+	// per window at batch 1, 100.4 vs 101.9 at 7)
+	const bool fuseSelf = nTokens == 1 && d <= 1280 && hp.n_text_ctx <= 512 && parity == 0 && batch > 8 && ( g_tuning & TUNE_FUSE_SELF_BLOCK );
 	// decode steps: the cross-attention kernel normalises the residual row and projects its own head's query
 	const bool fuseCrossQ = nTokens == 1 && d <= 1280 && parity <= 8 && ( g_tuning & TUNE_FUSE_CROSS_Q );
 
