@@ -644,7 +644,7 @@ namespace wh
 		// The VALU version (8 lanes per weight row, FP16 -> FP32 converts + FMAs) is bound by those converts: ~2500 VALU
 		// instructions per lane at NQ = 4, d = 1024.
 		template<int NQ, bool MF>
-		__global__ void __launch_bounds__( NT, 2 ) selfBlockDec( const DecSelfArgs a )
+		__global__ void __launch_bounds__( NT, NQ > 4 ? 1 : 2 ) selfBlockDec( const DecSelfArgs a )
 		{
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemS[];
 			using Lds = std::conditional_t<MF, SelfBlockLdsMf<NQ>, SelfBlockLds<NQ>>;
@@ -999,7 +999,16 @@ namespace wh
 		int launchSelfBlockK( const DecSelfArgs& a, hipStream_t stream )
 		{
 			constexpr int lds = (int)sizeof( std::conditional_t<MF, SelfBlockLdsMf<NQ>, SelfBlockLds<NQ>> );
-			static_assert( lds <= 64 * 1024, "selfBlockDec LDS" );
+			static_assert( lds <= 160 * 1024, "selfBlockDec LDS" );
+			if( lds > 48 * 1024 )
+			{
+				static PerDeviceOnce once;
+				if( once.needed() )
+				{
+					WH_HIP( hipFuncSetAttribute( (const void*)selfBlockDec<NQ, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+					once.mark();
+				}
+			}
 			hipLaunchKernelGGL( ( selfBlockDec<NQ, MF> ), dim3( a.H, ( a.batch + NQ - 1 ) / NQ ), dim3( NT ), lds, stream, a );
 			WH_HIP( hipGetLastError() );
 			return 0;
@@ -1078,6 +1087,7 @@ namespace wh
 		// a head is then read from L2 once per sequence group instead of once per sequence
 		const int wgs1 = a.H * a.batch;
 		const bool mf = ( g_tuning & TUNE_SELF_MFMA ) != 0;
+		// (8 sequences per workgroup at 1792 pairs: 34.3 vs 32.7 us per launch -- the kernel is a latency chain, not L2-bound; not kept)
 		if( wgs1 > 768 ) return mf ? launchSelfBlockK<4, true>( a, stream ) : launchSelfBlockK<4, false>( a, stream );
 		if( wgs1 > 320 ) return mf ? launchSelfBlockK<2, true>( a, stream ) : launchSelfBlockK<2, false>( a, stream );
 		return mf ? launchSelfBlockK<1, true>( a, stream ) : launchSelfBlockK<1, false>( a, stream );
