@@ -148,13 +148,10 @@ namespace wh
 			static constexpr int ABL = ABL_;
 			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_, NBUF = NBUF_;
 			// PIPE (GL only): 1 = FRAGPF, the MFMA fragments of k-substep s+1 are read from LDS before the MFMAs of substep s are
-			// issued; 2 = SPREAD on top of it: the direct-to-LDS loads of the next tile are issued one or two at a time BEHIND
-			// the MFMA groups of the current tile instead of as a burst at the top of the K step. Right after the barrier every
-			// wave of the workgroup is at the same instruction, and a burst makes the 16 waves queue 64 one-KiB loads through the
-			// CU's single address path before any of them can issue its first fragment read: measured with the loads removed
-			// 1298 vs 776 TFLOP/s, with the loads issued but never waited for 767 (so it is the issue, not the latency).
+			// issued (two register sets; hipcc on its own re-uses one set, so every substep starts with an exposed LDS round trip).
+			// (Issuing the next tile's direct-to-LDS loads one or two at a time behind the MFMA groups instead of as a burst at the
+			// top of the K step was measured too: no difference, profiles/r02_gemm_kloop_ablation.txt.)
 			static constexpr bool FRAGPF = PIPE_ >= 1;
-			static constexpr bool SPREAD = PIPE_ >= 2;
 			static constexpr bool GL = GL_;
 			static constexpr int WAVES_M = BM / ( 32 * TI ), WAVES_N = BN / ( 32 * TJ ), NT = WAVES_M * WAVES_N * 64;
 			static_assert( GL || ( TI == 2 && TJ == 2 ), "the register-staged path is written for 64x64 wave tiles" );
@@ -179,8 +176,6 @@ namespace wh
 		using CfgGlBig = TileCfg<256, 256, 64, 4, 1, true>;
 		using CfgGlPf = TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>;
 		using CfgGlBigPf = TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>;
-		// half a CU per workgroup (8 waves, 96 KB LDS): leaves registers and LDS for the kernels of another stream on the same CU
-		using CfgGlHalfPf = TileCfg<256, 128, 64, 2, 1, true, 2, 2, 2, 1>;
 
 		// physical position (in halfs) of logical 16-byte chunk c of tile row `row` in a GL tile
 		template<class C>
@@ -664,7 +659,6 @@ namespace wh
 				constexpr int NB = C::NBUF;
 				constexpr int PER_TILE = C::IA + C::IW;	  // LDS-DMA instructions of one tile per wave
 				auto issue = [ & ]( int kt, int buf ) { issuePieces( kt, buf, 0, PER_TILE ); };
-				static_assert( !C::SPREAD || ( NB == 2 && C::FRAGPF ), "spread loads are written for the two-stage fragment-prefetch loop" );
 	#pragma unroll
 				for( int p = 0; p < NB - 1; p++ )
 					if( p < nk ) issue( p, p );
@@ -686,11 +680,7 @@ namespace wh
 							asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 						__builtin_amdgcn_s_barrier();
 					}
-					const bool more = kt + NB - 1 < nk;
-					if constexpr( !C::SPREAD )
-					{
-						if( more ) issue( kt + NB - 1, ( kt + NB - 1 ) % NB );
-					}
+					if( kt + NB - 1 < nk ) issue( kt + NB - 1, ( kt + NB - 1 ) % NB );
 					const f16* const ldsA = lds + buf * C::STAGE;
 					const f16* const ldsW = ldsA + C::A_HALFS;
 					if constexpr( C::FRAGPF )
@@ -727,24 +717,13 @@ namespace wh
 						for( int ks = 0; ks < BK / 16; ks += 2 )
 						{
 							// the scheduling fences keep hipcc from sinking the reads back below the MFMAs to save registers
-							// load pieces behind each MFMA group of the FIRST half of the K step: the data then still has half a step
-							// plus the barrier skew to land before the wait at the top of the next step
-							constexpr int NSUB = BK / 16, HALF = NSUB / 2, PPS = ( PER_TILE + HALF - 1 ) / HALF;
 							readFrags( S1{}, ks + 1 );
 							__builtin_amdgcn_sched_barrier( 0 );
 							mfmas( S0{} );
-							if constexpr( C::SPREAD )
-							{
-								if( more ) issuePieces( kt + 1, buf ^ 1, ks * PPS, ( ks + 1 ) * PPS < PER_TILE ? ( ks + 1 ) * PPS : PER_TILE );
-							}
 							__builtin_amdgcn_sched_barrier( 0 );
 							if( ks + 2 < BK / 16 ) readFrags( S0{}, ks + 2 );
 							__builtin_amdgcn_sched_barrier( 0 );
 							mfmas( S1{} );
-							if constexpr( C::SPREAD )
-							{
-								if( more ) issuePieces( kt + 1, buf ^ 1, ( ks + 1 ) * PPS, ( ks + 2 ) * PPS < PER_TILE ? ( ks + 2 ) * PPS : PER_TILE );
-							}
 							__builtin_amdgcn_sched_barrier( 0 );
 						}
 					}
@@ -1561,10 +1540,6 @@ namespace wh
 		switch( variant )
 		{
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
-		case 28: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 2>>( a, stream );
-		case 30: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 2, 1, true, 4, 2, 2, 1>>( a, stream );
-		case 35: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 2, 1, true, 2, 4, 2, 1>>( a, stream );
-		case 29: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 2>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
 		case 33: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 3>>( a, stream );
@@ -1634,9 +1609,7 @@ namespace wh
 		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
 		const bool pf = gl && ( g_tuning & TUNE_GEMM_FRAGPF ) != 0;
-		const bool half = pf && big && ( g_tuning & TUNE_GEMM_HALF_CU );
 #define WH_TILED( E )                                                    \
-	if( half ) return launchTiledT<E, CfgGlHalfPf>( a, stream );         \
 	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
 	if( pf ) return launchTiledT<E, CfgGlPf>( a, stream );               \
 	if( gl && big ) return launchTiledT<E, CfgGlBig>( a, stream );       \

@@ -20,11 +20,10 @@ namespace wh
 									 // (measured round 2, 28 rows: +11 ms per 28-window batch pass against the separate launch -- OFF)
 		TUNE_GEMV_K8 = 16384,		 // decode steps: 8 waves split K when K >= 2048 (the MLP down-projection)
 		TUNE_SPLIT_STREAMS = 32768,	 // contexts run the encoder on a second, low-priority stream and the decode chain on a high-priority one
-		TUNE_ATTN_ENC_F = 65536,		 // encoder attention: scores recomputed in three sweeps (32 queries x all keys per wave, K/V tiles through LDS)
+		TUNE_ATTN_ENC_F = 65536,		 // encoder attention: scores recomputed per sweep (32 queries x all keys per wave, K/V tiles through LDS) instead of kept in registers
 		TUNE_GEMM_WIDE_EPI = 131072,	 // tiled GEMM: accumulators leave through LDS as 16-byte row stores instead of 2/4-byte column stores
 		TUNE_GEMM_FRAGPF = 262144,	 // direct-to-LDS tiled GEMM: MFMA fragments of k-substep s+1 are read before the MFMAs of substep s (two register sets, counted LDS waits)
 		TUNE_ATTN_ENC_2SWEEP = 524288,	 // attentionEncF: row sum and P.V in one sweep with the unnormalised FP16 e, O scaled by 1 / sum at the end
-		TUNE_GEMM_HALF_CU = 8388608,	 // big encoder GEMMs as 256x128 tiles, 512 threads, 96 KB LDS: half a CU per workgroup (OFF: experiment)
 		TUNE_SELF_MFMA = 4194304,		 // selfBlockDec: the head's Q/K/V rows as MFMA tiles instead of 8 lanes per weight row on the VALU
 		TUNE_GEMV_ALLROWS = 1048576,	 // 33 .. 128 decode rows, N >= 16384 (vocabulary projection): 32 columns x all rows per workgroup (gemmAllRows)
 		TUNE_GEMV_ROWGROUPS = 2097152,	 // 33 .. 128 decode rows: 32 instead of 64 rows per workgroup while that leaves fewer than 256 workgroups
