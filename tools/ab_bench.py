@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 NAMES = {2: "rows4", 8: "gemmBig", 32: "gemvSmallReg", 64: "gemmGlds", 128: "lnSeparateBigM", 256: "attnXcd", 512: "attnDecG",
-         1024: "fuseCrossQ", 2048: "gemmGroupM", 4096: "selfBlock", 16384: "gemvK8", 65536: "attnEncF", 131072: "wideEpi", 262144: "fragPf"}
+         1024: "fuseCrossQ", 2048: "gemmGroupM", 4096: "selfBlock", 16384: "gemvK8", 65536: "attnEncF", 131072: "wideEpi", 262144: "fragPf", 524288: "attnEnc2Sweep",
+         1048576: "allRows", 2097152: "rowGroups", 4194304: "selfMfma"}
 
 
 def main():
