@@ -5,6 +5,7 @@
 // behind include/whisper_hip.h. Structure here is ours: one WindowDecoder per 30 s window feeds a token stream (filled
 // from the device-side greedy loop in chunks) through the reference's stop rules, then SegmentBuilder cuts it at the
 // timestamp tokens.
+#include <cstdlib>
 #include "hostCommon.h"
 #include <algorithm>
 #include <chrono>
@@ -25,7 +26,14 @@ namespace Whisper
 		eHostLoopRules g_hostLoopRules = eHostLoopRules::ReferenceCpu;
 
 		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
-		constexpr int GREEDY_CHUNK = 8; 	   // greedy steps enqueued per chunk; one chunk always runs behind the one being scanned
+		// greedy steps enqueued per chunk; one chunk always runs behind the one being scanned, so up to two chunks are decoded in
+		// vain when a window ends: one sequential 199 s clip through runFull, medium shape, ran at 247 / 296 / 311 audio-s/s with
+		// chunks of 8 / 4 / 2 (a fetch is an event wait + a 40-byte copy). WHISPER_GREEDY_CHUNK overrides (1 .. 64).
+		static const int GREEDY_CHUNK = []() {
+			const char* e = getenv( "WHISPER_GREEDY_CHUNK" );
+			const int v = e ? atoi( e ) : 0;
+			return v >= 1 && v <= 64 ? v : 2;
+		}();
 
 
 		// ---- iTranscribeResult ------------------------------------------------------------------------------------
