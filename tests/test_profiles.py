@@ -1,0 +1,75 @@
+"""The committed measurement artefacts are consistent with each other: the roofline of the bench line can be recomputed from the
+rocprofv3 kernel statistics of the same command, and the PMC traffic file covers the kernel classes the line cites."""
+import csv
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PROF = os.path.join(os.path.dirname(HERE), "profiles")
+
+
+def _load():
+    line = json.load(open(os.path.join(PROF, "r02_bench.json")))
+    stats = list(csv.DictReader(open(os.path.join(PROF, "r02_kernel_stats.csv"))))
+    pmc = json.load(open(os.path.join(PROF, "r02_pmc.json")))
+    return line, stats, pmc
+
+
+def _avg_us(stats, match):
+    rows = [r for r in stats if match(r["Name"])]
+    calls = sum(int(r["Calls"]) for r in rows)
+    return sum(float(r["TotalDurationNs"]) for r in rows) / calls / 1e3, calls
+
+
+def test_bench_line_has_the_contract_fields():
+    line, _, _ = _load()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["dtype"] == "f16" and "workload" in line["config"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["traffic"] is not None and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = line["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # value = audio seconds of one clip pass / time per pass
+    assert abs(line["value"] - 198.762 / (line["ms_per_step"] * 1e-3)) / line["value"] < 2e-3
+
+
+def test_roofline_recomputed_from_the_rocprof_statistics():
+    """roofline.achieved = algorithmic FLOP per launch / average launch duration; the average duration of the same kernels in the
+    rocprofv3 --kernel-trace --stats summary of the same command must give the same fraction to +-5 %, and the big kernels of
+    the per-class table must agree with it to +-5 % as well."""
+    line, stats, _ = _load()
+    r = line["roofline"]
+    assert r["kernel"] == "gemmTiled" and r["bound"] == "mfma"
+    avg, calls = _avg_us(stats, lambda n: "gemmTiled" in n)
+    assert calls % r["launches_per_batch_pass"] == 0
+    frac = r["algorithmic_per_launch"] / (avg * 1e-6) / 1e12 / r["peak"]
+    print("gemmTiled: bench %.4f, rocprof %.4f" % (r["frac"], frac))
+    assert abs(frac - r["frac"]) / r["frac"] < 0.05
+    k = line["kernels"]
+    for cls, match in (("attentionDecCross", lambda n: "attentionDecG<" in n and ", true>" in n), ("attentionEnc", lambda n: "attentionEncF" in n),
+                       ("selfBlockDec", lambda n: "selfBlockDec" in n)):
+        avg, _ = _avg_us(stats, match)
+        print("%s: bench %.2f us, rocprof %.2f us" % (cls, k[cls]["avg_us"], avg))
+        assert abs(avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.05
+    # the HBM-bound kernel of the decode step: achieved bandwidth from the same table
+    cross = k["attentionDecCross"]
+    assert 0.6 < cross["gbs"] / 8000.0 < 1.0
+
+
+def test_pmc_traffic_covers_the_cited_kernel_classes():
+    line, _, pmc = _load()
+    kernels = pmc["kernels"]
+    for cls in ("gemmTiled", "gemvFused", "attentionDecCross", "attentionDec", "attentionEnc", "layerNorm"):
+        e = kernels[cls]
+        assert e["launches"] > 0 and e["hbm_read_bytes_per_launch"] > 0 and e.get("traffic_over_algorithmic") is not None, cls
+    g = kernels["gemmTiled"]
+    # (the line reads the PMC file of the previous counter pass: the same build one session earlier, so equal to a percent or two)
+    t = g["hbm_read_bytes_per_launch"] + g["hbm_write_bytes_per_launch"]
+    assert abs(line["roofline"]["traffic"] - t) / t < 0.02
+    # nothing on the path re-reads more than ~2x its algorithmic bytes; the streaming kernels sit at 1.0x
+    assert kernels["attentionDecCross"]["traffic_over_algorithmic"] < 1.1 and kernels["layerNorm"]["traffic_over_algorithmic"] < 1.1
+    assert g["traffic_over_algorithmic"] < 2.5
