@@ -70,6 +70,32 @@ def test_mel_spectrogram(hip_tiny, golden, tiny_model):
     ctx.close()
 
 
+def test_mel_matrix_core_kernel_against_the_valu_kernel(hip_tiny, golden, tiny_model):
+    """TUNE_MEL_MFMA: DFT + filterbank as FP64 MFMA tiles vs the FP64 FMA kernel -- same arithmetic, different summation order
+    (1e-15 relative before the log) -- on the sample clip, ragged lengths and the streamed-window entry point; both against
+    the float64 restatement."""
+    ctx = binding.HipContext(hip_tiny, 1)
+    pcm = golden["pcm16"].astype(np.float32) / 32768.0
+    L = binding.lib()
+    for n in (len(pcm), 16000 + 77, 401, 160 * 37):
+        x = np.ascontiguousarray(pcm[:n])
+        want = wn.log_mel_spectrogram(x, tiny_model.filters)
+        outs = {}
+        for name, mask in (("mfma", binding.TUNE_DEFAULT | binding.TUNE_MEL_MFMA), ("valu", binding.TUNE_DEFAULT & ~binding.TUNE_MEL_MFMA)):
+            L.wh_debug_set_tuning(mask)
+            try:
+                outs[name] = ctx.mel_spectrogram(torch.from_numpy(x).cuda()).cpu().numpy()
+                win = ctx.mel_spectrogram_window(torch.from_numpy(x).cuda(), 0, n // 160).cpu().numpy() if n >= 1600 else None
+            finally:
+                L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+            d = report("mel %s kernel, %d samples, vs float64 restatement" % (name, n), outs[name], want)
+            assert outs[name].shape == want.shape and d.max() < 2e-5
+            if win is not None:
+                assert np.abs(win - outs[name]).max() < 1e-6
+        assert np.abs(outs["mfma"] - outs["valu"]).max() < 2e-6
+    ctx.close()
+
+
 def test_encoder(hip_tiny, golden, np_tiny):
     ctx = binding.HipContext(hip_tiny, 2)
     mel = torch.from_numpy(golden["mel"]).cuda()

@@ -24,6 +24,7 @@ namespace wh
 		TUNE_GEMM_WIDE_EPI = 131072,	 // tiled GEMM: accumulators leave through LDS as 16-byte row stores instead of 2/4-byte column stores
 		TUNE_GEMM_FRAGPF = 262144,	 // direct-to-LDS tiled GEMM: MFMA fragments of k-substep s+1 are read before the MFMAs of substep s (two register sets, counted LDS waits)
 		TUNE_ATTN_ENC_2SWEEP = 524288,	 // attentionEncF: row sum and P.V in one sweep with the unnormalised FP16 e, O scaled by 1 / sum at the end
+		TUNE_MEL_MFMA = 8388608,		 // spectrogram: DFT and filterbank as v_mfma_f64_16x16x4_f64 tiles (16 frames per workgroup) instead of FP64 FMAs
 		TUNE_SELF_MFMA = 4194304,		 // selfBlockDec: the head's Q/K/V rows as MFMA tiles instead of 8 lanes per weight row on the VALU
 		TUNE_GEMV_ALLROWS = 1048576,	 // 33 .. 128 decode rows, N >= 16384 (vocabulary projection): 32 columns x all rows per workgroup (gemmAllRows)
 		TUNE_GEMV_ROWGROUPS = 2097152,	 // 33 .. 128 decode rows: 32 instead of 64 rows per workgroup while that leaves fewer than 256 workgroups
@@ -32,7 +33,7 @@ namespace wh
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA
+		TUNE_DEFAULT = TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA
 	};
 	extern unsigned g_tuning;
 

@@ -97,6 +97,101 @@ namespace wh
 			if( tid == 0 && shMax != (int)0x80000000 ) atomicMax( maxOrdered, shMax );
 		}
 
+
+		// -----------------------------------------------------------------------------------------------------------
+		// melKernelMf: the same arithmetic on the FP64 matrix cores (v_mfma_f64_16x16x4_f64). The direct DFT is a GEMM
+		//   X[frame][bin] = sum_n a[frame][n] * tw[(n * bin) mod 400],   a = (double)( hann[n] * pcm[frame * 160 + n] )
+		// and so is the filterbank  mel[frame][j] = sum_bin pw[frame][bin] * filters[j][bin]. The VALU kernel above reads one
+		// LDS operand per 1.6 FMAs and runs at ~8 TFLOP/s; an MFMA reads one operand pair per 2048 FLOP.
+		//   * workgroup = 16 frames (one M tile), 512 threads; the 13 tiles of 16 bins are dealt to the 8 waves, a wave keeps
+		//     the real and the imaginary accumulator of its tile (A: lane & 15 = frame, lane >> 4 = sample within the 4-deep
+		//     K step; B: lane & 15 = bin, lane >> 4 = sample; D: column lane & 15 = bin, row (lane >> 4) + 4 r = frame);
+		//   * the 2800 raw samples the 16 overlapping frames cover sit in LDS once (11 KB), the window is applied when the
+		//     operand is formed (same FP32 product as the reference), the twiddle index advances by 4 * bin mod 400 per step;
+		//   * folded power spectrum [16][208] in LDS, then waves 0 .. nMel/16 - 1 run the filterbank as 51 MFMA steps each.
+		constexpr int MF_FR = 16, MF_BINS = 208, MF_PW_STRIDE = 209, MF_SAMPLES = ( MF_FR - 1 ) * HOP + N_FFT;
+		typedef double f64x4 __attribute__( ( ext_vector_type( 4 ) ) );
+
+		__global__ void __launch_bounds__( 512 ) melKernelMf( const float* __restrict__ pcm, long long nSamples,
+			const float* __restrict__ filters, const double* __restrict__ dft, float* __restrict__ mel, long long nLen, int nMel,
+			int* __restrict__ maxOrdered, long long nValidFrames )
+		{
+			__shared__ double tw[ 2 ][ N_FFT ];
+			__shared__ float hannS[ N_FFT ];
+			__shared__ float pcmS[ MF_SAMPLES ];
+			__shared__ double pw[ MF_FR ][ MF_PW_STRIDE ];
+			__shared__ int shMax;
+
+			const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+			const long long f0 = (long long)blockIdx.x * MF_FR;
+			for( int i = tid; i < 2 * N_FFT; i += 512 ) ( &tw[ 0 ][ 0 ] )[ i ] = dft[ i ];
+			for( int i = tid; i < N_FFT; i += 512 ) hannS[ i ] = (float)( 0.5 * ( 1.0 - dft[ i ] ) );
+			if( tid == 0 ) shMax = (int)0x80000000;
+			for( int i = tid; i < MF_SAMPLES; i += 512 )
+			{
+				const long long s = f0 * HOP + i;
+				pcmS[ i ] = s < nSamples ? pcm[ s ] : 0.0f;
+			}
+			__syncthreads();
+
+			const int row = lane & 15, kq = lane >> 4;
+			// a frame at or beyond nLen is all zeros (its samples may exist: the last partial hop of the clip)
+			const bool frameLive = f0 + row < nLen;
+			const float* const px = pcmS + row * HOP + kq;
+			for( int tile = wave; tile < MF_BINS / 16; tile += 8 )
+			{
+				const int bin = tile * 16 + row;
+				int idx = ( kq * bin ) % N_FFT;
+				const int step = ( 4 * bin ) % N_FFT;
+				f64x4 re = { 0.0, 0.0, 0.0, 0.0 }, im = { 0.0, 0.0, 0.0, 0.0 };
+				for( int n0 = 0; n0 < N_FFT; n0 += 4 )
+				{
+					const double a = frameLive ? (double)( hannS[ n0 + kq ] * px[ n0 ] ) : 0.0;
+					const double c = tw[ 0 ][ idx ], s = tw[ 1 ][ idx ];
+					re = __builtin_amdgcn_mfma_f64_16x16x4f64( a, c, re, 0, 0, 0 );
+					im = __builtin_amdgcn_mfma_f64_16x16x4f64( a, s, im, 0, 0, 0 );
+					idx += step;
+					idx = idx >= N_FFT ? idx - N_FFT : idx;
+				}
+				// D: column = lane & 15 = bin of this tile, row = (lane >> 4) + 4 r = frame
+				const double fold = ( bin >= 1 && bin < N_FFT / 2 ) ? 2.0 : 1.0;
+	#pragma unroll
+				for( int r = 0; r < 4; r++ ) pw[ kq + 4 * r ][ bin ] = fold * ( re[ r ] * re[ r ] + im[ r ] * im[ r ] );
+			}
+			__syncthreads();
+
+			// ---- filterbank + log10: A = pw (row = frame, k = bin), B = filters (column = mel band, k = bin; zero beyond bin 200) ----
+			float localMax = -INFINITY;
+			if( wave * 16 < nMel )
+			{
+				const int j = wave * 16 + row;
+				const float* const w = filters + (long long)j * N_BINS;
+				f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+				for( int b0 = 0; b0 < 204; b0 += 4 )
+				{
+					const int b = b0 + kq;
+					const double a = pw[ row ][ b ];
+					const double f = b < N_BINS ? (double)w[ b ] : 0.0;
+					acc = __builtin_amdgcn_mfma_f64_16x16x4f64( a, f, acc, 0, 0, 0 );
+				}
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+				{
+					const long long f = f0 + kq + 4 * r;
+					if( f >= nLen ) continue;
+					double sum = acc[ r ];
+					sum = sum < 1e-10 ? 1e-10 : sum;
+					const float v = ( f < nValidFrames ) ? (float)log10( sum ) : 0.0f;
+					mel[ (long long)j * nLen + f ] = v;
+					localMax = fmaxf( localMax, v );
+				}
+			}
+			localMax = waveReduceMax( localMax );
+			if( lane == 0 && localMax > -INFINITY ) atomicMax( &shMax, orderedInt( localMax ) );
+			__syncthreads();
+			if( tid == 0 && shMax != (int)0x80000000 ) atomicMax( maxOrdered, shMax );
+		}
+
 		__global__ void __launch_bounds__( 256 ) melNormalize( float* __restrict__ mel, long long count, const int* __restrict__ maxOrdered )
 		{
 			const double mmax = (double)fromOrderedInt( *maxOrdered ) - 8.0;
@@ -127,14 +222,27 @@ namespace wh
 		__global__ void melKeepMax( int* maxOrdered ) { maxOrdered[ 1 ] = maxOrdered[ 0 ]; }
 	}	// namespace
 
+	// the spectrogram kernel of both entry points: FP64 matrix cores when the band count is a multiple of 16 (80, 128)
+	static void launchMelFrames( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
+		int nMel, int* mx, long long nValidFrames, hipStream_t stream )
+	{
+		if( ( g_tuning & TUNE_MEL_MFMA ) && ( nMel % 16 ) == 0 && nMel <= 128 )
+		{
+			const int blocks = (int)( ( nLen + MF_FR - 1 ) / MF_FR );
+			hipLaunchKernelGGL( melKernelMf, dim3( blocks ), dim3( 512 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nValidFrames );
+			return;
+		}
+		const int blocks = (int)( ( nLen + FR - 1 ) / FR );
+		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nValidFrames );
+	}
+
 	int launchMel( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
 		int nMel, float* maxScratch, hipStream_t stream )
 	{
 		if( nLen <= 0 ) return 0;
 		int* const mx = (int*)maxScratch;
 		hipLaunchKernelGGL( melInitMax, dim3( 1 ), dim3( 1 ), 0, stream, mx );
-		const int blocks = (int)( ( nLen + FR - 1 ) / FR );
-		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nLen );
+		launchMelFrames( pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nLen, stream );
 		const long long count = nLen * nMel;
 		const int nb = (int)( ( count + 255 ) / 256 < 2048 ? ( count + 255 ) / 256 : 2048 );
 		hipLaunchKernelGGL( melNormalize, dim3( nb ), dim3( 256 ), 0, stream, mel, count, mx );
@@ -150,8 +258,7 @@ namespace wh
 		if( nLen <= 0 ) return 0;
 		int* const mx = (int*)maxScratch;
 		hipLaunchKernelGGL( melInitMaxFloor, dim3( 1 ), dim3( 1 ), 0, stream, mx, 1e-20f );
-		const int blocks = (int)( ( nLen + FR - 1 ) / FR );
-		hipLaunchKernelGGL( melKernel, dim3( blocks ), dim3( 256 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nValidFrames );
+		launchMelFrames( pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nValidFrames, stream );
 		const long long count = nLen * nMel;
 		const int nb = (int)( ( count + 255 ) / 256 < 2048 ? ( count + 255 ) / 256 : 2048 );
 		hipLaunchKernelGGL( melNormalizeWindow, dim3( nb ), dim3( 256 ), 0, stream, mel, count, mx, reusePreviousMax ? 1 : 0 );
