@@ -110,6 +110,9 @@ namespace wh
 		//     operand is formed (same FP32 product as the reference), the twiddle index advances by 4 * bin mod 400 per step;
 		//   * folded power spectrum [16][208] in LDS, then waves 0 .. nMel/16 - 1 run the filterbank as 51 MFMA steps each.
 		constexpr int MF_FR = 16, MF_BINS = 208, MF_PW_STRIDE = 209, MF_SAMPLES = ( MF_FR - 1 ) * HOP + N_FFT;
+		// sample s of the workgroup lives at s + s / 160: frames start 160 samples apart = a multiple of the 32 LDS banks, and the A
+		// operand reads one sample of each of the 16 frames per instruction (16-way conflict without the skew)
+		constexpr int MF_SAMPLES_SKEWED = MF_SAMPLES + MF_SAMPLES / HOP + 1;
 		typedef double f64x4 __attribute__( ( ext_vector_type( 4 ) ) );
 
 		__global__ void __launch_bounds__( 512 ) melKernelMf( const float* __restrict__ pcm, long long nSamples,
@@ -118,7 +121,7 @@ namespace wh
 		{
 			__shared__ double tw[ 2 ][ N_FFT ];
 			__shared__ float hannS[ N_FFT ];
-			__shared__ float pcmS[ MF_SAMPLES ];
+			__shared__ float pcmS[ MF_SAMPLES_SKEWED ];
 			__shared__ double pw[ MF_FR ][ MF_PW_STRIDE ];
 			__shared__ int shMax;
 
@@ -130,14 +133,14 @@ namespace wh
 			for( int i = tid; i < MF_SAMPLES; i += 512 )
 			{
 				const long long s = f0 * HOP + i;
-				pcmS[ i ] = s < nSamples ? pcm[ s ] : 0.0f;
+				pcmS[ i + i / HOP ] = s < nSamples ? pcm[ s ] : 0.0f;
 			}
 			__syncthreads();
 
 			const int row = lane & 15, kq = lane >> 4;
 			// a frame at or beyond nLen is all zeros (its samples may exist: the last partial hop of the clip)
 			const bool frameLive = f0 + row < nLen;
-			const float* const px = pcmS + row * HOP + kq;
+			const float* const px = pcmS + row * ( HOP + 1 ) + kq;	  // sample n of frame `row` = s = row * 160 + n -> s + row + n / 160
 			for( int tile = wave; tile < MF_BINS / 16; tile += 8 )
 			{
 				const int bin = tile * 16 + row;
@@ -146,7 +149,8 @@ namespace wh
 				f64x4 re = { 0.0, 0.0, 0.0, 0.0 }, im = { 0.0, 0.0, 0.0, 0.0 };
 				for( int n0 = 0; n0 < N_FFT; n0 += 4 )
 				{
-					const double a = frameLive ? (double)( hannS[ n0 + kq ] * px[ n0 ] ) : 0.0;
+					const int n = n0 + kq;
+					const double a = frameLive ? (double)( hannS[ n ] * px[ n0 + ( n >= HOP ) + ( n >= 2 * HOP ) ] ) : 0.0;
 					const double c = tw[ 0 ][ idx ], s = tw[ 1 ][ idx ];
 					re = __builtin_amdgcn_mfma_f64_16x16x4f64( a, c, re, 0, 0, 0 );
 					im = __builtin_amdgcn_mfma_f64_16x16x4f64( a, s, im, 0, 0, 0 );
