@@ -104,7 +104,7 @@ namespace wh
 		// and so is the filterbank  mel[frame][j] = sum_bin pw[frame][bin] * filters[j][bin]. The VALU kernel above reads one
 		// LDS operand per 1.6 FMAs and runs at ~8 TFLOP/s; an MFMA reads one operand pair per 2048 FLOP.
 		//   * workgroup = 16 frames (one M tile), 512 threads; the 13 tiles of 16 bins are dealt to the 8 waves, a wave keeps
-		//     the real and the imaginary accumulator of its tile (A: lane & 15 = frame, lane >> 4 = sample within the 4-deep
+		//     the real and the imaginary accumulators of its one or two tiles (A: lane & 15 = frame, lane >> 4 = sample within the 4-deep
 		//     K step; B: lane & 15 = bin, lane >> 4 = sample; D: column lane & 15 = bin, row (lane >> 4) + 4 r = frame);
 		//   * the 2800 raw samples the 16 overlapping frames cover sit in LDS once (11 KB), the window is applied when the
 		//     operand is formed (same FP32 product as the reference), the twiddle index advances by 4 * bin mod 400 per step;
@@ -141,26 +141,38 @@ namespace wh
 			// a frame at or beyond nLen is all zeros (its samples may exist: the last partial hop of the clip)
 			const bool frameLive = f0 + row < nLen;
 			const float* const px = pcmS + row * ( HOP + 1 ) + kq;	  // sample n of frame `row` = s = row * 160 + n -> s + row + n / 160
-			for( int tile = wave; tile < MF_BINS / 16; tile += 8 )
+			// a wave owns bin tiles `wave` and `wave + 8` (13 tiles: waves 0 .. 4 have two) and runs them in ONE K loop: the A
+			// operand is formed once per step and four independent accumulator chains keep the matrix core busy
 			{
-				const int bin = tile * 16 + row;
-				int idx = ( kq * bin ) % N_FFT;
-				const int step = ( 4 * bin ) % N_FFT;
-				f64x4 re = { 0.0, 0.0, 0.0, 0.0 }, im = { 0.0, 0.0, 0.0, 0.0 };
+				const int bin0 = wave * 16 + row, bin1 = ( wave + 8 ) * 16 + row;
+				const bool two = wave + 8 < MF_BINS / 16;
+				int idx0 = ( kq * bin0 ) % N_FFT, idx1 = ( kq * bin1 ) % N_FFT;
+				const int step0 = ( 4 * bin0 ) % N_FFT, step1 = ( 4 * bin1 ) % N_FFT;
+				f64x4 re0 = { 0.0, 0.0, 0.0, 0.0 }, im0 = re0, re1 = re0, im1 = re0;
 				for( int n0 = 0; n0 < N_FFT; n0 += 4 )
 				{
 					const int n = n0 + kq;
 					const double a = frameLive ? (double)( hannS[ n ] * px[ n0 + ( n >= HOP ) + ( n >= 2 * HOP ) ] ) : 0.0;
-					const double c = tw[ 0 ][ idx ], s = tw[ 1 ][ idx ];
-					re = __builtin_amdgcn_mfma_f64_16x16x4f64( a, c, re, 0, 0, 0 );
-					im = __builtin_amdgcn_mfma_f64_16x16x4f64( a, s, im, 0, 0, 0 );
-					idx += step;
-					idx = idx >= N_FFT ? idx - N_FFT : idx;
+					re0 = __builtin_amdgcn_mfma_f64_16x16x4f64( a, tw[ 0 ][ idx0 ], re0, 0, 0, 0 );
+					im0 = __builtin_amdgcn_mfma_f64_16x16x4f64( a, tw[ 1 ][ idx0 ], im0, 0, 0, 0 );
+					idx0 += step0;
+					idx0 = idx0 >= N_FFT ? idx0 - N_FFT : idx0;
+					if( two )	  // wave-uniform
+					{
+						re1 = __builtin_amdgcn_mfma_f64_16x16x4f64( a, tw[ 0 ][ idx1 ], re1, 0, 0, 0 );
+						im1 = __builtin_amdgcn_mfma_f64_16x16x4f64( a, tw[ 1 ][ idx1 ], im1, 0, 0, 0 );
+						idx1 += step1;
+						idx1 = idx1 >= N_FFT ? idx1 - N_FFT : idx1;
+					}
 				}
-				// D: column = lane & 15 = bin of this tile, row = (lane >> 4) + 4 r = frame
-				const double fold = ( bin >= 1 && bin < N_FFT / 2 ) ? 2.0 : 1.0;
+				// D: column = lane & 15 = bin of the tile, row = (lane >> 4) + 4 r = frame
+				const double fold0 = ( bin0 >= 1 && bin0 < N_FFT / 2 ) ? 2.0 : 1.0, fold1 = ( bin1 >= 1 && bin1 < N_FFT / 2 ) ? 2.0 : 1.0;
 	#pragma unroll
-				for( int r = 0; r < 4; r++ ) pw[ kq + 4 * r ][ bin ] = fold * ( re[ r ] * re[ r ] + im[ r ] * im[ r ] );
+				for( int r = 0; r < 4; r++ )
+				{
+					pw[ kq + 4 * r ][ bin0 ] = fold0 * ( re0[ r ] * re0[ r ] + im0[ r ] * im0[ r ] );
+					if( two ) pw[ kq + 4 * r ][ bin1 ] = fold1 * ( re1[ r ] * re1[ r ] + im1[ r ] * im1[ r ] );
+				}
 			}
 			__syncthreads();
 
