@@ -1003,10 +1003,10 @@ namespace wh
 			if( lds > 48 * 1024 )
 			{
 				static PerDeviceOnce once;
-				if( once.needed() )
+				if( const int onceDev = once.needed(); onceDev >= 0 )
 				{
 					WH_HIP( hipFuncSetAttribute( (const void*)selfBlockDec<NQ, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
-					once.mark();
+					once.mark( onceDev );
 				}
 			}
 			hipLaunchKernelGGL( ( selfBlockDec<NQ, MF> ), dim3( a.H, ( a.batch + NQ - 1 ) / NQ ), dim3( NT ), lds, stream, a );
@@ -1021,10 +1021,10 @@ namespace wh
 			if( lds > 64 * 1024 )
 			{
 				static PerDeviceOnce once;
-				if( once.needed() )
+				if( const int onceDev = once.needed(); onceDev >= 0 )
 				{
 					WH_HIP( hipFuncSetAttribute( (const void*)attentionDecG<NQ, FUSEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
-					once.mark();
+					once.mark( onceDev );
 				}
 			}
 			hipLaunchKernelGGL( ( attentionDecG<NQ, FUSEQ> ), dim3( a.H, a.batch / NQ, a.nTok ), dim3( NT ), lds, stream, a );

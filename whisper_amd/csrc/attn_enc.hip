@@ -562,11 +562,11 @@ namespace wh
 		int launchEncF( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream )
 		{
 			static PerDeviceOnce once;
-			if( once.needed() )
+			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<false>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
 				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncF<true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES ) );
-				once.mark();
+				once.mark( onceDev );
 			}
 			const int nQ = ( T + FQ - 1 ) / FQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
@@ -583,10 +583,10 @@ namespace wh
 		int launchEncT( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
 		{
 			static PerDeviceOnce once;
-			if( once.needed() )
+			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)attentionEnc<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS_BYTES ) );
-				once.mark();
+				once.mark( onceDev );
 			}
 			const int nQ = ( T + AQ - 1 ) / AQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;

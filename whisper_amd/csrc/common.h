@@ -167,17 +167,21 @@ namespace wh
 	// ---- host side ----
 	// hipFuncSetAttribute is a per-DEVICE setting: one bit per device ordinal remembers where it has been applied, so a
 	// model on adapter N > 0 gets its dynamic-LDS limit too (the reference binds one D3D device per model,
-	// Whisper/ML/Device.cpp:163-177). Setting it twice from racing threads is harmless.
+	// Whisper/ML/Device.cpp:163-177). The object is a function-local static shared by every host thread, so it keeps NO
+	// per-call state: needed() hands the calling thread's device ordinal back to the caller (or -1 when the attribute is
+	// already set there) and mark( ordinal ) records exactly that device. Two threads on different adapters can interleave
+	// freely; two threads on the same adapter may both set the attribute, which is idempotent.
 	struct PerDeviceOnce
 	{
 		std::atomic<unsigned long long> done{ 0 };
-		int device = 0;
-		bool needed()
+		int needed() const
 		{
+			int device = 0;
 			if( hipGetDevice( &device ) != hipSuccess ) device = 0;
-			return ( ( done.load( std::memory_order_acquire ) >> ( device & 63 ) ) & 1ull ) == 0;
+			device &= 63;
+			return ( ( done.load( std::memory_order_acquire ) >> device ) & 1ull ) == 0 ? device : -1;
 		}
-		void mark() { done.fetch_or( 1ull << ( device & 63 ), std::memory_order_release ); }
+		void mark( int device ) { done.fetch_or( 1ull << ( device & 63 ), std::memory_order_release ); }
 	};
 	void setError( const std::string& s );
 	int hipFail( hipError_t e, const char* what, const char* file, int line );

@@ -61,11 +61,16 @@ namespace wh
 
 		// ---- token + position embedding (addRows.hlsl; whisper.cpp:1544-1548) ---------------------------------------
 		__global__ void __launch_bounds__( 256 ) embedKernel( const int* __restrict__ tokens, const f16* __restrict__ te,
-			const float* __restrict__ pe, float* __restrict__ x, int rows, int nTok, int nPast, const int* __restrict__ nPastDev, int d )
+			const float* __restrict__ pe, float* __restrict__ x, int rows, int nTok, int nPast, const int* __restrict__ nPastDev, int d,
+			int nVocab, int nTextCtx )
 		{
 			const int row = blockIdx.x;
-			const int tok = tokens[ row ];
-			const int pos = ( nPastDev ? *nPastDev : nPast ) + row % nTok;
+			// ids and positions index two tables: both are clamped to the tables' extents, so that no value in tokensDev or in the
+			// device-resident position can turn into an out-of-range read (the host entry points reject such ids before they get here)
+			int tok = tokens[ row ];
+			tok = tok < 0 ? 0 : ( tok >= nVocab ? nVocab - 1 : tok );
+			int pos = ( nPastDev ? *nPastDev : nPast ) + row % nTok;
+			pos = pos < 0 ? 0 : ( pos >= nTextCtx ? nTextCtx - 1 : pos );
 			for( int c = threadIdx.x; c < d; c += 256 )
 				x[ (long long)row * d + c ] = (float)te[ (long long)tok * d + c ] + pe[ (long long)pos * d + c ];
 		}
@@ -339,9 +344,9 @@ namespace wh
 	}
 
 	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, const int* nPastDev, int d,
-		hipStream_t stream )
+		int nVocab, int nTextCtx, hipStream_t stream )
 	{
-		hipLaunchKernelGGL( embedKernel, dim3( rows ), dim3( 256 ), 0, stream, tokens, te, pe, x, rows, nTok, nPast, nPastDev, d );
+		hipLaunchKernelGGL( embedKernel, dim3( rows ), dim3( 256 ), 0, stream, tokens, te, pe, x, rows, nTok, nPast, nPastDev, d, nVocab, nTextCtx );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

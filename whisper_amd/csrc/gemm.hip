@@ -642,11 +642,11 @@ namespace wh
 	#pragma unroll
 						for( int i = 0; i < C::IA; i++ )
 							if( i >= p0 && i < p1 && ( ( C::ABL & 16 ) == 0 || kt == 0 ) )
-								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory" );
+								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory", "m0" );
 	#pragma unroll
 						for( int i = 0; i < C::IW; i++ )
 							if( C::IA + i >= p0 && C::IA + i < p1 && ( ( C::ABL & 8 ) == 0 || kt == 0 ) )
-								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory" );
+								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory", "m0" );
 						return;
 					}
 #pragma unroll
@@ -1371,10 +1371,10 @@ namespace wh
 		if( lds > 48 * 1024 )
 		{
 			static PerDeviceOnce once;
-			if( once.needed() )
+			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)gemmAllRows<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
-				once.mark();
+				once.mark( onceDev );
 			}
 		}
 		hipLaunchKernelGGL( ( gemmAllRows<EPI, MT> ), dim3( tiles ), dim3( 256 ), lds, stream, a );
@@ -1405,10 +1405,10 @@ namespace wh
 		if( lds > 64 * 1024 )
 		{
 			static PerDeviceOnce once;
-			if( once.needed() )
+			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
 				WH_HIP( hipFuncSetAttribute( (const void*)gemvFused<EPI, PRO, ROWS, NW, UNROLL, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds ) );
-				once.mark();
+				once.mark( onceDev );
 			}
 		}
 		const int groups = ( a.M + 16 * MT - 1 ) / ( 16 * MT );
@@ -1493,10 +1493,10 @@ namespace wh
 	static int launchTiledK( const GemmArgs& b, hipStream_t stream )
 	{
 		static PerDeviceOnce once;
-		if( once.needed() )
+		if( const int onceDev = once.needed(); onceDev >= 0 )
 		{
 			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled<EPI, C, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES ) );
-			once.mark();
+			once.mark( onceDev );
 		}
 		const int tilesM = ( b.M + C::BM - 1 ) / C::BM, tilesN = ( b.N + C::BN - 1 ) / C::BN;
 		hipLaunchKernelGGL( ( gemmTiled<EPI, C, WIDE> ), dim3( tilesM * tilesN ), dim3( C::NT ), C::LDS_BYTES, stream, b );

@@ -105,8 +105,9 @@ namespace wh
 	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets,
 		f16* x16, long long xBatchStride, int nMels, int T, int batch, hipStream_t stream );
 	// x[m] = float(te[token[m]]) + pe[nPast + m % nTok]   (addRows.hlsl)
+	// token ids are clamped to [0, nVocab), positions to [0, nTextCtx): no input can index outside the two tables
 	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, const int* nPastDev, int d,
-		hipStream_t stream );
+		int nVocab, int nTextCtx, hipStream_t stream );
 	// in-place table softmax of FP32 rows (softMax*.hlsl with the CPU path's FP16 exp table semantics)
 	int launchSoftMaxRows( float* x, int rows, int cols, hipStream_t stream );
 

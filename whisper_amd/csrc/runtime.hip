@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <cstdlib>
 #include <set>
 #include <string>
 #include <vector>
@@ -270,18 +272,64 @@ struct wh_context
 	// pinned host staging for fully asynchronous enqueues (offsets, tokens, state)
 	int32_t* pinned = nullptr;
 	static constexpr int PINNED_INTS = 4096;
-	std::vector<void*> allocations;
+	struct Allocation { void* base; void* body; int64_t bytes; const char* name; };
+	std::vector<Allocation> allocations;
 
-	template<class T> int alloc( T*& p, int64_t count, bool zero = false )
+	// Every buffer starts zeroed. MUST_BE_ZERO marks the ones whose correctness depends on it: the convolution padding
+	// rows, the V operand padding, the K/V caches (rows beyond n_past are masked, not skipped: they must be finite) and the
+	// device-resident decode state. The others are written before they are read and are zeroed only as hygiene -- which is
+	// exactly what WH_DEBUG_POISON=<byte> checks: in that mode those buffers are filled with the byte instead (0xFF = NaN in
+	// FP16 / FP32 and -1 as an index), every buffer gets a guard region on both sides, and wh_context_destroy verifies the
+	// guards. A run whose results or faults change under WH_DEBUG_POISON depends on stale device memory.
+	enum eInit { DONT_CARE, MUST_BE_ZERO };
+	template<class T> int alloc( T*& p, int64_t count, eInit init, const char* name )
 	{
 		void* v = nullptr;
 		const int64_t bytes = count * (int64_t)sizeof( T );
-		WH_HIP( hipMalloc( &v, (size_t)bytes ) );
-		if( zero ) WH_HIP( hipMemsetAsync( v, 0, (size_t)bytes, stream ) );
-		allocations.push_back( v );
+		const int64_t guard = debugGuardBytes();
+		WH_HIP( hipMalloc( &v, (size_t)( bytes + 2 * guard ) ) );
+		uint8_t* const body = (uint8_t*)v + guard;
+		if( guard )
+		{
+			WH_HIP( hipMemsetAsync( v, GUARD_BYTE, (size_t)guard, stream ) );
+			WH_HIP( hipMemsetAsync( body + bytes, GUARD_BYTE, (size_t)guard, stream ) );
+		}
+		const int fill = ( init == DONT_CARE && debugPoison() >= 0 ) ? debugPoison() : 0;
+		WH_HIP( hipMemsetAsync( body, fill, (size_t)bytes, stream ) );
+		allocations.push_back( { v, body, bytes, name } );
 		vram += bytes;
-		p = (T*)v;
+		p = (T*)body;
 		return 0;
+	}
+	static constexpr int GUARD_BYTE = 0xA5;
+	static int debugPoison()
+	{
+		static const int v = []() { const char* e = getenv( "WH_DEBUG_POISON" ); return ( e && *e ) ? (int)( strtol( e, nullptr, 0 ) & 0xFF ) : -1; }();
+		return v;
+	}
+	static int64_t debugGuardBytes() { return debugPoison() >= 0 ? 65536 : 0; }
+	// Guard regions intact? Violations go to stderr with the buffer's name and the first damaged offset (negative = before the body).
+	int verifyGuards() const
+	{
+		const int64_t guard = debugGuardBytes();
+		if( !guard ) return 0;
+		int bad = 0;
+		std::vector<uint8_t> h( (size_t)guard );
+		for( const Allocation& a : allocations )
+			for( int side = 0; side < 2; side++ )
+			{
+				const uint8_t* const src = side ? (const uint8_t*)a.body + a.bytes : (const uint8_t*)a.base;
+				if( hipMemcpy( h.data(), src, (size_t)guard, hipMemcpyDeviceToHost ) != hipSuccess ) continue;
+				for( int64_t i = 0; i < guard; i++ )
+					if( h[ (size_t)i ] != GUARD_BYTE )
+					{
+						fprintf( stderr, "WH_GUARD_VIOLATION: buffer '%s' (%lld bytes): write at offset %lld\n", a.name, (long long)a.bytes,
+							(long long)( side ? a.bytes + i : i - guard ) );
+						bad++;
+						break;
+					}
+			}
+		return bad;
 	}
 };
 
@@ -291,7 +339,7 @@ template<class T>
 static int capture( wh_context* c, T*& dst, const T* src, int64_t count, int64_t capacity )
 {
 	if( !( c->flags & WH_FLAG_DEBUG_CAPTURE ) ) return 0;
-	if( !dst ) WH_CHECK( c->alloc( dst, capacity ) );
+	if( !dst ) WH_CHECK( c->alloc( dst, capacity, wh_context::DONT_CARE, "debug capture" ) );
 	WH_HIP( hipMemcpyAsync( dst, src, (size_t)count * sizeof( T ), hipMemcpyDeviceToDevice, c->stream ) );
 	return 0;
 }
@@ -718,8 +766,8 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 		}
 		else
 			e = hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking );
-		if( e != hipSuccess ) { delete c; return hipFail( e, "hipStreamCreate", __FILE__, __LINE__ ); }
 		c->ownsStream = true;
+		if( e != hipSuccess ) { wh_context_destroy( c ); return hipFail( e, "hipStreamCreate", __FILE__, __LINE__ ); }	// releases whichever streams / events exist
 	}
 	const wh_hparams& hp = m->hp;
 	const int64_t d = hp.n_audio_state, B = maxBatch, H = hp.n_audio_head, S = c->maxSeq;
@@ -731,39 +779,45 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	c->convInStride = ( 2ll * T + 2 ) * hp.n_mels;
 	c->conv1Stride = ( 2ll * T + 2 ) * d;
 	int rc = 0;
-	rc = rc ? rc : c->alloc( c->convIn, B * c->convInStride + 1024, true );
-	rc = rc ? rc : c->alloc( c->conv1Out, B * c->conv1Stride + 1024, true );
-	rc = rc ? rc : c->alloc( c->x, rowsE * d );
-	rc = rc ? rc : c->alloc( c->encOut, rowsE * d );
-	rc = rc ? rc : c->alloc( c->xn, rowsE * d );
-	rc = rc ? rc : c->alloc( c->q, rowsE * d );
-	rc = rc ? rc : c->alloc( c->k, rowsE * d );
-	rc = rc ? rc : c->alloc( c->vT, B * H * HEAD_DIM * c->Tpad, true );
-	rc = rc ? rc : c->alloc( c->attn, rowsE * d );
-	rc = rc ? rc : c->alloc( c->h, rowsE * 4 * d );
-	rc = rc ? rc : c->alloc( c->crossK, (int64_t)hp.n_text_layer * rowsE * d, true );
-	rc = rc ? rc : c->alloc( c->crossV, (int64_t)hp.n_text_layer * rowsE * d, true );
-	rc = rc ? rc : c->alloc( c->selfK, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, true );
-	rc = rc ? rc : c->alloc( c->selfV, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, true );
+	// conv1 is an implicit GEMM whose row t is the K = conv1Kpad halfs starting at padded row t (stride n_mels): the last
+	// row of the last window therefore reads conv1Kpad - 3 n_mels halfs (16 at 80 mels, 0 at 128) past the logical end. Those
+	// columns meet zero weights (the padded part of conv1w's rows), but the operand must still be finite: the tail is part
+	// of the allocation and, like the padding rows, stays zero for the life of the context. conv2 (K = 3 d over rows of
+	// stride 2 d, last row ending at (2 T + 1) d) never leaves its (2 T + 2) d rows.
+	const int64_t conv1Tail = conv1Kpad( hp ) - 3 * hp.n_mels;
+	rc = rc ? rc : c->alloc( c->convIn, B * c->convInStride + conv1Tail, wh_context::MUST_BE_ZERO, "convIn" );
+	rc = rc ? rc : c->alloc( c->conv1Out, B * c->conv1Stride, wh_context::MUST_BE_ZERO, "conv1Out" );
+	rc = rc ? rc : c->alloc( c->x, rowsE * d, wh_context::DONT_CARE, "x" );
+	rc = rc ? rc : c->alloc( c->encOut, rowsE * d, wh_context::DONT_CARE, "encOut" );
+	rc = rc ? rc : c->alloc( c->xn, rowsE * d, wh_context::DONT_CARE, "xn" );
+	rc = rc ? rc : c->alloc( c->q, rowsE * d, wh_context::DONT_CARE, "q" );
+	rc = rc ? rc : c->alloc( c->k, rowsE * d, wh_context::DONT_CARE, "k" );
+	rc = rc ? rc : c->alloc( c->vT, B * H * HEAD_DIM * c->Tpad, wh_context::MUST_BE_ZERO, "vT" );
+	rc = rc ? rc : c->alloc( c->attn, rowsE * d, wh_context::DONT_CARE, "attn" );
+	rc = rc ? rc : c->alloc( c->h, rowsE * 4 * d, wh_context::DONT_CARE, "h" );
+	rc = rc ? rc : c->alloc( c->crossK, (int64_t)hp.n_text_layer * rowsE * d, wh_context::MUST_BE_ZERO, "crossK" );
+	rc = rc ? rc : c->alloc( c->crossV, (int64_t)hp.n_text_layer * rowsE * d, wh_context::MUST_BE_ZERO, "crossV" );
+	rc = rc ? rc : c->alloc( c->selfK, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, wh_context::MUST_BE_ZERO, "selfK" );
+	rc = rc ? rc : c->alloc( c->selfV, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, wh_context::MUST_BE_ZERO, "selfV" );
 	const int64_t rowsD = c->maxRows;
-	rc = rc ? rc : c->alloc( c->dx, rowsD * d );
-	rc = rc ? rc : c->alloc( c->dxn, rowsD * d );
-	rc = rc ? rc : c->alloc( c->dq, rowsD * d );
-	rc = rc ? rc : c->alloc( c->dattn, rowsD * d );
-	rc = rc ? rc : c->alloc( c->dh, rowsD * 4 * d );
-	rc = rc ? rc : c->alloc( c->logits, S * (int64_t)hp.n_vocab );
-	rc = rc ? rc : c->alloc( c->probs, S * (int64_t)hp.n_vocab );
-	rc = rc ? rc : c->alloc( c->tokensDev, rowsD );
-	rc = rc ? rc : c->alloc( c->melOffsetsDev, B );
-	rc = rc ? rc : c->alloc( c->tokDataDev, S );
-	rc = rc ? rc : c->alloc( c->melScratch, 64 );
-	rc = rc ? rc : c->alloc( c->state, 1, true );
+	rc = rc ? rc : c->alloc( c->dx, rowsD * d, wh_context::DONT_CARE, "dx" );
+	rc = rc ? rc : c->alloc( c->dxn, rowsD * d, wh_context::DONT_CARE, "dxn" );
+	rc = rc ? rc : c->alloc( c->dq, rowsD * d, wh_context::DONT_CARE, "dq" );
+	rc = rc ? rc : c->alloc( c->dattn, rowsD * d, wh_context::DONT_CARE, "dattn" );
+	rc = rc ? rc : c->alloc( c->dh, rowsD * 4 * d, wh_context::DONT_CARE, "dh" );
+	rc = rc ? rc : c->alloc( c->logits, S * (int64_t)hp.n_vocab, wh_context::DONT_CARE, "logits" );
+	rc = rc ? rc : c->alloc( c->probs, S * (int64_t)hp.n_vocab, wh_context::DONT_CARE, "probs" );
+	rc = rc ? rc : c->alloc( c->tokensDev, rowsD, wh_context::DONT_CARE, "tokensDev" );
+	rc = rc ? rc : c->alloc( c->melOffsetsDev, B, wh_context::DONT_CARE, "melOffsetsDev" );
+	rc = rc ? rc : c->alloc( c->tokDataDev, S, wh_context::DONT_CARE, "tokDataDev" );
+	rc = rc ? rc : c->alloc( c->melScratch, 64, wh_context::DONT_CARE, "melScratch" );
+	rc = rc ? rc : c->alloc( c->state, 1, wh_context::MUST_BE_ZERO, "state" );
 	if( rc == 0 )
 	{
 		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * wh_context::PINNED_INTS, hipHostMallocDefault );
 		if( e != hipSuccess ) rc = hipFail( e, "hipHostMalloc", __FILE__, __LINE__ );
 	}
-	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * S );
+	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * S, wh_context::DONT_CARE, "greedyOut" );
 	if( rc == 0 )
 	{
 		const hipError_t e = hipStreamSynchronize( c->stream );
@@ -790,9 +844,10 @@ void wh_context_destroy( wh_context* c )
 	if( c->encStream ) { (void)hipStreamSynchronize( c->encStream ); (void)hipStreamDestroy( c->encStream ); }
 	if( c->encReady ) (void)hipEventDestroy( c->encReady );
 	if( c->encDone ) (void)hipEventDestroy( c->encDone );
-	for( void* p : c->allocations ) (void)hipFree( p );
+	if( c->verifyGuards() != 0 ) fprintf( stderr, "WH_GUARD_VIOLATION: context %p wrote outside its buffers\n", (void*)c );
+	for( const auto& a : c->allocations ) (void)hipFree( a.base );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
-	if( c->ownsStream ) (void)hipStreamDestroy( c->stream );
+	if( c->ownsStream && c->stream ) (void)hipStreamDestroy( c->stream );
 	delete c;
 }
 
@@ -812,19 +867,66 @@ int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
 }
 
 // ---- plain device buffers for host code that must not include HIP headers (replaces Whisper/D3D/createBuffer.cpp) ----
+// With WH_DEBUG_POISON set these buffers get the same treatment as the context's own: poison fill, guard regions on both
+// sides, guards verified by wh_buffer_free.
+namespace
+{
+	struct GuardedBuffer { void* base; int64_t bytes; };
+	std::mutex g_guardedMutex;
+	std::map<void*, GuardedBuffer> g_guarded;
+}
 int wh_buffer_alloc( int64_t bytes, void** dev )
 {
 	if( !dev || bytes <= 0 ) { setError( "buffer_alloc: bad argument" ); return WH_E_INVALIDARG; }
 	void* p = nullptr;
-	const hipError_t e = hipMalloc( &p, (size_t)bytes );
+	const int64_t guard = wh_context::debugGuardBytes();
+	const hipError_t e = hipMalloc( &p, (size_t)( bytes + 2 * guard ) );
 	if( e != hipSuccess ) { hipFail( e, "hipMalloc", __FILE__, __LINE__ ); return e == hipErrorOutOfMemory ? WH_E_OUTOFMEMORY : WH_E_HIP; }
+	if( guard )
+	{
+		uint8_t* const body = (uint8_t*)p + guard;
+		WH_HIP( hipMemset( p, wh_context::GUARD_BYTE, (size_t)guard ) );
+		WH_HIP( hipMemset( body, wh_context::debugPoison(), (size_t)bytes ) );
+		WH_HIP( hipMemset( body + bytes, wh_context::GUARD_BYTE, (size_t)guard ) );
+		std::lock_guard<std::mutex> lock( g_guardedMutex );
+		g_guarded[ body ] = { p, bytes };
+		p = body;
+	}
 	*dev = p;
 	return 0;
 }
 
 int wh_buffer_free( void* dev )
 {
-	if( dev ) WH_HIP( hipFree( dev ) );
+	if( !dev ) return 0;
+	if( wh_context::debugGuardBytes() )
+	{
+		GuardedBuffer g = { nullptr, 0 };
+		{
+			std::lock_guard<std::mutex> lock( g_guardedMutex );
+			auto it = g_guarded.find( dev );
+			if( it != g_guarded.end() ) { g = it->second; g_guarded.erase( it ); }
+		}
+		if( g.base )
+		{
+			const int64_t guard = wh_context::debugGuardBytes();
+			std::vector<uint8_t> h( (size_t)guard );
+			for( int side = 0; side < 2; side++ )
+			{
+				const uint8_t* const src = side ? (const uint8_t*)dev + g.bytes : (const uint8_t*)g.base;
+				if( hipMemcpy( h.data(), src, (size_t)guard, hipMemcpyDeviceToHost ) != hipSuccess ) continue;
+				for( int64_t i = 0; i < guard; i++ )
+					if( h[ (size_t)i ] != wh_context::GUARD_BYTE )
+					{
+						fprintf( stderr, "WH_GUARD_VIOLATION: wh_buffer_alloc buffer (%lld bytes): write at offset %lld\n", (long long)g.bytes,
+							(long long)( side ? g.bytes + i : i - guard ) );
+						break;
+					}
+			}
+			dev = g.base;
+		}
+	}
+	WH_HIP( hipFree( dev ) );
 	return 0;
 }
 
@@ -964,7 +1066,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 		g.ldc = d; g.cBatchStride = c->conv1Stride;
 		WH_CHECK( gemmP( c, g, false ) );
 	}
-	WH_CHECK( capture( c, c->capTemp1, c->conv1Out, (int64_t)batch * c->conv1Stride, (int64_t)c->maxBatch * c->conv1Stride + 1024 ) );	// "enc.temp1"
+	WH_CHECK( capture( c, c->capTemp1, c->conv1Out, (int64_t)batch * c->conv1Stride, (int64_t)c->maxBatch * c->conv1Stride ) );	// "enc.temp1"
 	// conv2 (stride 2) + bias + GELU + positional embedding -> residual stream x [batch*T][d] (whisper.cpp:1138-1167)
 	{
 		GemmArgs g = plainGemm( c->conv1Out, m->at<f16>( L.conv2w ), M, d, 3 * d );
@@ -1074,7 +1176,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	};
 
 	WH_CHECK( profiled( c, KC_EMBED, 1.0 * M * d, 10.0 * M * d,
-		[ & ]() { return launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, nPastDev, d, st ); } ) );
+		[ & ]() { return launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, nPastDev, d, hp.n_vocab, hp.n_text_ctx, st ); } ) );
 
 	for( int il = 0; il < hp.n_text_layer; il++ )
 	{
@@ -1195,6 +1297,21 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	return 0;
 }
 
+// Token ids index the embedding table: anything outside [0, n_vocab) is rejected at the boundary (the reference's addRows
+// shader reads whatever the id selects, MlContext.cpp:588-618; here a bad id is the caller's error, not a device fault).
+static int checkTokens( const wh_hparams& hp, const int32_t* tokens, int64_t count, const char* who )
+{
+	for( int64_t i = 0; i < count; i++ )
+		if( tokens[ i ] < 0 || tokens[ i ] >= hp.n_vocab )
+		{
+			char buf[ 160 ];
+			snprintf( buf, sizeof( buf ), "%s: token id %d at index %lld is outside [0, %d)", who, (int)tokens[ i ], (long long)i, hp.n_vocab );
+			setError( buf );
+			return WH_E_INVALIDARG;
+		}
+	return 0;
+}
+
 int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int nPast, float* logitsHost, float* probsHost )
 {
 	if( !c || !tokens || batch <= 0 || batch > c->maxSeq || ( batch % c->hyp ) != 0 || nTokens <= 0 || nPast < 0 ) { setError( "decode: bad argument" ); return WH_E_INVALIDARG; }
@@ -1204,6 +1321,7 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 	if( nPast + nTokens > hp.n_text_ctx ) { setError( "decode: n_past + n_tokens exceeds n_text_ctx" ); return WH_E_BOUNDS; }
 	hipStream_t st = c->stream;
 	const int M = batch * nTokens;
+	WH_CHECK( checkTokens( hp, tokens, M, "decode" ) );
 	WH_HIP( hipMemcpyAsync( c->tokensDev, tokens, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
 	WH_CHECK( decodeGraph( c, batch, nTokens, nPast, false ) );
 	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab,
@@ -1235,6 +1353,7 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
 	if( nPast + nSteps > hp.n_text_ctx ) { setError( "decode_greedy: n_past + n_steps exceeds n_text_ctx" ); return WH_E_BOUNDS; }
+	WH_CHECK( checkTokens( hp, firstTokens, batch, "decode_greedy" ) );
 	hipStream_t st = c->stream;
 	const DecodeState init = { nPast, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0 };
 	WH_HIP( hipMemcpyAsync( c->state, &init, sizeof( init ), hipMemcpyHostToDevice, st ) );
@@ -1309,6 +1428,7 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
 	if( nPrompt + nSteps > hp.n_text_ctx || batch * nPrompt + 8 > wh_context::PINNED_INTS - 1024 ) { setError( "decode_window_start: too many tokens" ); return WH_E_BOUNDS; }
+	WH_CHECK( checkTokens( hp, promptTokens, (int64_t)batch * nPrompt, "decode_window_start" ) );
 	hipStream_t st = c->stream;
 	for( auto& mk : c->marks ) c->markPool.push_back( mk.ev );
 	c->marks.clear();

@@ -353,7 +353,7 @@ namespace Whisper
 			if( mel.nSamples > 0 )
 			{
 				hr = ensureBuffer( pcmDev, pcmCapacity, mel.nSamples * 4 );
-				if( SUCCEEDED( hr ) ) hr = ensureBuffer( melDev, melCapacity, (int64_t)CHUNK_FRAMES * model->hp.n_mels * 4 );
+				if( SUCCEEDED( hr ) ) hr = ensureBuffer( melDev, melCapacity, (int64_t)std::max( CHUNK_FRAMES, 2 * model->hp.n_audio_ctx ) * model->hp.n_mels * 4 );	// encodeWindow asks for up to 2 * n_audio_ctx frames
 				if( SUCCEEDED( hr ) && 0 != wh_buffer_upload( gpu, pcmDev, pcm.data(), mel.nSamples * 4 ) ) hr = E_FAIL;
 			}
 			if( SUCCEEDED( hr ) ) hr = runFullImpl( params, progress );
