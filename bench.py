@@ -154,8 +154,10 @@ def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, par
         spans = []
         n_past = 0
         toks = list(prompt)
+        refN_logits = []
         for s in range(len(ids)):
             rl = w.decode(toks, n_past)[0][-1]
+            refN_logits.append(rl.astype(np.float64))
             gl = g["logits"][s]
             d = np.abs(rl.astype(np.float64) - gl)
             worst_max, worst_mean = max(worst_max, float(d.max())), max(worst_mean, float(d.mean()))
@@ -163,6 +165,23 @@ def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, par
             agree += int(np.argmax(rl) == np.argmax(gl))
             n_past += len(toks)
             toks = [ids[s]]
+        # the reference's own band at this shape: the same teacher-forced steps replayed with ONE thread on the same encoder
+        # state (the encoder and the cross-K/V are thread-count invariant; the decoder's FP16 P.V partition is not)
+        w.n_threads = 1
+        n_past = 0
+        toks = list(prompt)
+        b_max = b_mean = g1_max = 0.0
+        for s in range(len(ids)):
+            r1 = w.decode(toks, n_past)[0][-1]
+            d = np.abs(r1.astype(np.float64) - refN_logits[s])
+            b_max, b_mean = max(b_max, float(d.max())), max(b_mean, float(d.mean()))
+            g1_max = max(g1_max, float(np.abs(r1.astype(np.float64) - g["logits"][s]).max()))
+            n_past += len(toks)
+            toks = [ids[s]]
+        w.n_threads = n_threads
+        par.update({"ref1_vs_ref%d_max" % n_threads: b_max, "ref1_vs_ref%d_mean" % n_threads: b_mean, "gpu_vs_ref1_max": g1_max})
+        if "truth" in g.files:
+            par["truth_d128"] = json.loads(str(g["truth"]))
         par.update({"steps": len(ids), "logits_max_abs_diff": worst_max, "logits_mean_abs_diff": worst_mean,
                     "logit_span_min": min(spans), "top1_agreement": "%d/%d" % (agree, len(ids)),
                     "note": "teacher-forced by the GPU's own greedy ids; the reference's decoder result itself moves by ~5e-2 between 1 and "
@@ -196,8 +215,47 @@ def gpu_parity_record(hip_model, hp, pcm_window, prompt, path):
         toks = np.asarray([[t]], np.int32)
     rec["logits"] = np.stack(logits)
     rec["ids"] = np.asarray(ids, np.int32)
-    np.savez(path, **rec)
     ctx.close()
+    t = truth_yardstick()
+    if t is not None:
+        rec["truth"] = np.asarray(json.dumps(t))
+    np.savez(path, **rec)
+
+
+def truth_yardstick():
+    """north_star's 1e-3 next to the oracle's own band, against EXACT arithmetic: the d = 128 test model of the committed
+    fixtures (tests/golden/ref_test_d128.npz = the reference at 1 thread, ref_e2e_d128.npz = the reference at 8 threads and the
+    float64 no-rounding restatement, tests/golden/make_golden_e2e.py), 5 teacher-forced steps through the measured GPU path."""
+    import torch
+    from whisper_amd import binding, ggml_format as gf
+    try:
+        g1 = np.load(os.path.join(ROOT, "tests", "golden", "ref_test_d128.npz"))
+        g8 = np.load(os.path.join(ROOT, "tests", "golden", "ref_e2e_d128.npz"))
+    except OSError:
+        return None
+    model = gf.synth_model("test-d128", seed=1234, attn_sharpness=2.0)
+    hm = binding.HipModel.from_ggml(model)
+    ctx = binding.HipContext(hm, 1)
+    ctx.encode(torch.from_numpy(g1["mel"]).cuda())
+    out = {"model": "test-d128 (seed 1234), 5 teacher-forced steps", "gpu_vs_truth_max": 0.0, "gpu_vs_truth_mean": 0.0,
+           "ref8_vs_truth_max": 0.0, "ref1_vs_truth_max": 0.0, "ref1_vs_ref8_max": 0.0, "gpu_vs_ref8_max": 0.0}
+    pos = n_past = 0
+    for i, ln in enumerate(g1["step_lens"]):
+        ln = int(ln)
+        gl, _ = ctx.decode(g1["steps"][pos:pos + ln][None, :], n_past)
+        truth, r1, r8 = g8["truth_logits%d" % i].astype(np.float64), g1["logits%d" % i].astype(np.float64), g8["ref8_logits%d" % i].astype(np.float64)
+        d = np.abs(gl[0] - truth)
+        out["gpu_vs_truth_max"] = max(out["gpu_vs_truth_max"], float(d.max()))
+        out["gpu_vs_truth_mean"] = max(out["gpu_vs_truth_mean"], float(d.mean()))
+        out["ref8_vs_truth_max"] = max(out["ref8_vs_truth_max"], float(np.abs(r8 - truth).max()))
+        out["ref1_vs_truth_max"] = max(out["ref1_vs_truth_max"], float(np.abs(r1 - truth).max()))
+        out["ref1_vs_ref8_max"] = max(out["ref1_vs_ref8_max"], float(np.abs(r1 - r8).max()))
+        out["gpu_vs_ref8_max"] = max(out["gpu_vs_ref8_max"], float(np.abs(gl[0] - r8).max()))
+        pos += ln
+        n_past += ln
+    ctx.close()
+    hm.close()
+    return out
 
 
 def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want_parity=True):

@@ -36,6 +36,11 @@ typedef int32_t HRESULT;
 #endif
 
 struct IMFSourceReader;	   // Windows-only type, never defined here
+// The reference's path type for media files: TCHAR* = UTF-16 on Windows, `using LPCTSTR = const char*` (UTF-8) everywhere
+// else (ComLightLib/comLightCommon.h:5-9). A caller compiled from the reference's own headers on Linux passes const char*.
+#ifndef _MSC_VER
+using LPCTSTR = const char*;
+#endif
 
 namespace ComLight
 {
@@ -194,6 +199,7 @@ namespace Whisper
 		void* encoder_begin_callback_user_data;
 
 		bool flag( eFullParamsFlags f ) const { return 0 != ( (uint32_t)flags & (uint32_t)f ); }
+		void resetFlag( eFullParamsFlags bit ) { flags = (eFullParamsFlags)( (uint32_t)flags & ~(uint32_t)bit ); }
 		void setFlag( eFullParamsFlags bit, bool set = true )
 		{
 			uint32_t f = (uint32_t)flags;
@@ -258,11 +264,11 @@ namespace Whisper
 	struct iMediaFoundation : public ComLight::IUnknown
 	{
 		static constexpr ComLight::GUID iid() { return { 0xfb9763a5, 0xd77d, 0x4b6e, { 0xaf, 0xf8, 0xf4, 0x94, 0x81, 0x3c, 0xeb, 0xd8 } }; }
-		virtual HRESULT loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const = 0;
-		virtual HRESULT openAudioFile( const wchar_t* path, bool stereo, iAudioReader** pp ) = 0;
+		virtual HRESULT loadAudioFile( LPCTSTR path, bool stereo, iAudioBuffer** pp ) const = 0;
+		virtual HRESULT openAudioFile( LPCTSTR path, bool stereo, iAudioReader** pp ) = 0;
 		virtual HRESULT loadAudioFileData( const void* data, uint64_t size, bool stereo, iAudioReader** pp ) = 0;
 		virtual HRESULT listCaptureDevices( pfnFoundCaptureDevices pfn, void* pv ) = 0;
-		virtual HRESULT openCaptureDevice( const wchar_t* endpoint, const sCaptureParams& captureParams, iAudioCapture** pp ) = 0;
+		virtual HRESULT openCaptureDevice( LPCTSTR endpoint, const sCaptureParams& captureParams, iAudioCapture** pp ) = 0;
 	};
 
 	// {b9956374-3b18-4943-90f2-2ab18a404537}

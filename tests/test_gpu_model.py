@@ -19,7 +19,9 @@ from whisper_amd import binding, ggml_format as gf  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-E2E_MAX, E2E_MEAN = 6e-3, 1e-3
+# about 2x the measured end-to-end differences on the d = 128 test model (max 2.3e-3, mean 4.2e-4 against the 8-thread reference;
+# the reference itself sits 1.7-2.0e-3 / 3.5e-4 from exact arithmetic, see test_decoder_fast_path)
+E2E_MAX, E2E_MEAN = 4e-3, 8e-4
 
 
 def report(name, got, want):
@@ -108,10 +110,10 @@ def test_encoder(hip_tiny, golden, np_tiny):
             got = ctx.debug_read("cross-" + nm, il)[0]
             want = golden["cross_%s%d" % (nm, il)].astype(np.float32)
             d = report("cross-%s[%d] vs reference" % (nm, il), got, want)
-            assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+            assert d.max() < 5e-3 and d.mean() < E2E_MEAN
             mine = np_tiny.kv.cross_k[il] if nm == "k" else np_tiny.kv.cross_v[il]
             d = report("cross-%s[%d] vs restatement" % (nm, il), got, mine)
-            assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+            assert d.max() < 5e-3 and d.mean() < E2E_MEAN
     ctx.close()
 
 
@@ -183,7 +185,7 @@ def test_decoder_parity_mode(hip_tiny, golden, np_tiny, tiny_model):
     for nm in ("k", "v"):
         got = ctx.debug_read("self-" + nm, 0, rows)[0]
         d = report("self-%s[0] vs reference" % nm, got, golden["self_%s0" % nm].astype(np.float32))
-        assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+        assert d.max() < 5e-3 and d.mean() < E2E_MEAN
     ctx.close()
 
 
@@ -422,8 +424,10 @@ def test_medium_shape_against_the_reference(ref_lib_available, tmp_path):
         dk = report("medium cross-k[%d] vs reference" % il, ctx.debug_read("cross-k", il)[0], k)
         dv = report("medium cross-v[%d] vs reference" % il, ctx.debug_read("cross-v", il)[0], v)
         scale_k, scale_v = float(np.abs(k).max()), float(np.abs(v).max())
-        assert dk.max() < 1e-2 * max(1.0, scale_k) and dk.mean() < 1e-3 * max(1.0, scale_k)
-        assert dv.max() < 1e-2 * max(1.0, scale_v) and dv.mean() < 1e-3 * max(1.0, scale_v)
+        # measured 2.0e-3 / 2.6e-4 (K, |k| <= 2.2) and 4.9e-3 / 7.4e-4 (V, |v| <= 5.2: one FP16 ulp there is 3.9e-3); bounds = 2x
+        assert scale_k < 4.0 and scale_v < 8.0
+        assert dk.max() < 4e-3 and dk.mean() < 6e-4
+        assert dv.max() < 1e-2 and dv.mean() < 1.5e-3
     prompt = [sp["sot"], sp["sot"] + 1, sp["transcribe"]]
     toks = np.array([prompt] * n_win, np.int32)
     n_past = 0
@@ -438,13 +442,18 @@ def test_medium_shape_against_the_reference(ref_lib_available, tmp_path):
         print("    logit span %.3f, top-1 gpu %d ref %d" % (span, int(np.argmax(gl[0])), int(np.argmax(rl))))
         worst = max(worst, d.max() / max(span, 1e-6))
         assert np.isfinite(gl).all()
-        # random weights at 24 layers: |logit| is O(1-10); the bound is relative to the logit span of the row
-        assert d.max() < 2e-2 * max(1.0, span) and d.mean() < 2e-3 * max(1.0, span)
-        agree += int(np.argmax(gl[0]) == np.argmax(rl))
+        # measured max 5.4e-3, mean 9.8e-4 on logits of magnitude 6.8 (span 12.4); bounds = 2x measured, absolute
+        assert d.max() < 1.2e-2 and d.mean() < 2e-3
+        top2 = np.sort(rl)[-2:]
+        same = int(np.argmax(gl[0]) == np.argmax(rl))
+        # a top-1 disagreement is admissible only where the reference's own top-2 margin is inside the error band
+        assert same or float(top2[1] - top2[0]) < 1e-2, ("top-1 differs with a reference margin of", float(top2[1] - top2[0]))
+        agree += same
         n_past += toks.shape[1]
         nxt = ctx.sample_best(n_win, step == 0, step == 0)
         toks = np.array([[t["id"]] for t in nxt], np.int32)
     print("medium shape: top-1 agreement %d / 7 steps, worst max-diff / span %.2e" % (agree, worst))
+    assert agree >= 6
     w.close()
     ctx.close()
     m.close()
@@ -513,7 +522,7 @@ def test_live_reference_if_present(hip_tiny, tiny_model, golden, ref_lib_availab
     assert d.max() < E2E_MAX and d.mean() < E2E_MEAN
     k, v = w.cross_kv(2)
     d = report("live reference cross-k[2]", ctx.debug_read("cross-k", 2)[0], k)
-    assert d.max() < 8e-3 and d.mean() < E2E_MEAN
+    assert d.max() < 5e-3 and d.mean() < E2E_MEAN
     ctx.close()
 
 

@@ -87,11 +87,33 @@ def build_cli(force: bool = False):
     return CLI_BIN
 
 
+ABI_SRC = os.path.join(ROOT, "tests", "abi_caller", "caller.cpp")
+ABI_REF_BIN = os.path.join(LIB_DIR, "abi-caller-ref")      # built from the REFERENCE's own headers (only where /root/reference exists)
+ABI_OUR_BIN = os.path.join(LIB_DIR, "abi-caller-our")      # the same source against include/whisperApi.h
+REFERENCE_ROOT = "/root/reference"
+
+
+def build_abi_callers(force: bool = False):
+    """The boundary proof of tests/test_abi_reference_headers.py: one caller source compiled against the reference's public
+    headers where they lie (never copied; the GPU box only gets the binary) and against ours, both linking libWhisper.so."""
+    if not os.path.exists(ABI_SRC):
+        return None
+    link = ["-L" + LIB_DIR, "-lWhisper", "-Wl,-rpath,$ORIGIN"]
+    if force or _newer(ABI_OUR_BIN, [ABI_SRC, HOST_LIB, os.path.join(ROOT, "include", "whisperApi.h")]):
+        _run(["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"), ABI_SRC, "-o", ABI_OUR_BIN] + link)
+    ref_hdr = os.path.join(REFERENCE_ROOT, "Whisper", "API", "whisperComLight.h")
+    if os.path.exists(ref_hdr) and (force or _newer(ABI_REF_BIN, [ABI_SRC, HOST_LIB])):
+        _run(["g++", "-std=c++20", "-O1", "-D__stdcall=", "-D__cdecl=", "-DUSE_REFERENCE_HEADERS", "-I" + REFERENCE_ROOT, ABI_SRC,
+              "-o", ABI_REF_BIN] + link)
+    return ABI_OUR_BIN
+
+
 def build_all(force: bool = False):
     t = time.time()
     build_hip(force)
     build_host(force)
     build_cli(force)
+    build_abi_callers(force)
     print("native build ok in %.1fs" % (time.time() - t), flush=True)
 
 

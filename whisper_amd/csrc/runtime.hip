@@ -344,11 +344,29 @@ static int capture( wh_context* c, T*& dst, const T* src, int64_t count, int64_t
 	return 0;
 }
 
+// WH_DEBUG_SYNC=1: every launch is announced on stderr and waited for (and nothing is captured into a hipGraph), so that a
+// device fault can be attributed to a kernel class from the log of a dead process.
+static bool debugSync()
+{
+	static const bool v = []() { const char* e = getenv( "WH_DEBUG_SYNC" ); return e && *e && *e != '0'; }();
+	return v;
+}
+
 // Runs one launch, optionally bracketed by events. flops / bytes are the ALGORITHMIC work of the launch.
 template<class F>
 static int profiled( wh_context* c, int kc, double flops, double bytes, F&& launch )
 {
 	Profiler& p = c->prof;
+	if( debugSync() )
+	{
+		// breadcrumbs: a `Memory access fault by GPU` kills the process, the last line on stderr then names the launch
+		fprintf( stderr, "[wh] launch %s\n", kernelClassNames[ kc ] );
+		fflush( stderr );
+		const int rc = launch();
+		const hipError_t e = hipStreamSynchronize( c->stream );
+		if( e != hipSuccess ) return hipFail( e, kernelClassNames[ kc ], __FILE__, __LINE__ );
+		return rc;
+	}
 	if( !p.on ) return launch();
 	hipEvent_t a = p.get(), b = p.get();
 	WH_HIP( hipEventRecord( a, c->stream ) );
@@ -1360,7 +1378,7 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	WH_HIP( hipMemcpyAsync( c->tokensDev, firstTokens, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
 	WH_HIP( hipStreamSynchronize( st ) );	 // `init` is a local
 
-	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH );
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && !debugSync();
 	if( useGraph )
 	{
 		const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
@@ -1432,7 +1450,7 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	hipStream_t st = c->stream;
 	for( auto& mk : c->marks ) c->markPool.push_back( mk.ev );
 	c->marks.clear();
-	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && nSteps > 0;
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && nSteps > 0 && !debugSync();
 	const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
 	if( useGraph && c->graphExec && ( c->graphBatch != batch || c->graphKey != key ) )
 	{
@@ -1503,7 +1521,7 @@ int wh_decode_window_continue( wh_context* c, int nSteps )
 	const wh_hparams& hp = c->m->hp;
 	if( c->windowPos + nSteps > hp.n_text_ctx ) { setError( "decode_window_continue: n_text_ctx exceeded" ); return WH_E_BOUNDS; }
 	const int batch = c->lastBatch;
-	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH );
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && !debugSync();
 	const uint32_t key = ( c->flags & WH_FLAG_PARITY_PV ) ? ( 0x10000u | (uint32_t)c->parityThreads ) : 0u;
 	if( useGraph && ( !c->graphExec || c->graphBatch != batch || c->graphKey != key ) )
 	{

@@ -375,12 +375,11 @@ int main( int argc, char** argv )
 		p.encoder_begin_callback = &onEncoderBegin;
 		p.encoder_begin_callback_user_data = &aborted;
 
-		const std::wstring wpath = widen( input );
 		hr = E_NOTIMPL;
 		if( !p.flag( eFullParamsFlags::TokenTimestamps ) )
 		{
 			ComLight::CComPtr<iAudioReader> reader;
-			if( SUCCEEDED( media->openAudioFile( wpath.c_str(), o.diarize, &reader ) ) )
+			if( SUCCEEDED( media->openAudioFile( input.c_str(), o.diarize, &reader ) ) )
 			{
 				sProgressSink sink{ nullptr, nullptr };
 				hr = context->runStreamed( p, sink, reader );
@@ -389,7 +388,7 @@ int main( int argc, char** argv )
 		if( hr == E_NOTIMPL )
 		{
 			ComLight::CComPtr<iAudioBuffer> buffer;
-			hr = media->loadAudioFile( wpath.c_str(), o.diarize, &buffer );
+			hr = media->loadAudioFile( input.c_str(), o.diarize, &buffer );
 			if( SUCCEEDED( hr ) ) hr = context->runFull( p, buffer );
 		}
 		if( FAILED( hr ) ) { printFailure( "Unable to process audio", hr ); return 10; }

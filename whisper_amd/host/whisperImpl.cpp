@@ -751,11 +751,11 @@ namespace Whisper
 		class WavLoader : public ComObject<iMediaFoundation>
 		{
 		public:
-			HRESULT loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const override;
-			HRESULT openAudioFile( const wchar_t* path, bool stereo, iAudioReader** pp ) override;
+			HRESULT loadAudioFile( LPCTSTR path, bool stereo, iAudioBuffer** pp ) const override;
+			HRESULT openAudioFile( LPCTSTR path, bool stereo, iAudioReader** pp ) override;
 			HRESULT loadAudioFileData( const void* data, uint64_t size, bool stereo, iAudioReader** pp ) override;
 			HRESULT listCaptureDevices( pfnFoundCaptureDevices, void* ) override { return E_NOTIMPL; }
-			HRESULT openCaptureDevice( const wchar_t*, const sCaptureParams&, iAudioCapture** ) override { return E_NOTIMPL; }
+			HRESULT openCaptureDevice( LPCTSTR, const sCaptureParams&, iAudioCapture** ) override { return E_NOTIMPL; }
 		};
 
 		// RIFF/WAVE, 16 kHz, mono or stereo, PCM16 or float32 -> mono (and interleaved stereo when asked for)
@@ -809,23 +809,23 @@ namespace Whisper
 			}
 			return S_OK;
 		}
-		static HRESULT readWavFile( const wchar_t* path, bool stereo, std::vector<float>& mono, std::vector<float>& st )
+		static HRESULT readWavFile( LPCTSTR path, bool stereo, std::vector<float>& mono, std::vector<float>& st )
 		{
-			const std::string p = utf8( path );
+			const std::string p = path;	  // LPCTSTR is UTF-8 off Windows (ComLightLib/comLightCommon.h:8)
 			std::ifstream f( p, std::ios::binary );
 			if( !f ) { logError( "failed to open audio file '%s'", p.c_str() ); return (HRESULT)0x80070002; }
 			std::vector<char> data( ( std::istreambuf_iterator<char>( f ) ), std::istreambuf_iterator<char>() );
 			return decodeWav( data.data(), data.size(), p, stereo, mono, st );
 		}
 
-		HRESULT WavLoader::loadAudioFile( const wchar_t* path, bool stereo, iAudioBuffer** pp ) const
+		HRESULT WavLoader::loadAudioFile( LPCTSTR path, bool stereo, iAudioBuffer** pp ) const
 		{
 			if( !pp || !path ) return E_POINTER;
 			std::vector<float> mono, st;
 			CHECK( readWavFile( path, stereo, mono, st ) );
 			return createAudioBuffer( std::move( mono ), std::move( st ), pp );
 		}
-		HRESULT WavLoader::openAudioFile( const wchar_t* path, bool stereo, iAudioReader** pp )
+		HRESULT WavLoader::openAudioFile( LPCTSTR path, bool stereo, iAudioReader** pp )
 		{
 			if( !pp || !path ) return E_POINTER;
 			std::vector<float> mono, st;
