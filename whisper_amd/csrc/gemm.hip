@@ -177,6 +177,16 @@ namespace wh
 		using CfgGlPf = TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>;
 		using CfgGlBigPf = TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>;
 
+		// one 16-byte-per-lane global -> LDS instruction; M0 (the LDS destination base) is saved and restored inside the
+		// statement because the compiler does not preserve it around inline assembly (cdna_hip_programming.md section 5.7)
+		__device__ __forceinline__ void ldsDma16( const void* src, unsigned ldsByteAddr )
+		{
+			unsigned keep;
+			asm volatile( "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+						  : "=&s"( keep )
+						  : "v"( src ), "s"( ldsByteAddr )
+						  : "memory" );
+		}
 		// physical position (in halfs) of logical 16-byte chunk c of tile row `row` in a GL tile
 		template<class C>
 		__device__ __forceinline__ int glOffset( int row, int c )
@@ -642,11 +652,11 @@ namespace wh
 	#pragma unroll
 						for( int i = 0; i < C::IA; i++ )
 							if( i >= p0 && i < p1 && ( ( C::ABL & 16 ) == 0 || kt == 0 ) )
-								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseA + i * C::RPI * BK * 2 ), "v"( gA[ i ] + ko ) : "memory", "m0" );
+								ldsDma16( gA[ i ] + ko, baseA + i * C::RPI * BK * 2 );
 	#pragma unroll
 						for( int i = 0; i < C::IW; i++ )
 							if( C::IA + i >= p0 && C::IA + i < p1 && ( ( C::ABL & 8 ) == 0 || kt == 0 ) )
-								asm volatile( "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"( baseW + i * C::RPI * BK * 2 ), "v"( gW[ i ] + ko ) : "memory", "m0" );
+								ldsDma16( gW[ i ] + ko, baseW + i * C::RPI * BK * 2 );
 						return;
 					}
 #pragma unroll
@@ -887,6 +897,244 @@ namespace wh
 			tileEpilogue<EPI, C>( a, acc, tm, tn, wm, wn, lane );
 			}
 		}
+
+		// ---------------------------------------------------------------------------------------------------------------
+		// gemmTiled8: the encoder GEMM for batches several clips deep. 256x256x64 tiles, EIGHT waves as 2 (M) x 4 (N), a
+		// wave owns 128 x 64 outputs = 4 x 2 MFMA 32x32x16 tiles (24 fragment reads per 32 MFMAs; the 16-wave 64x64 layout of
+		// gemmTiled reads 16 per 16), both operands global -> LDS directly in full 128-byte lines, XOR-swizzled source, two
+		// 64 KiB K-tile buffers. What differs from gemmTiled is the SCHEDULE (cdna_hip_programming.md section 5, T3+T4):
+		//   * a K tile is four phases, one 64x32 quadrant of the wave's outputs each (8 MFMAs = 256 matrix-pipe cycles):
+		//       phase    fragments read from LDS        MFMAs          staged global -> LDS (2 x 1 KiB per wave)
+		//       1        a0 (8 reads), b0 (4 reads)     a0 x b0        W rows 128..255 of K tile t+1
+		//       2        b1 (4)                         a0 x b1        A rows   0..127 of K tile t+1
+		//       3        a1 (8)                         a1 x b1        A rows 128..255 of K tile t+1
+		//       4        --                             a1 x b0        W rows   0..127 of K tile t+2
+		//     every phase is  { ds_reads, LDS-DMA issue } s_barrier { MFMAs, counted vmcnt } s_barrier;
+		//   * the two wave rows run ONE barrier apart (the waves of row 1 execute an extra s_barrier before the loop, those of
+		//     row 0 after it): on every SIMD one wave is in its MFMA segment while the other reads fragments and issues DMA,
+		//     so the matrix pipe never waits for a barrier, an LDS round trip or a DMA issue slot;
+		//   * vmcnt never drops to 0 inside the loop: at the end of an MFMA segment a wave waits for the half tile it issued
+		//     one phase EARLIER (vmcnt(2): the two instructions issued in this phase stay in flight across the barriers), i.e.
+		//     every DMA has three barrier intervals (~770 cycles) to land before anybody stalls on it.
+		// Hazards (interval = barrier to barrier, tile t occupies intervals 0..7 of wave row 0 and 1..8 of row 1):
+		//   RAW  a half tile issued by row 0 in interval s (row 1: s+1) is waited for at the end of s+3 (s+4), each followed by a
+		//        barrier both rows pass, and first read in: W 128.. of t+1: issued 0/1, read 8; A 0.. of t+1: 2/3, read 8 (row 0
+		//        only); A 128.. of t+1: 4/5, read 9 (row 1 only); W 0.. of t+2: 6/7, read 16.
+		//   WAR  buffer (t+1)&1 was last read by tile t-1: its W in interval -5 (row 1, phase 2), A 0..127 in -4 (row 0, phase 3),
+		//        A 128..255 in -3 (row 1, phase 3); those reads are retired by the MFMAs of the following interval and the first
+		//        DMA into each region is issued in -2, 2 and 4: at least two barriers later.
+		struct Cfg8
+		{
+			static constexpr int BM = 256, BN = 256, BK = 64, NT = 512, TI = 4, TJ = 2;
+			static constexpr int A_HALFS = BM * BK, STAGE = ( BM + BN ) * BK;	   // halfs per K-tile buffer: A tile, then W tile
+			static constexpr int LDS_BYTES = 2 * STAGE * 2;						   // 128 KiB; the wide epilogue needs 8 x 8 KiB of it
+		};
+		struct Cfg8Quad : Cfg8	  // a 64x64 quarter of a wave's block, what tileEpilogueWide is written for
+		{
+			static constexpr int TI = 2, TJ = 2;
+		};
+
+#define WH_BAR() asm volatile( "s_barrier" ::: "memory" )
+
+		template<int EPI, bool WIDE>
+		__global__ void __launch_bounds__( 512, 2 ) gemmTiled8( const GemmArgs a )
+		{
+			using C = Cfg8;
+			constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[];
+			f16* const lds = (f16*)smem;
+			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+			const int wr = wave >> 2, wc = wave & 3;
+
+			const int tilesN = ( a.N + BN - 1 ) / BN;
+			int lin;
+			{
+				const int nb = gridDim.x, bid = blockIdx.x;
+				const int q = nb >> 3, r = nb & 7;
+				const int xcd = bid & 7, idx = bid >> 3;
+				lin = ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + idx;
+			}
+			int tm, tn;
+			if( a.groupM > 1 )
+			{
+				const int tilesM = ( a.M + BM - 1 ) / BM;
+				const int perBand = a.groupM * tilesN;
+				const int band = lin / perBand;
+				const int first = band * a.groupM;
+				const int rows = min( tilesM - first, a.groupM );
+				const int r = lin - band * perBand;
+				tm = first + r % rows;
+				tn = r / rows;
+			}
+			else
+			{
+				tm = lin / tilesN;
+				tn = lin - tm * tilesN;
+			}
+
+			// ---- LDS-DMA sources: a half tile is 128 rows x 128 bytes = 16 pieces of 8 rows, a wave owns pieces 2 wave, 2 wave + 1.
+			// Lane l of a piece lands at row l / 8, physical 16-byte chunk l % 8, which must hold logical chunk (l % 8) ^ ((row >> 1) & 7)
+			const int rIn = lane >> 3, cPhys = lane & 7;
+			const f16* gA[ 2 ][ 2 ];
+			const f16* gW[ 2 ][ 2 ];
+	#pragma unroll
+			for( int h = 0; h < 2; h++ )
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+				{
+					const int row = h * 128 + ( wave * 2 + i ) * 8 + rIn;
+					const int c = cPhys ^ ( ( row >> 1 ) & 7 );
+					int m = tm * BM + row;
+					m = m < a.M ? m : a.M - 1;
+					gA[ h ][ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + c * 8;
+					int n = tn * BN + row;
+					n = n < a.N ? n : a.N - 1;
+					gW[ h ][ i ] = a.W + (long long)n * a.K + c * 8;
+				}
+			const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)lds );
+			// byte address of this wave's first piece of a half tile inside buffer 0: + buf * STAGE * 2, + (W ? A_HALFS * 2 : 0), + h * 16384
+			const unsigned pieceBase = ldsBase + (unsigned)wave * 2048u;
+			// part: 0 = W rows 0.., 1 = W rows 128.., 2 = A rows 0.., 3 = A rows 128..
+			auto stage = [ & ]( int kt, auto part )
+			{
+				constexpr int P = decltype( part )::value;
+				constexpr bool isW = P < 2;
+				constexpr int h = P & 1;
+				const unsigned dst = pieceBase + (unsigned)( kt & 1 ) * ( C::STAGE * 2 ) + ( isW ? C::A_HALFS * 2 : 0 ) + h * 16384;
+				const int ko = kt * BK;
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+					ldsDma16( ( isW ? gW[ h ][ i ] : gA[ h ][ i ] ) + ko, dst + i * 1024 );
+			};
+			using PW0 = std::integral_constant<int, 0>;
+			using PW1 = std::integral_constant<int, 1>;
+			using PA0 = std::integral_constant<int, 2>;
+			using PA1 = std::integral_constant<int, 3>;
+
+			// ---- fragment reads: lane l reads row l & 31 of a 32-row tile, logical chunk 2 ks + (l >> 5), stored at chunk ^ ((row >> 1) & 7);
+			// the tile origins are multiples of 32 rows, so the XOR term depends on the lane only
+			const int x0 = ( lane >> 5 ) ^ ( ( lane >> 1 ) & 7 );
+			int laneK[ 4 ];
+	#pragma unroll
+			for( int ks = 0; ks < 4; ks++ ) laneK[ ks ] = ( lane & 31 ) * BK + ( ( x0 ^ ( ks << 1 ) ) << 3 );
+			const int aRow0 = wr * 128, wRow0 = wc * 64;
+
+			f32x16 acc[ 4 ][ 2 ];
+	#pragma unroll
+			for( int i = 0; i < 4; i++ )
+	#pragma unroll
+				for( int j = 0; j < 2; j++ )
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
+			f16x8 fa[ 2 ][ 4 ], fb0[ 4 ], fb1[ 4 ];
+
+			auto readA = [ & ]( const f16* bufA, int half )
+			{
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+	#pragma unroll
+					for( int ks = 0; ks < 4; ks++ )
+						fa[ i ][ ks ] = *(const f16x8*)( bufA + ( aRow0 + ( half * 2 + i ) * 32 ) * BK + laneK[ ks ] );
+			};
+			auto readB = [ & ]( const f16* bufW, int j, f16x8( &fb )[ 4 ] )
+			{
+	#pragma unroll
+				for( int ks = 0; ks < 4; ks++ ) fb[ ks ] = *(const f16x8*)( bufW + ( wRow0 + j * 32 ) * BK + laneK[ ks ] );
+			};
+			auto quadrant = [ & ]( auto i0c, auto jc, const f16x8( &fb )[ 4 ] )
+			{
+				constexpr int i0 = decltype( i0c )::value, j = decltype( jc )::value;
+				__builtin_amdgcn_s_setprio( 1 );
+	#pragma unroll
+				for( int ks = 0; ks < 4; ks++ )
+	#pragma unroll
+					for( int i = 0; i < 2; i++ )
+						acc[ i0 + i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ][ ks ], fb[ ks ], acc[ i0 + i ][ j ], 0, 0, 0 );
+				__builtin_amdgcn_s_setprio( 0 );
+			};
+			using I0 = std::integral_constant<int, 0>;
+			using I1 = std::integral_constant<int, 1>;
+			using I2 = std::integral_constant<int, 2>;
+			// end of an MFMA segment: the half tile issued one phase earlier must have landed; the one issued in this phase (if any) stays in flight
+			auto landed = [ & ]( bool issuedThisPhase )
+			{
+				if( issuedThisPhase )
+					asm volatile( "s_waitcnt vmcnt(2)" ::: "memory" );
+				else
+					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			};
+
+			const int nk = a.K / BK;
+			stage( 0, PW0{} );
+			stage( 0, PW1{} );
+			stage( 0, PA0{} );
+			stage( 0, PA1{} );
+			if( nk > 1 ) stage( 1, PW0{} );
+			landed( nk > 1 );
+			WH_BAR();
+			if( wr == 1 ) WH_BAR();	   // wave row 1 runs one barrier behind row 0
+
+			for( int kt = 0; kt < nk; kt++ )
+			{
+				const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
+				const f16* const bufW = bufA + C::A_HALFS;
+				const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
+				// phase 1
+				readB( bufW, 0, fb0 );
+				readA( bufA, 0 );
+				if( next ) stage( kt + 1, PW1{} );
+				WH_BAR();
+				quadrant( I0{}, I0{}, fb0 );
+				landed( next );
+				WH_BAR();
+				// phase 2
+				readB( bufW, 1, fb1 );
+				if( next ) stage( kt + 1, PA0{} );
+				WH_BAR();
+				quadrant( I0{}, I1{}, fb1 );
+				landed( next );
+				WH_BAR();
+				// phase 3
+				readA( bufA, 1 );
+				if( next ) stage( kt + 1, PA1{} );
+				WH_BAR();
+				quadrant( I2{}, I1{}, fb1 );
+				landed( next );
+				WH_BAR();
+				// phase 4
+				if( next2 ) stage( kt + 2, PW0{} );
+				WH_BAR();
+				quadrant( I2{}, I0{}, fb0 );
+				landed( next2 );
+				WH_BAR();
+			}
+			if( wr == 0 ) WH_BAR();
+			// every wave has passed the same number of barriers and retired all its fragment reads: the operand tiles are dead
+
+			if constexpr( WIDE )
+			{
+				const bool vPart = EPI == EPI_QKV_ENC && ( tn * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM;
+				if( !vPart )
+				{
+	#pragma unroll
+					for( int half = 0; half < 2; half++ )
+					{
+						tileEpilogueWide<EPI, Cfg8Quad>( a, *(f32x16( * )[ 2 ][ 2 ])&acc[ 2 * half ], tm, tn, wr * 2 + half, wc, lane, smem + wave * 8192 );
+						// the second quarter re-uses the wave's 8 KiB: its LDS reads of the first must have retired
+						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+						__builtin_amdgcn_wave_barrier();
+						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+					}
+					return;
+				}
+			}
+			tileEpilogue<EPI, Cfg8>( a, acc, tm, tn, wr, wc, lane );
+		}
+#undef WH_BAR
 
 		// ---- skinny: M <= 32 ----
 		constexpr int SK_WAVES = 4;
@@ -1534,11 +1782,51 @@ namespace wh
 		return launchTiledK<EPI, C, false>( b, stream );
 	}
 
+	template<int EPI, bool WIDE>
+	static int launchTiled8K( const GemmArgs& b, hipStream_t stream )
+	{
+		static PerDeviceOnce once;
+		if( const int onceDev = once.needed(); onceDev >= 0 )
+		{
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled8<EPI, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg8::LDS_BYTES ) );
+			once.mark( onceDev );
+		}
+		const int tilesM = ( b.M + Cfg8::BM - 1 ) / Cfg8::BM, tilesN = ( b.N + Cfg8::BN - 1 ) / Cfg8::BN;
+		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE> ), dim3( tilesM * tilesN ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	// the 8-wave 256x256x64 kernel; same preconditions for the LDS-transposed epilogue as launchTiledT
+	template<int EPI>
+	static int launchTiled8( const GemmArgs& a, hipStream_t stream )
+	{
+		GemmArgs b = a;
+		if( b.groupM == 0 ) b.groupM = ( g_tuning & TUNE_GEMM_GROUP_M ) ? 4 : 1;
+		bool wide = false;
+		if( g_tuning & TUNE_GEMM_WIDE_EPI )
+		{
+			const bool al16 = ( a.N % 8 ) == 0 && ( a.ldc % 8 ) == 0 && ( a.cBatchStride % 8 ) == 0;
+			switch( EPI )
+			{
+			case EPI_F32: wide = al16 && ( ( (size_t)a.out32 | (size_t)a.res ) % 16 ) == 0; break;
+			case EPI_CONV2: wide = al16 && ( ( (size_t)a.out32 | (size_t)a.pe ) % 16 ) == 0; break;
+			case EPI_F16_GELU: wide = al16 && ( (size_t)a.out16 % 16 ) == 0; break;
+			case EPI_QKV_ENC: wide = ( a.N % 64 ) == 0 && ( ( (size_t)a.q | (size_t)a.k ) % 16 ) == 0; break;
+			case EPI_CROSS_KV: wide = ( a.N % 64 ) == 0 && ( ( (size_t)a.k | (size_t)a.v ) % 16 ) == 0; break;
+			default: break;
+			}
+		}
+		b.wideEpi = wide ? 1 : 0;
+		return wide ? launchTiled8K<EPI, true>( b, stream ) : launchTiled8K<EPI, false>( b, stream );
+	}
+
 	// Tile-shape experiments on the plain FP32 epilogue (tools/gemm_probe.py): variant -> configuration
 	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream )
 	{
 		switch( variant )
 		{
+		case 40: return launchTiled8<EPI_F32>( a, stream );
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
@@ -1609,7 +1897,9 @@ namespace wh
 		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
 		const bool pf = gl && ( g_tuning & TUNE_GEMM_FRAGPF ) != 0;
+		const bool w8 = big && ( g_tuning & TUNE_GEMM_8WAVE ) != 0;
 #define WH_TILED( E )                                                    \
+	if( w8 ) return launchTiled8<E>( a, stream );                        \
 	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
 	if( pf ) return launchTiledT<E, CfgGlPf>( a, stream );               \
 	if( gl && big ) return launchTiledT<E, CfgGlBig>( a, stream );       \

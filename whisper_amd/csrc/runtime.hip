@@ -1953,7 +1953,7 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 			WH_HIP( hipMemsetAsync( diff, 0, 4, st ) );
 			GemmArgs g2 = plainGemm( (const f16*)A, (const f16*)W, M, N, K );
 			g2.epi = EPI_F32; g2.out32 = (float*)ref;
-			rc = launchGemm( g2, st );
+			rc = launchGemmVariant( g2, 2, st );	   // the register-staged 128x128x32 kernel: shares no staging or scheduling code with the variants under test
 			if( rc == 0 )
 			{
 				hipLaunchKernelGGL( probeMaxDiff, dim3( 2048 ), dim3( 256 ), 0, st, (const float*)out, (const float*)ref, (long long)M * N, diff );
