@@ -936,7 +936,9 @@ namespace wh
 
 #define WH_BAR() asm volatile( "s_barrier" ::: "memory" )
 
-		template<int EPI, bool WIDE>
+		// ABL (probe only, wrong results by construction): 1 = no LDS-DMA inside the K loop, 2 = fragments read from LDS for the first K tile
+		// only, 4 = no MFMAs, 8 = barriers of the K loop removed: what the K loop costs without one of its streams
+		template<int EPI, bool WIDE, int ABL = 0>
 		__global__ void __launch_bounds__( 512, 2 ) gemmTiled8( const GemmArgs a )
 		{
 			using C = Cfg8;
@@ -1006,6 +1008,10 @@ namespace wh
 				constexpr int h = P & 1;
 				const unsigned dst = pieceBase + (unsigned)( kt & 1 ) * ( C::STAGE * 2 ) + ( isW ? C::A_HALFS * 2 : 0 ) + h * 16384;
 				const int ko = kt * BK;
+				if constexpr( ( ABL & 1 ) != 0 )
+				{
+					if( kt > 1 || ( kt == 1 && P != 0 ) ) return;
+				}
 	#pragma unroll
 				for( int i = 0; i < 2; i++ )
 					ldsDma16( ( isW ? gW[ h ][ i ] : gA[ h ][ i ] ) + ko, dst + i * 1024 );
@@ -1032,8 +1038,13 @@ namespace wh
 					for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
 			f16x8 fa[ 2 ][ 4 ], fb0[ 4 ], fb1[ 4 ];
 
+			int ablTile = 0;
 			auto readA = [ & ]( const f16* bufA, int half )
 			{
+				if constexpr( ( ABL & 2 ) != 0 )
+				{
+					if( ablTile > 0 ) return;
+				}
 	#pragma unroll
 				for( int i = 0; i < 2; i++ )
 	#pragma unroll
@@ -1042,12 +1053,23 @@ namespace wh
 			};
 			auto readB = [ & ]( const f16* bufW, int j, f16x8( &fb )[ 4 ] )
 			{
+				if constexpr( ( ABL & 2 ) != 0 )
+				{
+					if( ablTile > 0 ) return;
+				}
 	#pragma unroll
 				for( int ks = 0; ks < 4; ks++ ) fb[ ks ] = *(const f16x8*)( bufW + ( wRow0 + j * 32 ) * BK + laneK[ ks ] );
 			};
 			auto quadrant = [ & ]( auto i0c, auto jc, const f16x8( &fb )[ 4 ] )
 			{
 				constexpr int i0 = decltype( i0c )::value, j = decltype( jc )::value;
+				if constexpr( ( ABL & 4 ) != 0 )
+				{
+					// keep the fragments live without the matrix pipe
+	#pragma unroll
+					for( int ks = 0; ks < 4; ks++ ) asm volatile( "" ::"v"( fa[ 0 ][ ks ] ), "v"( fa[ 1 ][ ks ] ), "v"( fb[ ks ] ) );
+					return;
+				}
 				__builtin_amdgcn_s_setprio( 1 );
 	#pragma unroll
 				for( int ks = 0; ks < 4; ks++ )
@@ -1111,6 +1133,7 @@ namespace wh
 				quadrant( I2{}, I0{}, fb0 );
 				landed( next2 );
 				WH_BAR();
+				ablTile = 1;
 			}
 			if( wr == 0 ) WH_BAR();
 			// every wave has passed the same number of barriers and retired all its fragment reads: the operand tiles are dead
@@ -1782,17 +1805,17 @@ namespace wh
 		return launchTiledK<EPI, C, false>( b, stream );
 	}
 
-	template<int EPI, bool WIDE>
+	template<int EPI, bool WIDE, int ABL = 0>
 	static int launchTiled8K( const GemmArgs& b, hipStream_t stream )
 	{
 		static PerDeviceOnce once;
 		if( const int onceDev = once.needed(); onceDev >= 0 )
 		{
-			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled8<EPI, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg8::LDS_BYTES ) );
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled8<EPI, WIDE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg8::LDS_BYTES ) );
 			once.mark( onceDev );
 		}
 		const int tilesM = ( b.M + Cfg8::BM - 1 ) / Cfg8::BM, tilesN = ( b.N + Cfg8::BN - 1 ) / Cfg8::BN;
-		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE> ), dim3( tilesM * tilesN ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
+		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE, ABL> ), dim3( tilesM * tilesN ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -1827,6 +1850,11 @@ namespace wh
 		switch( variant )
 		{
 		case 40: return launchTiled8<EPI_F32>( a, stream );
+		case 41: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1>( b, stream ); }	 // ablations: 31 .. 39 and 41 .. 49 are not checked
+		case 42: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2>( b, stream ); }
+		case 43: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 3>( b, stream ); }
+		case 44: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 4>( b, stream ); }
+		case 45: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 6>( b, stream ); }
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
