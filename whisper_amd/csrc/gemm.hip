@@ -904,25 +904,27 @@ namespace wh
 		// gemmTiled reads 16 per 16), both operands global -> LDS directly in full 128-byte lines, XOR-swizzled source, two
 		// 64 KiB K-tile buffers. What differs from gemmTiled is the SCHEDULE (cdna_hip_programming.md section 5, T3+T4):
 		//   * a K tile is four phases, one 64x32 quadrant of the wave's outputs each (8 MFMAs = 256 matrix-pipe cycles):
-		//       phase    fragments read from LDS        MFMAs          staged global -> LDS (2 x 1 KiB per wave)
-		//       1        a0 (8 reads), b0 (4 reads)     a0 x b0        W rows 128..255 of K tile t+1
-		//       2        b1 (4)                         a0 x b1        A rows   0..127 of K tile t+1
-		//       3        a1 (8)                         a1 x b1        A rows 128..255 of K tile t+1
-		//       4        --                             a1 x b0        W rows   0..127 of K tile t+2
+		//       phase    fragments read from LDS        MFMAs          staged global -> LDS (4 x 1 KiB per wave)
+		//       1        a0 (8 reads), b0 (4 reads)     a0 x b0        --
+		//       2        b1 (4)                         a0 x b1        A tile (256 rows) of K tile t+1
+		//       3        a1 (8)                         a1 x b1        --
+		//       4        --                             a1 x b0        W tile (256 rows) of K tile t+2, then vmcnt(4)
 		//     every phase is  { ds_reads, LDS-DMA issue } s_barrier { MFMAs, counted vmcnt } s_barrier;
 		//   * the two wave rows run ONE barrier apart (the waves of row 1 execute an extra s_barrier before the loop, those of
 		//     row 0 after it): on every SIMD one wave is in its MFMA segment while the other reads fragments and issues DMA,
 		//     so the matrix pipe never waits for a barrier, an LDS round trip or a DMA issue slot;
-		//   * vmcnt never drops to 0 inside the loop: at the end of an MFMA segment a wave waits for the half tile it issued
-		//     one phase EARLIER (vmcnt(2): the two instructions issued in this phase stay in flight across the barriers), i.e.
-		//     every DMA has three barrier intervals (~770 cycles) to land before anybody stalls on it.
+		//   * vmcnt never drops to 0 inside the loop and there is ONE wait per K tile: a tile's operands are requested as early as
+		//     its buffer allows (W of t+2 in phase 4 of t, A of t+1 in phase 2 of t) and waited for in phase 4 of the tile before
+		//     (vmcnt(4): the W instructions issued just before stay in flight), so 32 .. 64 KiB per CU are in flight at any time
+		//     and every DMA has at least four barrier intervals (~1000 cycles) to land. Waiting per half tile three intervals
+		//     after its issue (the first version) kept 16 .. 32 KiB in flight: 54 GB/s per CU, latency-bound (profiles/r03_gemm8.txt).
 		// Hazards (interval = barrier to barrier, tile t occupies intervals 0..7 of wave row 0 and 1..8 of row 1):
-		//   RAW  a half tile issued by row 0 in interval s (row 1: s+1) is waited for at the end of s+3 (s+4), each followed by a
-		//        barrier both rows pass, and first read in: W 128.. of t+1: issued 0/1, read 8; A 0.. of t+1: 2/3, read 8 (row 0
-		//        only); A 128.. of t+1: 4/5, read 9 (row 1 only); W 0.. of t+2: 6/7, read 16.
-		//   WAR  buffer (t+1)&1 was last read by tile t-1: its W in interval -5 (row 1, phase 2), A 0..127 in -4 (row 0, phase 3),
-		//        A 128..255 in -3 (row 1, phase 3); those reads are retired by the MFMAs of the following interval and the first
-		//        DMA into each region is issued in -2, 2 and 4: at least two barriers later.
+		//   RAW  the operands of tile t+1 are issued by row 0 in intervals -2 (W) and 2 (A), by row 1 in -1 and 3; both rows wait for
+		//        them at the end of their phase-4 read segment (intervals 6 and 7), each followed by a barrier both rows pass;
+		//        the first read of tile t+1 is in interval 8.
+		//   WAR  buffer (t+1)&1 was last read by tile t-1: its W in interval -5 (row 1, phase 2), its A in -4 and -3 (phase 3);
+		//        those reads are retired by the MFMAs of the following interval and the first DMA into the W region is issued in
+		//        interval -2, into the A region in interval 2: at least two barriers later.
 		struct Cfg8
 		{
 			static constexpr int BM = 256, BN = 256, BK = 64, NT = 512, TI = 4, TJ = 2;
@@ -1095,8 +1097,14 @@ namespace wh
 			stage( 0, PW1{} );
 			stage( 0, PA0{} );
 			stage( 0, PA1{} );
-			if( nk > 1 ) stage( 1, PW0{} );
-			landed( nk > 1 );
+			if( nk > 1 )
+			{
+				stage( 1, PW0{} );
+				stage( 1, PW1{} );
+				asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+			}
+			else
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 			WH_BAR();
 			if( wr == 1 ) WH_BAR();	   // wave row 1 runs one barrier behind row 0
 
@@ -1105,33 +1113,39 @@ namespace wh
 				const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
 				const f16* const bufW = bufA + C::A_HALFS;
 				const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
-				// phase 1
+				// phase 1: 12 fragment reads, no DMA
 				readB( bufW, 0, fb0 );
 				readA( bufA, 0 );
-				if( next ) stage( kt + 1, PW1{} );
 				WH_BAR();
 				quadrant( I0{}, I0{}, fb0 );
-				landed( next );
 				WH_BAR();
-				// phase 2
+				// phase 2: 4 reads, the A tile of K tile t+1 (its buffer's A rows were last read two and three barriers ago)
 				readB( bufW, 1, fb1 );
-				if( next ) stage( kt + 1, PA0{} );
+				if( next )
+				{
+					stage( kt + 1, PA0{} );
+					stage( kt + 1, PA1{} );
+				}
 				WH_BAR();
 				quadrant( I0{}, I1{}, fb1 );
-				landed( next );
 				WH_BAR();
-				// phase 3
+				// phase 3: 8 reads
 				readA( bufA, 1 );
-				if( next ) stage( kt + 1, PA1{} );
 				WH_BAR();
 				quadrant( I2{}, I1{}, fb1 );
-				landed( next );
 				WH_BAR();
-				// phase 4
-				if( next2 ) stage( kt + 2, PW0{} );
+				// phase 4: no reads, the W tile of K tile t+2 (this buffer's W rows were last read in phase 2), then the ONE wait of
+				// the K tile: everything of tile t+1 has landed, the four instructions just issued stay in flight
+				if( next2 )
+				{
+					stage( kt + 2, PW0{} );
+					stage( kt + 2, PW1{} );
+					asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+				}
+				else
+					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 				WH_BAR();
 				quadrant( I2{}, I0{}, fb0 );
-				landed( next2 );
 				WH_BAR();
 				ablTile = 1;
 			}
