@@ -992,7 +992,7 @@ namespace wh
 				{
 					const int row = h * 128 + ( wave * 2 + i ) * 8 + rIn;
 					const int c = cPhys ^ ( ( row >> 1 ) & 7 );
-					int m = tm * BM + row;
+					int m = ( ( ABL & 16 ) ? 0 : tm ) * BM + row;	  // ABL 16: every tile reads the first A tile (operands stay in L2)
 					m = m < a.M ? m : a.M - 1;
 					gA[ h ][ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + c * 8;
 					int n = tn * BN + row;
@@ -1869,6 +1869,8 @@ namespace wh
 		case 43: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 3>( b, stream ); }
 		case 44: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 4>( b, stream ); }
 		case 45: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 6>( b, stream ); }
+		case 46: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16>( b, stream ); }
+		case 47: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16 + 6>( b, stream ); }
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
