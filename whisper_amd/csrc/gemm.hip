@@ -899,47 +899,218 @@ namespace wh
 		}
 
 		// ---------------------------------------------------------------------------------------------------------------
-		// gemmTiled8: the encoder GEMM for batches several clips deep. 256x256x64 tiles, EIGHT waves as 2 (M) x 4 (N), a
-		// wave owns 128 x 64 outputs = 4 x 2 MFMA 32x32x16 tiles (24 fragment reads per 32 MFMAs; the 16-wave 64x64 layout of
-		// gemmTiled reads 16 per 16), both operands global -> LDS directly in full 128-byte lines, XOR-swizzled source, two
-		// 64 KiB K-tile buffers. What differs from gemmTiled is the SCHEDULE (cdna_hip_programming.md section 5, T3+T4):
+		// gemmTiled8: the encoder GEMM for batches several clips deep. PERSISTENT: one workgroup per CU walks its share of the
+		// 256x256 output tiles. EIGHT waves as 2 (M) x 4 (N), a wave owns 128 x 64 outputs = 4 x 2 MFMA 32x32x16 tiles (24
+		// fragment reads per 32 MFMAs; the 16-wave 64x64 layout of gemmTiled reads 16 per 16), both operands global -> LDS
+		// directly in full 128-byte lines, XOR-swizzled source, two 64 KiB K-tile buffers + 32 KiB of epilogue staging = all
+		// 160 KiB of a CU. What differs from gemmTiled is the SCHEDULE (cdna_hip_programming.md section 5, T3+T4):
 		//   * a K tile is four phases, one 64x32 quadrant of the wave's outputs each (8 MFMAs = 256 matrix-pipe cycles):
-		//       phase    fragments read from LDS        MFMAs          staged global -> LDS (4 x 1 KiB per wave)
+		//       phase    fragments read from LDS        MFMAs          staged global -> LDS (1 KiB per instruction and wave)
 		//       1        a0 (8 reads), b0 (4 reads)     a0 x b0        --
-		//       2        b1 (4)                         a0 x b1        A tile (256 rows) of K tile t+1
-		//       3        a1 (8)                         a1 x b1        --
-		//       4        --                             a1 x b0        W tile (256 rows) of K tile t+2, then vmcnt(4)
-		//     every phase is  { ds_reads, LDS-DMA issue } s_barrier { MFMAs, counted vmcnt } s_barrier;
+		//       2        b1 (4)                         a0 x b1        A rows   0..127 of K tile t+1 (2)
+		//       3        a1 (8)                         a1 x b1        A rows 128..255 of K tile t+1 (2)
+		//       4        --                             a1 x b0        W tile (256 rows) of K tile t+2 (4)
+		//     every phase is  { ds_reads, LDS-DMA issue } s_barrier { MFMAs } s_barrier;
 		//   * the two wave rows run ONE barrier apart (the waves of row 1 execute an extra s_barrier before the loop, those of
 		//     row 0 after it): on every SIMD one wave is in its MFMA segment while the other reads fragments and issues DMA,
-		//     so the matrix pipe never waits for a barrier, an LDS round trip or a DMA issue slot;
-		//   * vmcnt never drops to 0 inside the loop and there is ONE wait per K tile: a tile's operands are requested as early as
-		//     its buffer allows (W of t+2 in phase 4 of t, A of t+1 in phase 2 of t) and waited for in phase 4 of the tile before
-		//     (vmcnt(4): the W instructions issued just before stay in flight), so 32 .. 64 KiB per CU are in flight at any time
-		//     and every DMA has at least four barrier intervals (~1000 cycles) to land. Waiting per half tile three intervals
-		//     after its issue (the first version) kept 16 .. 32 KiB in flight: 54 GB/s per CU, latency-bound (profiles/r03_gemm8.txt).
-		// Hazards (interval = barrier to barrier, tile t occupies intervals 0..7 of wave row 0 and 1..8 of row 1):
-		//   RAW  the operands of tile t+1 are issued by row 0 in intervals -2 (W) and 2 (A), by row 1 in -1 and 3; both rows wait for
-		//        them at the end of their phase-4 read segment (intervals 6 and 7), each followed by a barrier both rows pass;
-		//        the first read of tile t+1 is in interval 8.
-		//   WAR  buffer (t+1)&1 was last read by tile t-1: its W in interval -5 (row 1, phase 2), its A in -4 and -3 (phase 3);
-		//        those reads are retired by the MFMAs of the following interval and the first DMA into the W region is issued in
-		//        interval -2, into the A region in interval 2: at least two barriers later.
+		//     so the matrix pipe never waits for a barrier, an LDS round trip or a DMA issue slot -- as long as a read/issue
+		//     segment fits under 256 cycles, which is why the eight DMA instructions of a K tile are spread over three phases;
+		//   * vmcnt never drops to 0 inside the loop: W is requested a whole K tile ahead (phase 4 of tile t for t+2), A as soon
+		//     as its buffer half is dead (phases 2 and 3 of tile t for t+1); the waits sit at the end of phase 4's issue segment
+		//     (vmcnt(6): W and the first A half of t+1) and of its MFMA segment (vmcnt(4): the second A half), so 24 .. 64 KiB per
+		//     CU are in flight at any time and a DMA has 3 (A rows 128..), 4 (A rows 0..) or 8 (W) barrier intervals to land.
+		//     Waiting per half tile three intervals after its issue (the first version) kept 16 .. 32 KiB in flight and was
+		//     latency-bound at 54 GB/s per CU (profiles/r03_gemm8_ablation.txt);
+		//   * DMA addresses are SGPR base (advanced per K tile on the scalar unit) + a per-lane 32-bit byte offset that never
+		//     changes: no vector ALU work per instruction;
+		//   * the NEXT tile's first operands are requested before this tile's epilogue starts, and the epilogue goes through its
+		//     own 4 KiB per wave, so a tile's stores drain under the next tile's K loop and its first-tile latency under the epilogue.
+		// Hazards (interval = barrier to barrier, K tile t occupies intervals 0..7 of wave row 0 and 1..8 of row 1):
+		//   RAW  operands of tile t+1: W issued in -2 / -1 (row 0 / row 1), A rows 0.. in 2 / 3, A rows 128.. in 4 / 5. Row 0 reads
+		//        W and A rows 0.. from interval 8, row 1 reads W and A rows 128.. from 9. Waits: vmcnt(6) at the end of 6 / 7
+		//        (W, A rows 0..), vmcnt(4) at the end of 7 / 8 (A rows 128..); each is followed by a barrier both rows pass
+		//        before the first read.
+		//   WAR  buffer (t+1)&1 was last read by tile t-1: its W in interval -5 (row 1, phase 2), A rows 0.. in -4 (row 0, phase
+		//        3), A rows 128.. in -3 (row 1, phase 3); those reads are retired by the MFMAs of the following interval, and the
+		//        first DMA into each region is issued in -2, 2 and 4: at least two barriers later.
 		struct Cfg8
 		{
 			static constexpr int BM = 256, BN = 256, BK = 64, NT = 512, TI = 4, TJ = 2;
 			static constexpr int A_HALFS = BM * BK, STAGE = ( BM + BN ) * BK;	   // halfs per K-tile buffer: A tile, then W tile
-			static constexpr int LDS_BYTES = 2 * STAGE * 2;						   // 128 KiB; the wide epilogue needs 8 x 8 KiB of it
-		};
-		struct Cfg8Quad : Cfg8	  // a 64x64 quarter of a wave's block, what tileEpilogueWide is written for
-		{
-			static constexpr int TI = 2, TJ = 2;
+			static constexpr int EPI_OFFSET = 2 * STAGE * 2;					   // bytes: the epilogue staging starts behind the two buffers
+			static constexpr int EPI_PER_WAVE = 4096;
+			static constexpr int LDS_BYTES = EPI_OFFSET + 8 * EPI_PER_WAVE;		   // 160 KiB
 		};
 
+		// Two 16-byte-per-lane global -> LDS instructions (2 x 1 KiB, LDS destinations dst and dst + 1024; global addresses
+		// base + off0 / base + off1 with a wave-uniform 64-bit base). M0 (the LDS destination) is saved and restored inside the
+		// statement: the compiler does not preserve it around inline assembly (cdna_hip_programming.md section 5.7).
+		__device__ __forceinline__ void ldsDmaPair( const void* base, unsigned off0, unsigned off1, unsigned dst )
+		{
+			unsigned keep;
+			// s_nop 1 / s_nop 0: wait states between the scalar writes (M0; a base computed just before the statement) and the
+			// memory instruction that reads them -- nothing inside an asm string is padded by the compiler
+			asm volatile( "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+						  "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %0"
+						  : "=&s"( keep )
+						  : "s"( base ), "v"( off0 ), "v"( off1 ), "s"( dst ), "s"( dst + 1024u )
+						  : "memory" );
+		}
 #define WH_BAR() asm volatile( "s_barrier" ::: "memory" )
 
+		// One 32-row x 64-column block of a wave's outputs (MFMA tiles c0 = columns 0..31, c1 = 32..63 of the block) through 4 KiB of
+		// LDS, leaving as 16-byte stores along the rows of the destination: the arithmetic of tileEpilogue / tileEpilogueWide per
+		// element, FP16 outputs in one pass ([32][64] halfs), FP32 outputs in two ([16][64] floats each), 16-byte chunk index XORed
+		// with the row so that the column-wise writes and the row-wise reads are both conflict free. m0 / n0 = first row / column.
+		// Preconditions as for tileEpilogueWide (a.wideEpi). Residual / positional rows are requested before the LDS round trip.
+		template<int EPI>
+		__device__ __forceinline__ void epilogueBlock32x64( const GemmArgs& a, const f32x16& c0, const f32x16& c1, int m0, int n0, int lane, unsigned char* ldsWave )
+		{
+			const int hi = lane >> 5, c = lane & 31;
+			float bias[ 2 ];
+	#pragma unroll
+			for( int j = 0; j < 2; j++ )
+			{
+				const int n = n0 + j * 32 + c;
+				bias[ j ] = ( a.bias && n < a.N ) ? a.bias[ n ] : 0.0f;
+			}
+			if constexpr( EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV )
+			{
+				f16* const L = (f16*)ldsWave;
+				const int d = a.H * HEAD_DIM;
+				int sel = 0, head = 0, layer = 0;
+				if constexpr( EPI == EPI_QKV_ENC )
+				{
+					sel = n0 / d;
+					head = ( n0 - sel * d ) >> 6;
+				}
+				if constexpr( EPI == EPI_CROSS_KV )
+				{
+					layer = n0 / ( 2 * d );
+					const int c2 = n0 - layer * 2 * d;
+					sel = c2 >= d ? 1 : 0;
+					head = ( sel ? c2 - d : c2 ) >> 6;
+				}
+	#pragma unroll
+				for( int j = 0; j < 2; j++ )
+	#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+						const int col = j * 32 + c;
+						const float v = j == 0 ? c0[ r ] : c1[ r ];
+						f16 hv;
+						if constexpr( EPI == EPI_F16_GELU )
+							hv = gelu16( v + bias[ j ] );
+						else if constexpr( EPI == EPI_QKV_ENC )
+							hv = (f16)( v + bias[ j ] );
+						else
+							hv = sel ? (f16)( v + bias[ j ] ) : (f16)( v * a.scale );
+						L[ row * 64 + ( ( ( col >> 3 ) ^ ( row & 7 ) ) << 3 ) + ( col & 7 ) ] = hv;
+					}
+				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+				const int chunk = lane & 7;
+	#pragma unroll
+				for( int it = 0; it < 4; it++ )
+				{
+					const int row = it * 8 + ( lane >> 3 );
+					const int m = m0 + row;
+					const f16x8 v = *(const f16x8*)( L + row * 64 + ( ( chunk ^ ( row & 7 ) ) << 3 ) );
+					const int n = n0 + chunk * 8;
+					if( m >= a.M || n >= a.N ) continue;
+					if constexpr( EPI == EPI_F16_GELU )
+						*(f16x8*)( a.out16 + rowOffset( m, a.Mb, a.ldc, a.cBatchStride ) + n ) = v;
+					else
+					{
+						const int b = m / a.T;
+						const int t = m - b * a.T;
+						if constexpr( EPI == EPI_QKV_ENC )
+						{
+							f16* const dst = sel == 0 ? a.q : a.k;
+							*(f16x8*)( dst + ( ( (long long)b * a.H + head ) * a.T + t ) * HEAD_DIM + chunk * 8 ) = v;
+						}
+						else
+						{
+							f16* const dst = sel ? a.v : a.k;
+							*(f16x8*)( dst + ( ( ( (long long)layer * a.B + b ) * a.H + head ) * a.T + t ) * HEAD_DIM + chunk * 8 ) = v;
+						}
+					}
+				}
+				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+			}
+			else
+			{
+				static_assert( EPI == EPI_F32 || EPI == EPI_CONV2, "FP32 block epilogue" );
+				float* const L = (float*)ldsWave;
+				const int chunk = lane & 15;
+				// everything the block READS from memory first: 2 halves x 4 rows x 16 bytes per lane
+				f32x4 ex[ 2 ][ 4 ];
+				long long off[ 2 ][ 4 ];
+	#pragma unroll
+				for( int hh = 0; hh < 2; hh++ )
+	#pragma unroll
+					for( int u = 0; u < 4; u++ )
+					{
+						int m = m0 + hh * 16 + u * 4 + ( lane >> 4 );
+						m = m < a.M ? m : a.M - 1;
+						int n = n0 + chunk * 4;
+						n = n < a.N ? n : a.N - 4;
+						if constexpr( EPI == EPI_F32 )
+						{
+							off[ hh ][ u ] = rowOffset( m, a.Mb, a.ldc, a.cBatchStride ) + n;
+							ex[ hh ][ u ] = a.res ? *(const f32x4*)( a.res + off[ hh ][ u ] ) : f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						}
+						else
+						{
+							const int b = m / a.Mb;
+							off[ hh ][ u ] = (long long)m * a.ldc + n;
+							ex[ hh ][ u ] = *(const f32x4*)( a.pe + (long long)( m - b * a.Mb ) * a.N + n );
+						}
+					}
+	#pragma unroll
+				for( int hh = 0; hh < 2; hh++ )
+				{
+	#pragma unroll
+					for( int j = 0; j < 2; j++ )
+	#pragma unroll
+						for( int q = 0; q < 8; q++ )
+						{
+							const int r = hh * 8 + q;
+							const int row = ( q & 3 ) + 8 * ( q >> 2 ) + 4 * hi;	  // within the 16-row half
+							const int col = j * 32 + c;
+							float v = ( j == 0 ? c0[ r ] : c1[ r ] ) + bias[ j ];
+							if constexpr( EPI == EPI_CONV2 ) v = (float)gelu16( v );
+							L[ row * 64 + ( ( ( col >> 2 ) ^ row ) << 2 ) + ( col & 3 ) ] = v;
+						}
+					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+	#pragma unroll
+					for( int u = 0; u < 4; u++ )
+					{
+						const int row = u * 4 + ( lane >> 4 );
+						const int m = m0 + hh * 16 + row;
+						const int n = n0 + chunk * 4;
+						const f32x4 v = *(const f32x4*)( L + row * 64 + ( ( chunk ^ row ) << 2 ) );
+						if( m >= a.M || n >= a.N ) continue;
+						f32x4 o;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) o[ e ] = EPI == EPI_F32 ? v[ e ] + ex[ hh ][ u ][ e ] : ex[ hh ][ u ][ e ] + v[ e ];
+						*(f32x4*)( a.out32 + off[ hh ][ u ] ) = o;
+					}
+					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+				}
+			}
+		}
+
 		// ABL (probe only, wrong results by construction): 1 = no LDS-DMA inside the K loop, 2 = fragments read from LDS for the first K tile
-		// only, 4 = no MFMAs, 8 = barriers of the K loop removed: what the K loop costs without one of its streams
+		// only, 4 = no MFMAs, 16 = every tile reads the first A tile (operands stay in L2), 32 = no epilogue stores
 		template<int EPI, bool WIDE, int ABL = 0>
 		__global__ void __launch_bounds__( 512, 2 ) gemmTiled8( const GemmArgs a )
 		{
@@ -954,51 +1125,60 @@ namespace wh
 			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
 			const int wr = wave >> 2, wc = wave & 3;
 
-			const int tilesN = ( a.N + BN - 1 ) / BN;
-			int lin;
+			// ---- this workgroup's tiles: XCD x (workgroup id % 8) owns a contiguous range of the band-walk order; its workgroups
+			// take consecutive tiles of that range round by round, so the ~32 tiles an XCD has in flight are neighbours in the walk
+			const int tilesM = ( a.M + BM - 1 ) / BM, tilesN = ( a.N + BN - 1 ) / BN;
+			const int nTiles = tilesM * tilesN;
+			int linFirst, linEnd, linStep;
 			{
-				const int nb = gridDim.x, bid = blockIdx.x;
-				const int q = nb >> 3, r = nb & 7;
-				const int xcd = bid & 7, idx = bid >> 3;
-				lin = ( xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q ) + idx;
+				const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+				const int q = nTiles >> 3, r = nTiles & 7;
+				const int start = xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q;
+				linEnd = start + ( xcd < r ? q + 1 : q );
+				linFirst = start + idx;
+				linStep = ( gridDim.x + 7 - xcd ) >> 3;	   // workgroups of this XCD
 			}
-			int tm, tn;
-			if( a.groupM > 1 )
+			auto tileCoords = [ & ]( int lin, int& tm, int& tn )
 			{
-				const int tilesM = ( a.M + BM - 1 ) / BM;
-				const int perBand = a.groupM * tilesN;
-				const int band = lin / perBand;
-				const int first = band * a.groupM;
-				const int rows = min( tilesM - first, a.groupM );
-				const int r = lin - band * perBand;
-				tm = first + r % rows;
-				tn = r / rows;
-			}
-			else
-			{
-				tm = lin / tilesN;
-				tn = lin - tm * tilesN;
-			}
+				if( a.groupM > 1 )
+				{
+					const int perBand = a.groupM * tilesN;
+					const int band = lin / perBand;
+					const int first = band * a.groupM;
+					const int rows = min( tilesM - first, a.groupM );
+					const int r = lin - band * perBand;
+					tm = first + r % rows;
+					tn = r / rows;
+				}
+				else
+				{
+					tm = lin / tilesN;
+					tn = lin - tm * tilesN;
+				}
+			};
 
 			// ---- LDS-DMA sources: a half tile is 128 rows x 128 bytes = 16 pieces of 8 rows, a wave owns pieces 2 wave, 2 wave + 1.
-			// Lane l of a piece lands at row l / 8, physical 16-byte chunk l % 8, which must hold logical chunk (l % 8) ^ ((row >> 1) & 7)
+			// Lane l of a piece lands at row l / 8, physical 16-byte chunk l % 8, which must hold logical chunk (l % 8) ^ ((row >> 1) & 7).
+			// offA / offW = byte offset of that chunk from a.A / a.W at k = 0 (the launcher guarantees they fit 32 bits).
 			const int rIn = lane >> 3, cPhys = lane & 7;
-			const f16* gA[ 2 ][ 2 ];
-			const f16* gW[ 2 ][ 2 ];
+			unsigned offA[ 2 ][ 2 ], offW[ 2 ][ 2 ];
+			auto tileOffsets = [ & ]( int tm, int tn )
+			{
 	#pragma unroll
-			for( int h = 0; h < 2; h++ )
+				for( int h = 0; h < 2; h++ )
 	#pragma unroll
-				for( int i = 0; i < 2; i++ )
-				{
-					const int row = h * 128 + ( wave * 2 + i ) * 8 + rIn;
-					const int c = cPhys ^ ( ( row >> 1 ) & 7 );
-					int m = ( ( ABL & 16 ) ? 0 : tm ) * BM + row;	  // ABL 16: every tile reads the first A tile (operands stay in L2)
-					m = m < a.M ? m : a.M - 1;
-					gA[ h ][ i ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + c * 8;
-					int n = tn * BN + row;
-					n = n < a.N ? n : a.N - 1;
-					gW[ h ][ i ] = a.W + (long long)n * a.K + c * 8;
-				}
+					for( int i = 0; i < 2; i++ )
+					{
+						const int row = h * 128 + ( wave * 2 + i ) * 8 + rIn;
+						const int c = cPhys ^ ( ( row >> 1 ) & 7 );
+						int m = ( ( ABL & 16 ) ? 0 : tm ) * BM + row;
+						m = m < a.M ? m : a.M - 1;
+						offA[ h ][ i ] = (unsigned)( ( rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + c * 8 ) * 2 );
+						int n = tn * BN + row;
+						n = n < a.N ? n : a.N - 1;
+						offW[ h ][ i ] = (unsigned)( ( (long long)n * a.K + c * 8 ) * 2 );
+					}
+			};
 			const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)lds );
 			// byte address of this wave's first piece of a half tile inside buffer 0: + buf * STAGE * 2, + (W ? A_HALFS * 2 : 0), + h * 16384
 			const unsigned pieceBase = ldsBase + (unsigned)wave * 2048u;
@@ -1008,20 +1188,35 @@ namespace wh
 				constexpr int P = decltype( part )::value;
 				constexpr bool isW = P < 2;
 				constexpr int h = P & 1;
-				const unsigned dst = pieceBase + (unsigned)( kt & 1 ) * ( C::STAGE * 2 ) + ( isW ? C::A_HALFS * 2 : 0 ) + h * 16384;
-				const int ko = kt * BK;
 				if constexpr( ( ABL & 1 ) != 0 )
 				{
-					if( kt > 1 || ( kt == 1 && P != 0 ) ) return;
+					if( kt > 1 || ( kt == 1 && P >= 2 ) ) return;
 				}
-	#pragma unroll
-				for( int i = 0; i < 2; i++ )
-					ldsDma16( ( isW ? gW[ h ][ i ] : gA[ h ][ i ] ) + ko, dst + i * 1024 );
+				const unsigned dst = pieceBase + (unsigned)( kt & 1 ) * ( C::STAGE * 2 ) + ( isW ? C::A_HALFS * 2 : 0 ) + h * 16384;
+				const f16* const base = ( isW ? a.W : a.A ) + kt * BK;
+				if constexpr( isW )
+					ldsDmaPair( base, offW[ h ][ 0 ], offW[ h ][ 1 ], dst );
+				else
+					ldsDmaPair( base, offA[ h ][ 0 ], offA[ h ][ 1 ], dst );
 			};
 			using PW0 = std::integral_constant<int, 0>;
 			using PW1 = std::integral_constant<int, 1>;
 			using PA0 = std::integral_constant<int, 2>;
 			using PA1 = std::integral_constant<int, 3>;
+			const int nk = a.K / BK;
+			// first operands of a tile: K tile 0 into buffer 0 and the W tile of K tile 1 into buffer 1 (12 instructions per wave)
+			auto stageFirst = [ & ]()
+			{
+				stage( 0, PW0{} );
+				stage( 0, PW1{} );
+				stage( 0, PA0{} );
+				stage( 0, PA1{} );
+				if( nk > 1 )
+				{
+					stage( 1, PW0{} );
+					stage( 1, PW1{} );
+				}
+			};
 
 			// ---- fragment reads: lane l reads row l & 31 of a 32-row tile, logical chunk 2 ks + (l >> 5), stored at chunk ^ ((row >> 1) & 7);
 			// the tile origins are multiples of 32 rows, so the XOR term depends on the lane only
@@ -1031,145 +1226,153 @@ namespace wh
 			for( int ks = 0; ks < 4; ks++ ) laneK[ ks ] = ( lane & 31 ) * BK + ( ( x0 ^ ( ks << 1 ) ) << 3 );
 			const int aRow0 = wr * 128, wRow0 = wc * 64;
 
-			f32x16 acc[ 4 ][ 2 ];
-	#pragma unroll
-			for( int i = 0; i < 4; i++ )
-	#pragma unroll
-				for( int j = 0; j < 2; j++ )
-	#pragma unroll
-					for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
-			f16x8 fa[ 2 ][ 4 ], fb0[ 4 ], fb1[ 4 ];
+			int tm, tn;
+			int lin = linFirst;
+			if( lin >= linEnd ) return;
+			tileCoords( lin, tm, tn );
+			tileOffsets( tm, tn );
+			stageFirst();
 
-			int ablTile = 0;
-			auto readA = [ & ]( const f16* bufA, int half )
+			for( ;; )
 			{
-				if constexpr( ( ABL & 2 ) != 0 )
+				f32x16 acc[ 4 ][ 2 ];
+	#pragma unroll
+				for( int i = 0; i < 4; i++ )
+	#pragma unroll
+					for( int j = 0; j < 2; j++ )
+	#pragma unroll
+						for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
+				f16x8 fa[ 2 ][ 4 ], fb0[ 4 ], fb1[ 4 ];
+				int ablTile = 0;
+				auto readA = [ & ]( const f16* bufA, int half )
 				{
-					if( ablTile > 0 ) return;
-				}
-	#pragma unroll
-				for( int i = 0; i < 2; i++ )
-	#pragma unroll
-					for( int ks = 0; ks < 4; ks++ )
-						fa[ i ][ ks ] = *(const f16x8*)( bufA + ( aRow0 + ( half * 2 + i ) * 32 ) * BK + laneK[ ks ] );
-			};
-			auto readB = [ & ]( const f16* bufW, int j, f16x8( &fb )[ 4 ] )
-			{
-				if constexpr( ( ABL & 2 ) != 0 )
-				{
-					if( ablTile > 0 ) return;
-				}
-	#pragma unroll
-				for( int ks = 0; ks < 4; ks++ ) fb[ ks ] = *(const f16x8*)( bufW + ( wRow0 + j * 32 ) * BK + laneK[ ks ] );
-			};
-			auto quadrant = [ & ]( auto i0c, auto jc, const f16x8( &fb )[ 4 ] )
-			{
-				constexpr int i0 = decltype( i0c )::value, j = decltype( jc )::value;
-				if constexpr( ( ABL & 4 ) != 0 )
-				{
-					// keep the fragments live without the matrix pipe
-	#pragma unroll
-					for( int ks = 0; ks < 4; ks++ ) asm volatile( "" ::"v"( fa[ 0 ][ ks ] ), "v"( fa[ 1 ][ ks ] ), "v"( fb[ ks ] ) );
-					return;
-				}
-				__builtin_amdgcn_s_setprio( 1 );
-	#pragma unroll
-				for( int ks = 0; ks < 4; ks++ )
+					if constexpr( ( ABL & 2 ) != 0 )
+					{
+						if( ablTile > 0 ) return;
+					}
 	#pragma unroll
 					for( int i = 0; i < 2; i++ )
-						acc[ i0 + i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ][ ks ], fb[ ks ], acc[ i0 + i ][ j ], 0, 0, 0 );
-				__builtin_amdgcn_s_setprio( 0 );
-			};
-			using I0 = std::integral_constant<int, 0>;
-			using I1 = std::integral_constant<int, 1>;
-			using I2 = std::integral_constant<int, 2>;
-			// end of an MFMA segment: the half tile issued one phase earlier must have landed; the one issued in this phase (if any) stays in flight
-			auto landed = [ & ]( bool issuedThisPhase )
-			{
-				if( issuedThisPhase )
-					asm volatile( "s_waitcnt vmcnt(2)" ::: "memory" );
-				else
-					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-			};
-
-			const int nk = a.K / BK;
-			stage( 0, PW0{} );
-			stage( 0, PW1{} );
-			stage( 0, PA0{} );
-			stage( 0, PA1{} );
-			if( nk > 1 )
-			{
-				stage( 1, PW0{} );
-				stage( 1, PW1{} );
-				asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
-			}
-			else
-				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-			WH_BAR();
-			if( wr == 1 ) WH_BAR();	   // wave row 1 runs one barrier behind row 0
-
-			for( int kt = 0; kt < nk; kt++ )
-			{
-				const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
-				const f16* const bufW = bufA + C::A_HALFS;
-				const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
-				// phase 1: 12 fragment reads, no DMA
-				readB( bufW, 0, fb0 );
-				readA( bufA, 0 );
-				WH_BAR();
-				quadrant( I0{}, I0{}, fb0 );
-				WH_BAR();
-				// phase 2: 4 reads, the A tile of K tile t+1 (its buffer's A rows were last read two and three barriers ago)
-				readB( bufW, 1, fb1 );
-				if( next )
+	#pragma unroll
+						for( int ks = 0; ks < 4; ks++ )
+							fa[ i ][ ks ] = *(const f16x8*)( bufA + ( aRow0 + ( half * 2 + i ) * 32 ) * BK + laneK[ ks ] );
+				};
+				auto readB = [ & ]( const f16* bufW, int j, f16x8( &fb )[ 4 ] )
 				{
-					stage( kt + 1, PA0{} );
-					stage( kt + 1, PA1{} );
-				}
-				WH_BAR();
-				quadrant( I0{}, I1{}, fb1 );
-				WH_BAR();
-				// phase 3: 8 reads
-				readA( bufA, 1 );
-				WH_BAR();
-				quadrant( I2{}, I1{}, fb1 );
-				WH_BAR();
-				// phase 4: no reads, the W tile of K tile t+2 (this buffer's W rows were last read in phase 2), then the ONE wait of
-				// the K tile: everything of tile t+1 has landed, the four instructions just issued stay in flight
-				if( next2 )
+					if constexpr( ( ABL & 2 ) != 0 )
+					{
+						if( ablTile > 0 ) return;
+					}
+	#pragma unroll
+					for( int ks = 0; ks < 4; ks++ ) fb[ ks ] = *(const f16x8*)( bufW + ( wRow0 + j * 32 ) * BK + laneK[ ks ] );
+				};
+				auto quadrant = [ & ]( auto i0c, auto jc, const f16x8( &fb )[ 4 ] )
 				{
-					stage( kt + 2, PW0{} );
-					stage( kt + 2, PW1{} );
+					constexpr int i0 = decltype( i0c )::value, j = decltype( jc )::value;
+					if constexpr( ( ABL & 4 ) != 0 )
+					{
+	#pragma unroll
+						for( int ks = 0; ks < 4; ks++ ) asm volatile( "" ::"v"( fa[ 0 ][ ks ] ), "v"( fa[ 1 ][ ks ] ), "v"( fb[ ks ] ) );
+						return;
+					}
+					__builtin_amdgcn_s_setprio( 1 );
+	#pragma unroll
+					for( int ks = 0; ks < 4; ks++ )
+	#pragma unroll
+						for( int i = 0; i < 2; i++ )
+							acc[ i0 + i ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ i ][ ks ], fb[ ks ], acc[ i0 + i ][ j ], 0, 0, 0 );
+					__builtin_amdgcn_s_setprio( 0 );
+				};
+				using I0 = std::integral_constant<int, 0>;
+				using I1 = std::integral_constant<int, 1>;
+				using I2 = std::integral_constant<int, 2>;
+
+				// the tile's first operands were requested before the previous tile's epilogue (or above): K tile 0 must have landed
+				if( nk > 1 )
 					asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
-				}
 				else
 					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 				WH_BAR();
-				quadrant( I2{}, I0{}, fb0 );
-				WH_BAR();
-				ablTile = 1;
-			}
-			if( wr == 0 ) WH_BAR();
-			// every wave has passed the same number of barriers and retired all its fragment reads: the operand tiles are dead
+				if( wr == 1 ) WH_BAR();	   // wave row 1 runs one barrier behind row 0
 
-			if constexpr( WIDE )
-			{
-				const bool vPart = EPI == EPI_QKV_ENC && ( tn * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM;
-				if( !vPart )
+				for( int kt = 0; kt < nk; kt++ )
+				{
+					const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
+					const f16* const bufW = bufA + C::A_HALFS;
+					const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
+					// phase 1: 12 fragment reads
+					readB( bufW, 0, fb0 );
+					readA( bufA, 0 );
+					WH_BAR();
+					quadrant( I0{}, I0{}, fb0 );
+					WH_BAR();
+					// phase 2: 4 reads, A rows 0..127 of K tile t+1
+					readB( bufW, 1, fb1 );
+					if( next ) stage( kt + 1, PA0{} );
+					WH_BAR();
+					quadrant( I0{}, I1{}, fb1 );
+					WH_BAR();
+					// phase 3: 8 reads, A rows 128..255 of K tile t+1
+					readA( bufA, 1 );
+					if( next ) stage( kt + 1, PA1{} );
+					WH_BAR();
+					quadrant( I2{}, I1{}, fb1 );
+					WH_BAR();
+					// phase 4: no reads, the W tile of K tile t+2; W and A rows 0.. of tile t+1 must have landed after the issue
+					// segment, A rows 128.. after the MFMA segment
+					if( next2 )
+					{
+						stage( kt + 2, PW0{} );
+						stage( kt + 2, PW1{} );
+						asm volatile( "s_waitcnt vmcnt(6)" ::: "memory" );
+					}
+					else if( next )
+						asm volatile( "s_waitcnt vmcnt(2)" ::: "memory" );
+					WH_BAR();
+					quadrant( I2{}, I0{}, fb0 );
+					if( next2 )
+						asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+					else
+						asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+					WH_BAR();
+					ablTile = 1;
+				}
+				if( wr == 0 ) WH_BAR();
+				// every wave has passed the same number of barriers and retired all its fragment reads: both operand buffers are dead
+
+				const int tmDone = tm, tnDone = tn;
+				lin += linStep;
+				const bool more = lin < linEnd;
+				if( more )
+				{
+					tileCoords( lin, tm, tn );
+					tileOffsets( tm, tn );
+					stageFirst();	  // lands under the epilogue below
+				}
+
+				if constexpr( ( ABL & 32 ) != 0 )
 				{
 	#pragma unroll
-					for( int half = 0; half < 2; half++ )
-					{
-						tileEpilogueWide<EPI, Cfg8Quad>( a, *(f32x16( * )[ 2 ][ 2 ])&acc[ 2 * half ], tm, tn, wr * 2 + half, wc, lane, smem + wave * 8192 );
-						// the second quarter re-uses the wave's 8 KiB: its LDS reads of the first must have retired
-						__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-						__builtin_amdgcn_wave_barrier();
-						__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-					}
-					return;
+					for( int i = 0; i < 4; i++ ) asm volatile( "" ::"v"( acc[ i ][ 0 ] ), "v"( acc[ i ][ 1 ] ) );
 				}
+				else
+				{
+					bool direct = !WIDE;
+					if constexpr( WIDE && EPI == EPI_QKV_ENC ) direct = ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM;	  // fragment-major V keeps the direct path
+					if( direct )
+						tileEpilogue<EPI, Cfg8>( a, acc, tmDone, tnDone, wr, wc, lane );
+					else
+					{
+						if constexpr( WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_CONV2 || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
+						{
+	#pragma unroll
+							for( int i = 0; i < 4; i++ )
+								epilogueBlock32x64<EPI>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
+									smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
+						}
+					}
+				}
+				if( !more ) break;
 			}
-			tileEpilogue<EPI, Cfg8>( a, acc, tm, tn, wr, wc, lane );
 		}
 #undef WH_BAR
 
@@ -1823,13 +2026,22 @@ namespace wh
 	static int launchTiled8K( const GemmArgs& b, hipStream_t stream )
 	{
 		static PerDeviceOnce once;
+		static int cusOfDevice[ 64 ];
+		int dev = 0;
+		if( hipGetDevice( &dev ) != hipSuccess ) dev = 0;
 		if( const int onceDev = once.needed(); onceDev >= 0 )
 		{
 			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled8<EPI, WIDE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg8::LDS_BYTES ) );
+			int cus = 0;
+			WH_HIP( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, dev ) );
+			cusOfDevice[ onceDev ] = cus;
 			once.mark( onceDev );
 		}
+		// persistent: one workgroup per CU (a workgroup takes all 160 KiB of LDS), each walks its share of the tiles
 		const int tilesM = ( b.M + Cfg8::BM - 1 ) / Cfg8::BM, tilesN = ( b.N + Cfg8::BN - 1 ) / Cfg8::BN;
-		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE, ABL> ), dim3( tilesM * tilesN ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
+		const int cus = cusOfDevice[ dev & 63 ] > 0 ? cusOfDevice[ dev & 63 ] : 256;
+		const int grid = tilesM * tilesN < cus ? tilesM * tilesN : cus;
+		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE, ABL> ), dim3( grid ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -1871,6 +2083,7 @@ namespace wh
 		case 45: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 6>( b, stream ); }
 		case 46: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16>( b, stream ); }
 		case 47: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16 + 6>( b, stream ); }
+		case 48: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 32>( b, stream ); }
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
@@ -1941,7 +2154,10 @@ namespace wh
 		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
 		const bool pf = gl && ( g_tuning & TUNE_GEMM_FRAGPF ) != 0;
-		const bool w8 = big && ( g_tuning & TUNE_GEMM_8WAVE ) != 0;
+		// gemmTiled8 addresses its operands as a 64-bit base + 32-bit byte offsets
+		const long long aBytes = 2ll * ( a.Mb > 0 && a.Mb < a.M ? ( (long long)( a.M / a.Mb ) + 1 ) * a.aBatchStride + (long long)a.Mb * a.lda : (long long)a.M * a.lda ) + 2ll * a.K;
+		const bool fits32 = aBytes < ( 1ll << 32 ) && 2ll * a.N * a.K < ( 1ll << 32 );
+		const bool w8 = big && fits32 && ( g_tuning & TUNE_GEMM_8WAVE ) != 0;
 #define WH_TILED( E )                                                    \
 	if( w8 ) return launchTiled8<E>( a, stream );                        \
 	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
