@@ -30,9 +30,15 @@ namespace wh
 	{
 		// 0.5 f (1 + tanh u) == f / (1 + exp(-2u)); the second form has no cancellation for negative f, so FP32
 		// evaluation stays within ~1e-6 relative of the reference's double evaluation before the FP16 rounding.
+		// exp(-2u) = 2^( f (C1 + C2 f^2) ): f^2 is exact in FP32 (f has 11 significant bits), one fma, one product, then the
+		// hardware's 2^x and reciprocal (1 ulp each). Nine instructions per element instead of ~30 for expf + an IEEE division:
+		// the encoder's MLP up-projection spends a third of its time in this epilogue otherwise. Checked against all 63488 finite
+		// inputs of the reference's table (tests/test_gpu_ops.py::test_gelu_table_exhaustive: at most 1 ulp, < 0.2 % of the entries).
 		const float f = round16( x );
-		const float u2 = -2.0f * 0.79788456080286535587989211986876f * f * ( 1.0f + 0.044715f * f * f );
-		const float y = f / ( 1.0f + expf( u2 ) );
+		constexpr float C1 = -2.0f * 0.79788456080286535587989211986876f * 1.44269504088896340736f;
+		constexpr float C2 = C1 * 0.044715f;
+		const float e = __builtin_amdgcn_exp2f( fmaf( f * f, C2, C1 ) * f );
+		const float y = f * __builtin_amdgcn_rcpf( 1.0f + e );
 		return (f16)y;
 	}
 

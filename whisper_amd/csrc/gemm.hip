@@ -963,7 +963,7 @@ namespace wh
 		// element, FP16 outputs in one pass ([32][64] halfs), FP32 outputs in two ([16][64] floats each), 16-byte chunk index XORed
 		// with the row so that the column-wise writes and the row-wise reads are both conflict free. m0 / n0 = first row / column.
 		// Preconditions as for tileEpilogueWide (a.wideEpi). Residual / positional rows are requested before the LDS round trip.
-		template<int EPI>
+		template<int EPI, bool NT = false>
 		__device__ __forceinline__ void epilogueBlock32x64( const GemmArgs& a, const f32x16& c0, const f32x16& c1, int m0, int n0, int lane, unsigned char* ldsWave )
 		{
 			const int hi = lane >> 5, c = lane & 31;
@@ -1100,11 +1100,113 @@ namespace wh
 						f32x4 o;
 	#pragma unroll
 						for( int e = 0; e < 4; e++ ) o[ e ] = EPI == EPI_F32 ? v[ e ] + ex[ hh ][ u ][ e ] : ex[ hh ][ u ][ e ] + v[ e ];
-						*(f32x4*)( a.out32 + off[ hh ][ u ] ) = o;
+						if constexpr( NT )
+							__builtin_nontemporal_store( o, (f32x4*)( a.out32 + off[ hh ][ u ] ) );
+						else
+							*(f32x4*)( a.out32 + off[ hh ][ u ] ) = o;
 					}
 					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
 					__builtin_amdgcn_wave_barrier();
 					__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+				}
+			}
+		}
+
+		// The V columns of the encoder's Q/K/V product, straight from the accumulators: fragment-major V (vFragIndex) keeps the
+		// keys k..k+3 and k+8..k+11 of one dimension in one 16-byte chunk, and a lane of the 32x32 accumulator tile holds
+		// exactly rows 4 hi + 8 g + {0..3} of one column -- so each group g of 4 registers is one 8-byte half of a chunk, and
+		// groups g, g+1 are one whole chunk when the first one's key is a multiple of 8 inside its 16-key block. The chunks of
+		// a store instruction are consecutive in memory (lane = dimension, hi = chunk + 32): 1 KiB per wave and instruction.
+		// Requires T % 4 == 0 (a group of 4 rows never straddles two sequences); m0 / n0 = first row / column of the
+		// 32 x 64 block, n0 a multiple of 64 inside the V third of the columns.
+		__device__ __forceinline__ void epilogueBlockV32x64( const GemmArgs& a, const f32x16& c0, const f32x16& c1, int m0, int n0, int lane )
+		{
+			const int hi = lane >> 5, dd = lane & 31;
+			const int d = a.H * HEAD_DIM;
+			const int head = ( n0 - 2 * d ) >> 6;
+			const int b0 = m0 / a.T;	   // wave-uniform
+			const long long perSeq = (long long)a.H * HEAD_DIM * a.Tpad;
+			f16* const vHead = a.v + (long long)head * HEAD_DIM * a.Tpad;
+			int bOf[ 4 ], tOf[ 4 ];
+			bool ok[ 4 ];
+	#pragma unroll
+			for( int g = 0; g < 4; g++ )
+			{
+				const int m = m0 + 4 * hi + 8 * g;
+				int t = m - b0 * a.T, b = b0;
+				if( t >= a.T )	  // the block runs into the next sequence (or, for T < 32, further)
+				{
+					b = m / a.T;
+					t = m - b * a.T;
+				}
+				bOf[ g ] = b;
+				tOf[ g ] = t;
+				ok[ g ] = m < a.M;
+			}
+	#pragma unroll
+			for( int j = 0; j < 2; j++ )
+			{
+				const int n = n0 + j * 32 + dd;
+				const float bias = ( a.bias && n < a.N ) ? a.bias[ n ] : 0.0f;
+				f16x4 pk[ 4 ];
+	#pragma unroll
+				for( int g = 0; g < 4; g++ )
+	#pragma unroll
+					for( int e = 0; e < 4; e++ ) pk[ g ][ e ] = (f16)( ( j == 0 ? c0[ 4 * g + e ] : c1[ 4 * g + e ] ) + bias );
+				if( n >= a.N ) continue;
+				auto dst = [ & ]( int g ) -> f16*
+				{
+					const int t = tOf[ g ];
+					return vHead + bOf[ g ] * perSeq + ( ( (long long)( t >> 4 ) * 2 + j ) * 64 + ( ( t >> 2 ) & 1 ) * 32 + dd ) * 8 + ( ( t >> 3 ) & 1 ) * 4;
+				};
+				// groups g and g + 1 are one 16-byte chunk when g's keys are the first half of their 16-key block and g + 1 belongs
+				// to the same sequence (a block that runs into the next sequence restarts the key count: checked per pair)
+				auto whole = [ & ]( int g ) { return ok[ g + 1 ] && bOf[ g + 1 ] == bOf[ g ] && ( ( tOf[ g ] >> 3 ) & 1 ) == 0; };
+				auto store16 = [ & ]( int g )
+				{
+					f16x8 w;
+	#pragma unroll
+					for( int e = 0; e < 4; e++ )
+					{
+						w[ e ] = pk[ g ][ e ];
+						w[ 4 + e ] = pk[ g + 1 ][ e ];
+					}
+					*(f16x8*)dst( g ) = w;
+				};
+				auto store8 = [ & ]( int g )
+				{
+					if( ok[ g ] ) *(f16x4*)dst( g ) = pk[ g ];
+				};
+				if( whole( 0 ) )
+				{
+					store16( 0 );
+					if( whole( 2 ) )
+						store16( 2 );
+					else
+					{
+						store8( 2 );
+						store8( 3 );
+					}
+				}
+				else
+				{
+					store8( 0 );
+					if( whole( 1 ) )
+					{
+						store16( 1 );
+						store8( 3 );
+					}
+					else
+					{
+						store8( 1 );
+						if( whole( 2 ) )
+							store16( 2 );
+						else
+						{
+							store8( 2 );
+							store8( 3 );
+						}
+					}
 				}
 			}
 		}
@@ -1229,6 +1331,12 @@ namespace wh
 			int tm, tn;
 			int lin = linFirst;
 			if( lin >= linEnd ) return;
+			if constexpr( ( ABL & 64 ) != 0 )
+			{
+				// start the workgroups of an XCD a quarter tile apart so that their epilogues (the HBM write bursts) do not coincide
+				const int q = ( blockIdx.x >> 3 ) & 3;
+				for( int i = 0; i < q * ( nk >> 3 ); i++ ) __builtin_amdgcn_s_sleep( 127 );
+			}
 			tileCoords( lin, tm, tn );
 			tileOffsets( tm, tn );
 			stageFirst();
@@ -1357,16 +1465,29 @@ namespace wh
 				else
 				{
 					bool direct = !WIDE;
-					if constexpr( WIDE && EPI == EPI_QKV_ENC ) direct = ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM;	  // fragment-major V keeps the direct path
+					if constexpr( WIDE && EPI == EPI_QKV_ENC )
+					{
+						// fragment-major V: straight from the registers (groups of 4 consecutive keys; T % 4 != 0 keeps the element-wise path)
+						if( ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM )
+						{
+							direct = ( a.T & 3 ) != 0;
+							if( !direct )
+							{
+		#pragma unroll
+								for( int i = 0; i < 4; i++ )
+									epilogueBlockV32x64( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane );
+							}
+						}
+					}
 					if( direct )
 						tileEpilogue<EPI, Cfg8>( a, acc, tmDone, tnDone, wr, wc, lane );
-					else
+					else if( !( WIDE && EPI == EPI_QKV_ENC && ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM ) )
 					{
 						if constexpr( WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_CONV2 || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
 						{
 	#pragma unroll
 							for( int i = 0; i < 4; i++ )
-								epilogueBlock32x64<EPI>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
+								epilogueBlock32x64<EPI, ( ABL & 128 ) != 0>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
 									smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
 						}
 					}
@@ -2084,6 +2205,9 @@ namespace wh
 		case 46: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16>( b, stream ); }
 		case 47: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16 + 6>( b, stream ); }
 		case 48: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 32>( b, stream ); }
+		case 49: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 64>( b, stream ); }	   // correct results: staggered start
+		case 39: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 128>( b, stream ); }   // correct results: non-temporal stores
+		case 38: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 192>( b, stream ); }
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
