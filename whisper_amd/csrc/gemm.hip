@@ -1334,7 +1334,7 @@ namespace wh
 			if constexpr( ( ABL & 64 ) != 0 )
 			{
 				// start the workgroups of an XCD a quarter tile apart so that their epilogues (the HBM write bursts) do not coincide
-				const int q = ( blockIdx.x >> 3 ) & 3;
+				const int q = ( ABL & 256 ) ? ( blockIdx.x & 3 ) : ( ( blockIdx.x >> 3 ) & 3 );	  // 256: whole XCDs a quarter tile apart
 				for( int i = 0; i < q * ( nk >> 3 ); i++ ) __builtin_amdgcn_s_sleep( 127 );
 			}
 			tileCoords( lin, tm, tn );
@@ -1394,6 +1394,8 @@ namespace wh
 				using I1 = std::integral_constant<int, 1>;
 				using I2 = std::integral_constant<int, 2>;
 
+				long long tStamp0 = 0;
+				if constexpr( ( ABL & 1024 ) != 0 ) tStamp0 = __builtin_readcyclecounter();
 				// the tile's first operands were requested before the previous tile's epilogue (or above): K tile 0 must have landed
 				if( nk > 1 )
 					asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
@@ -1401,6 +1403,8 @@ namespace wh
 					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 				WH_BAR();
 				if( wr == 1 ) WH_BAR();	   // wave row 1 runs one barrier behind row 0
+				long long tStamp1 = 0;
+				if constexpr( ( ABL & 1024 ) != 0 ) tStamp1 = __builtin_readcyclecounter();
 
 				for( int kt = 0; kt < nk; kt++ )
 				{
@@ -1447,6 +1451,8 @@ namespace wh
 				if( wr == 0 ) WH_BAR();
 				// every wave has passed the same number of barriers and retired all its fragment reads: both operand buffers are dead
 
+				long long tStamp2 = 0;
+				if constexpr( ( ABL & 1024 ) != 0 ) tStamp2 = __builtin_readcyclecounter();
 				const int tmDone = tm, tnDone = tn;
 				lin += linStep;
 				const bool more = lin < linEnd;
@@ -1487,9 +1493,22 @@ namespace wh
 						{
 	#pragma unroll
 							for( int i = 0; i < 4; i++ )
-								epilogueBlock32x64<EPI, ( ABL & 128 ) != 0>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
+								epilogueBlock32x64<EPI, ( ABL & 128 ) != 0>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], ( ( ABL & 512 ) ? 0 : tmDone ) * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
 									smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
 						}
+					}
+				}
+				if constexpr( ( ABL & 1024 ) != 0 )
+				{
+					// probe: cycles of wave 0 spent waiting for the first operands, in the K loop and in the epilogue (a.pe = 4 counters)
+					const long long tStamp3 = __builtin_readcyclecounter();
+					if( tid == 0 )
+					{
+						unsigned long long* const dbg = (unsigned long long*)a.pe;
+						atomicAdd( dbg + 0, (unsigned long long)( tStamp1 - tStamp0 ) );
+						atomicAdd( dbg + 1, (unsigned long long)( tStamp2 - tStamp1 ) );
+						atomicAdd( dbg + 2, (unsigned long long)( tStamp3 - tStamp2 ) );
+						atomicAdd( dbg + 3, 1ull );
 					}
 				}
 				if( !more ) break;
@@ -2207,14 +2226,15 @@ namespace wh
 		case 48: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 32>( b, stream ); }
 		case 49: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 64>( b, stream ); }	   // correct results: staggered start
 		case 39: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 128>( b, stream ); }   // correct results: non-temporal stores
+		case 37: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 64 + 256>( b, stream ); }   // correct results: XCDs staggered
+		case 36: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 512>( b, stream ); }   // every tile stores into tile row 0 (L2-resident writes)
+		case 35: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1024>( b, stream ); }   // correct results: cycle stamps into a.pe
 		case 38: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 192>( b, stream ); }
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
 		case 33: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 3>>( a, stream );
 		case 34: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 4>>( a, stream );
-		case 36: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 8>>( a, stream );	 // no W loads
-		case 37: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 16>>( a, stream );	 // no A loads
 		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, 1>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );

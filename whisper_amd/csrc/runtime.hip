@@ -1932,6 +1932,13 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 		g.epi = EPI_F32; g.out32 = (float*)out;
 		g.groupM = variant / 100;	   // variant = tile variant + 100 * M tiles per band of the block walk (0 = default)
 		variant %= 100;
+		unsigned long long* stamps = nullptr;
+		if( variant == 35 )
+		{
+			WH_HIP( hipMalloc( (void**)&stamps, 32 ) );
+			WH_HIP( hipMemsetAsync( stamps, 0, 32, st ) );
+			g.pe = (const float*)stamps;
+		}
 		for( int i = 0; i < 2 && rc == 0; i++ ) rc = launchGemmVariant( g, variant, st );
 		if( rc == 0 )
 		{
@@ -1942,6 +1949,15 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 			WH_HIP( hipEventSynchronize( e1 ) );
 			WH_HIP( hipEventElapsedTime( &ms, e0, e1 ) );
 		}
+		if( stamps && rc == 0 )
+		{
+			unsigned long long h[ 4 ] = {};
+			WH_HIP( hipMemcpy( h, stamps, 32, hipMemcpyDeviceToHost ) );
+			const double n = h[ 3 ] ? (double)h[ 3 ] : 1.0;
+			fprintf( stderr, "[gemm8 stamps] %dx%dx%d: per tile (wave 0, cycles) first-operand wait %.0f, K loop %.0f, epilogue %.0f; %.0f tiles\n", M, N, K,
+				h[ 0 ] / n, h[ 1 ] / n, h[ 2 ] / n, n );
+		}
+		if( stamps ) (void)hipFree( stamps );
 		// every variant is checked against the production path on the same operands: a pipeline that races is fast and wrong
 		// (variants 31 .. 39 are ablations, wrong by construction)
 		if( rc == 0 && !( variant >= 31 && variant <= 39 ) && !( variant >= 41 && variant <= 49 ) )
