@@ -325,13 +325,18 @@ def test_hypotheses_share_cross_attention(hip_tiny, golden):
                                        # its projection on the matrix cores vs on the VALU (1 and 4 sequences per workgroup)
                                        ("TUNE_SELF_MFMA", 10), ("TUNE_SELF_MFMA", 390),
                                        # 40 and 100 rows: 32 instead of 64 rows per workgroup in the decode products
-                                       ("TUNE_GEMV_ROWGROUPS", 40), ("TUNE_GEMV_ROWGROUPS", 100)])
+                                       ("TUNE_GEMV_ROWGROUPS", 40), ("TUNE_GEMV_ROWGROUPS", 100),
+                                       # one stream (1 .. 4 sequences): the chip-wide launches of decode1.hip against the batch kernels;
+                                       # their prefetch workgroups on / off must not change a bit
+                                       ("TUNE_DECODE_SMALL", 1), ("TUNE_DECODE_SMALL", 2), ("TUNE_DECODE_SMALL", 3), ("TUNE_DECODE_SMALL", 4),
+                                       ("TUNE_DECODE_PREFETCH", 1), ("TUNE_DECODE_PREFETCH", 3)])
 def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
     """Decode steps with a fusion switched on against the same steps with the separate launches (tuning bit off):
     LayerNorm + cross-attention query inside the attention kernel; LayerNorm + per-head QKV + cache append + self-attention
     as one kernel (1, 2 or 4 sequences per workgroup), its Q/K/V projection as MFMA tiles; the workgroup-wide LayerNorm
     prologue of the 17..32-row gemv; 8 waves splitting K in the MLP down-projection; the row grouping of the 33..128-row
-    products. Only FP32 summation order may differ."""
+    products; the single-stream path (gemvSmall + cross-attention over 8 key ranges, decode1.hip). Only FP32 summation
+    order may differ."""
     pad = np.zeros((80, 3000), np.float32)
     pad[:, :1100] = golden["mel"]
     mel = torch.from_numpy(pad).cuda()
@@ -352,6 +357,8 @@ def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
     for i in range(2):
         d = report("%s on vs off, step %d" % (bit, i), res["fused"][i][0], res["separate"][i][0])
         assert d.max() < 3e-3 and d.mean() < 4e-4
+        if bit == "TUNE_DECODE_PREFETCH":
+            assert d.max() == 0.0
         assert all(np.array_equal(res["fused"][i][0], res["fused"][i][k]) for k in range(batch))
     for i in (2, 3):
         d = report("%s on vs off, self cache" % bit, res["fused"][i][0], res["separate"][i][0])

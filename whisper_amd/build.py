@@ -20,7 +20,7 @@ HIP_LIB = os.path.join(LIB_DIR, "libwhisper_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "libWhisper.so")
 CLI_BIN = os.path.join(LIB_DIR, "whisper-main")
 
-HIP_SOURCES = ["gemm.hip", "attn_enc.hip", "attn_dec.hip", "elementwise.hip", "mel.hip", "runtime.hip"]
+HIP_SOURCES = ["gemm.hip", "decode1.hip", "attn_enc.hip", "attn_dec.hip", "elementwise.hip", "mel.hip", "runtime.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -44,7 +44,7 @@ def _run(cmd):
 def build_hip(force: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + [os.path.join(ROOT, "include", "whisper_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "epilogue.h")] + [os.path.join(ROOT, "include", "whisper_hip.h")]
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     for s in HIP_SOURCES:

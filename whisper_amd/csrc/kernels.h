@@ -30,11 +30,13 @@ namespace wh
 		TUNE_GEMV_ALLROWS = 1048576,	 // 33 .. 128 decode rows, N >= 16384 (vocabulary projection): 32 columns x all rows per workgroup (gemmAllRows)
 		TUNE_GEMV_ROWGROUPS = 2097152,	 // 33 .. 128 decode rows: 32 instead of 64 rows per workgroup while that leaves fewer than 256 workgroups
 		TUNE_GEMM_GROUP_M = 2048,	 // tiled GEMM: blocks walk bands of 4 M tiles (A band stays in the XCD's L2) instead of rows of tiles
+		TUNE_DECODE_SMALL = 16777216,	 // single-token steps of up to 4 sequences: the chip-wide launches of decode1.hip (gemvSmall, cross-attention over 8 key ranges)
+		TUNE_DECODE_PREFETCH = 33554432,	 // ... each carrying 256 workgroups that pull the next launch's weights into the L2 of the XCD that will read them
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA
+		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_DECODE_PREFETCH
 	};
 	extern unsigned g_tuning;
 
@@ -166,6 +168,54 @@ namespace wh
 	};
 	int launchSelfBlockDec( const DecSelfArgs& a, hipStream_t stream );
 
+
+	// ---------------------------------------------------------------------------------------------------------------
+	// decode steps of ONE stream (up to 4 sequences), decode1.hip: every launch covers the chip, and every launch pulls the
+	// weights of the launch after it into the L2 of the XCD that will read them
+	// ---------------------------------------------------------------------------------------------------------------
+	// What the NEXT launch will stream: its workgroup c reads bytes [c * chunkBytes, (c + 1) * chunkBytes) of the region, and
+	// workgroup c runs on XCD c % 8 (dispatch order; a wrong guess costs the L2 hit, never correctness).
+	struct PrefetchHint
+	{
+		const void* ptr;
+		long long bytes;
+		int chunkBytes;
+	};
+	constexpr int SMALL_MAX_ROWS = 4;		// activation rows (sequences) of the small-batch decode path
+	constexpr int CROSS_SPLITS = 8;			// workgroups that share the keys of one (sequence, head) in cross-attention
+	constexpr int CROSS_PART = 68;			// floats per partial result: 64 dims of sum( e * V ), the double sum( e ), padding
+	struct SmallGemvArgs
+	{
+		GemmArgs g;			  // W, M <= 4, N, K, epi and its operands; pro 0: A (FP16 rows, lda); pro 1: lnX / lnW / lnB (row length K)
+		int pro;			  // 0 = FP16 activations, 1 = LayerNorm prologue, 3 = cross-attention partials combined into the activations
+		const float* part;	  // pro 3: [M][H][CROSS_SPLITS][CROSS_PART]
+		PrefetchHint pf[ 2 ];
+	};
+	int launchGemvSmall( const SmallGemvArgs& a, hipStream_t stream );
+	// Cross-attention of single-token steps in two launches of H x CROSS_SPLITS x sequences workgroups:
+	//   scores   LayerNorm of the residual row, this head's query (as attentionDecG's fused query), K . q for the split's keys
+	//            -> scores[seq][h][key], splitMax[seq][h][split]
+	//   softmaxPV  e = exp16( score - max over all splits ), sum( e ) in double, sum( e * V ) -> part[seq][h][split]
+	// The consumer (launchGemvSmall, pro 3) adds the splits in order and scales by float( 1 / sum ): the table softmax of the
+	// reference with its GLOBAL maximum (ggml.c:5030-5090), only the FP32 summation order differs from attentionDecG.
+	struct CrossSplitArgs
+	{
+		const float* lnX;	  // [seq][d] residual stream
+		const float* lnW;
+		const float* lnB;
+		const f16* qW;		  // [d][d]
+		const float* qB;
+		float qScale;
+		const f16* kc;		  // [seq][H][keyStride][64]
+		const f16* vc;
+		float* scores;		  // [seq][H][keyStride]
+		float* splitMax;	  // [seq][H][CROSS_SPLITS]
+		float* part;		  // [seq][H][CROSS_SPLITS][CROSS_PART]
+		int batch, H, nKeys, keyStride;
+		PrefetchHint pf[ 2 ];
+	};
+	int launchCrossScores( const CrossSplitArgs& a, hipStream_t stream );
+	int launchCrossSoftmaxPV( const CrossSplitArgs& a, hipStream_t stream );
 
 	// ---------------------------------------------------------------------------------------------------------------
 	// logits -> probabilities -> greedy token, on the device

@@ -243,6 +243,8 @@ struct wh_context
 	// decoder activations
 	float *dx = nullptr, *logits = nullptr, *probs = nullptr;
 	f16 *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr;
+	// single-stream decode steps (decode1.hip): cross-attention scores, per-split maxima and partial results of up to 4 sequences
+	float *crossScores = nullptr, *crossSplitMax = nullptr, *crossPart = nullptr;
 	int* tokensDev = nullptr;
 	int* melOffsetsDev = nullptr;
 	TokenData* tokDataDev = nullptr;
@@ -823,6 +825,12 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	rc = rc ? rc : c->alloc( c->dq, rowsD * d, wh_context::DONT_CARE, "dq" );
 	rc = rc ? rc : c->alloc( c->dattn, rowsD * d, wh_context::DONT_CARE, "dattn" );
 	rc = rc ? rc : c->alloc( c->dh, rowsD * 4 * d, wh_context::DONT_CARE, "dh" );
+	{
+		const int64_t sm = S < SMALL_MAX_ROWS ? S : SMALL_MAX_ROWS;
+		rc = rc ? rc : c->alloc( c->crossScores, sm * hp.n_text_head * T, wh_context::DONT_CARE, "crossScores" );
+		rc = rc ? rc : c->alloc( c->crossSplitMax, sm * hp.n_text_head * CROSS_SPLITS, wh_context::DONT_CARE, "crossSplitMax" );
+		rc = rc ? rc : c->alloc( c->crossPart, sm * hp.n_text_head * CROSS_SPLITS * CROSS_PART, wh_context::DONT_CARE, "crossPart" );
+	}
 	rc = rc ? rc : c->alloc( c->logits, S * (int64_t)hp.n_vocab, wh_context::DONT_CARE, "logits" );
 	rc = rc ? rc : c->alloc( c->probs, S * (int64_t)hp.n_vocab, wh_context::DONT_CARE, "probs" );
 	rc = rc ? rc : c->alloc( c->tokensDev, rowsD, wh_context::DONT_CARE, "tokensDev" );
@@ -1195,6 +1203,130 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 
 	WH_CHECK( profiled( c, KC_EMBED, 1.0 * M * d, 10.0 * M * d,
 		[ & ]() { return launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), c->dx, M, nTokens, nPast, nPastDev, d, hp.n_vocab, hp.n_text_ctx, st ); } ) );
+
+	// ---- single-token steps of up to 4 sequences (one stream through iContext::runFull): decode1.hip. Eight launches per layer,
+	// each of ~256 workgroups, each pulling the weights of the next one into the L2 of the XCD that will read them.
+	const bool small = nTokens == 1 && batch <= SMALL_MAX_ROWS && c->hyp == 1 && parity == 0 && d <= 1280 && ( d % 64 ) == 0 && c->T <= 1536 &&
+		!( c->flags & WH_FLAG_DEBUG_CAPTURE ) && ( g_tuning & TUNE_DECODE_SMALL );
+	if( small )
+	{
+		const bool pfOn = ( g_tuning & TUNE_DECODE_PREFETCH ) != 0;
+		// what a gemvSmall launch of N rows x K columns streams per workgroup (must mirror launchGemvSmall's row split)
+		auto gemvChunk = [ & ]( int N, int K ) -> int
+		{
+			const int nch = ( K + 511 ) >> 9;
+			int rw = ( N + 1023 ) / 1024;
+			if( rw < 1 ) rw = 1;
+			const int mr = batch <= 2 ? batch : 4;
+			while( rw > 1 && ( rw * nch > 16 || rw * 4 * mr > 64 ) ) rw--;
+			return rw * 4 * K * 2;
+		};
+		auto hint = [ & ]( const void* p, int64_t bytes, int chunk ) -> PrefetchHint
+		{
+			PrefetchHint h = { nullptr, 0, 0 };
+			if( pfOn ) { h.ptr = p; h.bytes = bytes; h.chunkBytes = chunk; }
+			return h;
+		};
+		auto smallGemv = [ & ]( SmallGemvArgs& a ) -> int
+		{
+			a.g.nPastDev = nPastDev;
+			const GemmArgs& g = a.g;
+			const double flops = 2.0 * g.M * g.N * g.K;
+			const double bytes = 2.0 * g.N * g.K + 2.0 * g.M * g.K + ( g.out32 ? 4.0 : 2.0 ) * g.M * g.N;
+			return profiled( c, KC_GEMV, flops, bytes, [ & ]() { return launchGemvSmall( a, st ); } );
+		};
+		const int64_t headKv = (int64_t)c->T * HEAD_DIM * 2;	   // bytes of one (sequence, head) of a cross-attention cache
+		for( int il = 0; il < hp.n_text_layer; il++ )
+		{
+			const DecLayer& e = L.dec[ il ];
+			const int64_t selfLayer = (int64_t)il * c->maxSeq * hp.n_text_ctx * d;
+			const int64_t crossLayer = (int64_t)il * c->maxBatch * c->T * d;
+			// 1. LayerNorm + Q/K/V (cache append)                          next but one: the self-attention output projection
+			{
+				SmallGemvArgs a = {};
+				a.g = plainGemm( nullptr, m->at<f16>( e.wqkv ), M, 3 * d, d );
+				a.g.epi = EPI_QKV_DEC; a.g.bias = m->at<float>( e.bqkv ); a.g.scale = kqScale;
+				a.g.q = c->dq; a.g.k = c->selfK + selfLayer; a.g.v = c->selfV + selfLayer;
+				a.g.H = H; a.g.nTok = 1; a.g.nPast = nPast; a.g.textCtx = hp.n_text_ctx;
+				a.pro = 1; a.g.lnX = c->dx; a.g.lnW = m->at<float>( e.ln1w ); a.g.lnB = m->at<float>( e.ln1b );
+				a.pf[ 0 ] = hint( m->at<f16>( e.wo ), (int64_t)d * d * 2, gemvChunk( d, d ) );
+				WH_CHECK( smallGemv( a ) );
+			}
+			// 2. self-attention (a head per workgroup: at most n_text_ctx keys)
+			{
+				DecAttnArgs a = {};
+				a.q = c->dq; a.kc = c->selfK + selfLayer; a.vc = c->selfV + selfLayer; a.out = c->dattn;
+				a.batch = batch; a.H = H; a.nTok = 1; a.nKeys = nPast + 1; a.keyStride = hp.n_text_ctx;
+				a.causal = 1; a.nPast = nPast; a.parityThreads = 0; a.nPastDev = nPastDev;
+				if( devState ) a.nKeys = hp.n_text_ctx;
+				WH_CHECK( attnDecP( c, a, devState ? c->profKeysHint : -1 ) );
+				if( il == 0 && !devState )
+				{
+					WH_CHECK( capture( c, c->capDecKqvSelf, c->dattn, (int64_t)M * d, (int64_t)c->maxRows * d ) );	 // "dec-KQV" (self)
+					c->capDecRows = M;
+				}
+			}
+			// 3. output projection + residual                              next: the query rows and the keys of the cross-attention
+			{
+				SmallGemvArgs a = {};
+				a.g = plainGemm( c->dattn, m->at<f16>( e.wo ), M, d, d );
+				a.g.epi = EPI_F32; a.g.bias = m->at<float>( e.bo ); a.g.res = c->dx; a.g.out32 = c->dx;
+				a.pf[ 0 ] = hint( m->at<f16>( e.wcq ), (int64_t)d * d * 2, HEAD_DIM * d * 2 );
+				a.pf[ 1 ] = hint( c->crossK + crossLayer, (int64_t)batch * H * headKv, (int)headKv );
+				WH_CHECK( smallGemv( a ) );
+			}
+			// 4. / 5. cross-attention over 8 key ranges per head            next: the values, then the output projection
+			CrossSplitArgs x = {};
+			x.lnX = c->dx; x.lnW = m->at<float>( e.lncw ); x.lnB = m->at<float>( e.lncb );
+			x.qW = m->at<f16>( e.wcq ); x.qB = m->at<float>( e.bcq ); x.qScale = kqScale;
+			x.kc = c->crossK + crossLayer; x.vc = c->crossV + crossLayer;
+			x.scores = c->crossScores; x.splitMax = c->crossSplitMax; x.part = c->crossPart;
+			x.batch = batch; x.H = H; x.nKeys = c->T; x.keyStride = c->T;
+			{
+				const double bytes = 2.0 * d * d + 2.0 * M * c->T * d + 4.0 * M * d;
+				x.pf[ 0 ] = hint( c->crossV + crossLayer, (int64_t)batch * H * headKv, (int)headKv );
+				WH_CHECK( profiled( c, KC_ATTN_DEC_CROSS, 2.0 * M * d * d + 2.0 * M * c->T * d, bytes, [ & ]() { return launchCrossScores( x, st ); } ) );
+				x.pf[ 0 ] = hint( m->at<f16>( e.wco ), (int64_t)d * d * 2, gemvChunk( d, d ) );
+				WH_CHECK( profiled( c, KC_ATTN_DEC_CROSS, 2.0 * M * c->T * d, 2.0 * M * c->T * d + 4.0 * M * H * c->T, [ & ]() { return launchCrossSoftmaxPV( x, st ); } ) );
+			}
+			// 6. splits combined + output projection + residual              next: the MLP up-projection
+			{
+				SmallGemvArgs a = {};
+				a.g = plainGemm( nullptr, m->at<f16>( e.wco ), M, d, d );
+				a.g.epi = EPI_F32; a.g.bias = m->at<float>( e.bco ); a.g.res = c->dx; a.g.out32 = c->dx;
+				a.pro = 3; a.part = c->crossPart;
+				a.pf[ 0 ] = hint( m->at<f16>( e.w1 ), (int64_t)4 * d * d * 2, gemvChunk( 4 * d, d ) );
+				WH_CHECK( smallGemv( a ) );
+			}
+			// 7. LayerNorm + MLP up + GELU                                    next: the MLP down-projection
+			{
+				SmallGemvArgs a = {};
+				a.g = plainGemm( nullptr, m->at<f16>( e.w1 ), M, 4 * d, d );
+				a.g.epi = EPI_F16_GELU; a.g.bias = m->at<float>( e.b1 ); a.g.out16 = c->dh;
+				a.pro = 1; a.g.lnX = c->dx; a.g.lnW = m->at<float>( e.ln2w ); a.g.lnB = m->at<float>( e.ln2b );
+				a.pf[ 0 ] = hint( m->at<f16>( e.w2 ), (int64_t)4 * d * d * 2, gemvChunk( d, 4 * d ) );
+				WH_CHECK( smallGemv( a ) );
+			}
+			// 8. MLP down + residual                                          next: the following layer's Q/K/V rows
+			{
+				SmallGemvArgs a = {};
+				a.g = plainGemm( c->dh, m->at<f16>( e.w2 ), M, d, 4 * d );
+				a.g.epi = EPI_F32; a.g.bias = m->at<float>( e.b2 ); a.g.res = c->dx; a.g.out32 = c->dx;
+				if( il + 1 < hp.n_text_layer )
+					a.pf[ 0 ] = hint( m->at<f16>( L.dec[ il + 1 ].wqkv ), (int64_t)3 * d * d * 2, gemvChunk( 3 * d, d ) );
+				WH_CHECK( smallGemv( a ) );
+			}
+		}
+		// final norm fused into the vocabulary projection's prologue (1621 workgroups normalise one row each: 4 KB from L2)
+		{
+			SmallGemvArgs a = {};
+			a.g = plainGemm( nullptr, m->at<f16>( L.te ), batch, hp.n_vocab, d );
+			a.g.epi = EPI_F32; a.g.out32 = c->logits; a.g.ldc = hp.n_vocab;
+			a.pro = 1; a.g.lnX = c->dx; a.g.lnW = m->at<float>( L.decLnW ); a.g.lnB = m->at<float>( L.decLnB );
+			WH_CHECK( smallGemv( a ) );
+		}
+		return 0;
+	}
 
 	for( int il = 0; il < hp.n_text_layer; il++ )
 	{
