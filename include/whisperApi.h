@@ -302,6 +302,9 @@ namespace Whisper
 	// ---- the seven exports of Whisper.dll (Whisper/whisper.def) ---------------------------------------------------
 	WHISPER_EXPORT HRESULT setupLogger( const sLoggerSetup& setup );
 	WHISPER_EXPORT HRESULT loadModel( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, iModel** pp );
+	// Extension (no counterpart in whisper.def): one process per GPU. whComm is a wh_comm* of include/whisper_hip.h; rank `root`
+	// reads the tensors, the other ranks receive the weight arena over RCCL and read only the header of the file.
+	WHISPER_EXPORT HRESULT loadModelShared( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, void* whComm, int root, iModel** pp );
 	WHISPER_EXPORT HRESULT initMediaFoundation( iMediaFoundation** pp );
 	WHISPER_EXPORT uint32_t findLanguageKeyW( const wchar_t* lang );
 	WHISPER_EXPORT uint32_t findLanguageKeyA( const char* lang );

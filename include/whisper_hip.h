@@ -69,6 +69,26 @@ WH_API int wh_model_finalize( wh_model* m );
 WH_API int wh_model_arena( wh_model* m, void** dev, int64_t* bytes );
 WH_API int wh_model_hparams( const wh_model* m, wh_hparams* out );
 
+/* ---- one process per GPU: the weights travel over xGMI (RCCL), not through every rank's file system ----
+ * The reference has one GPU per model and shares a loaded model between contexts of ONE device (iModel::clone,
+ * Whisper/Whisper/ModelImpl.cpp:40-60; the adapter is chosen once, API/sModelSetup.h:30-34). Windows of a recording
+ * (and recordings) are independent, so N GPUs hold N copies of the arena and split the windows; the only exchange is
+ * this broadcast before the first window. The communicator is RCCL's (librccl.so is opened on first use, the library
+ * does not link it): rank `root` calls wh_comm_unique_id and ships the 128 bytes to the other ranks by whatever the
+ * host program has (a file, a socket, MPI, an environment variable); every rank -- one process per GPU, its device
+ * selected with wh_device_set -- then calls wh_comm_create with the same id. wh_model_broadcast sends the FINALIZED
+ * arena of `root` into the arena of every other rank (models created with the same hparams and arenaDev == NULL or the
+ * caller's own buffer) and marks those models finalized; it returns the measured seconds in *secondsOut when non-NULL. */
+#define WH_COMM_ID_BYTES 128
+typedef struct wh_comm wh_comm;
+WH_API int wh_comm_unique_id( void* id128 );
+WH_API int wh_comm_create( const void* id128, int rank, int worldSize, wh_comm** out );
+WH_API int wh_comm_destroy( wh_comm* comm );
+WH_API int wh_comm_info( const wh_comm* comm, int* rank, int* worldSize );
+WH_API int wh_model_broadcast( wh_model* m, wh_comm* comm, int root, double* secondsOut );
+/* All ranks: blocks until every rank has arrived (a 4-byte all-reduce on the communicator's stream). */
+WH_API int wh_comm_barrier( wh_comm* comm );
+
 /* ---- context (replaces DirectCompute::WhisperContext, Whisper/Whisper/WhisperContext.h:20-140) ----
  * One context owns activations, the FP16 self- and cross-attention KV caches (KeyValueBuffers.h:7-53) for up to
  * maxBatch independent 30 s windows that are processed in lock step, and its workspace.  Single-threaded use,

@@ -104,3 +104,53 @@ def test_transcribes_like_the_reference_host_loop(exe, tmp_path):
     table = err2[err2.index("    Compute Shaders"):err2.index("    Memory Usage")].splitlines()[1:]
     assert any(t.startswith("gemvFused\t") for t in table) and any(t.startswith("attentionEnc\t") for t in table)
     assert all(" calls, " in t or t.endswith("seconds") for t in table)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# whisper-mgpu: one process per GPU over the C ABI (wh_comm_* + loadModelShared), no torch
+# ----------------------------------------------------------------------------------------------------------------------
+def test_mgpu_harness_arguments():
+    """CPU: the harness exists, refuses a call without model / audio, and libwhisper_hip.so exports the communicator entry
+    points it binds (the broadcast itself needs GPUs: see the gpu test below and INTEGRATION.md section E)."""
+    if not os.path.exists(build.MGPU_BIN):
+        build.build_all()
+    r = subprocess.run([build.MGPU_BIN], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"-m and -f are required" in r.stderr
+    r = subprocess.run([build.MGPU_BIN, "--bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"usage: whisper-mgpu" in r.stderr
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_LIB], stdout=subprocess.PIPE, text=True).stdout
+    for name in ("wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_model_broadcast"):
+        assert (" T " + name) in syms, name
+    syms = subprocess.run(["nm", "-D", "--defined-only", "-C", build.HOST_LIB], stdout=subprocess.PIPE, text=True).stdout
+    assert "Whisper::loadModelShared" in syms
+
+
+@pytest.mark.gpu
+def test_mgpu_harness_one_rank_matches_the_cli(exe, tmp_path):
+    """One rank end to end: RCCL communicator of size 1, loadModelShared (file -> arena -> ncclBroadcast in place), the
+    window range of the rank through runFull. The transcript must be the one whisper-main prints for the same input."""
+    case = [c for c in json.load(open(GOLDEN))["cases"] if c["name"] == "first_window_no_prompt"][0]
+    model = str(tmp_path / "m.bin")
+    gf.write_model(model, gf.scripted_model(case["script"], case["prompt_len"]))
+    rng = np.random.default_rng(case["pcm_seed"])
+    pcm = (0.05 * rng.standard_normal(case["n_samples"])).astype(np.float32)
+    wav = str(tmp_path / "clip.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2").tobytes())
+    out = str(tmp_path / "t.txt")
+    r = subprocess.run([build.MGPU_BIN, "-n", "1", "-m", model, "-f", wav, "-l", case["lang"], "-o", out],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    print(r.stdout.decode(), r.stderr.decode()[-3000:])
+    assert r.returncode == 0
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["ranks"] == 1 and line["windows"] >= 1
+    got = open(out).read().splitlines()
+    segs = case["segments"]
+    assert len(got) == len(segs)
+    for g, s in zip(got, segs):
+        assert g.endswith("] " + s["text"]), (g, s)
+        t0, t1 = float(g[1:10]), float(g[15:24])
+        assert abs(t0 - s["t0"] / 100.0) < 0.006 and abs(t1 - s["t1"] / 100.0) < 0.006

@@ -29,13 +29,14 @@ TUNE_DECODE_SMALL, TUNE_DECODE_PREFETCH = 16777216, 33554432
 TUNE_DEFAULT = (TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD |
                 TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI |
                 TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS |
-                TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_DECODE_PREFETCH)
+                TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL)
 
 # every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "wh_last_error", "wh_device_count", "wh_device_info", "wh_device_set",
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
+    "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
     "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",

@@ -55,7 +55,7 @@ def build_hip(force: bool = False) -> str:
                   "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
         objs.append(obj)
     if force or _newer(HIP_LIB, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"])
     return HIP_LIB
 
 
@@ -87,6 +87,21 @@ def build_cli(force: bool = False):
     return CLI_BIN
 
 
+MGPU_BIN = os.path.join(LIB_DIR, "whisper-mgpu")
+
+
+def build_mgpu(force: bool = False):
+    """whisper-mgpu: one process per GPU over libWhisper.so + the RCCL broadcast of libwhisper_hip.so (plain C++, no torch)."""
+    src = os.path.join(HOST, "mgpu", "whisperMgpu.cpp")
+    if not os.path.exists(src):
+        return None
+    hdrs = [os.path.join(ROOT, "include", "whisperApi.h"), os.path.join(ROOT, "include", "whisper_hip.h")]
+    if force or _newer(MGPU_BIN, [src, HOST_LIB, HIP_LIB] + hdrs):
+        _run(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", MGPU_BIN, src,
+              "-L" + LIB_DIR, "-lWhisper", "-lwhisper_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+    return MGPU_BIN
+
+
 ABI_SRC = os.path.join(ROOT, "tests", "abi_caller", "caller.cpp")
 ABI_REF_BIN = os.path.join(LIB_DIR, "abi-caller-ref")      # built from the REFERENCE's own headers (only where /root/reference exists)
 ABI_OUR_BIN = os.path.join(LIB_DIR, "abi-caller-our")      # the same source against include/whisperApi.h
@@ -113,6 +128,7 @@ def build_all(force: bool = False):
     build_hip(force)
     build_host(force)
     build_cli(force)
+    build_mgpu(force)
     build_abi_callers(force)
     print("native build ok in %.1fs" % (time.time() - t), flush=True)
 

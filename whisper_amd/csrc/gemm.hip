@@ -2075,7 +2075,8 @@ namespace wh
 		}
 		// persistent: one workgroup per CU (a workgroup takes all 160 KiB of LDS), each walks its share of the tiles
 		const int tilesM = ( b.M + Cfg8::BM - 1 ) / Cfg8::BM, tilesN = ( b.N + Cfg8::BN - 1 ) / Cfg8::BN;
-		const int cus = cusOfDevice[ dev & 63 ] > 0 ? cusOfDevice[ dev & 63 ] : 256;
+		int cus = cusOfDevice[ dev & 63 ] > 0 ? cusOfDevice[ dev & 63 ] : 256;
+		if( b.cuLimit > 0 && b.cuLimit < cus ) cus = b.cuLimit;
 		const int grid = tilesM * tilesN < cus ? tilesM * tilesN : cus;
 		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE, ABL> ), dim3( grid ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );

@@ -22,6 +22,11 @@
 #include <set>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <dlfcn.h>
+
+// ncclUniqueId by value, as ncclCommInitRank takes it (rccl.h: struct { char internal[128]; })
+struct ncclUniqueIdBlob { char internal[ 128 ]; };
 
 namespace wh
 {
@@ -262,6 +267,7 @@ struct wh_context
 	// OTHER contexts (high-priority streams) get their workgroups dispatched first whenever CUs free up
 	hipStream_t encStream = nullptr;
 	hipEvent_t encReady = nullptr, encDone = nullptr;
+	int encCus = 0, totalCus = 0;	   // WH_ENC_CUS: CUs of the encoder stream's mask (0 = no spatial split)
 	struct Mark { int endSample; hipEvent_t ev; };
 	std::vector<Mark> marks;   // after each enqueued chunk of samples: an event wh_decode_window_fetch can wait for
 	std::vector<hipEvent_t> markPool;
@@ -387,7 +393,10 @@ static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
 	const double flops = 2.0 * g.M * g.N * g.K;
 	// algorithmic bytes: each operand once + the output once (FP16 in, 2..4 bytes out)
 	const double bytes = 2.0 * g.N * g.K + 2.0 * g.M * g.K + ( g.out32 ? 4.0 : 2.0 ) * g.M * g.N;
-	return profiled( c, sk ? KC_GEMM_SKINNY : KC_GEMM_TILED, flops, bytes, [ & ]() { return sk ? launchGemmSkinny( g, c->stream ) : launchGemm( g, c->stream ); } );
+	// a stream with a CU mask (WH_ENC_CUS): the persistent tiled kernel sizes its grid to the CUs it may use
+	GemmArgs gl = g;
+	if( c->encCus > 0 ) gl.cuLimit = c->stream == c->encStream ? c->encCus : c->totalCus - c->encCus;
+	return profiled( c, sk ? KC_GEMM_SKINNY : KC_GEMM_TILED, flops, bytes, [ & ]() { return sk ? launchGemmSkinny( gl, c->stream ) : launchGemm( gl, c->stream ); } );
 }
 static int lnP( wh_context* c, const float* x, const float* w, const float* b, f16* out, int rows, int d )
 {
@@ -741,6 +750,149 @@ int wh_model_arena( wh_model* m, void** dev, int64_t* bytes )
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// RCCL: the arena of rank `root` into every rank's arena (one process per GPU). librccl.so is opened on first use.
+// ------------------------------------------------------------------------------------------------------------------
+namespace
+{
+	struct RcclApi
+	{
+		void* lib = nullptr;
+		int ( *getUniqueId )( void* ) = nullptr;
+		int ( *commInitRank )( void**, int, ncclUniqueIdBlob, int ) = nullptr;
+		int ( *commDestroy )( void* ) = nullptr;
+		int ( *broadcast )( const void*, void*, size_t, int, int, void*, hipStream_t ) = nullptr;
+		int ( *allReduce )( const void*, void*, size_t, int, int, void*, hipStream_t ) = nullptr;
+		const char* ( *errorString )( int ) = nullptr;
+		std::string why;
+	};
+	RcclApi* rccl()
+	{
+		static RcclApi api;
+		static std::once_flag once;
+		std::call_once( once, []() {
+			const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+			for( const char* n : names )
+			{
+				api.lib = dlopen( n, RTLD_NOW | RTLD_LOCAL );
+				if( api.lib ) break;
+			}
+			if( !api.lib )
+			{
+				const char* e = dlerror();
+				api.why = std::string( "librccl.so not found: " ) + ( e ? e : "" );
+				return;
+			}
+			auto sym = [ & ]( const char* name ) -> void* {
+				void* p = dlsym( api.lib, name );
+				if( !p && api.why.empty() ) api.why = std::string( "librccl.so lacks " ) + name;
+				return p;
+			};
+			api.getUniqueId = (decltype( api.getUniqueId ))sym( "ncclGetUniqueId" );
+			api.commInitRank = (decltype( api.commInitRank ))sym( "ncclCommInitRank" );
+			api.commDestroy = (decltype( api.commDestroy ))sym( "ncclCommDestroy" );
+			api.broadcast = (decltype( api.broadcast ))sym( "ncclBroadcast" );
+			api.allReduce = (decltype( api.allReduce ))sym( "ncclAllReduce" );
+			api.errorString = (decltype( api.errorString ))sym( "ncclGetErrorString" );
+		} );
+		return &api;
+	}
+	int rcclFail( int rc, const char* what )
+	{
+		RcclApi* r = rccl();
+		setError( std::string( what ) + ": " + ( r->errorString ? r->errorString( rc ) : "RCCL error" ) );
+		return WH_E_HIP;
+	}
+}	// namespace
+
+struct wh_comm
+{
+	void* comm = nullptr;
+	int rank = 0, world = 1;
+	hipStream_t stream = nullptr;
+	int* scratch = nullptr;
+};
+
+int wh_comm_unique_id( void* id128 )
+{
+	if( !id128 ) { setError( "comm_unique_id: null argument" ); return WH_E_INVALIDARG; }
+	RcclApi* r = rccl();
+	if( !r->getUniqueId ) { setError( "comm_unique_id: " + r->why ); return WH_E_NO_DEVICE; }
+	const int rc = r->getUniqueId( id128 );
+	return rc == 0 ? 0 : rcclFail( rc, "ncclGetUniqueId" );
+}
+
+int wh_comm_create( const void* id128, int rank, int worldSize, wh_comm** out )
+{
+	if( !id128 || !out || worldSize <= 0 || rank < 0 || rank >= worldSize ) { setError( "comm_create: bad argument" ); return WH_E_INVALIDARG; }
+	RcclApi* r = rccl();
+	if( !r->commInitRank || !r->broadcast || !r->commDestroy ) { setError( "comm_create: " + r->why ); return WH_E_NO_DEVICE; }
+	wh_comm* c = new wh_comm();
+	c->rank = rank; c->world = worldSize;
+	ncclUniqueIdBlob id;
+	memcpy( id.internal, id128, WH_COMM_ID_BYTES );
+	const int rc = r->commInitRank( &c->comm, worldSize, id, rank );		// uses the calling thread's current device
+	if( rc != 0 ) { delete c; return rcclFail( rc, "ncclCommInitRank" ); }
+	hipError_t e = hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking );
+	if( e == hipSuccess ) e = hipMalloc( (void**)&c->scratch, 8 );
+	if( e == hipSuccess ) e = hipMemset( c->scratch, 0, 8 );
+	if( e != hipSuccess ) { (void)wh_comm_destroy( c ); return hipFail( e, "comm_create", __FILE__, __LINE__ ); }
+	*out = c;
+	return 0;
+}
+
+int wh_comm_destroy( wh_comm* c )
+{
+	if( !c ) return 0;
+	if( c->stream ) (void)hipStreamSynchronize( c->stream );
+	if( c->comm && rccl()->commDestroy ) (void)rccl()->commDestroy( c->comm );
+	if( c->scratch ) (void)hipFree( c->scratch );
+	if( c->stream ) (void)hipStreamDestroy( c->stream );
+	delete c;
+	return 0;
+}
+
+int wh_comm_info( const wh_comm* c, int* rank, int* worldSize )
+{
+	if( !c ) { setError( "comm_info: null communicator" ); return WH_E_INVALIDARG; }
+	if( rank ) *rank = c->rank;
+	if( worldSize ) *worldSize = c->world;
+	return 0;
+}
+
+int wh_comm_barrier( wh_comm* c )
+{
+	if( !c ) { setError( "comm_barrier: null communicator" ); return WH_E_INVALIDARG; }
+	RcclApi* r = rccl();
+	if( !r->allReduce ) { setError( "comm_barrier: " + r->why ); return WH_E_NO_DEVICE; }
+	const int rc = r->allReduce( c->scratch, c->scratch + 1, 1, 2 /* ncclInt32 */, 0 /* ncclSum */, c->comm, c->stream );
+	if( rc != 0 ) return rcclFail( rc, "ncclAllReduce" );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int wh_model_broadcast( wh_model* m, wh_comm* c, int root, double* secondsOut )
+{
+	if( !m || !c || root < 0 || root >= c->world ) { setError( "model_broadcast: bad argument" ); return WH_E_INVALIDARG; }
+	if( c->rank == root && !m->finalized ) { setError( "model_broadcast: the root's model is not finalized" ); return WH_E_NOT_READY; }
+	WH_BIND( m );
+	RcclApi* r = rccl();
+	const int64_t bytes = wh_model_arena_bytes( &m->hp );
+	WH_HIP( hipDeviceSynchronize() );	   // the root's uploads (synchronous copies on the null stream) are behind us on every stream
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = r->broadcast( m->arena, m->arena, (size_t)bytes, 0 /* ncclInt8 */, root, c->comm, c->stream );
+	if( rc != 0 ) return rcclFail( rc, "ncclBroadcast" );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	if( secondsOut ) *secondsOut = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+	if( c->rank != root )
+	{
+		// the image holds everything wh_model_finalize builds on the root (derived tables live in the arena)
+		m->finalized = true;
+		m->filtersSet = true;
+	}
+	return 0;
+}
+
 int wh_model_hparams( const wh_model* m, wh_hparams* out )
 {
 	if( !m || !out ) return WH_E_INVALIDARG;
@@ -779,8 +931,30 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 		{
 			int lo = 0, hi = 0;
 			(void)hipDeviceGetStreamPriorityRange( &lo, &hi );	   // lo = least, hi = greatest priority (numerically lower)
-			e = hipStreamCreateWithPriority( &c->stream, hipStreamNonBlocking, hi );
-			if( e == hipSuccess ) e = hipStreamCreateWithPriority( &c->encStream, hipStreamNonBlocking, lo );
+			// WH_ENC_CUS = n: SPATIAL split instead of priorities -- the encoder stream may use n CUs, the decode stream the others.
+			// The persistent encoder GEMM takes a whole CU (160 KiB of LDS, every register), so two batches in flight otherwise
+			// take turns; with disjoint CU sets the MFMA-bound encoder of one batch runs beside the HBM-bound decode chain of the
+			// other. Mask bit i is a CU of XCD i % 8 (the driver spreads a queue's mask over the XCDs), so the low n bits give the
+			// encoder n / 8 CUs of EVERY XCD and both sides keep all eight L2s and fabric links.
+			int encCus = 0, cus = 0;
+			if( const char* ev = getenv( "WH_ENC_CUS" ) ) encCus = atoi( ev );
+			(void)hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, m->device );
+			if( encCus >= 8 && encCus <= cus - 8 )
+			{
+				encCus &= ~7;
+				uint32_t maskE[ 16 ] = {}, maskD[ 16 ] = {};
+				for( int i = 0; i < cus && i < 512; i++ ) ( i < encCus ? maskE : maskD )[ i >> 5 ] |= 1u << ( i & 31 );
+				const uint32_t words = (uint32_t)( ( cus + 31 ) / 32 );
+				e = hipExtStreamCreateWithCUMask( &c->stream, words, maskD );
+				if( e == hipSuccess ) e = hipExtStreamCreateWithCUMask( &c->encStream, words, maskE );
+				c->encCus = encCus;
+				c->totalCus = cus;
+			}
+			else
+			{
+				e = hipStreamCreateWithPriority( &c->stream, hipStreamNonBlocking, hi );
+				if( e == hipSuccess ) e = hipStreamCreateWithPriority( &c->encStream, hipStreamNonBlocking, lo );
+			}
 			if( e == hipSuccess ) e = hipEventCreateWithFlags( &c->encReady, hipEventDisableTiming );
 			if( e == hipSuccess ) e = hipEventCreateWithFlags( &c->encDone, hipEventDisableTiming );
 		}

@@ -131,7 +131,10 @@ namespace Whisper
 		Vocabulary vocab;
 		~LoadedModel();
 	};
-	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out );
+	// comm != nullptr: one process per GPU -- only rank `root` reads the tensors, every other rank reads the header (hparams, filterbank,
+	// vocabulary) and receives the weight arena over RCCL (wh_model_broadcast)
+	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out,
+		wh_comm* comm = nullptr, int root = 0 );
 	// only the vocabulary of a model file (no device needed)
 	HRESULT loadVocabulary( const std::string& path, Vocabulary& vocab );
 

@@ -329,7 +329,7 @@ namespace Whisper
 		return readGgmlHeader( f, path, hp, nMel, nFft, filters, vocab );
 	}
 
-	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out )
+	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out, wh_comm* comm, int root )
 	{
 		std::ifstream f( path, std::ios::binary );
 		if( !f )
@@ -349,8 +349,11 @@ namespace Whisper
 		CHECK_WH( wh_model_create( &lm->hp, nullptr, 0, &lm->gpu ) );
 		CHECK_WH( wh_model_set_filters( lm->gpu, nMel, nFft, filters.data() ) );
 
+		int rank = 0, world = 1;
+		if( comm ) CHECK_WH( wh_comm_info( comm, &rank, &world ) );
+		const bool readsTensors = !comm || rank == root;
 		std::vector<char> payload;
-		while( true )
+		while( readsTensors )
 		{
 			int32_t nDims = 0, nameLen = 0, ftype = 0;
 			if( !rd( f, nDims ) ) break;	// clean end of file
@@ -380,7 +383,19 @@ namespace Whisper
 				if( callbacks->progress ) CHECK( callbacks->progress( (double)f.tellg() / (double)fileSize, callbacks->pv ) );
 			}
 		}
-		CHECK_WH( wh_model_finalize( lm->gpu ) );
+		if( readsTensors ) CHECK_WH( wh_model_finalize( lm->gpu ) );
+		if( comm )
+		{
+			double seconds = 0;
+			CHECK_WH( wh_model_broadcast( lm->gpu, comm, root, &seconds ) );
+			if( rank == root )
+			{
+				void* dev = nullptr;
+				int64_t bytes = 0;
+				(void)wh_model_arena( lm->gpu, &dev, &bytes );
+				logInfo( "model arena broadcast to %d ranks: %.1f MB in %.3f s (%.1f GB/s)", world, bytes / 1e6, seconds, seconds > 0 ? bytes / 1e9 / seconds : 0.0 );
+			}
+		}
 		out = lm;
 		return S_OK;
 	}

@@ -869,7 +869,20 @@ namespace Whisper
 	}
 
 	// ---- exports ----------------------------------------------------------------------------------------------------
+	static HRESULT loadModelImpl( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, wh_comm* comm, int root, iModel** pp );
 	HRESULT loadModel( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, iModel** pp )
+	{
+		return loadModelImpl( path, setup, callbacks, nullptr, 0, pp );
+	}
+	// One process per GPU (extension; the reference has one GPU per model, ModelImpl.cpp:40-60): every rank calls this with its
+	// own sModelSetup.adapter and the communicator of include/whisper_hip.h; rank `root` reads the file, the others receive the
+	// weights over xGMI (RCCL broadcast) and read only the file's header.
+	HRESULT loadModelShared( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, void* whComm, int root, iModel** pp )
+	{
+		if( !whComm ) return E_POINTER;
+		return loadModelImpl( path, setup, callbacks, (wh_comm*)whComm, root, pp );
+	}
+	static HRESULT loadModelImpl( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, wh_comm* comm, int root, iModel** pp )
 	{
 		if( !path || !pp ) return E_POINTER;
 		if( setup.impl != eModelImplementation::GPU )
@@ -905,7 +918,7 @@ namespace Whisper
 			}
 		}
 		std::shared_ptr<LoadedModel> lm;
-		CHECK( loadGgmlFile( utf8( path ), device, callbacks, lm ) );
+		CHECK( loadGgmlFile( utf8( path ), device, callbacks, lm, comm, root ) );
 		return createModelImpl( lm, pp );
 	}
 
