@@ -48,6 +48,25 @@ def main():
         ctx.decode_greedy(first, n_prompt, steps)
         dt = time.perf_counter() - t0
         print("greedy graph: %d steps from n_past %d: %.1f us per token" % (steps, n_prompt, dt / steps * 1e6), flush=True)
+    # the host loop's pattern: one captured step per launch, an event behind each; (a) nobody waits, (b) the host fetches every
+    # sample while one step runs ahead of the one it reads (WindowDecoder in host/whisperImpl.cpp)
+    n = min(steps, hp.n_text_ctx - n_prompt - 8)
+    for lead in (0, 1, 2, 3, 4):
+        ctx.decode_window_start(prompt[:, :n_prompt], 1)
+        ctx.decode_window_fetch(0, 1)
+        t0 = time.perf_counter()
+        enq = 2                                   # samples enqueued (the first one and one greedy step)
+        for _ in range(lead - 1):
+            ctx.decode_window_continue(1)
+            enq += 1
+        for i in range(1, n):
+            if lead:
+                ctx.decode_window_fetch(i, 1)       # sample i exists ...
+            ctx.decode_window_continue(1)           # ... and `lead` steps are in flight behind it again
+            enq += 1
+        ctx.decode_window_finish()
+        dt = time.perf_counter() - t0
+        print("window loop (%s): %.1f us per token" % ("no fetch" if not lead else "fetch, %d step(s) ahead" % lead, dt / (enq - 1) * 1e6), flush=True)
     ctx.close()
     m.close()
 

@@ -18,11 +18,13 @@ def main():
     hp = gf.hparams_for(kind)
     cap = 102
     positions, kept = gf.carry_over_script(hp, 7, 49, cap)
-    model = gf.scripted_model_at(positions, kind=kind, seed=7)
+    cached = os.environ.get("SS_MODEL_FILE")
+    model = None if cached and os.path.exists(cached) else gf.scripted_model_at(positions, kind=kind, seed=7)
     pcm = bench.synth_pcm(7, seed=100).reshape(-1)[:int(bench.CLIP_SECONDS * 16000)]
     with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "scripted.bin")
-        gf.write_model(path, model)
+        path = os.environ.get("SS_MODEL_FILE") or os.path.join(td, "scripted.bin")
+        if not os.path.exists(path):
+            gf.write_model(path, model)
         del model
         m = api.Model(path)
         ctx = m.create_context()
@@ -32,6 +34,7 @@ def main():
             ctx.run_full(pcm, n_max_text_ctx=cap)
             dt = time.perf_counter() - t0
             print("run_full %.4f s = %.1f audio-s/s, %d decode steps" % (dt, bench.CLIP_SECONDS / dt, 7 * (kept + 1)), flush=True)
+        ctx.timings_print()
         ctx.close()
         m.close()
 

@@ -224,7 +224,7 @@ namespace wh
 		constexpr int SS_PER = 51;	   // ceil( 51866 / 1024 )
 		__global__ void __launch_bounds__( 1024 ) softMaxSampleKernel( const float* __restrict__ logits, float* __restrict__ probsOut,
 			int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot, const DecodeState* __restrict__ state,
-			TokenData* __restrict__ out, int* __restrict__ nextTokens )
+			TokenData* __restrict__ out, int* __restrict__ nextTokens, const SampleMailbox mail )
 		{
 			__shared__ float shf[ 16 ];
 			__shared__ double shd[ 16 ];
@@ -308,8 +308,17 @@ namespace wh
 				r.p = pick.v;
 				r.pt = (float)( (double)ts.v / ( sumTs + 1e-10 ) );
 				r.ptsum = (float)sumTs;
-				out[ (long long)state->step * gridDim.x + blockIdx.x ] = r;
+				const long long slot = (long long)state->step * gridDim.x + blockIdx.x;
+				out[ slot ] = r;
 				nextTokens[ blockIdx.x ] = pick.i;
+				const int gen = state->gen;
+				if( mail.data && gen != 0 )
+				{
+					// host mailbox (pinned, uncached): the record, a system-scope fence, then the stamp the host polls
+					mail.data[ slot ] = r;
+					__threadfence_system();
+					__hip_atomic_store( mail.flag + slot, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM );
+				}
 			}
 		}
 
@@ -375,7 +384,7 @@ namespace wh
 	}
 
 	int launchSoftMaxSample( const float* logits, float* probsOut, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm,
-		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, hipStream_t stream )
+		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, SampleMailbox mail, hipStream_t stream )
 	{
 		if( nVocab > SS_PER * 1024 )
 		{
@@ -383,7 +392,7 @@ namespace wh
 			return -1;
 		}
 		hipLaunchKernelGGL( softMaxSampleKernel, dim3( rows ), dim3( 1024 ), 0, stream, logits, probsOut, nVocab, tokenBeg, tokenSot, tokenSolm,
-			tokenNot, state, out, nextTokens );
+			tokenNot, state, out, nextTokens, mail );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

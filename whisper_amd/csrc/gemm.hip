@@ -1302,6 +1302,54 @@ namespace wh
 				long long tStamp1 = 0;
 				if constexpr( ( ABL & 1024 ) != 0 ) tStamp1 = __builtin_readcyclecounter();
 
+				if constexpr( ( ABL & 2048 ) != 0 )
+				{
+					// TWO phases per K tile (16 MFMAs = 512 matrix-pipe cycles per barrier interval instead of 8 = 256: the hand-over
+					// between the wave rows costs ~100 cycles per interval, profiles/r03_gemm8_ablation.txt section 5):
+					//   phase    fragments read from LDS          MFMAs              staged global -> LDS
+					//   1        b0, b1 (8 reads), a0 (8)         a0 x b0, a0 x b1   A rows 0..127 of K tile t+1 (2)
+					//   2        a1 (8)                           a1 x b1, a1 x b0   A rows 128..255 of t+1 (2), W of t+2 (4)
+					// A read segment ends with lgkmcnt(0) BEFORE its barrier, so every fragment read of an interval has left the LDS
+					// when the other wave row issues the DMA that overwrites it one interval later (W of t+2 over the W tile read in
+					// phase 1; A rows 128.. of t+1 two intervals after their last read, rows 0..127 two intervals after theirs).
+					for( int kt = 0; kt < nk; kt++ )
+					{
+						const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
+						const f16* const bufW = bufA + C::A_HALFS;
+						const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
+						readB( bufW, 0, fb0 );
+						readB( bufW, 1, fb1 );
+						readA( bufA, 0 );
+						if( next ) stage( kt + 1, PA0{} );
+						asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+						WH_BAR();
+						quadrant( I0{}, I0{}, fb0 );
+						quadrant( I0{}, I1{}, fb1 );
+						WH_BAR();
+						readA( bufA, 1 );
+						if( next ) stage( kt + 1, PA1{} );
+						if( next2 )
+						{
+							stage( kt + 2, PW0{} );
+							stage( kt + 2, PW1{} );
+							asm volatile( "s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory" );
+						}
+						else if( next )
+							asm volatile( "s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory" );
+						else
+							asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
+						WH_BAR();
+						quadrant( I2{}, I1{}, fb1 );
+						quadrant( I2{}, I0{}, fb0 );
+						if( next2 )
+							asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+						else
+							asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+						WH_BAR();
+						ablTile = 1;
+					}
+				}
+				else
 				for( int kt = 0; kt < nk; kt++ )
 				{
 					const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
@@ -2125,13 +2173,13 @@ namespace wh
 		case 39: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 128>( b, stream ); }   // correct results: non-temporal stores
 		case 37: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 64 + 256>( b, stream ); }   // correct results: XCDs staggered
 		case 36: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 512>( b, stream ); }   // every tile stores into tile row 0 (L2-resident writes)
+		case 34: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2048>( b, stream ); }   // correct results: two phases per K tile
+		case 33: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2048 + 1024>( b, stream ); }   // ... with cycle stamps
 		case 35: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1024>( b, stream ); }   // correct results: cycle stamps into a.pe
 		case 38: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 192>( b, stream ); }
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
-		case 33: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 3>>( a, stream );
-		case 34: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 4>>( a, stream );
 		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, 1>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );

@@ -240,11 +240,20 @@ namespace wh
 		int step;			 // index of the next sample in the output array
 		int forceTimestamp;	 // consumed (cleared) by the sampler
 		int isInitial;
+		int gen;			 // window generation: stamped into the host mailbox with every sample (0 = no mailbox writes)
+	};
+	// Pinned, host-coherent mirror of the greedy loop's samples: the sampler writes sample `step` of row r to data[step * rows + r]
+	// and then (system-scope fence in between) stamps flag[step * rows + r] = gen. A host thread that polls the flag gets the
+	// token without an event, a copy or a stream synchronisation on the decode stream.
+	struct SampleMailbox
+	{
+		TokenData* data;	 // device-visible address of the pinned array
+		int* flag;
 	};
 	// logits row -> table softmax -> ContextImpl::sampleBest, one kernel; writes TokenData to out[state->step * rows + row],
 	// the chosen id to nextTokens[row]; probsOut optional.
 	int launchSoftMaxSample( const float* logits, float* probsOut, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm,
-		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, hipStream_t stream );
+		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, SampleMailbox mail, hipStream_t stream );
 	int launchAdvanceState( DecodeState* state, hipStream_t stream );
 
 	// ---------------------------------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@
 #include <vector>
 #include <chrono>
 #include <dlfcn.h>
+#include <atomic>
+#include <thread>
 
 // ncclUniqueId by value, as ncclCommInitRank takes it (rccl.h: struct { char internal[128]; })
 struct ncclUniqueIdBlob { char internal[ 128 ]; };
@@ -256,6 +258,11 @@ struct wh_context
 	float* melScratch = nullptr;
 	// device-side greedy loop
 	DecodeState* state = nullptr;
+	// host mailbox of the greedy loop (pinned, coherent): [n_text_ctx * maxSeq] records + stamps, and the generation of the window in progress
+	TokenData* mailData = nullptr;
+	int* mailFlag = nullptr;
+	SampleMailbox mailDev = { nullptr, nullptr };
+	int mailGen = 0;
 	TokenData* greedyOut = nullptr;	   // [n_text_ctx][maxBatch]
 	hipGraphExec_t graphExec = nullptr;
 	int graphBatch = 0;
@@ -1018,6 +1025,27 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 		if( e != hipSuccess ) rc = hipFail( e, "hipHostMalloc", __FILE__, __LINE__ );
 	}
 	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * S, wh_context::DONT_CARE, "greedyOut" );
+	if( rc == 0 && !getenv( "WH_NO_MAILBOX" ) )
+	{
+		// optional: without it (allocation refused, WH_NO_MAILBOX) wh_decode_window_fetch waits for an event and copies
+		const size_t n = (size_t)hp.n_text_ctx * S;
+		void *d = nullptr, *f = nullptr;
+		if( hipHostMalloc( &d, n * sizeof( TokenData ), hipHostMallocMapped | hipHostMallocCoherent ) == hipSuccess &&
+			hipHostMalloc( &f, n * sizeof( int ), hipHostMallocMapped | hipHostMallocCoherent ) == hipSuccess )
+		{
+			memset( f, 0, n * sizeof( int ) );
+			void *dd = nullptr, *fd = nullptr;
+			if( hipHostGetDevicePointer( &dd, d, 0 ) == hipSuccess && hipHostGetDevicePointer( &fd, f, 0 ) == hipSuccess )
+			{
+				c->mailData = (TokenData*)d; c->mailFlag = (int*)f;
+				c->mailDev = { (TokenData*)dd, (int*)fd };
+				d = f = nullptr;
+			}
+		}
+		if( d ) (void)hipHostFree( d );
+		if( f ) (void)hipHostFree( f );
+		(void)hipGetLastError();
+	}
 	if( rc == 0 )
 	{
 		const hipError_t e = hipStreamSynchronize( c->stream );
@@ -1047,6 +1075,8 @@ void wh_context_destroy( wh_context* c )
 	if( c->verifyGuards() != 0 ) fprintf( stderr, "WH_GUARD_VIOLATION: context %p wrote outside its buffers\n", (void*)c );
 	for( const auto& a : c->allocations ) (void)hipFree( a.base );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
+	if( c->mailData ) (void)hipHostFree( c->mailData );
+	if( c->mailFlag ) (void)hipHostFree( c->mailFlag );
 	if( c->ownsStream && c->stream ) (void)hipStreamDestroy( c->stream );
 	delete c;
 }
@@ -1665,7 +1695,7 @@ static int greedyStep( wh_context* c, int batch )
 	const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
 	WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
-		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->stream ); } ) );
+		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, c->stream ); } ) );
 	return launchAdvanceState( c->state, c->stream );
 }
 
@@ -1679,7 +1709,7 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	if( nPast + nSteps > hp.n_text_ctx ) { setError( "decode_greedy: n_past + n_steps exceeds n_text_ctx" ); return WH_E_BOUNDS; }
 	WH_CHECK( checkTokens( hp, firstTokens, batch, "decode_greedy" ) );
 	hipStream_t st = c->stream;
-	const DecodeState init = { nPast, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0 };
+	const DecodeState init = { nPast, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, 0 };
 	WH_HIP( hipMemcpyAsync( c->state, &init, sizeof( init ), hipMemcpyHostToDevice, st ) );
 	WH_HIP( hipMemcpyAsync( c->tokensDev, firstTokens, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
 	WH_HIP( hipStreamSynchronize( st ) );	 // `init` is a local
@@ -1768,7 +1798,7 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	{
 		// first use for this batch size: one eager step (sets the per-kernel function attributes), then capture. Blocking,
 		// once per context; the state it leaves behind is overwritten below.
-		const DecodeState warm = { 0, 0, 0, 0 };
+		const DecodeState warm = { 0, 0, 0, 0, 0 };
 		WH_HIP( hipMemcpyAsync( c->state, &warm, sizeof( warm ), hipMemcpyHostToDevice, st ) );
 		WH_HIP( hipMemsetAsync( c->tokensDev, 0, sizeof( int32_t ) * batch, st ) );
 		WH_HIP( hipStreamSynchronize( st ) );
@@ -1786,13 +1816,15 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 		c->graphBatch = batch;
 		c->graphKey = key;
 	}
-	// staging: ints [1024, 1024 + batch*nPrompt) = prompt tokens, then 4 ints of DecodeState
+	// staging: ints [1024, 1024 + batch*nPrompt) = prompt tokens, then the 5 ints of DecodeState
 	int32_t* const stTok = c->pinned + 1024;
 	const int M = batch * nPrompt;
 	for( int i = 0; i < M; i++ ) stTok[ i ] = promptTokens[ i ];
 	DecodeState* const stState = (DecodeState*)( stTok + M );
 	// after the sampler's advance the position must be nPrompt: start one below it
-	*stState = DecodeState{ nPrompt - 1, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0 };
+	// a new generation per window: stamps of earlier windows in the mailbox can never be taken for this one's
+	if( c->mailData ) c->mailGen = c->mailGen == 0x7fffffff ? 1 : c->mailGen + 1;
+	*stState = DecodeState{ nPrompt - 1, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, c->mailData ? c->mailGen : 0 };
 	WH_HIP( hipMemcpyAsync( c->tokensDev, stTok, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
 	WH_HIP( hipMemcpyAsync( c->state, stState, sizeof( DecodeState ), hipMemcpyHostToDevice, st ) );
 	WH_CHECK( decodeGraph( c, batch, nPrompt, 0, false ) );
@@ -1800,7 +1832,7 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 		const SpecialIds sp = specialIds( hp );
 		const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 		WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
-			[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, st ); } ) );
+			[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, st ); } ) );
 		WH_CHECK( launchAdvanceState( c->state, st ) );
 	}
 	if( useGraph )
@@ -1878,6 +1910,35 @@ int wh_decode_window_fetch( wh_context* c, int first, int count, wh_token_data* 
 	for( const auto& x : c->marks )
 		if( x.endSample >= first + count ) { mk = &x; break; }
 	if( !mk ) { setError( "decode_window_fetch: no completion mark for that range" ); return WH_E_INVALIDARG; }
+	if( c->mailData && c->mailGen != 0 && !c->prof.on )
+	{
+		// the sampler stamps the pinned mailbox after each sample: poll the last stamp of the range (samples are produced in
+		// order on one stream, rows of a step by concurrent workgroups: every row of the last step is checked). Nothing is
+		// enqueued anywhere -- an event wait + copy + synchronise costs the DECODE stream ~0.2 ms per step (measured, decode1_prof).
+		const size_t rows = (size_t)c->lastBatch;
+		const volatile int* const flag = c->mailFlag;
+		const auto t0 = std::chrono::steady_clock::now();
+		bool ready = false;
+		for( long spins = 0; !ready; spins++ )
+		{
+			ready = true;
+			for( size_t r = 0; r < rows * (size_t)count && ready; r++ )
+				ready = flag[ (size_t)first * rows + r ] == c->mailGen;
+			if( ready ) break;
+			if( ( spins & 255 ) == 255 )
+			{
+				// a stamp that does not arrive (a driver that does not make the mailbox visible) must not hang the caller
+				if( std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count() > 0.25 ) break;
+				std::this_thread::yield();
+			}
+		}
+		if( ready )
+		{
+			std::atomic_thread_fence( std::memory_order_acquire );
+			memcpy( out, c->mailData + (size_t)first * rows, sizeof( TokenData ) * rows * (size_t)count );
+			return 0;
+		}
+	}
 	if( !c->copyStream ) WH_HIP( hipStreamCreateWithFlags( &c->copyStream, hipStreamNonBlocking ) );
 	WH_HIP( hipStreamWaitEvent( c->copyStream, mk->ev, 0 ) );
 	WH_HIP( hipMemcpyAsync( out, c->greedyOut + (size_t)first * c->lastBatch, sizeof( TokenData ) * (size_t)count * c->lastBatch, hipMemcpyDeviceToHost, c->copyStream ) );
@@ -2239,7 +2300,7 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 		g.groupM = variant / 100;	   // variant = tile variant + 100 * M tiles per band of the block walk (0 = default)
 		variant %= 100;
 		unsigned long long* stamps = nullptr;
-		if( variant == 35 )
+		if( variant == 35 || variant == 33 )
 		{
 			WH_HIP( hipMalloc( (void**)&stamps, 32 ) );
 			WH_HIP( hipMemsetAsync( stamps, 0, 32, st ) );
@@ -2266,7 +2327,7 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 		if( stamps ) (void)hipFree( stamps );
 		// every variant is checked against the production path on the same operands: a pipeline that races is fast and wrong
 		// (variants 31 .. 39 are ablations, wrong by construction)
-		if( rc == 0 && !( variant >= 31 && variant <= 39 ) && !( variant >= 41 && variant <= 49 ) )
+		if( rc == 0 && ( variant == 34 || ( !( variant >= 31 && variant <= 39 ) && !( variant >= 41 && variant <= 49 ) ) ) )
 		{
 			void* ref = nullptr;
 			int* diff = nullptr;

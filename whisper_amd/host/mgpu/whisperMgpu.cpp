@@ -149,7 +149,10 @@ namespace
 		fprintf( stderr, "[rank %d] windows %d..%d of %d: %d segments in %.3f s (%.1f audio-s/s on this rank); all ranks done after %.3f s\n", rank, wb, we, windows,
 			nSeg, tRun, tRun > 0 ? ( we - wb ) * 30.0 / tRun : 0.0, tAll );
 		if( rank == 0 )
+		{
 			printf( "{\"ranks\": %d, \"windows\": %d, \"seconds\": %.4f, \"audio_seconds_per_sec\": %.2f}\n", world, windows, tAll, windows * 30.0 / tAll );
+			fflush( stdout );	   // the rank leaves through _exit
+		}
 		ctx->Release();
 		audio->Release();
 		mf->Release();

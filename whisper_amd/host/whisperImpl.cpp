@@ -27,12 +27,13 @@ namespace Whisper
 
 		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
 		// greedy steps enqueued per chunk; one chunk always runs behind the one being scanned, so up to two chunks are decoded in
-		// vain when a window ends: one sequential 199 s clip through runFull, medium shape, ran at 247 / 296 / 311 audio-s/s with
-		// chunks of 8 / 4 / 2 (a fetch is an event wait + a 40-byte copy). WHISPER_GREEDY_CHUNK overrides (1 .. 64).
+		// vain when a window ends: one sequential 199 s clip through runFull, medium shape, ran at 265 / 308 / 330 / 351 audio-s/s
+		// with chunks of 8 / 4 / 2 / 1 in round 3 (1.13 ms per step; a fetch polls the sampler's pinned mailbox, it enqueues
+		// nothing). WHISPER_GREEDY_CHUNK overrides (1 .. 64).
 		static const int GREEDY_CHUNK = []() {
 			const char* e = getenv( "WHISPER_GREEDY_CHUNK" );
 			const int v = e ? atoi( e ) : 0;
-			return v >= 1 && v <= 64 ? v : 2;
+			return v >= 1 && v <= 64 ? v : 1;
 		}();
 
 
@@ -410,6 +411,7 @@ namespace Whisper
 			}
 		public:
 			int steps = 0;
+			double msFetch = 0, msEnqueue = 0;	   // host time waiting for samples / enqueueing further steps (WHISPER_HOSTPROF)
 			WindowDecoder( wh_context* c, int nTextCtx_ ) : gpu( c ), nTextCtx( nTextCtx_ ) {}
 			HRESULT start( const std::vector<int>& prompt, TokenData& first )
 			{
@@ -435,10 +437,14 @@ namespace Whisper
 					// the chunk that follows what has been read: everything up to the next chunk boundary
 					const int n = std::min( GREEDY_CHUNK, enqueued - fetched );
 					buf.resize( (size_t)n );
+					const auto t0 = std::chrono::steady_clock::now();
 					CHECK_WH( wh_decode_window_fetch( gpu, fetched, n, buf.data() ) );
+					const auto t1 = std::chrono::steady_clock::now();
 					fetched += n;
 					cursor = 0;
 					CHECK( enqueueChunk() );	  // keeps one chunk in flight behind the one about to be scanned
+					msFetch += std::chrono::duration<double, std::milli>( t1 - t0 ).count();
+					msEnqueue += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t1 ).count();
 				}
 				const wh_token_data& t = buf[ cursor++ ];
 				out.id = t.id; out.tid = t.tid; out.p = t.p; out.pt = t.pt; out.ptsum = t.ptsum;
@@ -591,6 +597,9 @@ namespace Whisper
 					}
 				}
 				msDecode += msSince( tDec );
+				if( getenv( "WHISPER_HOSTPROF" ) )
+					fprintf( stderr, "[hostprof] window at %d: decode %.2f ms for %d tokens, of which waiting for samples %.2f ms, enqueueing steps %.2f ms\n", seek,
+						msSince( tDec ), dec.steps, dec.msFetch, dec.msEnqueue );
 				nDecodeSteps += dec.steps;	   // tokens the loop consumed (the reference counts one DecodeStep per token)
 				nDecodeWindows++;
 				if( failed )
