@@ -386,6 +386,18 @@ namespace wh
 				kv[ u ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + c * 8 );
 			}
 
+			// the head's query weight rows do not depend on the LayerNorm either: all of this thread's fragments (d / 64 <= 20 loads
+			// of 16 bytes, 8 lanes per weight row) are requested now, one memory round trip for K, the residual row and the weights
+			constexpr int WQ_MAX = CS_MAXD / 64;
+			const int steps = d >> 6;
+			f16x8 wq[ WQ_MAX ];
+			{
+				const f16* const wr = a.qW + ( (long long)h * HEAD_DIM + g ) * d + c * 8;
+#pragma unroll
+				for( int u = 0; u < WQ_MAX; u++ )
+					if( u < steps ) wq[ u ] = *(const f16x8*)( wr + u * 64 );
+			}
+
 			// ---- LayerNorm of the residual row (FP32 two-pass like attentionDecG) ----
 			{
 				const int nv = d >> 2;
@@ -432,26 +444,17 @@ namespace wh
 				}
 				__syncthreads();
 			}
-			// ---- q[j] = fp16( ( W[h*64 + j] . xn + bias ) * scale ): 8 lanes per weight row ----
+			// ---- q[j] = fp16( ( W[h*64 + j] . xn + bias ) * scale ): 8 lanes per weight row, same order of the products as attentionDecG ----
 			{
-				const f16* const wr = a.qW + ( (long long)h * HEAD_DIM + g ) * d + c * 8;
 				float acc = 0.0f;
-				const int steps = d >> 6;
-				for( int s0 = 0; s0 < steps; s0 += 8 )
-				{
-					f16x8 wq[ 8 ];
 #pragma unroll
-					for( int u = 0; u < 8; u++ )
-						if( s0 + u < steps ) wq[ u ] = *(const f16x8*)( wr + ( s0 + u ) * 64 );
+				for( int u = 0; u < WQ_MAX; u++ )
+					if( u < steps )
+					{
+						const f16x8 xq = *(const f16x8*)( &L.xn[ u * 64 + c * 8 ] );
 #pragma unroll
-					for( int u = 0; u < 8; u++ )
-						if( s0 + u < steps )
-						{
-							const f16x8 xq = *(const f16x8*)( &L.xn[ ( s0 + u ) * 64 + c * 8 ] );
-#pragma unroll
-							for( int e = 0; e < 8; e++ ) acc = fmaf( (float)wq[ u ][ e ], (float)xq[ e ], acc );
-						}
-				}
+						for( int e = 0; e < 8; e++ ) acc = fmaf( (float)wq[ u ][ e ], (float)xq[ e ], acc );
+					}
 				const float t = xorReduce8( acc );
 				if( c == 0 ) L.qs[ g ] = round16( ( t + a.qB[ h * HEAD_DIM + g ] ) * a.qScale );
 				__syncthreads();

@@ -262,7 +262,8 @@ struct wh_context
 	TokenData* mailData = nullptr;
 	int* mailFlag = nullptr;
 	SampleMailbox mailDev = { nullptr, nullptr };
-	int mailGen = 0;
+	int mailGen = 0;		   // generation of the window in progress (0 = its samples are not mirrored)
+	int mailCounter = 0;	   // last generation handed out
 	TokenData* greedyOut = nullptr;	   // [n_text_ctx][maxBatch]
 	hipGraphExec_t graphExec = nullptr;
 	int graphBatch = 0;
@@ -394,6 +395,7 @@ static int profiled( wh_context* c, int kc, double flops, double bytes, F&& laun
 	if( p.pending.size() >= 4096 ) p.resolve();
 	return rc;
 }
+static std::atomic<int> g_liveContexts{ 0 };
 static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
 {
 	const bool sk = skinny && g.M <= 32;
@@ -403,6 +405,15 @@ static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
 	// a stream with a CU mask (WH_ENC_CUS): the persistent tiled kernel sizes its grid to the CUs it may use
 	GemmArgs gl = g;
 	if( c->encCus > 0 ) gl.cuLimit = c->stream == c->encStream ? c->encCus : c->totalCus - c->encCus;
+	// Several contexts alive (batches in flight on their own streams): a workgroup of the persistent product owns its CU for the
+	// whole launch (160 KiB of LDS, every register), so with all CUs taken a 10 us decode launch of the neighbouring batch waits up
+	// to 2 ms for one. Leaving 4 CUs per XCD free costs the product 12 % of its CUs and returns 3 % of the whole job
+	// (7389 -> 7627 audio-s/s, profiles/r03_ab_variants.txt); a lone context keeps the whole chip.
+	else if( g_liveContexts.load( std::memory_order_relaxed ) > 1 && c->totalCus >= 128 )
+	{
+		static const int spare = []() { const char* e = getenv( "WH_GEMM_SPARE_CUS" ); const int v = e ? atoi( e ) : 32; return v >= 0 && v <= 128 ? v & ~7 : 32; }();
+		gl.cuLimit = c->totalCus - spare;
+	}
 	return profiled( c, sk ? KC_GEMM_SKINNY : KC_GEMM_TILED, flops, bytes, [ & ]() { return sk ? launchGemmSkinny( gl, c->stream ) : launchGemm( gl, c->stream ); } );
 }
 static int lnP( wh_context* c, const float* x, const float* w, const float* b, f16* out, int rows, int d )
@@ -925,7 +936,9 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	if( !m->finalized ) { setError( "context_create: model is not finalized" ); return WH_E_NOT_READY; }
 	WH_BIND( m );
 	wh_context* c = new wh_context();
+	g_liveContexts.fetch_add( 1 );
 	c->m = m;
+	(void)hipDeviceGetAttribute( &c->totalCus, hipDeviceAttributeMultiprocessorCount, m->device );
 	c->maxBatch = maxBatch;
 	c->hyp = hypotheses;
 	c->maxSeq = maxBatch * hypotheses;
@@ -1063,6 +1076,7 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 void wh_context_destroy( wh_context* c )
 {
 	if( !c ) return;
+	g_liveContexts.fetch_sub( 1 );
 	(void)bindDevice( c->m );
 	if( c->stream ) (void)hipStreamSynchronize( c->stream );
 	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
@@ -1823,8 +1837,11 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	DecodeState* const stState = (DecodeState*)( stTok + M );
 	// after the sampler's advance the position must be nPrompt: start one below it
 	// a new generation per window: stamps of earlier windows in the mailbox can never be taken for this one's
-	if( c->mailData ) c->mailGen = c->mailGen == 0x7fffffff ? 1 : c->mailGen + 1;
-	*stState = DecodeState{ nPrompt - 1, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, c->mailData ? c->mailGen : 0 };
+	// (only for the few sequences of a stream whose host loop reads every sample; a lock-step batch is read once, at the end)
+	const bool mailbox = c->mailData && batch <= SMALL_MAX_ROWS;
+	if( mailbox ) c->mailCounter = c->mailCounter == 0x7fffffff ? 1 : c->mailCounter + 1;
+	c->mailGen = mailbox ? c->mailCounter : 0;
+	*stState = DecodeState{ nPrompt - 1, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, c->mailGen };
 	WH_HIP( hipMemcpyAsync( c->tokensDev, stTok, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
 	WH_HIP( hipMemcpyAsync( c->state, stState, sizeof( DecodeState ), hipMemcpyHostToDevice, st ) );
 	WH_CHECK( decodeGraph( c, batch, nPrompt, 0, false ) );
