@@ -52,6 +52,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
 MFMA_CLASSES = ("gemmTiled", "attentionEnc")
 PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+BCAST_NOTE = {}        # model kind -> what the weight broadcast of this run was (ranks, bytes, seconds, GB/s)
 EMPTY_KERNEL_US = 1.9
 METRIC = "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU"
 
@@ -565,7 +566,7 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
                                "%d contexts in flight, %d-token prompt + %d greedy steps per sequence; token ids gathered on rank 0"
                                % (args.model, n_chunks, world, per, hyp, len(ctxs), N_PROMPT, n_steps),
                    "model": "ggml-" + args.model, "chunks": n_chunks, "hypotheses": hyp, "windows_per_batch": per,
-                   "parallelism": "dp%d (independent windows; RCCL weight broadcast %.3f s outside the timed region; no collective in the step)" % (world, t_bcast)},
+                   "parallelism": "dp%d (independent windows; RCCL weight broadcast outside the timed region: %s; no collective in the step)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
         "rtf": round(elapsed / (args.steps * n_chunks * 30.0), 6), "roofline": None, "cpu_baseline": None,
         "sequences_per_second": round(n_chunks * hyp * args.steps / elapsed, 2),
         "tokens_checksum": int(np.asarray(toks, np.int64).clip(min=0).sum() % 1000003),
@@ -613,10 +614,17 @@ def main():
     torch.cuda.set_device(local)
     binding.check(binding.lib().wh_device_set(local))
     if world > 1:
+        # a rank that never arrives must end the job with an error, not hang the node: collectives time out after 10 minutes
+        import datetime
+        limit = datetime.timedelta(minutes=10)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=limit)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
+        if dist.get_world_size() != world or dist.get_rank() != rank:
+            raise SystemExit("bench.py: the process group (%d of %d) does not match RANK / WORLD_SIZE (%d of %d)" %
+                             (dist.get_rank(), dist.get_world_size(), rank, world))
+        log("rank %d of %d on device %d (%s backend)" % (rank, world, local, args.backend))
 
     def load(kind):
         """Rank 0 builds the model and fills its arena; the others receive one RCCL broadcast over xGMI."""
@@ -640,6 +648,10 @@ def main():
             t_bcast = time.time() - t0
             if rank != 0:
                 hm = binding.HipModel(hp, arena_ptr=arena.data_ptr(), already_filled=True, keepalive=arena)
+        if world > 1 and rank == 0:
+            log("RCCL saw %d ranks; arena broadcast %.2f GB in %.3f s = %.1f GB/s" % (dist.get_world_size(), arena.numel() / 1e9, t_bcast,
+                                                                                    arena.numel() / 1e9 / max(t_bcast, 1e-9)))
+        BCAST_NOTE[kind] = "%d ranks, %.2f GB in %.3f s = %.1f GB/s" % (world, arena.numel() / 1e9, t_bcast, arena.numel() / 1e9 / max(t_bcast, 1e-9)) if world > 1 else "1 rank, none"
         return hp, model, hm, t_load, t_bcast
 
     hp, model, hip_model, t_load, t_bcast = load(args.model)
@@ -733,7 +745,7 @@ def main():
                        "model": "ggml-" + args.model, "task": "translate" if args.workload == "v3stream" else "transcribe",
                        "baseline": "BASELINE.md section 1 publishes one sequential clip on a GTX 1080Ti (13.30 audio-s/s medium): compared in single_stream, not here",
                        "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": args.inflight, "decode_steps_per_window": N_GREEDY + 1,
-                       "parallelism": "dp%d (independent windows, RCCL weight broadcast %.3f s outside the timed region)" % (world, t_bcast)},
+                       "parallelism": "dp%d (independent windows, RCCL weight broadcast outside the timed region: %s)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -64,7 +64,7 @@ fi
 if has workloads; then
   echo "== workloads"; date
   timeout 400 python bench.py --workload shard256 --steps 1 --warmup 1 > $out/shard256.json 2> $out/shard256.err; tail -c 600 $out/shard256.json
-  timeout 400 python bench.py --workload beam5 --steps 4 --warmup 1 > $out/beam5.json 2> $out/beam5.err; tail -c 600 $out/beam5.json
+  timeout 400 python bench.py --workload beam5 --steps 8 --warmup 2 > $out/beam5.json 2> $out/beam5.err; tail -c 600 $out/beam5.json
   timeout 400 python bench.py --workload v3stream --steps 16 --warmup 1 --no-cpu-baseline > $out/v3.json 2> $out/v3.err; head -c 400 $out/v3.json
 fi
 if has extra; then
