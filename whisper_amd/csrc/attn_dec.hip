@@ -278,7 +278,10 @@ namespace wh
 			return v;
 		}
 
-		template<int NQ, bool FUSEQ>
+		// NT_LOADS: K and V rows are read with the non-temporal policy -- every row is read exactly once per launch by exactly one
+		// workgroup (the cross-attention caches of a decode step: 690 MB per launch at 112 windows), so keeping it in L2 only
+		// evicts what the neighbouring launches want there
+		template<int NQ, bool FUSEQ, bool NT_LOADS = false>
 		__global__ void __launch_bounds__( NT, 2 ) attentionDecG( const DecAttnArgs a )
 		{
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemG[];
@@ -312,7 +315,10 @@ namespace wh
 				{
 					int key = ( it0 + u ) * G_ROWS + g;
 					key = key < limit ? key : limit;
-					dst[ u ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + c * 8 );
+					if constexpr( NT_LOADS )
+						dst[ u ] = __builtin_nontemporal_load( (const f16x8*)( K + (long long)key * HEAD_DIM + c * 8 ) );
+					else
+						dst[ u ] = *(const f16x8*)( K + (long long)key * HEAD_DIM + c * 8 );
 				}
 			};
 			loadK( kA, 0, lastRow );
@@ -476,7 +482,10 @@ namespace wh
 				{
 					int key = ( it0 + u ) * G_ROWS + g;
 					key = key < nk ? key : nk - 1;
-					dst[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + c * 8 );
+					if constexpr( NT_LOADS )
+						dst[ u ] = __builtin_nontemporal_load( (const f16x8*)( V + (long long)key * HEAD_DIM + c * 8 ) );
+					else
+						dst[ u ] = *(const f16x8*)( V + (long long)key * HEAD_DIM + c * 8 );
 				}
 			};
 			const bool fast = a.parityThreads <= 0;
@@ -1014,7 +1023,7 @@ namespace wh
 			return 0;
 		}
 
-		template<int NQ, bool FUSEQ>
+		template<int NQ, bool FUSEQ, bool NT_LOADS = false>
 		int launchDecG( const DecAttnArgs& a, hipStream_t stream )
 		{
 			constexpr int lds = (int)sizeof( DecGLds<NQ> );
@@ -1023,11 +1032,11 @@ namespace wh
 				static PerDeviceOnce once;
 				if( const int onceDev = once.needed(); onceDev >= 0 )
 				{
-					WH_HIP( hipFuncSetAttribute( (const void*)attentionDecG<NQ, FUSEQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+					WH_HIP( hipFuncSetAttribute( (const void*)attentionDecG<NQ, FUSEQ, NT_LOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
 					once.mark( onceDev );
 				}
 			}
-			hipLaunchKernelGGL( ( attentionDecG<NQ, FUSEQ> ), dim3( a.H, a.batch / NQ, a.nTok ), dim3( NT ), lds, stream, a );
+			hipLaunchKernelGGL( ( attentionDecG<NQ, FUSEQ, NT_LOADS> ), dim3( a.H, a.batch / NQ, a.nTok ), dim3( NT ), lds, stream, a );
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}
@@ -1060,6 +1069,8 @@ namespace wh
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}
+		// the decode step's cross-attention (a query per window, fused query projection, all of a window's keys): streamed rows
+		if( group == 1 && fuse && !a.causal && ( g_tuning & TUNE_ATTN_DEC_NT ) ) return launchDecG<1, true, true>( a, stream );
 	#define WH_DECG( N ) case N: return fuse ? launchDecG<N, true>( a, stream ) : launchDecG<N, false>( a, stream );
 		switch( group )
 		{
