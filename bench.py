@@ -421,9 +421,12 @@ def roofline_from(kernels, batch_ms_timed, lone_ms, n_batches=1):
 
     name, dom = max(classes.items(), key=lambda kv: kv[1]["ms_net"])
     r = entry(name)
-    # the matrix-core product (the dominant class of rounds 1 and 2) stays in the line when another class has overtaken it
-    if name != "gemmTiled" and "gemmTiled" in classes:
+    # the two classes that take turns at the top (the encoder's matrix-core product, the decode step's HBM-bound cross-attention:
+    # 27-32 % of the kernel time each) are both in every line, whichever of them is the dominant one of this run
+    if "gemmTiled" in classes:
         r["mfma_kernel"] = entry("gemmTiled")
+    if "attentionDecCross" in classes:
+        r["hbm_kernel"] = entry("attentionDecCross")
     floor_ms = sum(1e3 * (c["flops"] / (MFMA_PEAK_TFLOPS * 1e12) if k in MFMA_CLASSES else c["bytes"] / (HBM_PEAK_GBS * 1e9)) for k, c in classes.items()) / n_batches
     r.update({
         "event_pair_us": round(calib_us, 2),

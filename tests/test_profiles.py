@@ -43,13 +43,20 @@ def test_roofline_recomputed_from_the_rocprof_statistics():
     the per-class table must agree with it to +-5 % as well."""
     line, stats, _ = _load()
     r = line["roofline"]
-    # round 3: the decode step's cross-attention (HBM-bound) has overtaken the matrix-core product as the class with the most
-    # kernel time; the product stays in the line as roofline.mfma_kernel. Both are recomputed here.
-    assert r["kernel"] == "attentionDecCross" and r["bound"] == "hbm"
-    avg, calls = _avg_us(stats, lambda n: "attentionDecG<" in n and ", true>" in n)
-    frac = r["algorithmic_per_launch"] / (avg * 1e-6) / 1e9 / r["peak"]
-    print("attentionDecCross: bench %.4f, rocprof %.4f" % (r["frac"], frac))
-    assert abs(frac - r["frac"]) / r["frac"] < 0.05
+    # round 3: the decode step's cross-attention (HBM-bound) and the encoder's matrix-core product take 27-32 % of the kernel time
+    # each and swap places from run to run; the line carries both (roofline.hbm_kernel / roofline.mfma_kernel) and its top level
+    # repeats whichever is the larger. Both are recomputed here from the rocprofv3 statistics of the same command.
+    assert r["kernel"] in ("attentionDecCross", "gemmTiled")
+    top = r["hbm_kernel"] if r["kernel"] == "attentionDecCross" else r["mfma_kernel"]
+    assert all(r[f] == top[f] for f in ("bound", "achieved", "peak", "frac", "traffic"))
+    x = r["hbm_kernel"]
+    assert x["kernel"] == "attentionDecCross" and x["bound"] == "hbm"
+    avg, calls = _avg_us(stats, lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n)
+    frac = x["algorithmic_per_launch"] / (avg * 1e-6) / 1e9 / x["peak"]
+    print("attentionDecCross: bench %.4f, rocprof %.4f" % (x["frac"], frac))
+    # the bracket times the launch with its batch alone on the GPU, rocprofv3 the same launch while the other batch in flight also
+    # streams from HBM: the trace can only be slower, by the few percent the two share
+    assert -0.01 < (x["frac"] - frac) / x["frac"] < 0.08
     g = r["mfma_kernel"]
     assert g["kernel"] == "gemmTiled" and g["bound"] == "mfma"
     avg, calls = _avg_us(stats, lambda n: "gemmTiled" in n)
@@ -58,16 +65,15 @@ def test_roofline_recomputed_from_the_rocprof_statistics():
     print("gemmTiled: bench %.4f, rocprof %.4f" % (g["frac"], frac))
     assert abs(frac - g["frac"]) / g["frac"] < 0.06
     k = line["kernels"]
-    for cls, match in (("attentionDecCross", lambda n: "attentionDecG<" in n and ", true>" in n), ("attentionEnc", lambda n: "attentionEncF" in n)):
+    for cls, match in (("attentionDecCross", lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n), ("attentionEnc", lambda n: "attentionEncF" in n)):
         avg, _ = _avg_us(stats, match)
         print("%s: bench %.2f us, rocprof %.2f us" % (cls, k[cls]["avg_us"], avg))
-        assert abs(avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.05
-    # a 40 us launch of the decode chain: rocprofv3 reports its execution time, the event bracket of the bench's eager pass
-    # also the time it waited for a CU while the OTHER batch's persistent encoder product held them (round 3: that product
-    # owns a CU per workgroup for the whole launch). The bracket can therefore only be longer.
+        assert -0.01 < (avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.08
+    # a 40 us launch of the decode chain: the bracket (batch alone, minus the calibrated cost of an empty bracket) and the trace
+    # (both batches in flight) agree to ~10 %
     avg, _ = _avg_us(stats, lambda n: "selfBlockDec" in n)
     print("selfBlockDec: bench %.2f us, rocprof %.2f us" % (k["selfBlockDec"]["avg_us"], avg))
-    assert 0.95 * avg < k["selfBlockDec"]["avg_us"] < 2.0 * avg
+    assert 0.85 * avg < k["selfBlockDec"]["avg_us"] < 2.0 * avg
     # the HBM-bound kernel of the decode step: achieved bandwidth from the same table
     cross = k["attentionDecCross"]
     assert 0.6 < cross["gbs"] / 8000.0 < 1.0
@@ -85,7 +91,7 @@ def test_pmc_traffic_covers_the_cited_kernel_classes():
     assert abs(line["roofline"]["mfma_kernel"]["traffic"] - t) / t < 0.02
     x = kernels["attentionDecCross"]
     t = x["hbm_read_bytes_per_launch"] + x["hbm_write_bytes_per_launch"]
-    assert abs(line["roofline"]["traffic"] - t) / t < 0.02
+    assert abs(line["roofline"]["hbm_kernel"]["traffic"] - t) / t < 0.02
     # nothing on the path re-reads more than ~2x its algorithmic bytes; the streaming kernels sit at 1.0x
     assert kernels["attentionDecCross"]["traffic_over_algorithmic"] < 1.1 and kernels["layerNorm"]["traffic_over_algorithmic"] < 1.1
     assert g["traffic_over_algorithmic"] < 2.5
