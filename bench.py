@@ -296,7 +296,23 @@ def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want
 # ----------------------------------------------------------------------------------------------------------------------
 # the batched pipeline (default workload; also the large_v2 sub-object)
 # ----------------------------------------------------------------------------------------------------------------------
-def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True):
+def plan_batches(steps, C, inflight):
+    """How `steps` clip passes are dealt into lock-step batches of at most C clips for `inflight` contexts: as few batches as C
+    allows, rounded up to a multiple of the contexts in flight (every context then runs the same number of batches and none
+    idles through the tail), sizes equal to within one clip. 20 passes, C = 16, two contexts: 10 + 10, not 16 + 4 -- a batch
+    costs about the same decode chain whatever its size, so the straggler would run for as long as the big one."""
+    steps, C, inflight = int(steps), max(1, int(C)), max(1, int(inflight))
+    if steps <= 0:
+        return []
+    nb = -(-steps // C)
+    if steps >= inflight and nb % inflight:
+        nb += inflight - nb % inflight
+    nb = min(nb, steps)
+    base, extra = divmod(steps, nb)
+    return [base + 1] * extra + [base] * (nb - extra)
+
+
+def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True, plan=None):
     import torch
     from whisper_amd import binding
     n_frames = WINDOW_SAMPLES // 160
@@ -308,10 +324,23 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
         mel = torch.empty((B * n_clips, hp.n_mels, n_frames), dtype=torch.float32, device="cuda")
         return (binding.HipContext(hip_model, B * n_clips), host if h2d else None, dev, mel)
 
-    slots = [make_slot(C) for _ in range(max(1, inflight))]
-    n_full, rem = divmod(steps, C)
-    rem_slot = make_slot(rem) if rem else None
-    sequence = [slots[i % len(slots)] for i in range(n_full)] + ([rem_slot] if rem_slot else [])
+    inflight = max(1, inflight)
+    sizes = list(plan) if plan else plan_batches(steps, C, inflight)
+    assert sum(sizes) == steps and all(0 < n <= 128 // B for n in sizes), sizes
+    # contexts: for every batch size of the plan as many as are ever in flight at once (at most `inflight`); a context is
+    # re-used, in order, by the later batches of its size
+    pool, sequence = {}, []
+    for n in sizes:
+        have = pool.setdefault(n, [])
+        if len(have) < min(inflight, sizes.count(n)):
+            have.append(make_slot(n))
+    counters = {n: 0 for n in pool}
+    for n in sizes:
+        sequence.append(pool[n][counters[n] % len(pool[n])])
+        counters[n] += 1
+    distinct = [sl for n in sorted(pool, reverse=True) for sl in pool[n]]
+    # the full-size contexts the per-kernel tables and the lone-batch latency are taken from
+    slots = (pool.get(C, []) + [make_slot(C) for _ in range(inflight)])[:inflight] if want_kernels else distinct[:inflight]
     torch.cuda.synchronize()
 
     def barrier():
@@ -321,17 +350,17 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        run_passes(slots + ([rem_slot] if rem_slot else []), prompt, N_GREEDY, len(slots))
+        run_passes(distinct, prompt, N_GREEDY, inflight)
     barrier()
     t0 = time.perf_counter()
-    toks = run_passes(sequence, prompt, N_GREEDY, len(slots))
+    toks = run_passes(sequence, prompt, N_GREEDY, inflight)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    out = {"elapsed": elapsed, "toks": toks, "slots": slots, "single_clip_ms": None, "kernels": {}, "lone_batch_ms": None}
+    out = {"elapsed": elapsed, "toks": toks, "slots": slots, "single_clip_ms": None, "kernels": {}, "lone_batch_ms": None, "plan": sizes}
     if want_kernels and rank == 0:
         grp = slots[0]
         # (a) one lone batch pass from the captured graph: latency of a batch with nothing else on the GPU
@@ -596,6 +625,7 @@ def main():
                     "CU in the cross-attention, the kernel that streams the most bytes (28 windows leave a quarter of the CUs with half the work); measured "
                     "on MI355X, ms per clip pass: 4 clips x 3 in flight 38.2, 8 x 3 35.8, 12 x 2 37.4, 16 x 1 40.2, 16 x 2 35.0")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight, each on its own context and HIP stream")
+    ap.add_argument("--plan", default=None, help="explicit batch sizes of the timed region, e.g. 16,4 (default: plan_batches(steps, clips-per-batch, inflight))")
     ap.add_argument("--batch", type=int, default=16, help="shard256 / beam5: windows per lock-step batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -686,11 +716,12 @@ def main():
     audio_seconds = CLIP_SECONDS * B / 7.0
     if rank == 0:
         log("warmup + timed region: %d steps ..." % args.steps)
+    plan = [int(x) for x in args.plan.split(",")] if args.plan else None
     m = measure_batched(hip_model, hp, prompt, args.steps, args.warmup, B, C, args.inflight, rank, world, dist,
-                        want_kernels=not args.no_roofline)
-    elapsed, toks = m["elapsed"], m["toks"]
+                        want_kernels=not args.no_roofline, plan=plan)
+    elapsed, toks, batch_plan = m["elapsed"], m["toks"], m.get("plan")
     if rank == 0:
-        log("timed region done: %.3f s" % elapsed)
+        log("timed region done: %.3f s (batches of %s clips)" % (elapsed, batch_plan))
 
     roofline, kernels = None, {}
     if rank == 0 and m["kernels"]:
@@ -751,7 +782,7 @@ def main():
                                    "last token id on the host" % (args.model, audio_seconds, B, C, args.inflight, N_PROMPT, N_GREEDY),
                        "model": "ggml-" + args.model, "task": "translate" if args.workload == "v3stream" else "transcribe",
                        "baseline": "BASELINE.md section 1 publishes one sequential clip on a GTX 1080Ti (13.30 audio-s/s medium): compared in single_stream, not here",
-                       "windows_per_clip": B, "clips_per_batch": C, "batches_in_flight": args.inflight, "decode_steps_per_window": N_GREEDY + 1,
+                       "windows_per_clip": B, "clips_per_batch": C, "batch_plan": batch_plan, "batches_in_flight": args.inflight, "decode_steps_per_window": N_GREEDY + 1,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast outside the timed region: %s)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,
