@@ -367,6 +367,39 @@ def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
         assert d.max() < 4e-3 and d.mean() < 2e-4
 
 
+@pytest.mark.parametrize("d,heads,batch", [(1280, 20, 1), (1280, 20, 3), (768, 12, 2), (384, 6, 4)])
+def test_single_stream_path_at_other_widths(d, heads, batch):
+    """decode1.hip at the widths of the other model sizes (large: K = 1280 is 2.5 KiB pieces per weight row, 20 heads; small
+    768 / 12; tiny 384 / 6 = less than one piece per row), two layers: decode steps with the chip-wide launches against the
+    batch kernels, step by step. Only FP32 summation order may differ; the sequences of a batch stay bit-identical."""
+    hp = gf.HParams(n_vocab=51865, n_audio_ctx=1500, n_audio_state=d, n_audio_head=heads, n_audio_layer=1,
+                    n_text_ctx=448, n_text_state=d, n_text_head=heads, n_text_layer=2, n_mels=80, f16=1)
+    model = gf.synth_model(hp=hp, seed=21, attn_sharpness=2.0)
+    hm = binding.HipModel.from_ggml(model)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    mel = torch.rand((80, 3000), generator=g, device="cuda") * 2.0 - 1.0
+    L = binding.lib()
+    res = {}
+    for name, mask in (("small", binding.TUNE_DEFAULT | binding.TUNE_DECODE_SMALL), ("batch", binding.TUNE_DEFAULT & ~binding.TUNE_DECODE_SMALL)):
+        L.wh_debug_set_tuning(mask)
+        try:
+            ctx = binding.HipContext(hm, batch)
+            ctx.encode(torch.stack([mel] * batch))
+            ctx.decode(np.array([[50258, 50259, 50359]] * batch, np.int32), 0)
+            a = ctx.decode(np.array([[1234]] * batch, np.int32), 3)[0]
+            b = ctx.decode(np.array([[777]] * batch, np.int32), 4)[0]
+            res[name] = (a, b)
+            ctx.close()
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+    for i in range(2):
+        d_ = report("d=%d, %d sequence(s), step %d" % (d, batch, i), res["small"][i][0], res["batch"][i][0])
+        span = float(res["batch"][i][0].max() - res["batch"][i][0].min())
+        assert np.isfinite(res["small"][i]).all() and d_.max() < 1e-3 * max(span, 1.0) and d_.mean() < 1e-4 * max(span, 1.0)
+        assert all(np.array_equal(res["small"][i][0], res["small"][i][k]) for k in range(batch))
+    hm.close()
+
+
 def test_large_v3_shape(tmp_path):
     """128 mel bins, vocabulary 51866 (BASELINE config 5). The reference cannot load this shape (N_MEL is a constexpr 80,
     audioConstants.h:13; special ids keyed on 51865): an extension whose only oracle is the numpy restatement, which is
