@@ -118,6 +118,13 @@ def test_mgpu_harness_arguments():
     assert r.returncode == 1 and b"-m and -f are required" in r.stderr
     r = subprocess.run([build.MGPU_BIN, "--bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1 and b"usage: whisper-mgpu" in r.stderr
+    # the harness deals windows to ranks exactly as the Python host does
+    from whisper_amd import distributed as wd
+    for n in (0, 1, 7, 8, 23, 256):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                out = subprocess.run([build.MGPU_BIN, "--shard-range", str(n), str(rank), str(world)], stdout=subprocess.PIPE, timeout=30)
+                assert out.returncode == 0 and tuple(int(x) for x in out.stdout.split()) == tuple(wd.shard_range(n, rank, world))
     syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_LIB], stdout=subprocess.PIPE, text=True).stdout
     for name in ("wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_model_broadcast"):
         assert (" T " + name) in syms, name

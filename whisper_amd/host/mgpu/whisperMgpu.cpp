@@ -174,6 +174,16 @@ int main( int argc, char** argv )
 		else if( !strcmp( argv[ i ], "-l" ) ) a.lang = val();
 		else if( !strcmp( argv[ i ], "-o" ) ) a.out = val();
 		else if( !strcmp( argv[ i ], "-id" ) ) a.idFile = val();
+		else if( !strcmp( argv[ i ], "--shard-range" ) )
+		{
+			// test hook (no GPU): the window range rank r of w gets out of n windows, "begin end" -- must equal whisper_amd/distributed.py shard_range
+			const int n = atoi( val() ), r = atoi( val() ), w = atoi( val() );
+			if( n < 0 || w < 1 || r < 0 || r >= w ) return 1;
+			int b = 0, e = 0;
+			shardRange( n, r, w, b, e );
+			printf( "%d %d\n", b, e );
+			return 0;
+		}
 		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-id id-file]\n" ); return 1; }
 	}
 	if( a.model.empty() || a.wav.empty() || a.ranks < 1 ) { fprintf( stderr, "whisper-mgpu: -m and -f are required\n" ); return 1; }
