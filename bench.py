@@ -12,18 +12,22 @@ Tools/PerfSummary/Summary.cs:50) = 7 windows of 30 s, processed as one lock-step
 weights never emit EOT sensibly, so the step count is forced while the sampled token IS fed back). One "step" of the
 bench = one pass over the whole clip; the span is first H2D byte to last token id on the host. value = audio seconds /
 wall seconds; weak scaling for N > 1 (every rank transcribes its own clip; the weight arena is broadcast once over RCCL
-before the timed region).
+before the timed region). The K clip passes are dealt into balanced lock-step batches of at most --clips-per-batch clips for
+the --inflight contexts (plan_batches: 32 passes = 16 + 16, 20 passes = 10 + 10; `config.batch_plan`).
 
 Objects next to the contract fields:
   roofline      dominant kernel class: algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on
-                the launch stream minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per launch from the
-                committed PMC pass (profiles/r03_pmc.json); `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured
+                the launch stream (one batch at a time) minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per
+                launch from the committed PMC pass (profiles/r03_pmc.json). Two classes take turns at the top, so both are in
+                every line: `mfma_kernel` (the encoder's matrix-core product) and `hbm_kernel` (the decode step's
+                cross-attention); the top level repeats the larger. `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured
   cpu_baseline  the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample, same run
   parity        ggml-medium shape, window 0: the measured (FP32 P.V) GPU path against the reference CPU path -- cross-KV,
                 logits of the prompt and of teacher-forced greedy steps, top-1 agreement
   single_stream the SAME clip through the drop-in boundary, sequentially: libWhisper.so iContext::runFull with prompt
                 carry-over on a scripted medium-shape model (7 windows x 52 steps) -- the like-for-like figure against the
-                reference's published single-clip number (`vs_baseline` lives here), plus T host threads x their own iContext
+                reference's published single-clip number (`vs_baseline` lives here; `roofline_frac` = its byte / FLOP floor over
+                the measured time), plus T host threads x their own iContext
   large_v2      the batched pipeline once more on the ggml-large-v2 shape (BASELINE names both models)
 
 Other workloads (BASELINE configs 3-5): --workload shard256 | beam5 | v3stream, see --help.
