@@ -389,9 +389,9 @@ namespace Whisper
 		}
 
 		// The token stream of one window. The prompt step, the first sample (sampleTimestamp(true) of the reference) and the
-		// first two chunks of greedy steps are enqueued at once; the host then reads chunk k while chunk k+1 runs and, if no
-		// stop rule fired, enqueues chunk k+2 before it looks at k+1 -- the device never waits for the host, and at most
-		// one chunk (GREEDY_CHUNK steps) is decoded in vain when a window ends.
+		// first chunk of greedy steps are enqueued at once; the host then reads chunk k while chunk k+1 runs and, if no stop
+		// rule fired on chunk k, enqueues chunk k+2 before it waits for k+1 -- the device never waits for the host, and one
+		// chunk (GREEDY_CHUNK steps) is decoded in vain when a window ends.
 		class WindowDecoder
 		{
 			wh_context* gpu;
@@ -419,7 +419,6 @@ namespace Whisper
 				const int n0 = std::max( 0, std::min( GREEDY_CHUNK, nTextCtx - nPrompt ) );
 				CHECK_WH( wh_decode_window_start( gpu, 1, prompt.data(), nPrompt, n0, 1, 1 ) );
 				enqueued = 1 + n0;
-				CHECK( enqueueChunk() );
 				buf.resize( 1 );
 				CHECK_WH( wh_decode_window_fetch( gpu, 0, 1, buf.data() ) );
 				fetched = 1;
@@ -433,18 +432,22 @@ namespace Whisper
 			{
 				if( cursor >= buf.size() )
 				{
+					// The caller has looked at everything handed out so far and wants more: NOW the chunk after the one in flight is
+					// queued (the one in flight has been running since the previous fetch returned, so the device does not wait
+					// for this), then the chunk in flight is awaited. A window that ends on the token just examined therefore
+					// leaves ONE chunk decoded in vain, not two.
+					const auto t0 = std::chrono::steady_clock::now();
+					CHECK( enqueueChunk() );
+					const auto t1 = std::chrono::steady_clock::now();
 					if( fetched >= enqueued ) return E_BOUNDS;
 					// the chunk that follows what has been read: everything up to the next chunk boundary
 					const int n = std::min( GREEDY_CHUNK, enqueued - fetched );
 					buf.resize( (size_t)n );
-					const auto t0 = std::chrono::steady_clock::now();
 					CHECK_WH( wh_decode_window_fetch( gpu, fetched, n, buf.data() ) );
-					const auto t1 = std::chrono::steady_clock::now();
 					fetched += n;
 					cursor = 0;
-					CHECK( enqueueChunk() );	  // keeps one chunk in flight behind the one about to be scanned
-					msFetch += std::chrono::duration<double, std::milli>( t1 - t0 ).count();
-					msEnqueue += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t1 ).count();
+					msEnqueue += std::chrono::duration<double, std::milli>( t1 - t0 ).count();
+					msFetch += std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now() - t1 ).count();
 				}
 				const wh_token_data& t = buf[ cursor++ ];
 				out.id = t.id; out.tid = t.tid; out.p = t.p; out.pt = t.pt; out.ptsum = t.ptsum;
