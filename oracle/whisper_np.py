@@ -465,6 +465,35 @@ class WhisperTruth:
 # ----------------------------------------------------------------------------------------------------------------------
 # sampling (host logic; restates ContextImpl::sampleBest, Whisper/Whisper/ContextImpl.cpp:71-157 == whisper.cpp:1875-1960)
 # ----------------------------------------------------------------------------------------------------------------------
+def cross_attention_split(q, K, V, n_splits=8):
+    """Restatement of the single-stream cross-attention of whisper_amd/csrc/decode1.hip (crossScores -> crossSoftmaxPV -> the
+    combine prologue of gemvSmall) for ONE head: q [64] FP32 (already scaled and rounded to FP16), K, V [n_keys][64] FP16-valued.
+    The keys are cut into n_splits ranges (the kernel's rounding of the range length to a multiple of 4); every range computes
+    its scores and its maximum, the exponentials use the maximum over ALL ranges -- which is what makes the result the
+    reference's table softmax (softmax_table, ggml.c:5030-5090) and not an online softmax with local maxima -- and each range
+    contributes sum(e) in double and sum(e * V) in FP32; the ranges are added in order and scaled by float(1 / sum).
+    Returns (out [64] FP32, e [n_keys] FP32): out differs from  softmax_table(s) @ V  by FP32 summation order only, e is
+    bit-identical to the reference's unnormalised exponentials."""
+    q = np.asarray(q, F32)
+    K = np.asarray(K, F32)
+    V = np.asarray(V, F32)
+    n_keys = K.shape[0]
+    per = ((n_keys + n_splits - 1) // n_splits + 3) & ~3
+    s = (K @ q).astype(F32)
+    ranges = [(i * per, min((i + 1) * per, n_keys)) for i in range(n_splits)]
+    maxima = [s[a:b].max() if b > a else F32(-np.inf) for a, b in ranges]
+    gmax = F32(max(maxima))
+    e = exp16((s - gmax).astype(F32))
+    acc = np.zeros(V.shape[1], F32)
+    tot = 0.0
+    for a, b in ranges:                                   # combine: the ranges in order
+        if b > a:
+            acc = (acc + (e[a:b, None] * V[a:b]).astype(F32).sum(axis=0, dtype=F32)).astype(F32)
+            tot += float(e[a:b].astype(np.float64).sum())
+    inv = F32(1.0 / tot)
+    return (acc * inv).astype(F32), e
+
+
 def sample_best(probs, token_beg, token_sot, token_solm, token_not, force_timestamp=False, is_initial=False):
     """probs: [n_vocab] of the last row. Returns dict(id, tid, p, pt, ptsum).
 

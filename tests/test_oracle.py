@@ -156,3 +156,33 @@ def test_truth_model_matches_restatement_structure(golden, tiny_model):
     lf = n.decode(golden["steps"][:ln], 0, exact_pv=False)[0][-1]
     d = np.abs(lf - lt)
     assert d.max() < 2.5e-3 and d.mean() < 4e-4
+
+
+def test_split_cross_attention_is_the_table_softmax():
+    """The single-stream cross-attention (decode1.hip: 8 key ranges per head, the maximum exchanged between the two launches) is
+    the reference's softmax: the unnormalised exponentials are bit-identical to softmax_table's (a split with LOCAL maxima is
+    not: exp16 rounds its argument to FP16, so a different maximum rounds differently), and the output differs from
+    softmax_table(s) @ V by FP32 summation order only."""
+    rng = np.random.default_rng(17)
+    for n_keys in (1500, 1499, 37, 8, 3):
+        q = wn.r16(rng.standard_normal(64).astype(np.float32) * 0.5)
+        K = wn.r16(rng.standard_normal((n_keys, 64)).astype(np.float32))
+        V = wn.r16(rng.standard_normal((n_keys, 64)).astype(np.float32))
+        out, e = wn.cross_attention_split(q, K, V)
+        s = (K @ q).astype(np.float32)
+        m = s.max()
+        e_ref = wn.exp16((s - m).astype(np.float32))
+        assert np.array_equal(e, e_ref)
+        P = wn.softmax_table(s[None, :])[0]
+        want = (P.astype(np.float64) @ V.astype(np.float64)).astype(np.float32)
+        assert np.abs(out - want).max() < 2e-6 * max(1.0, np.abs(want).max())
+        if n_keys >= 37:
+            # local maxima + rescale (an online softmax) does NOT reproduce the table's exponentials
+            per = ((n_keys + 7) // 8 + 3) & ~3
+            differs = 0
+            for i in range(8):
+                a, b = i * per, min((i + 1) * per, n_keys)
+                if b > a and s[a:b].max() < m:
+                    local = wn.exp16((s[a:b] - s[a:b].max()).astype(np.float32)) * np.exp(np.float64(s[a:b].max()) - np.float64(m))
+                    differs += int((np.abs(local - e_ref[a:b]) > 0).sum())
+            assert differs > 0
