@@ -319,6 +319,62 @@ def scripted_model_at(position_tokens: Dict[int, int], kind: str = "test-d128-ml
     return m
 
 
+def conditioned_model(layout, prompt_len: int, kind: str = "test-d128-ml", seed: int = 6, gain: float = 0.3, beta: float = 2.0,
+                      alpha: float = 10.0, n_cand: int = 4) -> GgmlModel:
+    """A model whose transcript has a known STRUCTURE but whose tokens and timestamps depend on the audio, for end-to-end runs of
+    the host loop in which numerics matter (scripted_model's tokens win by ~15 vs 4 logits whatever the audio).
+
+    layout[i] says what token i of a window is: ("tok", id) one scripted token, ("text", None) one of n_cand text tokens,
+    ("ts", (lo, hi)) one of n_cand timestamps beg + linspace(lo, hi). All candidates of a position get the same +gain * c_p on
+    their embedding row (c_p = the position's +-1 code, as in scripted_model), so they tie on the scripted term, plus
+    beta * u_j / sqrt(d) with u_j random and orthogonal to c_p: the winner is decided by u_j . (previous token + cross-attention
+    output). The cross-attention output projections are kept and scaled by alpha (self-attention and MLP outputs stay zero), so
+    the winner -- including WHICH timestamp, hence the next window's seek -- depends on the encoder output through the real
+    cross-attention arithmetic. tests/golden/make_golden_runfull.py asserts that the reference's transcript on these models does
+    not depend on its own thread count (1, 4 and 8 threads identical) before it commits it."""
+    m = synth_model(kind, seed=seed, w_std=0.02, attn_sharpness=4.0)
+    hp = m.hparams
+    d = hp.n_text_state
+    sp = special_tokens(hp)
+    rng = np.random.default_rng(seed + 1)
+    codes = rng.choice(np.array([-1.0, 1.0], np.float32), size=(hp.n_text_ctx, d))
+    m.tensors["decoder.positional_embedding"] = codes.astype(np.float32)
+    te = (0.02 * rng.standard_normal((hp.n_vocab, d))).astype(np.float32)
+    for i, (cls, arg) in enumerate(layout):
+        c = codes[prompt_len - 1 + i]
+        if cls == "tok":
+            cands = [int(arg)]
+        elif cls == "text":
+            cands = [2000 + 64 * i + j for j in range(n_cand)]
+        elif cls == "ts":
+            cands = [sp["beg"] + int(v) for v in np.linspace(arg[0], arg[1], n_cand)]
+        else:
+            raise ValueError(cls)
+        for t in cands:
+            u = rng.standard_normal(d).astype(np.float32)
+            u -= (u @ c) / d * c
+            te[t] += gain * c + (beta * u / np.sqrt(d) if len(cands) > 1 else 0.0)
+    m.tensors["decoder.token_embedding.weight"] = te.astype(np.float16)
+    m.tensors["decoder.ln.weight"] = np.ones(d, np.float32)
+    m.tensors["decoder.ln.bias"] = np.zeros(d, np.float32)
+    for il in range(hp.n_text_layer):
+        p = "decoder.blocks.%d" % il
+        for nm in (".attn.out", ".mlp.2"):
+            m.tensors[p + nm + ".weight"] = np.zeros_like(m.tensors[p + nm + ".weight"])
+            m.tensors[p + nm + ".bias"] = np.zeros_like(m.tensors[p + nm + ".bias"])
+        w = m.tensors[p + ".cross_attn.out.weight"].astype(np.float32) * alpha
+        m.tensors[p + ".cross_attn.out.weight"] = w.astype(np.float16)
+    return m
+
+
+def conditioned_layout(hp: HParams):
+    """[timestamp <= 0.8 s, 5 text, two timestamps 6-10 s, 6 text, a timestamp 14-22 s, EOT]: two segments per window, the next
+    window seeks to the last timestamp."""
+    sp = special_tokens(hp)
+    return ([("ts", (0, 40))] + [("text", None)] * 5 + [("ts", (300, 500)), ("ts", (300, 500))] + [("text", None)] * 6 +
+            [("ts", (700, 1100)), ("tok", sp["eot"])])
+
+
 def carry_over_script(hp: HParams, n_windows: int, text_per_window: int, n_max_text_ctx: int):
     """Positions -> tokens for a sequential run with prompt carry-over in which EVERY window transcribes as
     [timestamp <= 1 s (forced by the sampler), text_per_window text tokens, the 30.00 s timestamp, EOT]:
