@@ -115,14 +115,13 @@ CPU_BASELINE_TIMEOUT_S = 300
 PARITY_STEPS = 8
 
 
-def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, parity_path, out_path):
+def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, parity_path, out_path, n_win=3):
     """Runs in a child process (so a slow host cannot stall the bench): the reference's own CPU path.
-    1. cpu_baseline: three times the same 30 s window end to end, timed. 2. parity: the GPU's spectrogram of that window and
+    1. cpu_baseline: n_win times the same 30 s window end to end, timed. 2. parity: the GPU's spectrogram of that window and
     the GPU's own greedy ids are fed to the reference; its cross-KV and logits are compared with what the GPU computed."""
     from oracle import ref
     w = ref.RefWhisper(model_path, n_threads=n_threads, log_level=0)
     pcm = np.load(pcm_path)
-    n_win = 3
     t_mel = t_enc = t_prompt = t_dec = 0.0
     for _ in range(n_win):
         t0 = time.time()
@@ -263,7 +262,7 @@ def truth_yardstick():
     return out
 
 
-def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want_parity=True):
+def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want_parity=True, n_win=3, timeout_s=None):
     """The reference's own CPU path (compiled unmodified into oracle/_ref) timed on this host, bounded by a timeout."""
     null = {"value": None, "unit": "audio-seconds/sec", "cores": 0, "kind": "reference"}
     try:
@@ -283,16 +282,16 @@ def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want
         np.save(pp, pcm_one_window)
         if gp:
             gpu_parity_record(hip_model, model.hparams, pcm_one_window, prompt, gp)
-        code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%r, %r, %r, %r, %d, %r, %r)"
-                % (ROOT, mp, model_kind, pp, list(map(int, prompt)), n_threads, gp, op))
+        code = ("import sys; sys.path.insert(0, %r); import bench; bench.cpu_baseline_worker(%r, %r, %r, %r, %d, %r, %r, %d)"
+                % (ROOT, mp, model_kind, pp, list(map(int, prompt)), n_threads, gp, op, n_win))
         try:
-            subprocess.run([sys.executable, "-c", code], timeout=CPU_BASELINE_TIMEOUT_S, check=True,
+            subprocess.run([sys.executable, "-c", code], timeout=timeout_s or CPU_BASELINE_TIMEOUT_S, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
             with open(op) as f:
                 r = json.load(f)
             return r["cpu_baseline"], r.get("parity")
         except subprocess.TimeoutExpired:
-            return dict(null, cores=n_threads, sample="reference CPU path did not finish within %d s on %d threads" % (CPU_BASELINE_TIMEOUT_S, n_threads)), None
+            return dict(null, cores=n_threads, sample="reference CPU path did not finish within %d s on %d threads" % (timeout_s or CPU_BASELINE_TIMEOUT_S, n_threads)), None
         except Exception as e:
             return dict(null, cores=n_threads, sample="reference CPU run failed: %s" % str(e)[:200]), None
 
@@ -763,9 +762,17 @@ def main():
                 large = {"model": "ggml-large-v2", "value": round(audio_seconds * n2 / m2["elapsed"], 2), "unit": "audio-seconds/sec", "steps": n2,
                          "ms_per_step": round(1e3 * m2["elapsed"] / n2, 3), "same_pipeline": True,
                          "vs_published_single_clip": "the reference publishes 7.22 audio-s/s for ONE sequential clip on a GTX 1080Ti (BASELINE.md section 1)"}
+                pcm2 = m2["slots"][0][2][0].cpu().numpy()
                 for s in m2["slots"]:
                     s[0].close()
                 log("large-v2: %s audio-s/s" % large["value"])
+                if not args.no_cpu_baseline:
+                    # BASELINE names both models: the reference's CPU path beside the large-v2 figure too (one window: its encoder alone
+                    # is ~15-20 s on 16 threads), and the same parity object as the headline's, at d = 1280 / 20 heads / 32 layers
+                    log("large-v2: cpu baseline + parity (reference CPU path, one window) ...")
+                    cpu2, par2 = cpu_baseline(model2, "large-v2", pcm2, p2, hm2, n_win=1, timeout_s=420)
+                    large["cpu_baseline"], large["parity"] = cpu2, par2
+                    log("large-v2 cpu baseline done: %s" % cpu2.get("value"))
             except Exception as e:
                 large = {"error": str(e)[:300]}
 

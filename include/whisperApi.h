@@ -305,6 +305,46 @@ namespace Whisper
 	// Extension (no counterpart in whisper.def): one process per GPU. whComm is a wh_comm* of include/whisper_hip.h; rank `root`
 	// reads the tensors, the other ranks receive the weight arena over RCCL and read only the header of the file.
 	WHISPER_EXPORT HRESULT loadModelShared( const wchar_t* path, const sModelSetup& setup, const sLoadModelCallbacks* callbacks, void* whComm, int root, iModel** pp );
+	// Extension (no counterpart in whisper.def): K recordings -- or K pieces of recordings -- transcribed in LOCK STEP on one GPU.
+	// Every stream keeps the semantics of iContext::runFull on its own (ContextImpl.cpp:452-793: seek by the last timestamp, prompt
+	// carry-over unless NoContext, stop rules, failure handling, callbacks on the calling thread), and its transcript is the transcript
+	// runFull gives for the same samples; what changes is the device work: the next windows of up to `maxSlots` streams are ONE encoder
+	// batch and ONE decode chain (a decode step costs about the same for 1 and for 64 sequences), `groups` such batches are in flight
+	// on separate HIP streams (the encoder of one runs under the decode chain of the other), and a slot whose stream has finished is
+	// refilled with the next stream. The reference's nearest facilities: whisper_full_parallel (Whisper/source/whisper.cpp:3127) and
+	// iModel::clone + one iContext per thread (Whisper/Whisper/ModelImpl.cpp:40-60).
+	struct sBatchStream
+	{
+		// Samples [firstSample, firstSample + countSamples) of the buffer's mono PCM (16 kHz), transcribed as a recording of its own:
+		// its spectrogram is normalised on its own maximum and windows never read past its end -- how independent 30 s chunks of one
+		// recording are declared. countSamples 0 = to the end of the buffer. Segment and token times are relative to the BUFFER
+		// (the stream's first sample adds firstSample / 16000 s), plus the buffer's media time (iAudioBuffer::getTime).
+		const iAudioBuffer* buffer;
+		int64_t firstSample, countSamples;
+		const sFullParams* params;	  // nullptr = the call's common parameters (callbacks receive a per-stream iContext: getResults, getModel)
+	};
+	struct sBatchSetup
+	{
+		uint32_t maxSlots;		// streams per lock-step batch (the device contexts are sized for it); 0 = 64, at most 128
+		uint32_t groups;		// lock-step batches in flight; 0 = 2
+		uint32_t greedyChunk;	// greedy steps enqueued at a time; 0 = 4. The host applies its stop rules chunk by chunk, so up to one chunk is decoded past the end of a round
+		uint32_t flags;			// 1 = keep one more chunk queued behind the one in flight (the device never waits for the host; up to two chunks are decoded in vain)
+	};
+	// {6f0c9a1e-3b52-4d7c-8e21-9a4f5c7d2b10}
+	struct iBatchRunner : public ComLight::IUnknown
+	{
+		static constexpr ComLight::GUID iid() { return { 0x6f0c9a1e, 0x3b52, 0x4d7c, { 0x8e, 0x21, 0x9a, 0x4f, 0x5c, 0x7d, 0x2b, 0x10 } }; }
+		// results[i] receives the transcript of streams[i] (a new object, the caller releases it; nullptr when the stream failed before it
+		// produced one). Returns the first failure of any stream, S_OK otherwise; perStream, when non-null, receives every stream's own
+		// HRESULT (S_FALSE: shorter than a second, an empty transcript -- runFull's S_FALSE). Not re-entrant; callbacks of sFullParams
+		// arrive on the calling thread and receive a per-stream iContext (getResults, getModel).
+		virtual HRESULT run( const sFullParams& params, const sBatchStream* streams, uint32_t count, iTranscribeResult** results, HRESULT* perStream ) = 0;
+	};
+	// The runner owns the device contexts of its groups (KV caches for maxSlots windows each, captured decode graphs): a service creates
+	// it once. runFullBatch = createBatchRunner + run + Release for a one-off call.
+	WHISPER_EXPORT HRESULT createBatchRunner( iModel* model, const sBatchSetup* setup, iBatchRunner** pp );
+	WHISPER_EXPORT HRESULT runFullBatch( iModel* model, const sFullParams& params, const sBatchStream* streams, uint32_t count, const sBatchSetup* setup,
+		iTranscribeResult** results, HRESULT* perStream );
 	WHISPER_EXPORT HRESULT initMediaFoundation( iMediaFoundation** pp );
 	WHISPER_EXPORT uint32_t findLanguageKeyW( const wchar_t* lang );
 	WHISPER_EXPORT uint32_t findLanguageKeyA( const char* lang );

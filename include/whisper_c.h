@@ -41,6 +41,19 @@ int32_t whisperc_result_segment( void* ctx, uint32_t index, uint64_t* t0, uint64
 int32_t whisperc_result_token( void* ctx, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum );
 /* sToken::time (100 ns ticks; 0 when unknown) and sToken::vlen of token `index` */
 int32_t whisperc_result_token_times( void* ctx, uint32_t index, uint64_t* t0, uint64_t* t1, float* vlen );
+/* Whisper::createBatchRunner( model, { maxSlots, groups, greedyChunk, flags } ) (0 = the defaults) -> iBatchRunner; release with whisperc_release */
+int32_t whisperc_batch_create( void* model, uint32_t maxSlots, uint32_t groups, uint32_t greedyChunk, uint32_t flags, void** runnerOut );
+/* iBatchRunner::run over `count` streams: stream i = samples [firstSample[i], firstSample[i] + countSamples[i]) (0 = to the end) of the mono FP32
+ * 16 kHz buffer pcm[i] of nSamples[i] samples (streams may name the same buffer: the chunks of one recording); the common sFullParams are
+ * fullDefaultParams( Greedy ) + the given fields, like whisperc_run_full. resultsOut[i] receives an iTranscribeResult (or NULL; release each with
+ * whisperc_release), perStream[i] the stream's own HRESULT; both HOST arrays of `count` entries, perStream may be NULL. */
+int32_t whisperc_batch_run( void* runner, uint32_t count, const float* const* pcm, const uint32_t* nSamples, const int64_t* firstSample,
+	const int64_t* countSamples, const char* language, uint32_t flags, int maxTokens, const int32_t* promptTokens, int nPrompt, int nMaxTextCtx,
+	void** resultsOut, int32_t* perStream );
+/* iTranscribeResult::getSize / getSegments / getTokens on a result object itself (times in 100 ns ticks) */
+int32_t whisperc_tr_counts( void* result, uint32_t* segments, uint32_t* tokens );
+int32_t whisperc_tr_segment( void* result, uint32_t index, uint64_t* t0, uint64_t* t1, uint32_t* firstToken, uint32_t* countTokens, char* text, uint32_t textCap );
+int32_t whisperc_tr_token( void* result, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum, uint64_t* t0, uint64_t* t1, float* vlen );
 /* iContext::timingsPrint */
 int32_t whisperc_timings_print( void* ctx );
 /* One line of the profiler output, formatted like ProfileCollection::Measure::print (Whisper/Utils/ProfileCollection.cpp:113-170):

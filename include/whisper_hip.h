@@ -168,6 +168,17 @@ WH_API int wh_mel_spectrogram_window( wh_context* c, const float* pcmDev, int64_
  * cross-attention caches of all decoder layers for batch slots 0..batch-1 and resets their self-attention state. */
 WH_API int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets );
 
+/* The same for windows that come from DIFFERENT spectrograms (recordings of different lengths: the streams of Whisper::runFullBatch):
+ * window b = frames [offset, offset + 2*n_audio_ctx) of the FP32 [n_mel][melLen] spectrogram at melDev, zero beyond its end
+ * (MelInputTensor.cpp:8-63); melDev == NULL is a window of zeros (an idle slot of a lock-step batch). windows: HOST [batch]. */
+typedef struct wh_mel_window
+{
+	const float* melDev;
+	int64_t melLen;
+	int32_t offset, reserved;
+} wh_mel_window;
+WH_API int wh_encode_windows( wh_context* c, const wh_mel_window* windows, int batch );
+
 /* Decoder step. Replaces WhisperContext::decode (WhisperContext.cpp:578-639) == whisper_decode (whisper.cpp:1508-1872).
  * tokens: HOST int32 [batch][nTokens]; every sequence advances from position nPast by nTokens.
  * Outputs for the LAST token of each sequence (the only row the reference ever consumes, ContextImpl.cpp:159-169):
@@ -205,12 +216,25 @@ WH_API int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstToken
 WH_API int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp,
 	int firstIsInitial );
 WH_API int wh_decode_window_finish( wh_context* c, wh_token_data* out );
+/* The same for a lock-step batch whose sequences carry prompts of DIFFERENT lengths -- the streams of a batch scheduler (Whisper::runFullBatch
+ * of libWhisper.so): every stream keeps the reference's sequential semantics, so its window's prompt is [prev] + its own past text + the task
+ * tokens (ContextImpl.cpp:565-576) and the streams of one batch stand at different decoder positions. promptTokens: HOST [batch][nPromptMax],
+ * row b = promptLens[b] tokens followed by padding (ignored); 1 <= promptLens[b] <= nPromptMax. Sequence b then computes exactly what it computes
+ * alone: its tokens sit at positions 0 .. promptLens[b]-1, its greedy step s feeds position promptLens[b] + s, its self-attention sees its own
+ * keys only (positions live per sequence in device memory; the padded rows of a shorter prompt are computed and never consumed: their cache
+ * rows are overwritten by the sequence's own later tokens before any query can see them). One hypothesis per window.
+ * nPromptMax + nSteps (and every later wh_decode_window_continue) is bounded by n_text_ctx. */
+WH_API int wh_decode_window_start_ragged( wh_context* c, int batch, const int32_t* promptTokens, const int32_t* promptLens, int nPromptMax, int nSteps,
+	int forceFirstTimestamp, int firstIsInitial );
 /* nSteps more greedy steps of the window in progress (no host round trip: position, last token and sampler flags are in
  * device memory), and a blocking read of samples [first, first + count) -> HOST [count][batch] that waits for those
  * samples only. The reference's loop looks at every token before it decodes the next one (ContextImpl.cpp:597-673); a
  * caller that keeps one chunk queued behind the one it is scanning loses at most that chunk when a stop token shows up. */
 WH_API int wh_decode_window_continue( wh_context* c, int nSteps );
 WH_API int wh_decode_window_fetch( wh_context* c, int first, int count, wh_token_data* out );
+/* Non-blocking: 1 when samples [first, first + count) of the window in progress exist (wh_decode_window_fetch would not wait), 0 when not
+ * yet, negative on error. Lets ONE host thread serve several contexts (a scheduler that keeps two lock-step batches in flight). */
+WH_API int wh_decode_window_ready( wh_context* c, int first, int count );
 
 /* Per-kernel-class GPU timings, the counterpart of the reference's GpuProfiler / iContext::timingsPrint
  * (Whisper/Utils/GpuProfiler.h:21-188, Whisper/Whisper/ContextImpl.misc.cpp:170-182). hipEvent pairs around every launch

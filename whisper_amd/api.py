@@ -19,6 +19,8 @@ TRANSLATE, NO_CONTEXT, SINGLE_SEGMENT, PRINT_SPECIAL = 1, 2, 4, 8
 TOKEN_TIMESTAMPS = 0x100
 
 CPP_EXPORTS = ["setupLogger", "loadModel", "initMediaFoundation", "findLanguageKeyW", "findLanguageKeyA", "getSupportedLanguages", "listGPUs"]
+# extensions next to the seven names of whisper.def: one process per GPU, and K streams in lock step on one GPU
+CPP_EXTENSIONS = ["loadModelShared", "createBatchRunner", "runFullBatch"]
 
 _lib = None
 
@@ -55,6 +57,13 @@ def lib():
         L.whisperc_timings_print.argtypes = [vp]
         L.whisperc_run_streamed.argtypes = [vp, vp, C.c_uint64, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int,
                                             C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
+        L.whisperc_batch_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.whisperc_batch_run.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+        L.whisperc_tr_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.whisperc_tr_segment.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32]
+        L.whisperc_tr_token.argtypes = [vp, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -90,6 +99,9 @@ class Model:
 
     def create_context(self) -> "Context":
         return Context(self)
+
+    def create_batch_runner(self, max_slots: int = 0, groups: int = 0, greedy_chunk: int = 0, flags: int = 0) -> "BatchRunner":
+        return BatchRunner(self, max_slots, groups, greedy_chunk, flags)
 
     def special_tokens(self):
         a = (C.c_int32 * 8)()
@@ -176,6 +188,70 @@ class Context:
 
     def timings_print(self):
         _check(lib().whisperc_timings_print(self.h), "timingsPrint")
+
+
+def read_result(h) -> list:
+    """iTranscribeResult -> list of segments {t0, t1 (100 ns ticks), text, tokens[{id, p, pt, ptsum, t0, t1, vlen}]}."""
+    L = lib()
+    ns, nt = C.c_uint32(), C.c_uint32()
+    _check(L.whisperc_tr_counts(h, C.byref(ns), C.byref(nt)), "getSize")
+    out = []
+    for i in range(ns.value):
+        t0, t1, ft, ct = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        text = C.create_string_buffer(4096)
+        _check(L.whisperc_tr_segment(h, i, C.byref(t0), C.byref(t1), C.byref(ft), C.byref(ct), text, 4096), "getSegments")
+        toks = []
+        for j in range(ft.value, ft.value + ct.value):
+            tid, p, pt, ps = C.c_int32(), C.c_float(), C.c_float(), C.c_float()
+            k0, k1, vl = C.c_uint64(), C.c_uint64(), C.c_float()
+            _check(L.whisperc_tr_token(h, j, C.byref(tid), C.byref(p), C.byref(pt), C.byref(ps), C.byref(k0), C.byref(k1), C.byref(vl)), "getTokens")
+            toks.append(dict(id=tid.value, p=p.value, pt=pt.value, ptsum=ps.value, t0=k0.value, t1=k1.value, vlen=vl.value))
+        out.append(dict(t0=t0.value, t1=t1.value, text=text.value, tokens=toks))
+    return out
+
+
+class BatchRunner:
+    """iBatchRunner (Whisper::createBatchRunner): K streams in lock step; each keeps the semantics of iContext::runFull."""
+
+    def __init__(self, model: Model, max_slots: int = 0, groups: int = 0, greedy_chunk: int = 0, flags: int = 0):
+        self.model = model
+        self.h = C.c_void_p()
+        _check(lib().whisperc_batch_create(model.h, max_slots, groups, greedy_chunk, flags, C.byref(self.h)), "createBatchRunner")
+
+    def close(self):
+        if self.h:
+            lib().whisperc_release(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, streams, language: str = "en", flags: int = 0, max_tokens: int = 0, prompt: Optional[Sequence[int]] = None,
+            n_max_text_ctx: int = -1, want_results: bool = True):
+        """streams: list of float32 PCM arrays, or of (pcm, first_sample, count_samples) -- pieces of a recording share the array.
+        Returns (HRESULT, [segments per stream or None], [per-stream HRESULT])."""
+        n = len(streams)
+        keep, ptrs, lens, first, cnt = [], (C.c_void_p * n)(), (C.c_uint32 * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+        for i, s in enumerate(streams):
+            pcm, f, c = (s, 0, 0) if not isinstance(s, tuple) else s
+            assert pcm.dtype == np.float32 and pcm.flags["C_CONTIGUOUS"]
+            keep.append(pcm)
+            ptrs[i], lens[i], first[i], cnt[i] = pcm.ctypes.data, len(pcm), f, c
+        pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        res = (C.c_void_p * n)()
+        per = (C.c_int32 * n)()
+        hr = lib().whisperc_batch_run(self.h, n, ptrs, lens, first, cnt, language.encode(), flags, max_tokens,
+                                      pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx, res, per)
+        out = []
+        for i in range(n):
+            out.append(read_result(res[i]) if (res[i] and want_results) else None)
+            if res[i]:
+                lib().whisperc_release(res[i])
+        _check(hr, "runFullBatch")
+        return hr, out, [int(x) & 0xFFFFFFFF for x in per]
 
 
 def wav_bytes(pcm: np.ndarray, rate: int = 16000) -> bytes:

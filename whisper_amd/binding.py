@@ -39,7 +39,7 @@ EXPORTS = [
     "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
+    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -50,6 +50,10 @@ class HParamsC(C.Structure):
 
 class TokenDataC(C.Structure):
     _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float)]
+
+
+class MelWindowC(C.Structure):
+    _fields_ = [("mel", C.c_void_p), ("len", C.c_int64), ("offset", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ProfileEntryC(C.Structure):
@@ -98,12 +102,15 @@ def lib():
         L.wh_buffer_upload_async.argtypes = [vp, vp, vp, i64]
         L.wh_mel_spectrogram.argtypes = [vp, vp, i64, vp, C.POINTER(i64)]
         L.wh_encode.argtypes = [vp, vp, i32, i64, i64, vp]
+        L.wh_encode_windows.argtypes = [vp, vp, i32]
         L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.wh_sample_best.argtypes = [vp, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_debug_read.argtypes = [vp, C.c_char_p, i32, i32, vp, i64]
         L.wh_decode_greedy.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_decode_window_start.argtypes = [vp, i32, vp, i32, i32, i32, i32]
         L.wh_decode_window_finish.argtypes = [vp, C.POINTER(TokenDataC)]
+        L.wh_decode_window_start_ragged.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32]
+        L.wh_decode_window_ready.argtypes = [vp, i32, i32]
         L.wh_decode_window_continue.argtypes = [vp, i32]
         L.wh_decode_window_fetch.argtypes = [vp, i32, i32, C.POINTER(TokenDataC)]
         L.wh_mel_spectrogram_window.argtypes = [vp, vp, i64, i64, i64, i64, i32, vp]
@@ -271,6 +278,17 @@ class HipContext:
         check(lib().wh_encode(self.handle, C.c_void_p(mel_dev.data_ptr()), b, ln, self.hp.n_mels * ln, offs))
         self.batch = b
 
+    def encode_windows(self, windows):
+        """windows: list of (mel_dev [n_mel][len] torch float32 CUDA tensor or None, offset): one window per spectrogram."""
+        self._wait_for_torch()
+        arr = (MelWindowC * len(windows))()
+        for i, (mel, off) in enumerate(windows):
+            if mel is not None:
+                assert mel.is_contiguous() and mel.shape[0] == self.hp.n_mels
+                arr[i] = MelWindowC(mel.data_ptr(), mel.shape[1], off, 0)
+        check(lib().wh_encode_windows(self.handle, arr, len(windows)))
+        self.batch = len(windows)
+
     def decode(self, tokens, n_past: int, want_logits: bool = True, want_probs: bool = True):
         """tokens: int array [batch][n_tokens]. Returns (logits, probs) of the LAST token, each [batch][n_vocab] or None."""
         t = np.ascontiguousarray(tokens, np.int32)
@@ -311,6 +329,23 @@ class HipContext:
         check(lib().wh_decode_window_start(self.handle, t.shape[0], t.ctypes.data_as(C.c_void_p), t.shape[1], n_steps,
                                            int(force_first_timestamp), int(first_is_initial)))
 
+    def decode_window_start_ragged(self, prompts, n_steps: int, force_first_timestamp: bool = True, first_is_initial: bool = True):
+        """prompts: one token list per sequence, of different lengths (the streams of a batch scheduler). Non-blocking."""
+        lens = np.asarray([len(p) for p in prompts], np.int32)
+        n_max = int(lens.max())
+        t = np.zeros((len(prompts), n_max), np.int32)
+        for b, p in enumerate(prompts):
+            t[b, :len(p)] = p
+        self._win = (t.shape[0], 1 + n_steps)
+        check(lib().wh_decode_window_start_ragged(self.handle, t.shape[0], t.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), n_max, n_steps,
+                                                  int(force_first_timestamp), int(first_is_initial)))
+
+    def decode_window_ready(self, first: int, count: int) -> bool:
+        rc = lib().wh_decode_window_ready(self.handle, first, count)
+        if rc < 0:
+            check(rc)
+        return rc == 1
+
     def decode_window_finish(self):
         """Blocks; returns (ids [1 + n_steps][batch], probabilities of the chosen tokens, same shape)."""
         b, n = self._win
@@ -331,6 +366,14 @@ class HipContext:
         out = (TokenDataC * (b * count))()
         check(lib().wh_decode_window_fetch(self.handle, first, count, out))
         return np.array([o.id for o in out], np.int32).reshape(count, b)
+
+    def decode_window_fetch_data(self, first: int, count: int):
+        """Like decode_window_fetch, all five fields: dict of arrays [count][batch] (id, tid int32; p, pt, ptsum float32)."""
+        b, _ = self._win
+        out = (TokenDataC * (b * count))()
+        check(lib().wh_decode_window_fetch(self.handle, first, count, out))
+        a = np.frombuffer(out, dtype=np.dtype([("id", "<i4"), ("tid", "<i4"), ("p", "<f4"), ("pt", "<f4"), ("ptsum", "<f4")])).reshape(count, b)
+        return {k: a[k].copy() for k in a.dtype.names}
 
     def mel_spectrogram_window(self, pcm_dev, frame0: int, n_frames: int, n_chunks: Optional[int] = None, reuse_previous_max: bool = False):
         """One window of a streamed spectrogram (MelStreamer semantics): torch float32 [n_mel][n_frames] on the device."""

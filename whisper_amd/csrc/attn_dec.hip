@@ -45,7 +45,7 @@ namespace wh
 			int nPast = a.nPast, nKeys = a.nKeys;
 			if( a.causal && a.nPastDev )
 			{
-				nPast = *a.nPastDev;
+				nPast = a.nPastDev[ b ];
 				nKeys = nPast + a.nTok;
 			}
 			// keys visible to this query row
@@ -298,7 +298,7 @@ namespace wh
 			int nPast = a.nPast, nKeys = a.nKeys;
 			if( a.causal && a.nPastDev )
 			{
-				nPast = *a.nPastDev;
+				nPast = a.nPastDev[ bw * NQ ];	  // the sequences of a group stand at one position (hypotheses of a window)
 				nKeys = nPast + a.nTok;
 			}
 			const int nk = a.causal ? min( nPast + i + 1, nKeys ) : nKeys;
@@ -662,10 +662,18 @@ namespace wh
 			const int g = tid >> 3, c = tid & 7;
 			const int h = blockIdx.x, sg = blockIdx.y;
 			const int d = a.H * HEAD_DIM;
-			const int pos = a.nPastDev ? *a.nPastDev : a.nPast;	  // position of the token being fed = number of cached keys
-			const int nk = pos + 1;
 			const int nSeq = min( NQ, a.batch - sg * NQ );
 			auto seqOf = [ & ]( int q ) { return sg * NQ + ( q < nSeq ? q : nSeq - 1 ); };
+			// position of the token being fed = number of cached keys, PER SEQUENCE: the sequences of a lock-step batch may carry prompts of
+			// different lengths (a batch scheduler's streams). Loops run to the group's longest; a sequence masks what lies beyond its own.
+			int pos[ NQ ];
+			int posMax = 0;
+	#pragma unroll
+			for( int q = 0; q < NQ; q++ )
+			{
+				pos[ q ] = a.nPastDev ? a.nPastDev[ seqOf( q ) ] : a.nPast;
+				posMax = max( posMax, pos[ q ] );
+			}
 			auto cacheOf = [ & ]( const f16* base, int q ) { return base + ( (long long)seqOf( q ) * a.H + h ) * a.keyStride * HEAD_DIM; };
 
 			// cached K rows 0..63 of every sequence go out first (clamped against the buffer: rows >= pos are ignored later)
@@ -807,7 +815,7 @@ namespace wh
 					L.vn[ q ][ g ] = (float)hv;
 					if( q < nSeq )
 					{
-						const long long o = ( ( (long long)seqOf( q ) * a.H + h ) * a.keyStride + pos ) * HEAD_DIM + g;
+						const long long o = ( ( (long long)seqOf( q ) * a.H + h ) * a.keyStride + pos[ q ] ) * HEAD_DIM + g;
 						a.kc[ o ] = hk;
 						a.vc[ o ] = hv;
 					}
@@ -862,7 +870,7 @@ namespace wh
 						L.vn[ q ][ g ] = (float)hv;
 						if( q < nSeq )
 						{
-							const long long o = ( ( (long long)seqOf( q ) * a.H + h ) * a.keyStride + pos ) * HEAD_DIM + g;
+							const long long o = ( ( (long long)seqOf( q ) * a.H + h ) * a.keyStride + pos[ q ] ) * HEAD_DIM + g;
 							a.kc[ o ] = hk;
 							a.vc[ o ] = hv;
 						}
@@ -880,19 +888,19 @@ namespace wh
 			float mx[ NQ ];
 	#pragma unroll
 			for( int q = 0; q < NQ; q++ ) mx[ q ] = -INFINITY;
-			const int nIt = ( pos + G_ROWS - 1 ) / G_ROWS;
+			const int nIt = ( posMax + G_ROWS - 1 ) / G_ROWS;
 			for( int it = 0; it < nIt; it++ )
 			{
 				const int key = it * G_ROWS + g;
 	#pragma unroll
 				for( int q = 0; q < NQ; q++ )
 				{
-					const f16x8 kv = it == 0 ? k0[ q ] : *(const f16x8*)( cacheOf( a.kc, q ) + (long long)min( key, pos - 1 ) * HEAD_DIM + c * 8 );
+					const f16x8 kv = it == 0 ? k0[ q ] : *(const f16x8*)( cacheOf( a.kc, q ) + (long long)max( min( key, pos[ q ] - 1 ), 0 ) * HEAD_DIM + c * 8 );
 					float sacc = 0.0f;
 	#pragma unroll
 					for( int e = 0; e < 8; e++ ) sacc = fmaf( (float)kv[ e ], qf[ q ][ e ], sacc );
 					sacc = xorReduce8( sacc );
-					if( key < pos )
+					if( key < pos[ q ] )
 					{
 						mx[ q ] = fmaxf( mx[ q ], sacc );
 						if( c == ( q & 7 ) ) L.sc[ q ][ key ] = sacc;
@@ -903,7 +911,7 @@ namespace wh
 			f16x8 v0[ NQ ];
 	#pragma unroll
 			for( int q = 0; q < NQ; q++ )
-				v0[ q ] = *(const f16x8*)( cacheOf( a.vc, q ) + (long long)min( g, max( pos - 1, 0 ) ) * HEAD_DIM + c * 8 );
+				v0[ q ] = *(const f16x8*)( cacheOf( a.vc, q ) + (long long)min( g, max( pos[ q ] - 1, 0 ) ) * HEAD_DIM + c * 8 );
 			if( wave == 0 )
 			{
 	#pragma unroll
@@ -911,7 +919,7 @@ namespace wh
 				{
 					const float sNew = waveReduceSum( L.qs[ q ][ lane ] * L.kn[ q ][ lane ] );
 					mx[ q ] = fmaxf( mx[ q ], sNew );
-					if( lane == 0 ) L.sc[ q ][ pos ] = sNew;
+					if( lane == 0 ) L.sc[ q ][ pos[ q ] ] = sNew;
 				}
 			}
 	#pragma unroll
@@ -933,7 +941,7 @@ namespace wh
 			for( int q = 0; q < NQ; q++ )
 			{
 				sum[ q ] = 0.0;
-				for( int key = tid; key < nk; key += NT )
+				for( int key = tid; key <= pos[ q ]; key += NT )
 				{
 					const float e = exp16( L.sc[ q ][ key ] - mx[ q ] );
 					L.sc[ q ][ key ] = e;
@@ -967,8 +975,8 @@ namespace wh
 	#pragma unroll
 				for( int q = 0; q < NQ; q++ )
 				{
-					const f16x8 vv = it == 0 ? v0[ q ] : *(const f16x8*)( cacheOf( a.vc, q ) + (long long)min( key, pos - 1 ) * HEAD_DIM + c * 8 );
-					const float p = key < pos ? L.sc[ q ][ key ] * inv[ q ] : 0.0f;
+					const f16x8 vv = it == 0 ? v0[ q ] : *(const f16x8*)( cacheOf( a.vc, q ) + (long long)max( min( key, pos[ q ] - 1 ), 0 ) * HEAD_DIM + c * 8 );
+					const float p = key < pos[ q ] ? L.sc[ q ][ key ] * inv[ q ] : 0.0f;
 	#pragma unroll
 					for( int e = 0; e < 8; e++ ) acc[ q ][ e ] = fmaf( (float)vv[ e ], p, acc[ q ][ e ] );
 				}
@@ -998,7 +1006,7 @@ namespace wh
 					float t = L.red[ q ][ 0 ][ j ];
 	#pragma unroll
 					for( int w = 1; w < NW; w++ ) t += L.red[ q ][ w ][ j ];
-					t = fmaf( L.vn[ q ][ j ], L.sc[ q ][ pos ] * inv[ q ], t );
+					t = fmaf( L.vn[ q ][ j ], L.sc[ q ][ pos[ q ] ] * inv[ q ], t );
 					a.out[ (long long)seqOf( q ) * d + h * HEAD_DIM + j ] = (f16)t;
 				}
 			}

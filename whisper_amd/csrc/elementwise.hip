@@ -30,15 +30,24 @@ namespace wh
 		// MelInputTensor::create (Whisper/Whisper/MelInputTensor.cpp:8-63) + convolutionPrep1.hlsl: slice
 		// [offset, offset + T) of each spectrogram, zero beyond its end, transposed to time-major and rounded to FP16
 		// (the convolution rounds its input, ggml.c:5252-5287). Row 0 and row T+1 stay zero: the conv's zero padding.
+		// `wins` non-null: every window names its own spectrogram (pointer, length, offset) -- the streams of a batch scheduler are
+		// recordings of different lengths; a null pointer is a window of zeros.
 		__global__ void __launch_bounds__( 256 ) melToConvInput( const float* __restrict__ mel, long long melStride, long long melLen,
-			const int* __restrict__ melOffsets, f16* __restrict__ x16, long long xBatchStride, int nMels, int T )
+			const int* __restrict__ melOffsets, const MelWindow* __restrict__ wins, f16* __restrict__ x16, long long xBatchStride, int nMels, int T )
 		{
 			__shared__ float tile[ 64 ][ 65 ];
 			const int b = blockIdx.z;
 			const int t0 = blockIdx.x * 64;
 			const int c0 = blockIdx.y * 64;
-			const int off = melOffsets ? melOffsets[ b ] : 0;
+			int off = melOffsets ? melOffsets[ b ] : 0;
 			const float* src = mel + (long long)b * melStride;
+			if( wins )
+			{
+				const MelWindow w = wins[ b ];
+				src = w.mel;
+				melLen = w.mel ? w.len : 0;
+				off = w.offset;
+			}
 			const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 			for( int r = ty; r < 64; r += 4 )
 			{
@@ -69,7 +78,7 @@ namespace wh
 			// device-resident position can turn into an out-of-range read (the host entry points reject such ids before they get here)
 			int tok = tokens[ row ];
 			tok = tok < 0 ? 0 : ( tok >= nVocab ? nVocab - 1 : tok );
-			int pos = ( nPastDev ? *nPastDev : nPast ) + row % nTok;
+			int pos = ( nPastDev ? nPastDev[ row / nTok ] : nPast ) + row % nTok;
 			pos = pos < 0 ? 0 : ( pos >= nTextCtx ? nTextCtx - 1 : pos );
 			for( int c = threadIdx.x; c < d; c += 256 )
 				x[ (long long)row * d + c ] = (float)te[ (long long)tok * d + c ] + pe[ (long long)pos * d + c ];
@@ -329,12 +338,28 @@ namespace wh
 			}
 		}
 
-		__global__ void advanceStateKernel( DecodeState* state )
+		__global__ void advanceStateKernel( DecodeState* state, int* seqPos, int rows )
 		{
-			state->nPast += 1;
-			state->step += 1;
-			state->forceTimestamp = 0;
-			state->isInitial = 0;
+			const int i = blockIdx.x * blockDim.x + threadIdx.x;
+			if( i < rows ) seqPos[ i ] += 1;
+			if( i == 0 )
+			{
+				state->step += 1;
+				state->forceTimestamp = 0;
+				state->isInitial = 0;
+			}
+		}
+
+		// ragged prompt step: the row of sequence b's last real token, lastPos[b], -> its row nTok - 1 (f16, d % 8 == 0)
+		__global__ void __launch_bounds__( 256 ) gatherLastRowsKernel( f16* __restrict__ xn, const int* __restrict__ lastPos, int nTok, int d )
+		{
+			const int b = blockIdx.x;
+			int last = lastPos[ b ];
+			last = last < 0 ? 0 : ( last > nTok - 1 ? nTok - 1 : last );
+			if( last == nTok - 1 ) return;
+			const f16* const src = xn + ( (long long)b * nTok + last ) * d;
+			f16* const dst = xn + ( (long long)b * nTok + nTok - 1 ) * d;
+			for( int c = threadIdx.x * 8; c < d; c += 256 * 8 ) *(f16x8*)( dst + c ) = *(const f16x8*)( src + c );
 		}
 	}	// namespace
 
@@ -350,11 +375,11 @@ namespace wh
 		return 0;
 	}
 
-	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets, f16* x16,
+	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets, const MelWindow* wins, f16* x16,
 		long long xBatchStride, int nMels, int T, int batch, hipStream_t stream )
 	{
 		dim3 grid( ( T + 63 ) / 64, ( nMels + 63 ) / 64, batch );
-		hipLaunchKernelGGL( melToConvInput, grid, dim3( 256 ), 0, stream, mel, melStride, melLen, melOffsets, x16, xBatchStride, nMels, T );
+		hipLaunchKernelGGL( melToConvInput, grid, dim3( 256 ), 0, stream, mel, melStride, melLen, melOffsets, wins, x16, xBatchStride, nMels, T );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -404,9 +429,17 @@ namespace wh
 		return 0;
 	}
 
-	int launchAdvanceState( DecodeState* state, hipStream_t stream )
+	int launchAdvanceState( DecodeState* state, int* seqPos, int rows, hipStream_t stream )
 	{
-		hipLaunchKernelGGL( advanceStateKernel, dim3( 1 ), dim3( 1 ), 0, stream, state );
+		hipLaunchKernelGGL( advanceStateKernel, dim3( ( rows + 127 ) / 128 ), dim3( 128 ), 0, stream, state, seqPos, rows );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchGatherLastRows( f16* xn, const int* lastPos, int batch, int nTok, int d, hipStream_t stream )
+	{
+		if( ( d & 7 ) != 0 || batch <= 0 || nTok <= 0 ) { setError( "gatherLastRows: bad shape" ); return -1; }
+		hipLaunchKernelGGL( gatherLastRowsKernel, dim3( batch ), dim3( 256 ), 0, stream, xn, lastPos, nTok, d );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

@@ -97,7 +97,7 @@ namespace wh
 				}
 				const int h = c >> 6, dd = c & 63;
 				const int b = m / a.nTok;
-				const int pos = ( a.nPastDev ? *a.nPastDev : a.nPast ) + ( m - b * a.nTok );
+				const int pos = ( a.nPastDev ? a.nPastDev[ b ] : a.nPast ) + ( m - b * a.nTok );
 				const long long o = ( ( (long long)b * a.H + h ) * a.textCtx + pos ) * HEAD_DIM + dd;
 				if( sel == 1 )
 					a.k[ o ] = (f16)( v * a.scale );

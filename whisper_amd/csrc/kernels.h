@@ -84,7 +84,7 @@ namespace wh
 		int T, Tpad, H, B;
 		int nTok, nPast, textCtx;
 		// decode-step extras (launchGemv only)
-		const int* nPastDev;  // when non-null the position comes from device memory (graph replay), else nPast
+		const int* nPastDev;  // when non-null the positions come from device memory (graph replay): nPastDev[sequence], else nPast for all
 		const float* lnX;	  // when non-null: A is produced on the fly as fp16( LayerNorm(lnX[m]) * lnW + lnB ), row length K
 		const float* lnW;
 		const float* lnB;
@@ -107,10 +107,17 @@ namespace wh
 	// ---------------------------------------------------------------------------------------------------------------
 	// out16[row] = fp16( norm(x[row]) * w + b ); rows of length d (multiple of 4, <= 2048). norm.hlsl + fmaRepeat1.hlsl
 	int launchLayerNorm( const float* x, const float* w, const float* b, f16* out, int rows, int d, hipStream_t stream );
-	// x16[b][t+1][c] = fp16( mel[b][c][off_b + t] ), zero outside the spectrogram; rows 0 and T+1 are the conv padding
-	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets,
+	// x16[b][t+1][c] = fp16( mel[b][c][off_b + t] ), zero outside the spectrogram; rows 0 and T+1 are the conv padding.
+	// wins (device, [batch]) non-null: window b comes from its own spectrogram wins[b] = { [nMels][len] FP32, len, offset }
+	struct MelWindow
+	{
+		const float* mel;
+		long long len;
+		int offset, reserved;
+	};
+	int launchMelToConvInput( const float* mel, long long melStride, long long melLen, const int* melOffsets, const MelWindow* wins,
 		f16* x16, long long xBatchStride, int nMels, int T, int batch, hipStream_t stream );
-	// x[m] = float(te[token[m]]) + pe[nPast + m % nTok]   (addRows.hlsl)
+	// x[m] = float(te[token[m]]) + pe[pos(m / nTok) + m % nTok], pos(b) = nPastDev ? nPastDev[b] : nPast   (addRows.hlsl)
 	// token ids are clamped to [0, nVocab), positions to [0, nTextCtx): no input can index outside the two tables
 	int launchEmbed( const int* tokens, const f16* te, const float* pe, float* x, int rows, int nTok, int nPast, const int* nPastDev, int d,
 		int nVocab, int nTextCtx, hipStream_t stream );
@@ -137,7 +144,7 @@ namespace wh
 		int causal;			   // 1: query i sees keys <= nPast + i
 		int nPast;
 		int parityThreads;	   // 0 = FP32 P.V; >0 = emulate ggml's FP16 thread-partitioned accumulation
-		const int* nPastDev;   // causal only: when non-null nPast (and nKeys = nPast + nTok) come from device memory
+		const int* nPastDev;   // causal only: when non-null nPast (and nKeys = nPast + nTok) of sequence b come from device memory, nPastDev[b]
 		// `group` consecutive sequences share one K/V block (the hypotheses of a window in cross-attention): kc / vc hold
 		// batch / group blocks and the rows b*group .. b*group + group - 1 are served by one pass over block b. 0 or 1 = none.
 		int group;
@@ -167,7 +174,7 @@ namespace wh
 		f16* out;
 		int batch, H, keyStride;
 		int nPast;
-		const int* nPastDev;   // when non-null the position comes from device memory (graph replay)
+		const int* nPastDev;   // when non-null the position of sequence b comes from device memory (graph replay): nPastDev[b]
 	};
 	int launchSelfBlockDec( const DecSelfArgs& a, hipStream_t stream );
 
@@ -234,10 +241,11 @@ namespace wh
 	int launchSampleBest( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
 		int forceTimestamp, int isInitial, TokenData* out, hipStream_t stream );
 
-	// Device-resident state of the greedy loop: lets one captured hipGraph be replayed for every token.
+	// Device-resident state of the greedy loop: lets one captured hipGraph be replayed for every token. The POSITIONS live next to
+	// it as one int per sequence (wh_context::seqPos): the sequences of a lock-step batch may stand at different positions (streams
+	// of a batch scheduler carry prompts of different lengths), every kernel that needs a position reads its own sequence's.
 	struct DecodeState
 	{
-		int nPast;			 // position of the token being fed
 		int step;			 // index of the next sample in the output array
 		int forceTimestamp;	 // consumed (cleared) by the sampler
 		int isInitial;
@@ -255,7 +263,11 @@ namespace wh
 	// the chosen id to nextTokens[row]; probsOut optional.
 	int launchSoftMaxSample( const float* logits, float* probsOut, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm,
 		int tokenNot, const DecodeState* state, TokenData* out, int* nextTokens, SampleMailbox mail, hipStream_t stream );
-	int launchAdvanceState( DecodeState* state, hipStream_t stream );
+	// step += 1, the sampler flags cleared, seqPos[0 .. rows) += 1
+	int launchAdvanceState( DecodeState* state, int* seqPos, int rows, hipStream_t stream );
+	// Prompt steps whose sequences differ in length (rows right-padded to nTok tokens): the normalised row of sequence b's LAST real
+	// token, lastPos[b] (device), is copied over its row nTok - 1, where the vocabulary product of a prompt step reads. In place, f16 rows.
+	int launchGatherLastRows( f16* xn, const int* lastPos, int batch, int nTok, int d, hipStream_t stream );
 
 	// ---------------------------------------------------------------------------------------------------------------
 	// mel spectrogram

@@ -254,10 +254,12 @@ struct wh_context
 	float *crossScores = nullptr, *crossSplitMax = nullptr, *crossPart = nullptr;
 	int* tokensDev = nullptr;
 	int* melOffsetsDev = nullptr;
+	MelWindow* melWindowsDev = nullptr;
 	TokenData* tokDataDev = nullptr;
 	float* melScratch = nullptr;
-	// device-side greedy loop
+	// device-side greedy loop: the sampler's state and one position per sequence (the sequences of a lock-step batch may differ)
 	DecodeState* state = nullptr;
+	int* seqPos = nullptr;
 	// host mailbox of the greedy loop (pinned, coherent): [n_text_ctx * maxSeq] records + stamps, and the generation of the window in progress
 	TokenData* mailData = nullptr;
 	int* mailFlag = nullptr;
@@ -268,6 +270,7 @@ struct wh_context
 	hipGraphExec_t graphExec = nullptr;
 	int graphBatch = 0;
 	uint32_t graphKey = 0;
+	const int* raggedLastPos = nullptr;	   // set around the prompt step of a window whose prompts differ in length: device [batch], position of each sequence's last prompt token
 	int windowSamples = 0;
 	int windowPos = 0;		   // position the next greedy step feeds (prompt length + steps enqueued so far)
 	hipStream_t copyStream = nullptr;
@@ -283,11 +286,15 @@ struct wh_context
 	f16 *capTemp1 = nullptr, *capEncKqv = nullptr, *capDecKqvSelf = nullptr, *capDecKqvCross = nullptr;
 	float* capLayer0In = nullptr;
 	int capDecRows = 0;
-	int profKeysHint = 1;	   // profiler only: keys a device-positioned self-attention launch sees (host mirror of DecodeState::nPast + 1)
+	int profKeysHint = 1;	   // profiler only: keys a device-positioned self-attention launch sees (host mirror of the largest position + 1)
 	bool ownsStream = false;
-	// pinned host staging for fully asynchronous enqueues (offsets, tokens, state)
+	// pinned host staging for fully asynchronous enqueues: ints [0, 1024) window offsets, [1024, 1032) the sampler state,
+	// [1032, 1032 + maxSeq) positions, then the prompt tokens of a window (up to n_text_ctx per sequence)
 	int32_t* pinned = nullptr;
-	static constexpr int PINNED_INTS = 4096;
+	int64_t pinnedInts = 0;
+	static constexpr int PIN_STATE = 1024, PIN_POS = 1032;
+	int32_t* pinTokens() const { return pinned + PIN_POS + maxSeq; }
+	int64_t pinTokenCap() const { return pinnedInts - PIN_POS - maxSeq; }
 	struct Allocation { void* base; void* body; int64_t bytes; const char* name; };
 	std::vector<Allocation> allocations;
 
@@ -1029,12 +1036,15 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	rc = rc ? rc : c->alloc( c->probs, S * (int64_t)hp.n_vocab, wh_context::DONT_CARE, "probs" );
 	rc = rc ? rc : c->alloc( c->tokensDev, rowsD, wh_context::DONT_CARE, "tokensDev" );
 	rc = rc ? rc : c->alloc( c->melOffsetsDev, B, wh_context::DONT_CARE, "melOffsetsDev" );
+	rc = rc ? rc : c->alloc( c->melWindowsDev, B, wh_context::MUST_BE_ZERO, "melWindowsDev" );
 	rc = rc ? rc : c->alloc( c->tokDataDev, S, wh_context::DONT_CARE, "tokDataDev" );
 	rc = rc ? rc : c->alloc( c->melScratch, 64, wh_context::DONT_CARE, "melScratch" );
 	rc = rc ? rc : c->alloc( c->state, 1, wh_context::MUST_BE_ZERO, "state" );
+	rc = rc ? rc : c->alloc( c->seqPos, S, wh_context::MUST_BE_ZERO, "seqPos" );
 	if( rc == 0 )
 	{
-		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * wh_context::PINNED_INTS, hipHostMallocDefault );
+		c->pinnedInts = wh_context::PIN_POS + S + S * (int64_t)hp.n_text_ctx;
+		const hipError_t e = hipHostMalloc( (void**)&c->pinned, sizeof( int32_t ) * (size_t)c->pinnedInts, hipHostMallocDefault );
 		if( e != hipSuccess ) rc = hipFail( e, "hipHostMalloc", __FILE__, __LINE__ );
 	}
 	rc = rc ? rc : c->alloc( c->greedyOut, (int64_t)hp.n_text_ctx * S, wh_context::DONT_CARE, "greedyOut" );
@@ -1260,7 +1270,13 @@ static GemmArgs plainGemm( const f16* A, const f16* W, int M, int N, int K )
 	return g;
 }
 
-static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets );
+static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets, const wh_mel_window* wins = nullptr );
+
+int wh_encode_windows( wh_context* c, const wh_mel_window* windows, int batch )
+{
+	if( !windows ) { setError( "encode_windows: windows is null" ); return WH_E_INVALIDARG; }
+	return encodeImpl( c, nullptr, batch, 0, 0, nullptr, windows );
+}
 
 int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets )
 {
@@ -1279,9 +1295,9 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 	return 0;
 }
 
-static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets )
+static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets, const wh_mel_window* wins )
 {
-	if( !c || !melDev || batch <= 0 || batch > c->maxBatch || melLen <= 0 ) { setError( "encode: bad argument" ); return WH_E_INVALIDARG; }
+	if( !c || ( !melDev && !wins ) || batch <= 0 || batch > c->maxBatch || ( !wins && melLen <= 0 ) ) { setError( "encode: bad argument" ); return WH_E_INVALIDARG; }
 	WH_BIND( c->m );
 	const wh_model* m = c->m;
 	const wh_hparams& hp = m->hp;
@@ -1294,10 +1310,28 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 	// offsets go through pinned staging (ints [0, 1024)): the copy is truly asynchronous and the call never blocks.
 	// The staging is rewritten by the next wh_encode only, which the stream orders after this copy has been consumed
 	// as long as the caller synchronises once per window (wh_decode / wh_decode_window_finish do).
-	for( int i = 0; i < batch; i++ ) c->pinned[ i ] = melOffsets ? melOffsets[ i ] : 0;
-	WH_HIP( hipMemcpyAsync( c->melOffsetsDev, c->pinned, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
+	const MelWindow* winsDev = nullptr;
+	if( wins )
+	{
+		// per-window sources (wh_encode_windows): descriptors through the same staging, 6 ints each
+		static_assert( sizeof( MelWindow ) == 24 && sizeof( wh_mel_window ) == 24, "window descriptor layout" );
+		if( (size_t)batch * sizeof( MelWindow ) > 1024 * sizeof( int32_t ) ) { setError( "encode_windows: batch too large" ); return WH_E_INVALIDARG; }
+		MelWindow* const stage = (MelWindow*)c->pinned;
+		for( int i = 0; i < batch; i++ )
+		{
+			if( wins[ i ].melDev && ( wins[ i ].melLen <= 0 || wins[ i ].offset < 0 ) ) { setError( "encode_windows: bad window" ); return WH_E_INVALIDARG; }
+			stage[ i ] = MelWindow{ wins[ i ].melDev, (long long)wins[ i ].melLen, wins[ i ].offset, 0 };
+		}
+		WH_HIP( hipMemcpyAsync( c->melWindowsDev, stage, sizeof( MelWindow ) * batch, hipMemcpyHostToDevice, st ) );
+		winsDev = c->melWindowsDev;
+	}
+	else
+	{
+		for( int i = 0; i < batch; i++ ) c->pinned[ i ] = melOffsets ? melOffsets[ i ] : 0;
+		WH_HIP( hipMemcpyAsync( c->melOffsetsDev, c->pinned, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
+	}
 	WH_CHECK( profiled( c, KC_MEL_TO_CONV, 0.0, 6.0 * batch * 2.0 * T * hp.n_mels,
-		[ & ]() { return launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ); } ) );
+		[ & ]() { return launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, winsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ); } ) );
 
 	// conv1 (k=3, stride 1, pad 1) + bias + GELU as an implicit GEMM over the padded time-major input:
 	// row t of the im2col matrix is the contiguous slice starting at padded row t (whisper.cpp:1127-1136; ggml.c:5199-5318)
@@ -1381,7 +1415,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 // decoder
 // ------------------------------------------------------------------------------------------------------------------
 // The decoder graph up to the logits of the last token of every sequence. With devState the position comes from device
-// memory (c->state->nPast), which makes the launch sequence identical for every token: that is what gets captured
+// memory (c->seqPos, one per sequence), which makes the launch sequence identical for every token: that is what gets captured
 // into a hipGraph by wh_decode_greedy. Single-token steps of up to 16 sequences take the gemv path (weights streamed
 // once, all loads of a wave in flight, LayerNorm fused into the product that consumes it); anything larger (prompt
 // steps) takes the M <= 32 skinny or the tiled kernel.
@@ -1395,7 +1429,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const int M = batch * nTokens;
 	const float kqScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
-	const int* const nPastDev = devState ? &c->state->nPast : nullptr;
+	const int* const nPastDev = devState ? c->seqPos : nullptr;
 	const bool gemv = M <= GEMV_MAX_ROWS && ( d % 128 ) == 0;
 	const bool fuseLn = gemv && d <= 1280 && M <= 32 && ( M <= 16 || ( g_tuning & TUNE_GEMV_LN_BLOCK ) || !( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
 	// decode steps: LayerNorm + this head's Q/K/V rows + cache append + self-attention in one launch
@@ -1656,6 +1690,9 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	// and then consumes just the last one, ContextImpl.cpp:159-169). The norm stays a separate launch here: fusing it
 	// into the 3242 workgroups of the vocabulary product would re-read the rows 3242 times.
 	WH_CHECK( lnP( c, c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d ) );
+	// prompts of different lengths (rows right-padded to nTokens): the row of every sequence's own last token moves to where the
+	// product below reads, row nTokens - 1 of the sequence
+	if( c->raggedLastPos && nTokens > 1 ) WH_CHECK( launchGatherLastRows( c->dxn, c->raggedLastPos, batch, nTokens, d, st ) );
 	{
 		GemmArgs g = plainGemm( c->dxn + (int64_t)( nTokens - 1 ) * d, m->at<f16>( L.te ), batch, hp.n_vocab, d );
 		g.lda = nTokens * d;
@@ -1701,6 +1738,20 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 	return 0;
 }
 
+// The sampler state and the positions of `batch` sequences -> device, through the pinned staging (asynchronous; the staging is
+// reused by the next call, which callers order behind a synchronisation of their own). positions == nullptr: `uniform` for all.
+static int uploadDecodeState( wh_context* c, int batch, const DecodeState& s, const int32_t* positions, int uniform )
+{
+	DecodeState* const stState = (DecodeState*)( c->pinned + wh_context::PIN_STATE );
+	int32_t* const stPos = c->pinned + wh_context::PIN_POS;
+	static_assert( sizeof( DecodeState ) <= sizeof( int32_t ) * ( wh_context::PIN_POS - wh_context::PIN_STATE ), "staging layout" );
+	*stState = s;
+	for( int i = 0; i < batch; i++ ) stPos[ i ] = positions ? positions[ i ] : uniform;
+	WH_HIP( hipMemcpyAsync( c->state, stState, sizeof( DecodeState ), hipMemcpyHostToDevice, c->stream ) );
+	WH_HIP( hipMemcpyAsync( c->seqPos, stPos, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, c->stream ) );
+	return 0;
+}
+
 // One greedy token on the device: decoder graph -> softmax + sampleBest -> advance the device-resident state.
 static int greedyStep( wh_context* c, int batch )
 {
@@ -1710,7 +1761,7 @@ static int greedyStep( wh_context* c, int batch )
 	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
 	WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
 		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, c->stream ); } ) );
-	return launchAdvanceState( c->state, c->stream );
+	return launchAdvanceState( c->state, c->seqPos, batch, c->stream );
 }
 
 int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int nPast, int nSteps, int forceFirstTimestamp, int firstIsInitial,
@@ -1723,10 +1774,11 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 	if( nPast + nSteps > hp.n_text_ctx ) { setError( "decode_greedy: n_past + n_steps exceeds n_text_ctx" ); return WH_E_BOUNDS; }
 	WH_CHECK( checkTokens( hp, firstTokens, batch, "decode_greedy" ) );
 	hipStream_t st = c->stream;
-	const DecodeState init = { nPast, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, 0 };
-	WH_HIP( hipMemcpyAsync( c->state, &init, sizeof( init ), hipMemcpyHostToDevice, st ) );
+	const DecodeState init = { 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, 0 };
+	WH_HIP( hipStreamSynchronize( st ) );	 // the staging may still be read by an earlier enqueue
+	WH_CHECK( uploadDecodeState( c, batch, init, nullptr, nPast ) );
 	WH_HIP( hipMemcpyAsync( c->tokensDev, firstTokens, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
-	WH_HIP( hipStreamSynchronize( st ) );	 // `init` is a local
+	WH_HIP( hipStreamSynchronize( st ) );
 
 	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && !debugSync();
 	if( useGraph )
@@ -1742,7 +1794,7 @@ int wh_decode_greedy( wh_context* c, int batch, const int32_t* firstTokens, int 
 			// one eager step first: it sets the per-kernel function attributes, which capture does not allow
 			WH_CHECK( greedyStep( c, batch ) );
 			WH_HIP( hipStreamSynchronize( st ) );
-			WH_HIP( hipMemcpyAsync( c->state, &init, sizeof( init ), hipMemcpyHostToDevice, st ) );
+			WH_CHECK( uploadDecodeState( c, batch, init, nullptr, nPast ) );
 			WH_HIP( hipMemcpyAsync( c->tokensDev, firstTokens, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
 			WH_HIP( hipStreamSynchronize( st ) );
 			hipGraph_t graph = nullptr;
@@ -1789,14 +1841,31 @@ static int markWindow( wh_context* c )
 // captured greedy steps. Token data of the 1 + nSteps samples stay on the device until wh_decode_window_finish.
 // Several contexts driven this way from one host thread overlap on the GPU (each owns a stream): single-token decode
 // steps are latency-bound and use a fraction of the chip, so independent windows fill it concurrently.
-int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp, int firstIsInitial )
+static int windowStart( wh_context* c, int batch, const int32_t* promptTokens, const int32_t* promptLens, int nPrompt, int nSteps, int forceFirstTimestamp,
+	int firstIsInitial, const char* who )
 {
 	if( !c || !promptTokens || batch <= 0 || batch > c->maxSeq || ( batch % c->hyp ) != 0 || nPrompt <= 0 || nSteps < 0 ) { setError( "decode_window_start: bad argument" ); return WH_E_INVALIDARG; }
 	if( !c->encoded ) { setError( "decode_window_start: wh_encode has not run" ); return WH_E_NOT_READY; }
 	WH_BIND( c->m );
 	const wh_hparams& hp = c->m->hp;
-	if( nPrompt + nSteps > hp.n_text_ctx || batch * nPrompt + 8 > wh_context::PINNED_INTS - 1024 ) { setError( "decode_window_start: too many tokens" ); return WH_E_BOUNDS; }
-	WH_CHECK( checkTokens( hp, promptTokens, (int64_t)batch * nPrompt, "decode_window_start" ) );
+	if( nPrompt + nSteps > hp.n_text_ctx || (int64_t)batch * nPrompt > c->pinTokenCap() ) { setError( "decode_window_start: too many tokens" ); return WH_E_BOUNDS; }
+	bool ragged = false;
+	if( promptLens )
+		for( int b = 0; b < batch; b++ )
+		{
+			if( promptLens[ b ] < 1 || promptLens[ b ] > nPrompt ) { setError( "decode_window_start: a prompt length is outside [1, nPromptMax]" ); return WH_E_INVALIDARG; }
+			ragged = ragged || promptLens[ b ] != nPrompt;
+		}
+	if( ragged && c->hyp != 1 ) { setError( "decode_window_start: prompts of different lengths need one hypothesis per window" ); return WH_E_INVALIDARG; }
+	// staging: the prompt tokens (padding of a shorter row = token 0: computed, never consumed), the sampler state, the positions
+	int32_t* const stTok = c->pinTokens();
+	const int M = batch * nPrompt;
+	for( int b = 0; b < batch; b++ )
+	{
+		const int len = promptLens ? promptLens[ b ] : nPrompt;
+		WH_CHECK( checkTokens( hp, promptTokens + (size_t)b * nPrompt, len, who ) );
+		for( int i = 0; i < nPrompt; i++ ) stTok[ (size_t)b * nPrompt + i ] = i < len ? promptTokens[ (size_t)b * nPrompt + i ] : 0;
+	}
 	hipStream_t st = c->stream;
 	for( auto& mk : c->marks ) c->markPool.push_back( mk.ev );
 	c->marks.clear();
@@ -1812,8 +1881,14 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	{
 		// first use for this batch size: one eager step (sets the per-kernel function attributes), then capture. Blocking,
 		// once per context; the state it leaves behind is overwritten below.
-		const DecodeState warm = { 0, 0, 0, 0, 0 };
-		WH_HIP( hipMemcpyAsync( c->state, &warm, sizeof( warm ), hipMemcpyHostToDevice, st ) );
+		const DecodeState warm = { 0, 0, 0, 0 };
+		WH_HIP( hipStreamSynchronize( st ) );
+		{
+			// not through the staging: it already holds this window's tokens
+			std::vector<int32_t> zeros( (size_t)batch, 0 );
+			WH_HIP( hipMemcpy( c->state, &warm, sizeof( warm ), hipMemcpyHostToDevice ) );
+			WH_HIP( hipMemcpy( c->seqPos, zeros.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
+		}
 		WH_HIP( hipMemsetAsync( c->tokensDev, 0, sizeof( int32_t ) * batch, st ) );
 		WH_HIP( hipStreamSynchronize( st ) );
 		WH_CHECK( greedyStep( c, batch ) );
@@ -1830,27 +1905,29 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 		c->graphBatch = batch;
 		c->graphKey = key;
 	}
-	// staging: ints [1024, 1024 + batch*nPrompt) = prompt tokens, then the 5 ints of DecodeState
-	int32_t* const stTok = c->pinned + 1024;
-	const int M = batch * nPrompt;
-	for( int i = 0; i < M; i++ ) stTok[ i ] = promptTokens[ i ];
-	DecodeState* const stState = (DecodeState*)( stTok + M );
-	// after the sampler's advance the position must be nPrompt: start one below it
 	// a new generation per window: stamps of earlier windows in the mailbox can never be taken for this one's
-	// (only for the few sequences of a stream whose host loop reads every sample; a lock-step batch is read once, at the end)
+	// (only for the few sequences of a stream whose host loop reads every sample; a lock-step batch is read chunk by chunk through events)
 	const bool mailbox = c->mailData && batch <= SMALL_MAX_ROWS;
 	if( mailbox ) c->mailCounter = c->mailCounter == 0x7fffffff ? 1 : c->mailCounter + 1;
 	c->mailGen = mailbox ? c->mailCounter : 0;
-	*stState = DecodeState{ nPrompt - 1, 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, c->mailGen };
+	// after the sampler's advance the position of sequence b must be its prompt length: start one below it
+	const DecodeState s0 = { 0, forceFirstTimestamp ? 1 : 0, firstIsInitial ? 1 : 0, c->mailGen };
+	{
+		int32_t* const stPos = c->pinned + wh_context::PIN_POS;
+		for( int b = 0; b < batch; b++ ) stPos[ b ] = ( promptLens ? promptLens[ b ] : nPrompt ) - 1;
+		WH_CHECK( uploadDecodeState( c, batch, s0, stPos, 0 ) );
+	}
 	WH_HIP( hipMemcpyAsync( c->tokensDev, stTok, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
-	WH_HIP( hipMemcpyAsync( c->state, stState, sizeof( DecodeState ), hipMemcpyHostToDevice, st ) );
-	WH_CHECK( decodeGraph( c, batch, nPrompt, 0, false ) );
+	c->raggedLastPos = ragged ? c->seqPos : nullptr;
+	const int rcGraph = decodeGraph( c, batch, nPrompt, 0, false );
+	c->raggedLastPos = nullptr;
+	WH_CHECK( rcGraph );
 	{
 		const SpecialIds sp = specialIds( hp );
 		const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 		WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
 			[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, st ); } ) );
-		WH_CHECK( launchAdvanceState( c->state, st ) );
+		WH_CHECK( launchAdvanceState( c->state, c->seqPos, batch, st ) );
 	}
 	if( useGraph )
 		for( int s = 0; s < nSteps; s++ ) WH_HIP( hipGraphLaunch( c->graphExec, st ) );
@@ -1864,6 +1941,18 @@ int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptToken
 	c->windowSamples = 1 + nSteps;
 	c->windowPos = nPrompt + nSteps;
 	return markWindow( c );
+}
+
+int wh_decode_window_start( wh_context* c, int batch, const int32_t* promptTokens, int nPrompt, int nSteps, int forceFirstTimestamp, int firstIsInitial )
+{
+	return windowStart( c, batch, promptTokens, nullptr, nPrompt, nSteps, forceFirstTimestamp, firstIsInitial, "decode_window_start" );
+}
+
+int wh_decode_window_start_ragged( wh_context* c, int batch, const int32_t* promptTokens, const int32_t* promptLens, int nPromptMax, int nSteps,
+	int forceFirstTimestamp, int firstIsInitial )
+{
+	if( !promptLens ) { setError( "decode_window_start_ragged: promptLens is null" ); return WH_E_INVALIDARG; }
+	return windowStart( c, batch, promptTokens, promptLens, nPromptMax, nSteps, forceFirstTimestamp, firstIsInitial, "decode_window_start_ragged" );
 }
 
 // More greedy steps of the window wh_decode_window_start began, still without blocking the host: the position, the last
@@ -1884,8 +1973,9 @@ int wh_decode_window_continue( wh_context* c, int nSteps )
 		// the window's device state, so the state and the pending token are saved around it.
 		WH_HIP( hipStreamSynchronize( c->stream ) );
 		DecodeState saved;
-		std::vector<int32_t> tok( (size_t)batch );
+		std::vector<int32_t> tok( (size_t)batch ), savedPos( (size_t)batch );
 		WH_HIP( hipMemcpy( &saved, c->state, sizeof( saved ), hipMemcpyDeviceToHost ) );
+		WH_HIP( hipMemcpy( savedPos.data(), c->seqPos, sizeof( int32_t ) * batch, hipMemcpyDeviceToHost ) );
 		WH_HIP( hipMemcpy( tok.data(), c->tokensDev, sizeof( int32_t ) * batch, hipMemcpyDeviceToHost ) );
 		if( c->graphExec ) { (void)hipGraphExecDestroy( c->graphExec ); c->graphExec = nullptr; }
 		WH_CHECK( greedyStep( c, batch ) );
@@ -1902,6 +1992,7 @@ int wh_decode_window_continue( wh_context* c, int nSteps )
 		c->graphBatch = batch;
 		c->graphKey = key;
 		WH_HIP( hipMemcpy( c->state, &saved, sizeof( saved ), hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->seqPos, savedPos.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
 		WH_HIP( hipMemcpy( c->tokensDev, tok.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
 	}
 	if( useGraph )
@@ -1961,6 +2052,22 @@ int wh_decode_window_fetch( wh_context* c, int first, int count, wh_token_data* 
 	WH_HIP( hipMemcpyAsync( out, c->greedyOut + (size_t)first * c->lastBatch, sizeof( TokenData ) * (size_t)count * c->lastBatch, hipMemcpyDeviceToHost, c->copyStream ) );
 	WH_HIP( hipStreamSynchronize( c->copyStream ) );
 	return 0;
+}
+
+int wh_decode_window_ready( wh_context* c, int first, int count )
+{
+	if( !c || first < 0 || count <= 0 || first + count > c->windowSamples ) { setError( "decode_window_ready: range not enqueued" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	for( const auto& x : c->marks )
+		if( x.endSample >= first + count )
+		{
+			const hipError_t e = hipEventQuery( x.ev );
+			if( e == hipSuccess ) return 1;
+			if( e == hipErrorNotReady ) { (void)hipGetLastError(); return 0; }
+			return hipFail( e, "hipEventQuery", __FILE__, __LINE__ );
+		}
+	setError( "decode_window_ready: no completion mark for that range" );
+	return WH_E_INVALIDARG;
 }
 
 int wh_decode_window_finish( wh_context* c, wh_token_data* out )

@@ -138,6 +138,14 @@ namespace Whisper
 	// only the vocabulary of a model file (no device needed)
 	HRESULT loadVocabulary( const std::string& path, Vocabulary& vocab );
 
+	// what runFullBatch needs from an iModel of this library: the loaded weights behind it
+	// {8c1f0d3a-52b7-4e0e-9a64-0f6d2b7c41e5}
+	struct iModelInternals : public ComLight::IUnknown
+	{
+		static constexpr ComLight::GUID iid() { return { 0x8c1f0d3a, 0x52b7, 0x4e0e, { 0x9a, 0x64, 0x0f, 0x6d, 0x2b, 0x7c, 0x41, 0xe5 } }; }
+		virtual const std::shared_ptr<LoadedModel>& loaded() const = 0;
+	};
+
 	HRESULT createContextImpl( const std::shared_ptr<LoadedModel>& model, iModel* owner, iContext** pp );
 	HRESULT createModelImpl( const std::shared_ptr<LoadedModel>& model, iModel** pp );
 	HRESULT createAudioBuffer( std::vector<float>&& mono, std::vector<float>&& stereo, iAudioBuffer** pp );

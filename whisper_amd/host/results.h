@@ -1,0 +1,65 @@
+// iTranscribeResult of the library: segments + tokens in the reference's POD layout (Whisper/Whisper/TranscribeResult.h), filled from
+// the transcript a stream built (hostLoop.h). Shared by iContext::getResults and Whisper::runFullBatch.
+#pragma once
+#include "hostCommon.h"
+
+namespace Whisper
+{
+	struct ResultData
+	{
+		std::vector<sSegment> segments;
+		std::vector<sToken> tokens;
+		std::vector<std::string> texts;
+	};
+	class TranscribeResult : public ComObject<iTranscribeResult>, public ResultData
+	{
+	public:
+		HRESULT getSize( sTranscribeLength& rdi ) const override
+		{
+			rdi.countSegments = (uint32_t)segments.size();
+			rdi.countTokens = (uint32_t)tokens.size();
+			return S_OK;
+		}
+		const sSegment* getSegments() const override { return segments.empty() ? nullptr : segments.data(); }
+		const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
+	};
+
+	// Segment times: 10 ms units -> 100 ns ticks, plus the media time of the first sample (ContextImpl.misc.cpp getResults)
+	inline HRESULT fillResultData( const std::vector<Segment>& resultAll, const Vocabulary& vocab, int64_t mediaTimeOffset, eResultFlags flags, ResultData& res )
+	{
+		const bool withTokens = flags & eResultFlags::Tokens, withTimes = flags & eResultFlags::Timestamps;
+		res.segments.resize( resultAll.size() );
+		res.texts.resize( resultAll.size() );
+		size_t tc = 0;
+		if( withTokens )
+			for( const Segment& s : resultAll ) tc += s.tokens.size();
+		res.tokens.resize( tc );
+		size_t soFar = 0;
+		auto ticks = []( int64_t t10ms ) { return (uint64_t)( t10ms * 100000 ); };	 // 10 ms -> 100 ns
+		for( size_t i = 0; i < resultAll.size(); i++ )
+		{
+			const Segment& src = resultAll[ i ];
+			sSegment& dst = res.segments[ i ];
+			res.texts[ i ] = src.text;
+			dst.text = res.texts[ i ].c_str();
+			dst.time.begin.ticks = withTimes ? ticks( src.t0 ) + (uint64_t)mediaTimeOffset : 0;
+			dst.time.end.ticks = withTimes ? ticks( src.t1 ) + (uint64_t)mediaTimeOffset : 0;
+			dst.firstToken = (uint32_t)soFar;
+			dst.countTokens = (uint32_t)src.tokens.size();
+			if( withTokens )
+				for( size_t j = 0; j < src.tokens.size(); j++ )
+				{
+					const TokenData& t = src.tokens[ j ];
+					sToken& o = res.tokens[ soFar + j ];
+					o.text = vocab.string( t.id );
+					o.time.begin.ticks = ( withTimes && t.t0 >= 0 ) ? ticks( t.t0 ) + (uint64_t)mediaTimeOffset : 0;
+					o.time.end.ticks = ( withTimes && t.t1 >= 0 ) ? ticks( t.t1 ) + (uint64_t)mediaTimeOffset : 0;
+					o.probability = t.p; o.probabilityTimestamp = t.pt; o.ptsum = t.ptsum; o.vlen = t.vlen;
+					o.id = t.id;
+					o.flags = t.id >= vocab.token_eot ? eTokenFlags::Special : eTokenFlags::None;
+				}
+			soFar += src.tokens.size();
+		}
+		return S_OK;
+	}
+}

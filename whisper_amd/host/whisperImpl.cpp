@@ -7,6 +7,8 @@
 // timestamp tokens.
 #include <cstdlib>
 #include "hostCommon.h"
+#include "hostLoop.h"
+#include "results.h"
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -15,17 +17,10 @@
 
 namespace Whisper
 {
+	eHostLoopRules g_hostLoopRules = eHostLoopRules::ReferenceCpu;
+
 	namespace
 	{
-		// The reference ships TWO host loops that differ in two rules: its CPU model (Whisper/source/whisper.cpp:2765-3120,
-		// the oracle every parity test is pinned to) drops the past prompt when < 5 s of audio remain and retries a failed
-		// window once without it; its GPU model's port (Whisper/Whisper/ContextImpl.cpp:452-793) does neither. The default
-		// follows the CPU path, because that is what north_star asks token ids to match; whisperc_set_host_loop_rules( 1 )
-		// selects the GPU model's behaviour for callers that depended on it.
-		enum struct eHostLoopRules : int { ReferenceCpu = 0, ContextImpl = 1 };
-		eHostLoopRules g_hostLoopRules = eHostLoopRules::ReferenceCpu;
-
-		constexpr int CHUNK_FRAMES = 3000;	   // 30 s of 10 ms frames (WHISPER_CHUNK_SIZE * 100)
 		// greedy steps enqueued per chunk; one chunk always runs behind the one being scanned, so up to two chunks are decoded in
 		// vain when a window ends: one sequential 199 s clip through runFull, medium shape, ran at 265 / 308 / 330 / 351 audio-s/s
 		// with chunks of 8 / 4 / 2 / 1 in round 3 (1.13 ms per step; a fetch polls the sampler's pinned mailbox, it enqueues
@@ -37,25 +32,6 @@ namespace Whisper
 		}();
 
 
-		// ---- iTranscribeResult ------------------------------------------------------------------------------------
-		struct ResultData
-		{
-			std::vector<sSegment> segments;
-			std::vector<sToken> tokens;
-			std::vector<std::string> texts;
-		};
-		class TranscribeResult : public ComObject<iTranscribeResult>, public ResultData
-		{
-		public:
-			HRESULT getSize( sTranscribeLength& rdi ) const override
-			{
-				rdi.countSegments = (uint32_t)segments.size();
-				rdi.countTokens = (uint32_t)tokens.size();
-				return S_OK;
-			}
-			const sSegment* getSegments() const override { return segments.empty() ? nullptr : segments.data(); }
-			const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
-		};
 		// The object embedded in a context: handed out without NewObject, it lives as long as the context and its
 		// Release never deletes (Whisper/Whisper/TranscribeResult.h:34-43)
 		class TranscribeResultStatic : public iTranscribeResult, public ResultData
@@ -458,259 +434,54 @@ namespace Whisper
 
 		HRESULT ContextImpl::runFullImpl( const sFullParams& params, const sProgressSink& progress )
 		{
-			const int64_t melLen = mel.length;
-			bool stoppedPrematurely = false;
+			// the stream's rules (seek range, prompt carry-over, stop rules, segments, callbacks) live in hostLoop.h, shared with the
+			// lock-step scheduler of runFullBatch; here: the device work of ONE stream, window after window
 			const Vocabulary& vocab = model->vocab;
 			const wh_hparams& hp = model->hp;
-			resultAll.clear();
-			if( params.flag( eFullParamsFlags::SpeedupAudio ) )
-			{
-				logError( "GPU model doesn't implement the SpeedupAudio flag" );
-				return E_NOTIMPL;
-			}
-			if( params.audio_ctx != 0 && params.audio_ctx != hp.n_audio_ctx )
-			{
-				logError( "audio_ctx override is not supported by this build" );
-				return E_NOTIMPL;
-			}
-
-			const int seekStart = params.offset_ms / 10;
-			const int seekEnd = seekStart + ( params.duration_ms == 0 ? (int)melLen : params.duration_ms / 10 );
-			// nothing shorter than one second is processed (ContextImpl.cpp:469-473)
-			if( seekEnd < 100 + seekStart ) return S_FALSE;
-
-			if( params.flag( eFullParamsFlags::NoContext ) ) promptPast.clear();
-			if( params.prompt_tokens && params.prompt_n_tokens > 0 )
-				promptPast.insert( promptPast.begin(), params.prompt_tokens, params.prompt_tokens + params.prompt_n_tokens );
-
-			// the tokens that select the task
-			std::vector<int> promptInit = { vocab.token_sot };
-			if( vocab.isMultilingual() )
-			{
-				const int langId = lookupLanguageId( params.language );
-				if( langId < 0 )
-				{
-					char lang[ 5 ] = { 0 };
-					memcpy( lang, &params.language, 4 );
-					logError( "runFull: unknown language '%s'", lang );
-					return E_INVALIDARG;
-				}
-				promptInit.push_back( vocab.token_sot + 1 + langId );
-				promptInit.push_back( params.flag( eFullParamsFlags::Translate ) ? vocab.token_translate : vocab.token_transcribe );
-			}
-
-			const int nMax = hp.n_text_ctx / 2 - 4;
-			std::vector<TokenData> tokensCur;
+			StreamRun run( params, vocab, hp, this, progress, resultAll, promptPast, &stamper );
+			const HRESULT hrBegin = run.begin( mel.length );
+			if( hrBegin != S_OK ) return hrBegin;
 			std::vector<int> prompt;
-			int seek = seekStart;
 			while( true )
 			{
-				if( progress.pfn )
-				{
-					// ContextImpl.cpp:533-540
-					const double percentage = (double)( seek - seekStart ) / (double)( seekEnd - seekStart );
-					CHECK( progress.pfn( percentage, this, progress.pv ) );
-				}
-				if( seek + 100 >= seekEnd ) break;
-				// whisper.cpp only: with less than 5 s left the past prompt is dropped, "since it tends to confuse the decoder"
-				// (Whisper/source/whisper.cpp:2874-2878; absent from ContextImpl.cpp)
-				if( g_hostLoopRules == eHostLoopRules::ReferenceCpu && seek > seekStart && seek + 500 >= seekEnd ) promptPast.clear();
-
-				if( params.encoder_begin_callback )
-				{
-					const HRESULT hr = params.encoder_begin_callback( this, params.encoder_begin_callback_user_data );
-					if( FAILED( hr ) ) return hr;
-					if( hr != S_OK )
-					{
-						stoppedPrematurely = true;
-						break;
-					}
-				}
+				const HRESULT hrNext = run.nextWindow( prompt );
+				if( FAILED( hrNext ) ) return hrNext;
+				if( hrNext != S_OK ) break;
 				{
 					// enqueued without a host sync: the decoder's launches line up behind the encoder's on the context's stream.
 					// With WHISPER_PROFILE=1 the two are separated so that the "Encode" block means what it means in the reference.
 					const auto t = Clock::now();
-					CHECK( encodeWindow( seek ) );
+					CHECK( encodeWindow( run.seek ) );
 					if( gpuProfile ) CHECK_WH( wh_context_synchronize( gpu ) );
 					msEncode += msSince( t );
 					nEncode++;
 				}
-
-				// previous text conditions this window: [prev] + the last n_take tokens + the task tokens (ContextImpl.cpp:565-576)
-				prompt.clear();
-				if( !promptPast.empty() )
-				{
-					const int nTake = std::min( std::min( params.n_max_text_ctx, hp.n_text_ctx / 2 ), (int)promptPast.size() );
-					prompt.push_back( vocab.token_prev );
-					prompt.insert( prompt.end(), promptPast.end() - nTake, promptPast.end() );
-					promptPast.assign( prompt.begin() + 1, prompt.end() );
-				}
-				prompt.insert( prompt.end(), promptInit.begin(), promptInit.end() );
-
-				int seekDelta = CHUNK_FRAMES;
-				int resultLen = 0;
-				bool failed = false, hasTs = false;
-				tokensCur.clear();
 				const auto tDec = Clock::now();
 				WindowDecoder dec( gpu, hp.n_text_ctx );
-				for( int i = 0; i < nMax; i++ )
+				WindowScan scan( run.fullParams(), vocab, run.seek, run.seekEnd(), run.maxTokens() );
+				for( bool first = true; !scan.over; first = false )
 				{
 					TokenData token;
-					if( i == 0 )
+					if( first )
 						CHECK( dec.start( prompt, token ) );
 					else
 						CHECK( dec.next( token ) );
-
-					if( token.id > vocab.token_beg )
-					{
-						// a timestamp token moves the sliding window; going back in time ends the window
-						const int seekDeltaNew = 2 * ( token.id - vocab.token_beg );
-						if( hasTs && seekDelta > seekDeltaNew && resultLen < i ) break;
-						seekDelta = seekDeltaNew;
-						resultLen = i + 1;
-						hasTs = true;
-					}
-					tokensCur.push_back( token );
-
-					const bool endOfAudio = hasTs && seek + seekDelta + 100 >= seekEnd;
-					if( token.id == vocab.token_eot || ( params.max_tokens > 0 && i >= params.max_tokens ) || endOfAudio )
-					{
-						if( resultLen == 0 )
-						{
-							if( seek + seekDelta + 100 >= seekEnd )
-								resultLen = i + 1;
-							else
-							{
-								failed = true;
-								break;
-							}
-						}
-						if( params.flag( eFullParamsFlags::SingleSegment ) )
-						{
-							resultLen = i + 1;
-							seekDelta = CHUNK_FRAMES;
-						}
-						break;
-					}
-					// stuck in a repetition loop: give up on this window (ContextImpl.cpp:665-672)
-					if( i == nMax - 1 && ( resultLen == 0 || seekDelta < CHUNK_FRAMES / 2 ) )
-					{
-						failed = true;
-						break;
-					}
+					scan.feed( token );
 				}
 				msDecode += msSince( tDec );
 				if( getenv( "WHISPER_HOSTPROF" ) )
-					fprintf( stderr, "[hostprof] window at %d: decode %.2f ms for %d tokens, of which waiting for samples %.2f ms, enqueueing steps %.2f ms\n", seek,
+					fprintf( stderr, "[hostprof] window at %d: decode %.2f ms for %d tokens, of which waiting for samples %.2f ms, enqueueing steps %.2f ms\n", run.seek,
 						msSince( tDec ), dec.steps, dec.msFetch, dec.msEnqueue );
 				nDecodeSteps += dec.steps;	   // tokens the loop consumed (the reference counts one DecodeStep per token)
 				nDecodeWindows++;
-				if( failed )
-				{
-					// whisper.cpp retries the same window once without the past prompt before skipping a second
-					// (whisper.cpp:3006-3016); ContextImpl.cpp:675-680 skips right away
-					if( g_hostLoopRules == eHostLoopRules::ReferenceCpu && !promptPast.empty() )
-					{
-						promptPast.clear();
-						continue;
-					}
-					logError( "runFull: failed to generate timestamp token - skipping one second" );
-					seek += 100;
-					continue;
-				}
-
-				tokensCur.resize( std::min( (size_t)resultLen, tokensCur.size() ) );
-				for( const TokenData& t : tokensCur ) promptPast.push_back( t.id );
-
-				// cut the window's tokens into segments at the timestamp tokens (ContextImpl.cpp:689-784)
-				if( !tokensCur.empty() )
-				{
-					const bool special = params.flag( eFullParamsFlags::PrintSpecial );
-					const bool single = params.flag( eFullParamsFlags::SingleSegment );
-					int i0 = 0;
-					int t0 = seek + 2 * ( tokensCur.front().tid - vocab.token_beg );
-					std::string text;
-					auto emit = [ & ]( int t1, int last ) -> HRESULT
-					{
-						Segment s;
-						s.t0 = t0; s.t1 = t1; s.text = text;
-						s.tokens.assign( tokensCur.begin() + i0, tokensCur.begin() + last + 1 );
-						if( params.flag( eFullParamsFlags::PrintRealtime ) ) logDebug( "[%d --> %d]  %s", t0, t1, text.c_str() );
-						resultAll.push_back( std::move( s ) );
-						uint32_t nNew = 1;
-						if( params.flag( eFullParamsFlags::TokenTimestamps ) && stamper.ready() )
-						{
-							// whisper.cpp:3063-3069 / ContextImpl.cpp:741-749
-							stamper.compute( resultAll.back(), vocab, params.thold_pt, params.thold_ptsum );
-							if( params.max_len > 0 ) nNew = (uint32_t)TokenTimestamper::wrapLast( resultAll, vocab, params.max_len );
-						}
-						if( params.new_segment_callback )
-						{
-							const HRESULT hr = params.new_segment_callback( this, nNew, params.new_segment_callback_user_data );
-							if( FAILED( hr ) ) return hr;
-						}
-						return S_OK;
-					};
-					for( int i = 0; i < (int)tokensCur.size(); i++ )
-					{
-						const int id = tokensCur[ i ].id;
-						if( special || id < vocab.token_eot ) text += vocab.string( id );
-						if( id > vocab.token_beg && !single )
-						{
-							const int t1 = seek + 2 * ( tokensCur[ i ].tid - vocab.token_beg );
-							if( !text.empty() ) CHECK( emit( t1, i ) );
-							text.clear();
-							while( i < (int)tokensCur.size() && tokensCur[ i ].id > vocab.token_beg ) i++;
-							i--;
-							t0 = t1;
-							i0 = i + 1;
-						}
-					}
-					if( !text.empty() ) CHECK( emit( seek + seekDelta, (int)tokensCur.size() - 1 ) );
-				}
-				seek += seekDelta;
+				CHECK( run.finishWindow( scan ) );
 			}
-			if( progress.pfn && !stoppedPrematurely ) CHECK( progress.pfn( 1.0, this, progress.pv ) );	   // ContextImpl.cpp:788-792
-			return S_OK;
+			return run.end();
 		}
 
 		HRESULT ContextImpl::fillResults( eResultFlags flags, ResultData& res ) const
 		{
-			const Vocabulary& vocab = model->vocab;
-			const bool withTokens = flags & eResultFlags::Tokens, withTimes = flags & eResultFlags::Timestamps;
-			res.segments.resize( resultAll.size() );
-			res.texts.resize( resultAll.size() );
-			size_t tc = 0;
-			if( withTokens )
-				for( const Segment& s : resultAll ) tc += s.tokens.size();
-			res.tokens.resize( tc );
-			size_t soFar = 0;
-			auto ticks = []( int64_t t10ms ) { return (uint64_t)( t10ms * 100000 ); };	 // 10 ms -> 100 ns
-			for( size_t i = 0; i < resultAll.size(); i++ )
-			{
-				const Segment& src = resultAll[ i ];
-				sSegment& dst = res.segments[ i ];
-				res.texts[ i ] = src.text;
-				dst.text = res.texts[ i ].c_str();
-				dst.time.begin.ticks = withTimes ? ticks( src.t0 ) + (uint64_t)mediaTimeOffset : 0;
-				dst.time.end.ticks = withTimes ? ticks( src.t1 ) + (uint64_t)mediaTimeOffset : 0;
-				dst.firstToken = (uint32_t)soFar;
-				dst.countTokens = (uint32_t)src.tokens.size();
-				if( withTokens )
-					for( size_t j = 0; j < src.tokens.size(); j++ )
-					{
-						const TokenData& t = src.tokens[ j ];
-						sToken& o = res.tokens[ soFar + j ];
-						o.text = vocab.string( t.id );
-						o.time.begin.ticks = ( withTimes && t.t0 >= 0 ) ? ticks( t.t0 ) + (uint64_t)mediaTimeOffset : 0;
-						o.time.end.ticks = ( withTimes && t.t1 >= 0 ) ? ticks( t.t1 ) + (uint64_t)mediaTimeOffset : 0;
-						o.probability = t.p; o.probabilityTimestamp = t.pt; o.ptsum = t.ptsum; o.vlen = t.vlen;
-						o.id = t.id;
-						o.flags = t.id >= vocab.token_eot ? eTokenFlags::Special : eTokenFlags::None;
-					}
-				soFar += src.tokens.size();
-			}
-			return S_OK;
+			return fillResultData( resultAll, model->vocab, mediaTimeOffset, flags, res );
 		}
 
 		HRESULT ContextImpl::getResults( eResultFlags flags, iTranscribeResult** pp ) const
@@ -730,11 +501,24 @@ namespace Whisper
 		}
 
 		// ---- iModel -----------------------------------------------------------------------------------------------
-		class ModelImpl : public ComObject<iModel>
+		class ModelImpl : public ComObject<iModel>, public iModelInternals
 		{
 			std::shared_ptr<LoadedModel> model;
 		public:
 			explicit ModelImpl( const std::shared_ptr<LoadedModel>& m ) : model( m ) {}
+			HRESULT QueryInterface( const ComLight::GUID& riid, void** ppv ) override
+			{
+				if( ppv && riid == iModelInternals::iid() )
+				{
+					*ppv = static_cast<iModelInternals*>( this );
+					ComObject<iModel>::AddRef();
+					return S_OK;
+				}
+				return ComObject<iModel>::QueryInterface( riid, ppv );
+			}
+			uint32_t AddRef() override { return ComObject<iModel>::AddRef(); }
+			uint32_t Release() override { return ComObject<iModel>::Release(); }
+			const std::shared_ptr<LoadedModel>& loaded() const override { return model; }
 			HRESULT createContext( iContext** pp ) override { return createContextImpl( model, this, pp ); }
 			HRESULT tokenize( const char* text, pfnDecodedTokens pfn, void* pv ) override
 			{
@@ -1116,6 +900,99 @@ WHISPER_EXPORT int32_t whisperc_tokenize( void* model, const char* text, int32_t
 	return FAILED( hr ) ? hr : sink.n;
 }
 WHISPER_EXPORT int32_t whisperc_timings_print( void* ctx ) { return ( (iContext*)ctx )->timingsPrint(); }
+
+// ---- the lock-step batch runner (Whisper::createBatchRunner / iBatchRunner::run) for FFI callers ----
+namespace
+{
+	// a caller's PCM as an iAudioBuffer without a copy; the memory stays the caller's for the duration of the call
+	class PcmView : public Whisper::ComObject<Whisper::iAudioBuffer>
+	{
+		const float* const pcm;
+		const uint32_t n;
+	public:
+		PcmView( const float* p, uint32_t count ) : pcm( p ), n( count ) {}
+		uint32_t countSamples() const override { return n; }
+		const float* getPcmMono() const override { return n ? pcm : nullptr; }
+		const float* getPcmStereo() const override { return nullptr; }
+		HRESULT getTime( int64_t& rdi ) const override { rdi = 0; return S_OK; }
+	};
+}
+WHISPER_EXPORT int32_t whisperc_batch_create( void* model, uint32_t maxSlots, uint32_t groups, uint32_t greedyChunk, uint32_t flags, void** runnerOut )
+{
+	if( !model || !runnerOut ) return E_POINTER;
+	const sBatchSetup setup{ maxSlots, groups, greedyChunk, flags };
+	iBatchRunner* r = nullptr;
+	const HRESULT hr = createBatchRunner( (iModel*)model, &setup, &r );
+	*runnerOut = r;
+	return hr;
+}
+WHISPER_EXPORT int32_t whisperc_batch_run( void* runner, uint32_t count, const float* const* pcm, const uint32_t* nSamples, const int64_t* firstSample,
+	const int64_t* countSamples, const char* language, uint32_t flags, int maxTokens, const int32_t* promptTokens, int nPrompt, int nMaxTextCtx,
+	void** resultsOut, int32_t* perStream )
+{
+	if( !runner || !resultsOut || ( count && ( !pcm || !nSamples ) ) ) return E_POINTER;
+	sFullParams p;
+	memset( &p, 0, sizeof( p ) );
+	p.strategy = eSamplingStrategy::Greedy;
+	p.cpuThreads = 4;
+	p.n_max_text_ctx = 16384;
+	p.thold_pt = p.thold_ptsum = 0.01f;
+	p.beam_search.n_past = p.beam_search.beam_width = p.beam_search.n_best = -1;
+	p.flags = (eFullParamsFlags)flags;
+	p.language = makeLanguageKey( language ? language : "en" );
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	// one view per distinct buffer: the chunks of a recording share it
+	std::map<std::pair<const float*, uint32_t>, PcmView*> views;
+	std::vector<sBatchStream> streams( count );
+	for( uint32_t i = 0; i < count; i++ )
+	{
+		PcmView*& v = views[ { pcm[ i ], nSamples[ i ] } ];
+		if( !v ) v = new PcmView( pcm[ i ], nSamples[ i ] );
+		streams[ i ] = sBatchStream{ v, firstSample ? firstSample[ i ] : 0, countSamples ? countSamples[ i ] : 0, nullptr };
+	}
+	std::vector<iTranscribeResult*> res( count, nullptr );
+	static_assert( sizeof( HRESULT ) == sizeof( int32_t ), "HRESULT" );
+	const HRESULT hr = ( (iBatchRunner*)runner )->run( p, streams.data(), count, res.data(), perStream );
+	for( uint32_t i = 0; i < count; i++ ) resultsOut[ i ] = res[ i ];
+	for( auto& kv : views ) kv.second->Release();
+	return hr;
+}
+WHISPER_EXPORT int32_t whisperc_tr_counts( void* result, uint32_t* segments, uint32_t* tokens )
+{
+	if( !result || !segments || !tokens ) return E_POINTER;
+	sTranscribeLength len;
+	( (iTranscribeResult*)result )->getSize( len );
+	*segments = len.countSegments;
+	*tokens = len.countTokens;
+	return S_OK;
+}
+WHISPER_EXPORT int32_t whisperc_tr_segment( void* result, uint32_t index, uint64_t* t0, uint64_t* t1, uint32_t* firstToken, uint32_t* countTokens, char* text, uint32_t textCap )
+{
+	if( !result ) return E_POINTER;
+	iTranscribeResult* r = (iTranscribeResult*)result;
+	sTranscribeLength len;
+	r->getSize( len );
+	if( index >= len.countSegments ) return E_BOUNDS;
+	const sSegment& s = r->getSegments()[ index ];
+	*t0 = s.time.begin.ticks; *t1 = s.time.end.ticks; *firstToken = s.firstToken; *countTokens = s.countTokens;
+	if( text && textCap ) snprintf( text, textCap, "%s", s.text ? s.text : "" );
+	return S_OK;
+}
+WHISPER_EXPORT int32_t whisperc_tr_token( void* result, uint32_t index, int32_t* id, float* p, float* pt, float* ptsum, uint64_t* t0, uint64_t* t1, float* vlen )
+{
+	if( !result ) return E_POINTER;
+	iTranscribeResult* r = (iTranscribeResult*)result;
+	sTranscribeLength len;
+	r->getSize( len );
+	if( index >= len.countTokens ) return E_BOUNDS;
+	const sToken& t = r->getTokens()[ index ];
+	*id = t.id; *p = t.probability; *pt = t.probabilityTimestamp; *ptsum = t.ptsum;
+	*t0 = t.time.begin.ticks; *t1 = t.time.end.ticks; *vlen = t.vlen;
+	return S_OK;
+}
 // Host-only post-processing of token data into token times, on its own (no device): what runFull does per segment under the
 // TokenTimestamps flag. Segments are processed in order (the anchors carry state from one to the next).
 WHISPER_EXPORT int32_t whisperc_debug_token_timestamps( const char* modelPath, const float* pcm, uint64_t nSamples, int32_t nSegments,
