@@ -24,6 +24,8 @@ Objects next to the contract fields:
   cpu_baseline  the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample, same run
   parity        ggml-medium shape, window 0: the measured (FP32 P.V) GPU path against the reference CPU path -- cross-KV,
                 logits of the prompt and of teacher-forced greedy steps, top-1 agreement
+  through_boundary  the SAME workload driven by the plain C++ host code: libWhisper.so createBatchRunner / iBatchRunner::run (lock-step
+                scheduler, the reference's host loop per stream) on a scripted model -- what a caller of the drop-in library gets
   single_stream the SAME clip through the drop-in boundary, sequentially: libWhisper.so iContext::runFull with prompt
                 carry-over on a scripted medium-shape model (7 windows x 52 steps) -- the like-for-like figure against the
                 reference's published single-clip number (`vs_baseline` lives here; `roofline_frac` = its byte / FLOP floor over
@@ -535,6 +537,62 @@ def single_stream(model_kind, n_threads_multi=4):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the batched pipeline THROUGH the drop-in boundary: libWhisper.so createBatchRunner / iBatchRunner::run (plain C++ scheduler)
+# ----------------------------------------------------------------------------------------------------------------------
+def through_boundary(model_kind, steps, C, inflight, B=7):
+    """The headline's workload driven by the C++ host code instead of this script: `steps` passes over the 198.762 s clip, every pass
+    declared as 7 independent 30 s streams (sBatchStream::firstSample / countSamples), all of them handed to ONE iBatchRunner::run call.
+    The runner keeps `inflight` lock-step groups in flight and applies the reference's host loop to every stream (stop rules on the
+    sampled tokens, segments, timestamps) -- so the model is scripted to transcribe 49 text tokens between two timestamps and EOT, the
+    reference's observed ~51 steps per window. Timed: the run() call, PCM in host memory to transcripts in host memory."""
+    import tempfile
+    from whisper_amd import api, ggml_format as gf
+    hp = gf.hparams_for(model_kind)
+    sp = gf.special_tokens(hp)
+    script = [sp["beg"]] + [1000 + i for i in range(49)] + [sp["beg"] + 1500, sp["eot"]]
+    n_prompt = 3 if hp.is_multilingual else 1
+    model = gf.scripted_model(script, n_prompt, kind=model_kind, seed=7)
+    n_clip = int(CLIP_SECONDS * 16000)
+    clips = [np.ascontiguousarray(synth_pcm(B, seed=100 + j).reshape(-1)[:n_clip]) for j in range(min(steps, 4))]
+    streams = []
+    for j in range(steps):
+        pcm = clips[j % len(clips)]
+        for k in range(B):
+            first = k * WINDOW_SAMPLES
+            if first < n_clip:
+                streams.append((pcm, first, min(WINDOW_SAMPLES, n_clip - first)))
+    sizes = plan_batches(steps, C, inflight)
+    slots = min(128, max(sizes) * B)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "scripted.bin")
+        gf.write_model(path, model)
+        del model
+        m = api.Model(path)
+        runner = m.create_batch_runner(max_slots=slots, groups=inflight)
+        runner.run(streams, flags=api.NO_CONTEXT, want_results=False)            # warm-up: contexts, graph capture
+        best, out = 1e9, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            hr, out, per = runner.run(streams, flags=api.NO_CONTEXT)
+            dt = time.perf_counter() - t0
+            # the conversion of the result objects into Python dicts (ctypes, ~35 k calls) is this script's, not the library's: timed apart
+            t_run = runner.last_run_seconds
+            best = min(best, t_run)
+        n_tok = sum(len(s["tokens"]) for r in out for s in r)
+        n_seg = sum(len(r) for r in out)
+        ok = all(p == 0 for p in per) and all(len(r) >= 1 for r in out)
+        res = {"value": round(steps * CLIP_SECONDS / best, 2), "unit": "audio-seconds/sec", "seconds": round(best, 4), "ms_per_step": round(1e3 * best / steps, 3),
+               "hr": hr, "streams": len(streams), "slots_per_group": slots, "groups": inflight, "segments": n_seg, "tokens_transcribed": n_tok,
+               "all_streams_ok": bool(ok), "seconds_with_python_result_conversion": round(dt, 4),
+               "api": "libWhisper.so: loadModel -> createBatchRunner( { maxSlots %d, groups %d } ) -> iBatchRunner::run( %d sBatchStream = %d clip passes x %d chunks "
+                      "of 30 s ) -> iTranscribeResult per stream; plain C++ scheduler (whisper_amd/host/batchScheduler.cpp): the reference's host loop per "
+                      "stream, lock-step rounds, greedy chunks of 4 steps; scripted ggml-%s-shape model (51 samples per window)" % (slots, inflight, len(streams), steps, B, model_kind)}
+        runner.close()
+        m.close()
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # BASELINE configs 3 / 4: N x 30 s synthetic-mel chunks, sharded over the ranks (strong scaling), optional hypotheses
 # ----------------------------------------------------------------------------------------------------------------------
 def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_steps, t_bcast):
@@ -634,6 +692,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the large_v2 sub-object of the default line")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the through_boundary sub-object (the workload through libWhisper.so's batch runner)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in a dry run)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device for this rank (default LOCAL_RANK)")
     args = ap.parse_args()
@@ -741,7 +800,14 @@ def main():
         s[0].close()
     del m
 
-    single = large = None
+    single = large = boundary = None
+    if rank == 0 and world == 1 and args.workload == "clip" and not args.no_boundary and args.model in ("medium", "large-v2"):
+        log("the same workload through libWhisper.so (createBatchRunner) ...")
+        try:
+            boundary = through_boundary(args.model, args.steps, C, args.inflight, B)
+            log("through the boundary: %s audio-s/s" % boundary["value"])
+        except Exception as e:
+            boundary = {"error": str(e)[:300]}
     if rank == 0 and world == 1 and args.workload == "clip":
         if not args.no_single_stream and args.model in ("medium", "large-v2"):
             log("single stream through libWhisper.so ...")
@@ -799,6 +865,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
+            "through_boundary": boundary,
             "single_stream": single,
             "large_v2": large,
             "kernels": kernels,

@@ -867,3 +867,25 @@ def test_ragged_prompts_equal_each_sequence_alone(hip_tiny, golden, tiny_model, 
     b_, _ = run([kinds[1]] * batch, False)
     assert all(np.array_equal(a[k], b_[k]) for k in a)
     ctx.close()
+
+
+def test_encode_windows_equals_encode(hip_tiny, golden):
+    """wh_encode_windows: every window of the batch from its OWN spectrogram (length, offset) -- what the batch scheduler feeds the
+    encoder with -- fills the cross-attention caches exactly as wh_encode does for that spectrogram alone; a null window is zeros."""
+    rng = np.random.default_rng(8)
+    mel_a = torch.from_numpy(golden["mel"]).cuda()                                         # [80][1100]
+    mel_b = torch.from_numpy(rng.uniform(-1, 1, (80, 4321)).astype(np.float32)).cuda()
+    ctx = binding.HipContext(hip_tiny, 4)
+    one = binding.HipContext(hip_tiny, 1)
+    want = []
+    for mel, off in ((mel_a, 0), (mel_b, 2000), (mel_a, 700)):
+        one.encode(mel, offsets=[off])
+        want.append((one.debug_read("cross-k", 1)[0].copy(), one.debug_read("cross-v", 3)[0].copy()))
+    one.encode(torch.zeros((80, 3000), device="cuda"))
+    want.append((one.debug_read("cross-k", 1)[0].copy(), one.debug_read("cross-v", 3)[0].copy()))
+    ctx.encode_windows([(mel_a, 0), (mel_b, 2000), (mel_a, 700), (None, 0)])
+    k, v = ctx.debug_read("cross-k", 1), ctx.debug_read("cross-v", 3)
+    for b in range(4):
+        assert np.array_equal(k[b], want[b][0]) and np.array_equal(v[b], want[b][1]), b
+    ctx.close()
+    one.close()

@@ -243,8 +243,11 @@ class BatchRunner:
         pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
         res = (C.c_void_p * n)()
         per = (C.c_int32 * n)()
+        import time
+        t0 = time.perf_counter()
         hr = lib().whisperc_batch_run(self.h, n, ptrs, lens, first, cnt, language.encode(), flags, max_tokens,
                                       pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx, res, per)
+        self.last_run_seconds = time.perf_counter() - t0          # the library call alone (bench.py)
         out = []
         for i in range(n):
             out.append(read_result(res[i]) if (res[i] and want_results) else None)

@@ -123,6 +123,20 @@ def build_abi_callers(force: bool = False):
     return ABI_OUR_BIN
 
 
+BATCH_CALLER_SRC = os.path.join(ROOT, "tests", "abi_caller", "batch_caller.cpp")
+BATCH_CALLER_BIN = os.path.join(LIB_DIR, "batch-caller")
+
+
+def build_batch_caller(force: bool = False):
+    """tests/abi_caller/batch_caller.cpp: runFullBatch with callbacks against K sequential runFull calls (tests/test_batch_api.py)."""
+    if not os.path.exists(BATCH_CALLER_SRC):
+        return None
+    if force or _newer(BATCH_CALLER_BIN, [BATCH_CALLER_SRC, HOST_LIB, os.path.join(ROOT, "include", "whisperApi.h")]):
+        _run(["g++", "-std=c++20", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), BATCH_CALLER_SRC, "-o", BATCH_CALLER_BIN,
+              "-L" + LIB_DIR, "-lWhisper", "-Wl,-rpath,$ORIGIN"])
+    return BATCH_CALLER_BIN
+
+
 def build_all(force: bool = False):
     t = time.time()
     build_hip(force)
@@ -130,6 +144,7 @@ def build_all(force: bool = False):
     build_cli(force)
     build_mgpu(force)
     build_abi_callers(force)
+    build_batch_caller(force)
     print("native build ok in %.1fs" % (time.time() - t), flush=True)
 
 

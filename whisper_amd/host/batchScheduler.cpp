@@ -89,6 +89,49 @@ namespace Whisper
 			HRESULT status = S_OK;
 		};
 
+		// Device buffers of the streams (PCM, spectrograms), recycled: hipFree waits for the whole device, i.e. for the OTHER group's
+		// queued chunk or encoder, so nothing is freed while a run is under way -- a retired stream's buffers serve the next stream.
+		class BufferPool
+		{
+			struct Buf { void* dev; int64_t bytes; };
+			std::vector<Buf> idle;
+			std::map<void*, int64_t> sizes;
+		public:
+			HRESULT acquire( int64_t bytes, void*& dev )
+			{
+				int best = -1;
+				for( int i = 0; i < (int)idle.size(); i++ )
+					if( idle[ i ].bytes >= bytes && ( best < 0 || idle[ i ].bytes < idle[ best ].bytes ) ) best = i;
+				if( best >= 0 && idle[ best ].bytes <= 2 * bytes + 65536 )
+				{
+					dev = idle[ best ].dev;
+					idle.erase( idle.begin() + best );
+					return S_OK;
+				}
+				CHECK_WH( wh_buffer_alloc( bytes, &dev ) );
+				sizes[ dev ] = bytes;
+				return S_OK;
+			}
+			void release( void* dev )
+			{
+				if( dev ) idle.push_back( Buf{ dev, sizes[ dev ] } );
+			}
+			// only with the device idle (the runner's destructor)
+			void freeAll()
+			{
+				for( auto& kv : sizes ) wh_buffer_free( kv.first );
+				sizes.clear();
+				idle.clear();
+			}
+		};
+		// What the groups of a runner share: the pool and a one-window context whose stream carries the uploads and spectrograms of
+		// newly admitted streams, so that admission waits for its own copies only -- not for a group's queued decode work.
+		struct Shared
+		{
+			wh_context* loader = nullptr;
+			BufferPool pool;
+		};
+
 		struct Group
 		{
 			wh_context* gpu = nullptr;
@@ -112,7 +155,9 @@ namespace Whisper
 			iTranscribeResult** const results;
 			HRESULT* const perStream;
 			std::vector<Group>& groups;
+			Shared& shared;
 			const int chunk, lookahead;
+			bool loaderBusy = false;
 			std::deque<uint32_t> pending;
 			HRESULT firstFailure = S_OK;
 
@@ -126,9 +171,8 @@ namespace Whisper
 			{
 				Stream* s = g.slot[ b ];
 				g.slot[ b ] = nullptr;
-				wh_context_bind( g.gpu );
-				if( s->melDev ) wh_buffer_free( s->melDev );
-				if( s->pcmDev ) wh_buffer_free( s->pcmDev );
+				shared.pool.release( s->melDev );
+				shared.pool.release( s->pcmDev );
 				if( perStream ) perStream[ s->index ] = s->status;
 				if( SUCCEEDED( s->status ) )
 				{
@@ -173,19 +217,15 @@ namespace Whisper
 					HRESULT hr = S_OK;
 					if( s->melLen > 0 )
 					{
+						// enqueued on the loader's stream; startRound waits for it once, after the last admission of the round
 						int64_t got = 0;
-						if( 0 != wh_context_bind( g.gpu ) || 0 != wh_buffer_alloc( s->nSamples * 4, &s->pcmDev ) ||
-							0 != wh_buffer_alloc( s->melLen * model->hp.n_mels * 4, &s->melDev ) ||
-							0 != wh_buffer_upload( g.gpu, s->pcmDev, s->pcm, s->nSamples * 4 ) ||
-							0 != wh_mel_spectrogram( g.gpu, (const float*)s->pcmDev, s->nSamples, (float*)s->melDev, &got ) )
+						wh_context_bind( shared.loader );
+						hr = shared.pool.acquire( s->nSamples * 4, s->pcmDev );
+						if( SUCCEEDED( hr ) ) hr = shared.pool.acquire( s->melLen * model->hp.n_mels * 4, s->melDev );
+						if( SUCCEEDED( hr ) && ( 0 != wh_buffer_upload_async( shared.loader, s->pcmDev, s->pcm, s->nSamples * 4 ) ||
+							0 != wh_mel_spectrogram( shared.loader, (const float*)s->pcmDev, s->nSamples, (float*)s->melDev, &got ) ) )
 							hr = hrFromStatus( -1, "runFullBatch: stream admission" );
-						else
-						{
-							// the PCM is needed on the device for the spectrogram only
-							wh_context_synchronize( g.gpu );
-							wh_buffer_free( s->pcmDev );
-							s->pcmDev = nullptr;
-						}
+						loaderBusy = true;
 					}
 					if( SUCCEEDED( hr ) )
 					{
@@ -231,6 +271,11 @@ namespace Whisper
 						}
 						retire( g, b );
 					}
+				}
+				if( loaderBusy )
+				{
+					CHECK_WH( wh_context_synchronize( shared.loader ) );
+					loaderBusy = false;
 				}
 				if( !any )
 				{
@@ -331,8 +376,8 @@ namespace Whisper
 
 		public:
 			Scheduler( const std::shared_ptr<LoadedModel>& m, iModel* o, const sFullParams& p, const sBatchStream* d, uint32_t n, iTranscribeResult** r, HRESULT* per,
-				std::vector<Group>& grp, int chunk_, int lookahead_ )
-				: model( m ), owner( o ), common( p ), descs( d ), count( n ), results( r ), perStream( per ), groups( grp ), chunk( chunk_ ), lookahead( lookahead_ ) {}
+				std::vector<Group>& grp, Shared& sh, int chunk_, int lookahead_ )
+				: model( m ), owner( o ), common( p ), descs( d ), count( n ), results( r ), perStream( per ), groups( grp ), shared( sh ), chunk( chunk_ ), lookahead( lookahead_ ) {}
 			~Scheduler()
 			{
 				// a failure left streams in their slots: their buffers go, the device work they queued is awaited
@@ -347,6 +392,7 @@ namespace Whisper
 					if( g.gpu ) wh_context_synchronize( g.gpu );
 					g.phase = Group::Idle;
 				}
+				if( shared.loader ) wh_context_synchronize( shared.loader );
 			}
 			HRESULT run( int slots, int nGroups )
 			{
@@ -402,6 +448,7 @@ namespace Whisper
 			uint32_t maxSlots = 64, nGroups = 2;
 			int chunk = 4, lookahead = 0;
 			std::vector<Group> groups;
+			Shared shared;
 		public:
 			BatchRunner( const std::shared_ptr<LoadedModel>& m, iModel* o, const sBatchSetup* setup ) : model( m ), owner( o )
 			{
@@ -421,11 +468,15 @@ namespace Whisper
 			~BatchRunner() override
 			{
 				for( Group& g : groups )
-					if( g.gpu )
-					{
-						wh_context_synchronize( g.gpu );
-						wh_context_destroy( g.gpu );
-					}
+					if( g.gpu ) wh_context_synchronize( g.gpu );
+				if( shared.loader )
+				{
+					wh_context_synchronize( shared.loader );
+					shared.pool.freeAll();
+					wh_context_destroy( shared.loader );
+				}
+				for( Group& g : groups )
+					if( g.gpu ) wh_context_destroy( g.gpu );
 				owner->Release();
 			}
 			HRESULT run( const sFullParams& params, const sBatchStream* streams, uint32_t count, iTranscribeResult** results, HRESULT* perStream ) override
@@ -441,7 +492,8 @@ namespace Whisper
 					CHECK_WH( wh_context_create( model->gpu, (int)maxSlots, nullptr, &g.gpu ) );
 					groups.push_back( std::move( g ) );
 				}
-				Scheduler s( model, owner, params, streams, count, results, perStream, groups, chunk, lookahead );
+				if( !shared.loader ) CHECK_WH( wh_context_create( model->gpu, 1, nullptr, &shared.loader ) );
+				Scheduler s( model, owner, params, streams, count, results, perStream, groups, shared, chunk, lookahead );
 				const HRESULT hr = s.run( (int)slots, (int)useGroups );
 				if( FAILED( hr ) ) logError( "runFullBatch: failed, HRESULT 0x%08x", (unsigned)hr );
 				return hr;
