@@ -29,7 +29,8 @@ typedef enum wh_status
 	WH_E_HIP = -3,			/* a HIP runtime call failed; see wh_last_error() */
 	WH_E_NOT_READY = -4,	/* model not finalized / encode not run before decode */
 	WH_E_NO_DEVICE = -5,
-	WH_E_BOUNDS = -6
+	WH_E_BOUNDS = -6,
+	WH_E_TIMEOUT = -7		/* a collective's deadline passed: a rank did not arrive (wh_comm_create_timeout, wh_comm_set_timeout) */
 } wh_status;
 
 WH_API const char* wh_last_error( void );
@@ -88,6 +89,15 @@ WH_API int wh_comm_info( const wh_comm* comm, int* rank, int* worldSize );
 WH_API int wh_model_broadcast( wh_model* m, wh_comm* comm, int root, double* secondsOut );
 /* All ranks: blocks until every rank has arrived (a 4-byte all-reduce on the communicator's stream). */
 WH_API int wh_comm_barrier( wh_comm* comm );
+/* RCCL has no deadlines: a rank that died leaves its siblings inside ncclCommInitRank / a collective for ever. With a timeout the
+ * rendezvous (wh_comm_create_timeout) and every later collective of the communicator (wh_comm_set_timeout; barrier, broadcasts) return
+ * WH_E_TIMEOUT after `seconds` instead; the caller is expected to give the job up (whisper-mgpu exits, its parent ends the other ranks).
+ * 0 = wait for ever (wh_comm_create). */
+WH_API int wh_comm_create_timeout( const void* id128, int rank, int worldSize, double timeoutSeconds, wh_comm** out );
+WH_API int wh_comm_set_timeout( wh_comm* comm, double seconds );
+/* Four bytes from `root` to every rank: how a root that failed BEFORE a collective (a model file it could not read) tells the ranks
+ * that are about to enter it -- failure has to be collective too. */
+WH_API int wh_comm_broadcast_i32( wh_comm* comm, int root, int32_t* value );
 
 /* ---- context (replaces DirectCompute::WhisperContext, Whisper/Whisper/WhisperContext.h:20-140) ----
  * One context owns activations, the FP16 self- and cross-attention KV caches (KeyValueBuffers.h:7-53) for up to

@@ -132,6 +132,36 @@ def test_mgpu_harness_arguments():
     assert "Whisper::loadModelShared" in syms
 
 
+def test_mgpu_harness_ends_the_job_when_a_rank_dies_or_hangs(tmp_path):
+    """CPU: no rank may hang the node. WHISPER_MGPU_TEST_FAULT makes a rank exit with a code, or sleep for ever, before it touches a
+    device: the parent reaps whichever child ends first, ends the others (SIGTERM, SIGKILL) and returns non-zero well inside the
+    deadline; with every rank stuck the job's own deadline ends it. (The collectives' deadlines -- wh_comm_create_timeout,
+    wh_comm_set_timeout -- are exported and used by the harness; they need GPUs to run.)"""
+    import time
+    if not os.path.exists(build.MGPU_BIN):
+        build.build_all()
+    args = [build.MGPU_BIN, "-m", str(tmp_path / "none.bin"), "-f", str(tmp_path / "none.wav"), "-o", str(tmp_path / "t.txt")]
+    # rank 1 dies at once, rank 0 and 2 hang: the parent must not wait for them
+    t0 = time.time()
+    r = subprocess.run(args + ["-n", "3", "-timeout", "60"], env=dict(os.environ, WHISPER_MGPU_TEST_FAULT="1:exit", HIP_VISIBLE_DEVICES=""),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and time.time() - t0 < 20, r.stderr.decode()[-500:]
+    assert b"ending the other ranks" in r.stderr
+    # every rank stuck: the job's deadline (4 x -timeout) ends them
+    t0 = time.time()
+    r = subprocess.run(args + ["-n", "2", "-timeout", "0.5"], env=dict(os.environ, WHISPER_MGPU_TEST_FAULT="all:hang"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and 1.5 < time.time() - t0 < 20, r.stderr.decode()[-500:]
+    assert b"did not finish within" in r.stderr
+    assert not any(f.startswith("t.txt") for f in os.listdir(tmp_path))
+    # under an external launcher every rank is its own process: the id file must be common (-id) or derivable (MASTER_PORT)
+    r = subprocess.run(args, env=dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"-id" in r.stderr
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_LIB], stdout=subprocess.PIPE, text=True).stdout
+    for name in ("wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32"):
+        assert (" T " + name) in syms, name
+
+
 @pytest.mark.gpu
 def test_mgpu_harness_one_rank_matches_the_cli(exe, tmp_path):
     """One rank end to end: RCCL communicator of size 1, loadModelShared (file -> arena -> ncclBroadcast in place), the

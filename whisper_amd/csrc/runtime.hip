@@ -18,6 +18,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <memory>
 #include <cstdlib>
 #include <set>
 #include <string>
@@ -836,7 +838,38 @@ struct wh_comm
 	int rank = 0, world = 1;
 	hipStream_t stream = nullptr;
 	int* scratch = nullptr;
+	double timeout = 0.0;	   // seconds a collective may take before the call gives up (0 = wait for ever)
 };
+
+namespace
+{
+	// Waits for the communicator's stream like hipStreamSynchronize, but not for ever: a rank that never arrives at a collective
+	// must turn into an error on the ranks that did, not into a hung node (RCCL itself has no deadline).
+	int waitComm( wh_comm* c, const char* what )
+	{
+		if( c->timeout <= 0.0 )
+		{
+			WH_HIP( hipStreamSynchronize( c->stream ) );
+			return 0;
+		}
+		const auto t0 = std::chrono::steady_clock::now();
+		for( long spins = 0;; spins++ )
+		{
+			const hipError_t e = hipStreamQuery( c->stream );
+			if( e == hipSuccess ) return 0;
+			if( e != hipErrorNotReady ) return hipFail( e, what, __FILE__, __LINE__ );
+			(void)hipGetLastError();
+			if( std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count() > c->timeout )
+			{
+				char buf[ 160 ];
+				snprintf( buf, sizeof( buf ), "%s: rank %d of %d gave up after %.0f s (a rank did not arrive)", what, c->rank, c->world, c->timeout );
+				setError( buf );
+				return WH_E_TIMEOUT;
+			}
+			if( spins > 64 ) std::this_thread::sleep_for( std::chrono::microseconds( 200 ) );
+		}
+	}
+}
 
 int wh_comm_unique_id( void* id128 )
 {
@@ -849,14 +882,51 @@ int wh_comm_unique_id( void* id128 )
 
 int wh_comm_create( const void* id128, int rank, int worldSize, wh_comm** out )
 {
+	return wh_comm_create_timeout( id128, rank, worldSize, 0.0, out );
+}
+
+int wh_comm_create_timeout( const void* id128, int rank, int worldSize, double timeoutSeconds, wh_comm** out )
+{
 	if( !id128 || !out || worldSize <= 0 || rank < 0 || rank >= worldSize ) { setError( "comm_create: bad argument" ); return WH_E_INVALIDARG; }
 	RcclApi* r = rccl();
 	if( !r->commInitRank || !r->broadcast || !r->commDestroy ) { setError( "comm_create: " + r->why ); return WH_E_NO_DEVICE; }
 	wh_comm* c = new wh_comm();
 	c->rank = rank; c->world = worldSize;
+	c->timeout = timeoutSeconds > 0.0 ? timeoutSeconds : 0.0;
 	ncclUniqueIdBlob id;
 	memcpy( id.internal, id128, WH_COMM_ID_BYTES );
-	const int rc = r->commInitRank( &c->comm, worldSize, id, rank );		// uses the calling thread's current device
+	int rc = 0;
+	if( c->timeout <= 0.0 )
+		rc = r->commInitRank( &c->comm, worldSize, id, rank );		// uses the calling thread's current device
+	else
+	{
+		// ncclCommInitRank blocks until every rank has called it. With a deadline it runs on a helper thread (bound to the caller's
+		// device); when the deadline passes the call returns WH_E_TIMEOUT and the helper is left behind -- the process is expected to
+		// exit (whisper-mgpu does), nothing else can be done with a rendezvous that never completes.
+		int device = 0;
+		WH_HIP( hipGetDevice( &device ) );
+		struct Rendezvous { std::mutex mx; std::condition_variable cv; bool done = false; int rc = 0; void* comm = nullptr; };
+		auto rv = std::make_shared<Rendezvous>();
+		std::thread( [ rv, r, worldSize, id, rank, device ]() {
+			(void)hipSetDevice( device );
+			void* comm = nullptr;
+			const int rcInit = r->commInitRank( &comm, worldSize, id, rank );
+			std::lock_guard<std::mutex> lk( rv->mx );
+			rv->rc = rcInit; rv->comm = comm; rv->done = true;
+			rv->cv.notify_all();
+		} ).detach();
+		std::unique_lock<std::mutex> lk( rv->mx );
+		if( !rv->cv.wait_for( lk, std::chrono::duration<double>( c->timeout ), [ & ]() { return rv->done; } ) )
+		{
+			char buf[ 160 ];
+			snprintf( buf, sizeof( buf ), "ncclCommInitRank: rank %d of %d gave up after %.0f s (a rank did not arrive)", rank, worldSize, c->timeout );
+			setError( buf );
+			delete c;
+			return WH_E_TIMEOUT;
+		}
+		rc = rv->rc;
+		c->comm = rv->comm;
+	}
 	if( rc != 0 ) { delete c; return rcclFail( rc, "ncclCommInitRank" ); }
 	hipError_t e = hipStreamCreateWithFlags( &c->stream, hipStreamNonBlocking );
 	if( e == hipSuccess ) e = hipMalloc( (void**)&c->scratch, 8 );
@@ -892,7 +962,27 @@ int wh_comm_barrier( wh_comm* c )
 	if( !r->allReduce ) { setError( "comm_barrier: " + r->why ); return WH_E_NO_DEVICE; }
 	const int rc = r->allReduce( c->scratch, c->scratch + 1, 1, 2 /* ncclInt32 */, 0 /* ncclSum */, c->comm, c->stream );
 	if( rc != 0 ) return rcclFail( rc, "ncclAllReduce" );
-	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return waitComm( c, "comm_barrier" );
+}
+
+int wh_comm_set_timeout( wh_comm* c, double seconds )
+{
+	if( !c ) { setError( "comm_set_timeout: null communicator" ); return WH_E_INVALIDARG; }
+	c->timeout = seconds > 0.0 ? seconds : 0.0;
+	return 0;
+}
+
+int wh_comm_broadcast_i32( wh_comm* c, int root, int32_t* value )
+{
+	if( !c || !value || root < 0 || root >= c->world ) { setError( "comm_broadcast_i32: bad argument" ); return WH_E_INVALIDARG; }
+	RcclApi* r = rccl();
+	if( !r->broadcast ) { setError( "comm_broadcast_i32: " + r->why ); return WH_E_NO_DEVICE; }
+	if( c->rank == root ) WH_HIP( hipMemcpyAsync( c->scratch, value, 4, hipMemcpyHostToDevice, c->stream ) );
+	const int rc = r->broadcast( c->scratch, c->scratch, 4, 0 /* ncclInt8 */, root, c->comm, c->stream );
+	if( rc != 0 ) return rcclFail( rc, "ncclBroadcast" );
+	WH_CHECK( waitComm( c, "comm_broadcast_i32" ) );
+	WH_HIP( hipMemcpy( value, c->scratch, 4, hipMemcpyDeviceToHost ) );
+	WH_HIP( hipMemset( c->scratch, 0, 8 ) );
 	return 0;
 }
 
@@ -907,7 +997,7 @@ int wh_model_broadcast( wh_model* m, wh_comm* c, int root, double* secondsOut )
 	const auto t0 = std::chrono::steady_clock::now();
 	const int rc = r->broadcast( m->arena, m->arena, (size_t)bytes, 0 /* ncclInt8 */, root, c->comm, c->stream );
 	if( rc != 0 ) return rcclFail( rc, "ncclBroadcast" );
-	WH_HIP( hipStreamSynchronize( c->stream ) );
+	WH_CHECK( waitComm( c, "model_broadcast" ) );
 	if( secondsOut ) *secondsOut = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
 	if( c->rank != root )
 	{

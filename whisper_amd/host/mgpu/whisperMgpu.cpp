@@ -1,19 +1,30 @@
 // One process per GPU over the C ABI, no Python and no torch: the multi-GPU harness of the drop-in library.
 //
-//   whisper-mgpu -n 8 -m ggml-medium.bin -f recording.wav [-l en] [-o out.txt]
+//   whisper-mgpu -n 8 -m ggml-medium.bin -f recording.wav [-l en] [-o out.txt] [-timeout 300] [-slots 64] [-id file]
 //
 // The parent forks N ranks (or, when RANK / WORLD_SIZE / LOCAL_RANK are set by an external launcher, runs as that rank).
-// Rank r binds GPU LOCAL_RANK % devices (sModelSetup.adapter); rank 0 creates the RCCL id and publishes it through a file
-// (-id, default a temp file); every rank builds its communicator, the model is read by rank 0 only and broadcast over xGMI
-// (loadModelShared, Whisper/Whisper/ModelImpl.cpp:40-60 is the reference's single-GPU counterpart), and the recording's
-// 30 s windows are split into contiguous ranges, one per rank (eFullParamsFlags::NoContext: windows are independent, the
-// only exchange is the broadcast). Each rank writes "<out>.rank<r>"; the parent concatenates them in rank order.
-// The same sharding as whisper_amd/distributed.py (shard_range) and bench.py --gpus N.
+// Rank r binds GPU LOCAL_RANK % devices (sModelSetup.adapter); rank 0 creates the RCCL id and publishes it through a file;
+// every rank builds its communicator, the model is read by rank 0 only and broadcast over xGMI (loadModelShared;
+// Whisper/Whisper/ModelImpl.cpp:40-60 is the reference's single-GPU counterpart), and the recording is cut into independent 30 s
+// chunks (north_star's sharding unit) dealt to the ranks as contiguous ranges -- the only exchange is the broadcast.
+//
+// A chunk is a recording of its own (sBatchStream::firstSample / countSamples: own spectrogram maximum, nothing read past its end,
+// times shifted by its start), and a rank transcribes ITS chunks as one Whisper::runFullBatch call -- lock-step batches on its GPU.
+// So the concatenated transcript does not depend on the number of ranks: N = 8 prints what N = 1 prints. (Round 3 gave each rank one
+// sequential runFull over offset_ms / duration_ms: a rank's last window read past its range and the next rank started mid-utterance.)
+//
+// No rank may hang the node: the rendezvous and every collective carry a deadline (wh_comm_create_timeout / wh_comm_set_timeout), a
+// root that cannot read the model says so to the ranks about to enter the broadcast (loadModelShared), and the parent reaps whichever
+// child ends first -- a non-zero exit or the job's deadline ends the remaining ranks (SIGTERM, then SIGKILL).
+// The same dealing of chunks as whisper_amd/distributed.py (shard_range) and bench.py --gpus N.
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <unistd.h>
+#include <sys/stat.h>
 #include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -26,7 +37,8 @@ namespace
 {
 	struct Args
 	{
-		int ranks = 1;
+		int ranks = 1, slots = 64;
+		double timeout = 300.0;
 		std::string model, wav, lang = "en", out = "transcript.txt", idFile;
 	};
 	std::wstring widen( const std::string& s )
@@ -42,17 +54,36 @@ namespace
 		b = rank * q + ( rank < r ? rank : r );
 		e = b + q + ( rank < r ? 1 : 0 );
 	}
-	bool readFile( const std::string& path, void* dst, size_t n )
+	// the id file of THIS job: present, complete, and not older than this process (a file a previous job left behind is not taken)
+	bool readFreshFile( const std::string& path, void* dst, size_t n, time_t notBefore )
 	{
+		struct stat st;
+		if( 0 != stat( path.c_str(), &st ) || st.st_mtime < notBefore ) return false;
 		FILE* f = fopen( path.c_str(), "rb" );
 		if( !f ) return false;
 		const size_t got = fread( dst, 1, n, f );
 		fclose( f );
 		return got == n;
 	}
+	// WHISPER_MGPU_TEST_FAULT="<rank|all>:<exit|hang>" -- test hook (tests/test_cli.py, no GPU needed): the named rank exits with code 7 or
+	// sleeps for ever before it touches a device, so that the parent's handling of a dead / stuck rank can be exercised anywhere
+	void injectedFault( int rank )
+	{
+		const char* e = getenv( "WHISPER_MGPU_TEST_FAULT" );
+		if( !e ) return;
+		const char* colon = strchr( e, ':' );
+		if( !colon ) return;
+		const bool mine = 0 == strncmp( e, "all", 3 ) || atoi( e ) == rank;
+		if( !mine ) return;
+		if( 0 == strcmp( colon + 1, "exit" ) ) _exit( 7 );
+		if( 0 == strcmp( colon + 1, "hang" ) )
+			while( true ) sleep( 1000 );
+	}
 
 	int runRank( const Args& a, int rank, int world, int localRank )
 	{
+		injectedFault( rank );
+		const time_t started = time( nullptr );
 		const auto t0 = std::chrono::steady_clock::now();
 		auto since = [ & ]() { return std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count(); };
 		const int nDev = wh_device_count();
@@ -65,6 +96,7 @@ namespace
 		const std::string tmp = a.idFile + ".tmp";
 		if( rank == 0 )
 		{
+			unlink( a.idFile.c_str() );	   // whatever an earlier job left under this name
 			if( 0 != wh_comm_unique_id( id ) ) { fprintf( stderr, "[rank 0] %s\n", wh_last_error() ); return 3; }
 			FILE* f = fopen( tmp.c_str(), "wb" );
 			if( !f || fwrite( id, 1, sizeof( id ), f ) != sizeof( id ) ) { fprintf( stderr, "[rank 0] cannot write %s\n", tmp.c_str() ); return 3; }
@@ -73,18 +105,20 @@ namespace
 		}
 		else
 		{
-			int waited = 0;
-			while( !readFile( a.idFile, id, sizeof( id ) ) )
+			while( !readFreshFile( a.idFile, id, sizeof( id ), started - 2 ) )
 			{
-				if( ++waited > 6000 ) { fprintf( stderr, "[rank %d] no communicator id after 60 s\n", rank ); return 3; }
+				if( since() > a.timeout ) { fprintf( stderr, "[rank %d] no communicator id in %s after %.0f s\n", rank, a.idFile.c_str(), a.timeout ); return 3; }
 				std::this_thread::sleep_for( std::chrono::milliseconds( 10 ) );
 			}
 		}
 		wh_comm* comm = nullptr;
-		if( 0 != wh_comm_create( id, rank, world, &comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 3; }
-		fprintf( stderr, "[rank %d/%d] device %d, communicator up after %.2f s\n", rank, world, device, since() );
+		if( 0 != wh_comm_create_timeout( id, rank, world, a.timeout, &comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 3; }
+		int seenRank = -1, seenWorld = -1;
+		wh_comm_info( comm, &seenRank, &seenWorld );
+		fprintf( stderr, "[rank %d/%d] device %d of %d, communicator up after %.2f s (RCCL: rank %d of %d)\n", rank, world, device, nDev, since(), seenRank, seenWorld );
+		if( seenRank != rank || seenWorld != world ) return 3;
 
-		// ---- model: rank 0 reads, everyone receives ----
+		// ---- model: rank 0 reads, everyone receives (a root that cannot read says so before the broadcast: loadModelShared) ----
 		const std::wstring adapter = std::to_wstring( device ) + L":";
 		sModelSetup setup;
 		setup.adapter = adapter.c_str();
@@ -93,39 +127,46 @@ namespace
 		if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] loadModelShared failed 0x%08x\n", rank, (unsigned)hr ); return 4; }
 		fprintf( stderr, "[rank %d] model ready after %.2f s\n", rank, since() );
 
-		// ---- audio: every rank decodes the file (16 kHz PCM is small next to the model), then takes its windows ----
+		// ---- audio: every rank decodes the file (16 kHz PCM is small next to the model), then takes its chunks ----
 		iMediaFoundation* mf = nullptr;
 		iAudioBuffer* audio = nullptr;
 		hr = initMediaFoundation( &mf );
 		if( SUCCEEDED( hr ) ) hr = mf->loadAudioFile( a.wav.c_str(), false, &audio );
 		if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] cannot load %s (0x%08x)\n", rank, a.wav.c_str(), (unsigned)hr ); return 5; }
-		const uint32_t nSamples = audio->countSamples();
-		const int windows = (int)( ( nSamples + 16000 * 30 - 1 ) / ( 16000 * 30 ) );
+		const int64_t nSamples = audio->countSamples();
+		const int64_t chunk = 16000 * 30;
+		const int windows = (int)( ( nSamples + chunk - 1 ) / chunk );
 		int wb = 0, we = 0;
 		shardRange( windows, rank, world, wb, we );
 
-		iContext* ctx = nullptr;
-		hr = model->createContext( &ctx );
-		if( FAILED( hr ) ) return 6;
 		sFullParams p;
-		ctx->fullDefaultParams( eSamplingStrategy::Greedy, &p );
+		memset( &p, 0, sizeof( p ) );
+		p.strategy = eSamplingStrategy::Greedy;
+		p.cpuThreads = 4;
+		p.n_max_text_ctx = 16384;
+		p.thold_pt = p.thold_ptsum = 0.01f;
+		p.beam_search.n_past = p.beam_search.beam_width = p.beam_search.n_best = -1;
 		p.language = findLanguageKeyA( a.lang.c_str() );
 		p.setFlag( eFullParamsFlags::NoContext );
-		p.setFlag( eFullParamsFlags::PrintRealtime, false );
-		p.setFlag( eFullParamsFlags::PrintProgress, false );
-		p.offset_ms = wb * 30000;
-		p.duration_ms = we == windows ? 0 : ( we - wb ) * 30000;	   // 0 = to the end of the recording (the last range is ragged)
-		wh_comm_barrier( comm );
+		std::vector<sBatchStream> streams;
+		for( int w = wb; w < we; w++ )
+			streams.push_back( sBatchStream{ audio, (int64_t)w * chunk, std::min( chunk, nSamples - (int64_t)w * chunk ), nullptr } );
+		iBatchRunner* runner = nullptr;
+		const sBatchSetup bs{ (uint32_t)std::max( 1, std::min( a.slots, 128 ) ), 0, 0, 0 };
+		if( !streams.empty() && FAILED( createBatchRunner( model, &bs, &runner ) ) ) return 6;
+
+		if( 0 != wh_comm_barrier( comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 8; }
 		const double tStart = since();
 		std::string text;
 		int nSeg = 0;
-		if( we > wb )
+		if( !streams.empty() )
 		{
-			hr = ctx->runFull( p, audio );
-			if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] runFull failed 0x%08x\n", rank, (unsigned)hr ); return 7; }
-			iTranscribeResult* res = nullptr;
-			if( SUCCEEDED( ctx->getResults( eResultFlags::Timestamps, &res ) ) && res )
+			std::vector<iTranscribeResult*> results( streams.size(), nullptr );
+			hr = runner->run( p, streams.data(), (uint32_t)streams.size(), results.data(), nullptr );
+			if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] runFullBatch failed 0x%08x\n", rank, (unsigned)hr ); return 7; }
+			for( iTranscribeResult* res : results )
 			{
+				if( !res ) continue;
 				sTranscribeLength len;
 				res->getSize( len );
 				const sSegment* seg = res->getSegments();
@@ -137,28 +178,69 @@ namespace
 					text += seg[ i ].text ? seg[ i ].text : "";
 					text += "\n";
 				}
-				nSeg = (int)len.countSegments;
+				nSeg += (int)len.countSegments;
 				res->Release();
 			}
 		}
 		const double tRun = since() - tStart;
-		wh_comm_barrier( comm );
+		if( 0 != wh_comm_barrier( comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 8; }
 		const double tAll = since() - tStart;
 		FILE* f = fopen( ( a.out + ".rank" + std::to_string( rank ) ).c_str(), "wb" );
 		if( f ) { fwrite( text.data(), 1, text.size(), f ); fclose( f ); }
-		fprintf( stderr, "[rank %d] windows %d..%d of %d: %d segments in %.3f s (%.1f audio-s/s on this rank); all ranks done after %.3f s\n", rank, wb, we, windows,
+		fprintf( stderr, "[rank %d] chunks %d..%d of %d: %d segments in %.3f s (%.1f audio-s/s on this rank); all ranks done after %.3f s\n", rank, wb, we, windows,
 			nSeg, tRun, tRun > 0 ? ( we - wb ) * 30.0 / tRun : 0.0, tAll );
 		if( rank == 0 )
 		{
 			printf( "{\"ranks\": %d, \"windows\": %d, \"seconds\": %.4f, \"audio_seconds_per_sec\": %.2f}\n", world, windows, tAll, windows * 30.0 / tAll );
 			fflush( stdout );	   // the rank leaves through _exit
 		}
-		ctx->Release();
+		if( runner ) runner->Release();
 		audio->Release();
 		mf->Release();
 		model->Release();
 		wh_comm_destroy( comm );
 		return 0;
+	}
+
+	// The parent: whichever child ends first is reaped first. A non-zero exit, a signal or the deadline ends the others.
+	int superviseRanks( const std::vector<pid_t>& kids, double deadlineSeconds )
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		size_t alive = kids.size();
+		int rc = 0;
+		std::chrono::steady_clock::time_point tTerm;
+		auto killAll = [ & ]( int sig ) { for( pid_t k : kids ) kill( k, sig ); };
+		auto giveUp = [ & ]() { rc = 1; tTerm = std::chrono::steady_clock::now(); killAll( SIGTERM ); };
+		while( alive > 0 )
+		{
+			int st = 0;
+			const pid_t done = waitpid( -1, &st, WNOHANG );
+			if( done > 0 )
+			{
+				alive--;
+				const bool ok = WIFEXITED( st ) && WEXITSTATUS( st ) == 0;
+				if( !ok && rc == 0 )
+				{
+					size_t r = 0;
+					while( r < kids.size() && kids[ r ] != done ) r++;
+					if( WIFEXITED( st ) ) fprintf( stderr, "whisper-mgpu: rank %zu exited with code %d; ending the other ranks\n", r, WEXITSTATUS( st ) );
+					else fprintf( stderr, "whisper-mgpu: rank %zu was ended by signal %d; ending the other ranks\n", r, WIFSIGNALED( st ) ? WTERMSIG( st ) : 0 );
+					giveUp();
+				}
+				continue;
+			}
+			if( done < 0 ) break;	   // no children left
+			const double elapsed = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+			if( rc == 0 && deadlineSeconds > 0 && elapsed > deadlineSeconds )
+			{
+				fprintf( stderr, "whisper-mgpu: the job did not finish within %.0f s; ending %zu rank(s)\n", deadlineSeconds, alive );
+				giveUp();
+			}
+			// ranks that ignore SIGTERM (stuck inside the driver) get SIGKILL two seconds later
+			if( rc != 0 && std::chrono::duration<double>( std::chrono::steady_clock::now() - tTerm ).count() > 2.0 ) killAll( SIGKILL );
+			std::this_thread::sleep_for( std::chrono::milliseconds( 20 ) );
+		}
+		return rc;
 	}
 }	// namespace
 
@@ -174,9 +256,11 @@ int main( int argc, char** argv )
 		else if( !strcmp( argv[ i ], "-l" ) ) a.lang = val();
 		else if( !strcmp( argv[ i ], "-o" ) ) a.out = val();
 		else if( !strcmp( argv[ i ], "-id" ) ) a.idFile = val();
+		else if( !strcmp( argv[ i ], "-timeout" ) ) a.timeout = atof( val() );
+		else if( !strcmp( argv[ i ], "-slots" ) ) a.slots = atoi( val() );
 		else if( !strcmp( argv[ i ], "--shard-range" ) )
 		{
-			// test hook (no GPU): the window range rank r of w gets out of n windows, "begin end" -- must equal whisper_amd/distributed.py shard_range
+			// test hook (no GPU): the chunk range rank r of w gets out of n chunks, "begin end" -- must equal whisper_amd/distributed.py shard_range
 			const int n = atoi( val() ), r = atoi( val() ), w = atoi( val() );
 			if( n < 0 || w < 1 || r < 0 || r >= w ) return 1;
 			int b = 0, e = 0;
@@ -184,34 +268,41 @@ int main( int argc, char** argv )
 			printf( "%d %d\n", b, e );
 			return 0;
 		}
-		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-id id-file]\n" ); return 1; }
+		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-timeout seconds] [-slots n] [-id id-file]\n" ); return 1; }
 	}
 	if( a.model.empty() || a.wav.empty() || a.ranks < 1 ) { fprintf( stderr, "whisper-mgpu: -m and -f are required\n" ); return 1; }
-	if( a.idFile.empty() ) a.idFile = "/tmp/whisper-mgpu." + std::to_string( (long)getpid() ) + ".id";
+	if( a.timeout <= 0 ) a.timeout = 300.0;
 
-	// launched by torchrun / mpirun / srun: be the rank the environment names
+	// launched by torchrun / mpirun / srun: be the rank the environment names. Every rank is its own process there, so the id file
+	// cannot be named after a pid: it is -id, or it is derived from the rendezvous the launcher exported.
 	if( const char* wr = getenv( "RANK" ) )
 	{
 		const int world = getenv( "WORLD_SIZE" ) ? atoi( getenv( "WORLD_SIZE" ) ) : 1;
 		const int local = getenv( "LOCAL_RANK" ) ? atoi( getenv( "LOCAL_RANK" ) ) : atoi( wr );
+		if( a.idFile.empty() )
+		{
+			const char* port = getenv( "MASTER_PORT" );
+			if( !port && world > 1 )
+			{
+				fprintf( stderr, "whisper-mgpu: under an external launcher (RANK is set) give every rank the same -id file, or export MASTER_PORT\n" );
+				return 1;
+			}
+			a.idFile = std::string( "/tmp/whisper-mgpu." ) + std::to_string( (long)getuid() ) + "." + ( port ? port : "0" ) + ".id";
+		}
 		return runRank( a, atoi( wr ), world, local );
 	}
+	if( a.idFile.empty() ) a.idFile = "/tmp/whisper-mgpu." + std::to_string( (long)getuid() ) + "." + std::to_string( (long)getpid() ) + ".id";
 	unlink( a.idFile.c_str() );
 	std::vector<pid_t> kids;
 	for( int r = 0; r < a.ranks; r++ )
 	{
 		const pid_t pid = fork();	// before any HIP call: a forked HIP runtime is not usable
 		if( pid == 0 ) _exit( runRank( a, r, a.ranks, r ) );
-		if( pid < 0 ) { perror( "fork" ); return 1; }
+		if( pid < 0 ) { perror( "fork" ); for( pid_t k : kids ) kill( k, SIGKILL ); return 1; }
 		kids.push_back( pid );
 	}
-	int rc = 0;
-	for( pid_t k : kids )
-	{
-		int st = 0;
-		waitpid( k, &st, 0 );
-		if( !WIFEXITED( st ) || WEXITSTATUS( st ) != 0 ) rc = 1;
-	}
+	// the ranks' own collectives give up after -timeout; the job as a whole gets that plus what model loading and decoding may take
+	const int rc = superviseRanks( kids, 4.0 * a.timeout );
 	unlink( a.idFile.c_str() );
 	if( rc == 0 )
 	{
@@ -230,5 +321,7 @@ int main( int argc, char** argv )
 		}
 		if( out ) fclose( out );
 	}
+	else
+		for( int r = 0; r < a.ranks; r++ ) unlink( ( a.out + ".rank" + std::to_string( r ) ).c_str() );
 	return rc;
 }

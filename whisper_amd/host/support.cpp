@@ -352,50 +352,66 @@ namespace Whisper
 		int rank = 0, world = 1;
 		if( comm ) CHECK_WH( wh_comm_info( comm, &rank, &world ) );
 		const bool readsTensors = !comm || rank == root;
-		std::vector<char> payload;
-		while( readsTensors )
+		// Failure has to be collective: a root that cannot read the file must not leave the other ranks inside ncclBroadcast. So the
+		// root reads (and keeps its HRESULT), every rank takes part in a 4-byte status broadcast, and only then the arena travels.
+		auto readTensors = [ & ]() -> HRESULT
 		{
-			int32_t nDims = 0, nameLen = 0, ftype = 0;
-			if( !rd( f, nDims ) ) break;	// clean end of file
-			if( !rd( f, nameLen ) || !rd( f, ftype ) || nDims < 1 || nDims > 3 || nameLen <= 0 || nameLen > 256 ) return E_INVALIDARG;
-			int32_t ne[ 3 ] = { 1, 1, 1 };
-			int64_t count = 1;
-			for( int i = 0; i < nDims; i++ )
+			std::vector<char> payload;
+			while( true )
 			{
-				if( !rd( f, ne[ i ] ) || ne[ i ] <= 0 ) return E_INVALIDARG;
-				count *= ne[ i ];
+				int32_t nDims = 0, nameLen = 0, ftype = 0;
+				if( !rd( f, nDims ) ) break;	// clean end of file
+				if( !rd( f, nameLen ) || !rd( f, ftype ) || nDims < 1 || nDims > 3 || nameLen <= 0 || nameLen > 256 ) return E_INVALIDARG;
+				int32_t ne[ 3 ] = { 1, 1, 1 };
+				int64_t count = 1;
+				for( int i = 0; i < nDims; i++ )
+				{
+					if( !rd( f, ne[ i ] ) || ne[ i ] <= 0 ) return E_INVALIDARG;
+					count *= ne[ i ];
+				}
+				std::string name( (size_t)nameLen, '\0' );
+				f.read( &name[ 0 ], nameLen );
+				const int64_t bytes = count * ( ftype == 0 ? 4 : 2 );
+				if( !f || bytes > fileSize ) return E_INVALIDARG;
+				payload.resize( (size_t)bytes );
+				f.read( payload.data(), bytes );
+				if( !f )
+				{
+					logError( "model file '%s' is truncated inside tensor '%s'", path.c_str(), name.c_str() );
+					return E_INVALIDARG;
+				}
+				CHECK_WH( wh_model_set_tensor( lm->gpu, name.c_str(), nDims, ne, ftype != 0, payload.data() ) );
+				if( callbacks )
+				{
+					if( callbacks->cancel && S_OK != callbacks->cancel( callbacks->pv ) ) return (HRESULT)0x800704C7;	 // ERROR_CANCELLED
+					if( callbacks->progress ) CHECK( callbacks->progress( (double)f.tellg() / (double)fileSize, callbacks->pv ) );
+				}
 			}
-			std::string name( (size_t)nameLen, '\0' );
-			f.read( &name[ 0 ], nameLen );
-			const int64_t bytes = count * ( ftype == 0 ? 4 : 2 );
-			if( !f || bytes > fileSize ) return E_INVALIDARG;
-			payload.resize( (size_t)bytes );
-			f.read( payload.data(), bytes );
-			if( !f )
-			{
-				logError( "model file '%s' is truncated inside tensor '%s'", path.c_str(), name.c_str() );
-				return E_INVALIDARG;
-			}
-			CHECK_WH( wh_model_set_tensor( lm->gpu, name.c_str(), nDims, ne, ftype != 0, payload.data() ) );
-			if( callbacks )
-			{
-				if( callbacks->cancel && S_OK != callbacks->cancel( callbacks->pv ) ) return (HRESULT)0x800704C7;	 // ERROR_CANCELLED
-				if( callbacks->progress ) CHECK( callbacks->progress( (double)f.tellg() / (double)fileSize, callbacks->pv ) );
-			}
-		}
-		if( readsTensors ) CHECK_WH( wh_model_finalize( lm->gpu ) );
+			CHECK_WH( wh_model_finalize( lm->gpu ) );
+			return S_OK;
+		};
+		HRESULT hrRead = readsTensors ? readTensors() : S_OK;
 		if( comm )
 		{
+			int32_t status = (int32_t)hrRead;
+			CHECK_WH( wh_comm_broadcast_i32( comm, root, &status ) );
+			if( rank == root && FAILED( hrRead ) ) return hrRead;
+			if( FAILED( (HRESULT)status ) )
+			{
+				logError( "loadModelShared: rank %d could not read the model (0x%08x); rank %d gives up with it", root, (unsigned)status, rank );
+				return (HRESULT)status;
+			}
 			double seconds = 0;
 			CHECK_WH( wh_model_broadcast( lm->gpu, comm, root, &seconds ) );
-			if( rank == root )
-			{
-				void* dev = nullptr;
-				int64_t bytes = 0;
-				(void)wh_model_arena( lm->gpu, &dev, &bytes );
-				logInfo( "model arena broadcast to %d ranks: %.1f MB in %.3f s (%.1f GB/s)", world, bytes / 1e6, seconds, seconds > 0 ? bytes / 1e9 / seconds : 0.0 );
-			}
+			void* dev = nullptr;
+			int64_t bytes = 0;
+			(void)wh_model_arena( lm->gpu, &dev, &bytes );
+			// every rank reports what it saw: a slow link shows up as one rank's figure
+			logInfo( "rank %d of %d: model arena %s, %.1f MB in %.3f s (%.1f GB/s)", rank, world, rank == root ? "sent" : "received", bytes / 1e6, seconds,
+				seconds > 0 ? bytes / 1e9 / seconds : 0.0 );
 		}
+		else if( FAILED( hrRead ) )
+			return hrRead;
 		out = lm;
 		return S_OK;
 	}
