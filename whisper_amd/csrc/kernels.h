@@ -34,6 +34,8 @@ namespace wh
 		TUNE_DECODE_SMALL = 16777216,	 // single-token steps of up to 4 sequences: the chip-wide launches of decode1.hip (gemvSmall, cross-attention over 8 key ranges)
 		TUNE_DECODE_PREFETCH = 33554432,	 // ... each carrying 256 workgroups that pull the next launch's weights into the L2 of the XCD that will read them
 										 // (measured round 3, medium shape, one sequence: 1216 vs 1129 us per token -- OFF)
+		TUNE_ENC_SERIAL = 134217728,	 // several contexts in flight: their ENCODERS run one at a time (an event chain between the contexts' streams), so that a
+										 // batch's MFMA-bound encoder runs under the latency- and HBM-bound decode chain of its neighbours instead of next to their encoders
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with

@@ -280,6 +280,7 @@ struct wh_context
 	// OTHER contexts (high-priority streams) get their workgroups dispatched first whenever CUs free up
 	hipStream_t encStream = nullptr;
 	hipEvent_t encReady = nullptr, encDone = nullptr;
+	hipEvent_t encGateEv = nullptr;	   // TUNE_ENC_SERIAL: recorded behind this context's encoder; the next context's encoder waits for it
 	int encCus = 0, totalCus = 0;	   // WH_ENC_CUS: CUs of the encoder stream's mask (0 = no spatial split)
 	struct Mark { int endSample; hipEvent_t ev; };
 	std::vector<Mark> marks;   // after each enqueued chunk of samples: an event wh_decode_window_fetch can wait for
@@ -405,6 +406,16 @@ static int profiled( wh_context* c, int kc, double flops, double bytes, F&& laun
 	return rc;
 }
 static std::atomic<int> g_liveContexts{ 0 };
+// TUNE_ENC_SERIAL: the encoders of the contexts of one device form a chain -- an encoder starts when the previous one (of another
+// context) has finished. Stream-ordered (hipStreamWaitEvent), the host never blocks. Two batches started together then run out of
+// phase from the first round on: while one decodes (launch latencies, HBM), the other's encoder has the matrix cores.
+namespace
+{
+	std::mutex g_encGateMx;
+	struct EncGate { hipEvent_t last = nullptr; const wh_context* owner = nullptr; };
+	EncGate g_encGate[ 64 ];
+	constexpr int ENC_SERIAL_MIN_WINDOWS = 8;	  // a one-window context (a single stream, a loader) neither waits nor makes others wait
+}
 static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
 {
 	const bool sk = skinny && g.M <= 32;
@@ -1186,6 +1197,12 @@ void wh_context_destroy( wh_context* c )
 	if( c->encStream ) { (void)hipStreamSynchronize( c->encStream ); (void)hipStreamDestroy( c->encStream ); }
 	if( c->encReady ) (void)hipEventDestroy( c->encReady );
 	if( c->encDone ) (void)hipEventDestroy( c->encDone );
+	{
+		std::lock_guard<std::mutex> lk( g_encGateMx );
+		for( EncGate& gate : g_encGate )
+			if( gate.owner == c ) gate = EncGate{};
+	}
+	if( c->encGateEv ) (void)hipEventDestroy( c->encGateEv );
 	if( c->verifyGuards() != 0 ) fprintf( stderr, "WH_GUARD_VIOLATION: context %p wrote outside its buffers\n", (void*)c );
 	for( const auto& a : c->allocations ) (void)hipFree( a.base );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
@@ -1397,6 +1414,13 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 	const int M = batch * T;
 
 	if( batch > 1024 ) { setError( "encode: batch too large" ); return WH_E_INVALIDARG; }
+	const bool gated = ( g_tuning & TUNE_ENC_SERIAL ) && batch >= ENC_SERIAL_MIN_WINDOWS && g_liveContexts.load( std::memory_order_relaxed ) > 1;
+	if( gated )
+	{
+		std::lock_guard<std::mutex> lk( g_encGateMx );
+		EncGate& gate = g_encGate[ m->device & 63 ];
+		if( gate.last && gate.owner != c ) WH_HIP( hipStreamWaitEvent( st, gate.last, 0 ) );
+	}
 	// offsets go through pinned staging (ints [0, 1024)): the copy is truly asynchronous and the call never blocks.
 	// The staging is rewritten by the next wh_encode only, which the stream orders after this copy has been consumed
 	// as long as the caller synchronises once per window (wh_decode / wh_decode_window_finish do).
@@ -1494,6 +1518,15 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 		g.k = c->crossK; g.v = c->crossV;
 		g.T = T; g.H = H; g.B = c->maxBatch;
 		WH_CHECK( gemmP( c, g, false ) );
+	}
+	if( gated )
+	{
+		std::lock_guard<std::mutex> lk( g_encGateMx );
+		if( !c->encGateEv ) WH_HIP( hipEventCreateWithFlags( &c->encGateEv, hipEventDisableTiming ) );
+		WH_HIP( hipEventRecord( c->encGateEv, st ) );
+		EncGate& gate = g_encGate[ m->device & 63 ];
+		gate.last = c->encGateEv;
+		gate.owner = c;
 	}
 	c->encoded = true;
 	c->lastEncBatch = batch;
