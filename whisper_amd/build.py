@@ -51,8 +51,10 @@ def build_hip(force: bool = False) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         if force or _newer(obj, [src] + headers):
-            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result",
-                  "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+            # WH_PROBES=1: the tile-shape experiments and ablation instances of tools/*probe* (not in the shipped objects)
+            probes = ["-DWH_PROBES"] if os.environ.get("WH_PROBES", "") not in ("", "0") else []
+            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + probes +
+                 ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
         objs.append(obj)
     if force or _newer(HIP_LIB, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"])

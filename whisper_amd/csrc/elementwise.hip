@@ -332,8 +332,14 @@ namespace wh
 					__hip_atomic_store( md + 2, __float_as_int( r.p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
 					__hip_atomic_store( md + 3, __float_as_int( r.pt ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
 					__hip_atomic_store( md + 4, __float_as_int( r.ptsum ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					// the record validates itself: a word that depends on every field and on the generation travels with it, so a host that
+					// ever saw the stamp before all of the record (the order below rests on store acknowledgements, not on a release) reads a
+					// checksum that does not match and keeps polling instead of consuming a torn record
+					const int check = (int)( (unsigned)gen ^ (unsigned)r.id ^ ( (unsigned)r.tid * 0x9E3779B1u ) ^ (unsigned)__float_as_int( r.p ) ^
+						( (unsigned)__float_as_int( r.pt ) * 3u ) ^ ( (unsigned)__float_as_int( r.ptsum ) * 5u ) );
+					__hip_atomic_store( mail.flag + 2 * slot + 1, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
 					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-					__hip_atomic_store( mail.flag + slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					__hip_atomic_store( mail.flag + 2 * slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
 				}
 			}
 		}

@@ -2136,7 +2136,9 @@ namespace wh
 	static int launchTiled8( const GemmArgs& a, hipStream_t stream )
 	{
 		GemmArgs b = a;
-		if( b.groupM == 0 ) b.groupM = ( g_tuning & TUNE_GEMM_GROUP_M ) ? 4 : 1;
+		// WH_GEMM_GROUP_M: M tiles per band of the walk, for A/B runs (4: the band's A rows are 2 MB of an XCD's 4 MB L2 at K = 1024 and W is re-streamed once per band)
+		static const int groupEnv = []() { const char* e = getenv( "WH_GEMM_GROUP_M" ); const int v = e ? atoi( e ) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+		if( b.groupM == 0 ) b.groupM = groupEnv ? groupEnv : ( ( g_tuning & TUNE_GEMM_GROUP_M ) ? 4 : 1 );
 		bool wide = false;
 		if( g_tuning & TUNE_GEMM_WIDE_EPI )
 		{
@@ -2160,7 +2162,11 @@ namespace wh
 	{
 		switch( variant )
 		{
-		case 40: return launchTiled8<EPI_F32>( a, stream );
+		case 40: return launchTiled8<EPI_F32>( a, stream );	   // the production instance
+#ifdef WH_PROBES
+		// Everything below exists for tools/*probe*: tile-shape experiments and ABLATIONS of the production kernels, several of them WRONG BY
+		// CONSTRUCTION (loads or fragment reads removed to see what the rest costs). The shipped objects do not contain them: build with
+		// WH_PROBES=1 python -m whisper_amd.build --force to get them back.
 		case 41: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1>( b, stream ); }	 // ablations: 31 .. 39 and 41 .. 49 are not checked
 		case 42: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2>( b, stream ); }
 		case 43: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 3>( b, stream ); }
@@ -2206,8 +2212,13 @@ namespace wh
 		case 6: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1>>( a, stream );
 		case 7: return launchTiledT<EPI_F32, TileCfg<128, 256, 64, 2, 1>>( a, stream );
 		case 8: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1>>( a, stream );
+#endif
 		}
+#ifdef WH_PROBES
 		setError( "gemm: unknown variant" );
+#else
+		setError( "gemm: probe variants are not part of this build (WH_PROBES=1 python -m whisper_amd.build --force)" );
+#endif
 		return -1;
 	}
 

@@ -256,6 +256,7 @@ namespace wh
 	// Pinned, host-coherent mirror of the greedy loop's samples: the sampler writes sample `step` of row r to data[step * rows + r]
 	// and then (system-scope fence in between) stamps flag[step * rows + r] = gen. A host thread that polls the flag gets the
 	// token without an event, a copy or a stream synchronisation on the decode stream.
+	// flag holds two ints per record: [2 * slot] = the stamp, [2 * slot + 1] = a checksum of the record and the generation.
 	struct SampleMailbox
 	{
 		TokenData* data;	 // device-visible address of the pinned array

@@ -405,7 +405,9 @@ static int profiled( wh_context* c, int kc, double flops, double bytes, F&& laun
 	if( p.pending.size() >= 4096 ) p.resolve();
 	return rc;
 }
-static std::atomic<int> g_liveContexts{ 0 };
+// contexts alive PER DEVICE: a model on another adapter of the same process is nobody's neighbour
+static std::atomic<int> g_liveContextsDev[ 64 ];
+static std::atomic<int>& liveContexts( const wh_model* m ) { return g_liveContextsDev[ m->device & 63 ]; }
 // TUNE_ENC_SERIAL: the encoders of the contexts of one device form a chain -- an encoder starts when the previous one (of another
 // context) has finished. Stream-ordered (hipStreamWaitEvent), the host never blocks. Two batches started together then run out of
 // phase from the first round on: while one decodes (launch latencies, HBM), the other's encoder has the matrix cores.
@@ -429,7 +431,7 @@ static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
 	// whole launch (160 KiB of LDS, every register), so with all CUs taken a 10 us decode launch of the neighbouring batch waits up
 	// to 2 ms for one. Leaving 4 CUs per XCD free costs the product 12 % of its CUs and returns 3 % of the whole job
 	// (7389 -> 7627 audio-s/s, profiles/r03_ab_variants.txt); a lone context keeps the whole chip.
-	else if( g_liveContexts.load( std::memory_order_relaxed ) > 1 && c->totalCus >= 128 )
+	else if( liveContexts( c->m ).load( std::memory_order_relaxed ) > 1 && c->totalCus >= 128 )
 	{
 		static const int spare = []() { const char* e = getenv( "WH_GEMM_SPARE_CUS" ); const int v = e ? atoi( e ) : 32; return v >= 0 && v <= 128 ? v & ~7 : 32; }();
 		gl.cuLimit = c->totalCus - spare;
@@ -1044,7 +1046,7 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	if( !m->finalized ) { setError( "context_create: model is not finalized" ); return WH_E_NOT_READY; }
 	WH_BIND( m );
 	wh_context* c = new wh_context();
-	g_liveContexts.fetch_add( 1 );
+	liveContexts( m ).fetch_add( 1 );
 	c->m = m;
 	(void)hipDeviceGetAttribute( &c->totalCus, hipDeviceAttributeMultiprocessorCount, m->device );
 	c->maxBatch = maxBatch;
@@ -1155,9 +1157,9 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 		const size_t n = (size_t)hp.n_text_ctx * S;
 		void *d = nullptr, *f = nullptr;
 		if( hipHostMalloc( &d, n * sizeof( TokenData ), hipHostMallocMapped | hipHostMallocCoherent ) == hipSuccess &&
-			hipHostMalloc( &f, n * sizeof( int ), hipHostMallocMapped | hipHostMallocCoherent ) == hipSuccess )
+			hipHostMalloc( &f, 2 * n * sizeof( int ), hipHostMallocMapped | hipHostMallocCoherent ) == hipSuccess )
 		{
-			memset( f, 0, n * sizeof( int ) );
+			memset( f, 0, 2 * n * sizeof( int ) );	   // stamp + checksum per record
 			void *dd = nullptr, *fd = nullptr;
 			if( hipHostGetDevicePointer( &dd, d, 0 ) == hipSuccess && hipHostGetDevicePointer( &fd, f, 0 ) == hipSuccess )
 			{
@@ -1187,7 +1189,7 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 void wh_context_destroy( wh_context* c )
 {
 	if( !c ) return;
-	g_liveContexts.fetch_sub( 1 );
+	liveContexts( c->m ).fetch_sub( 1 );
 	(void)bindDevice( c->m );
 	if( c->stream ) (void)hipStreamSynchronize( c->stream );
 	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
@@ -1414,7 +1416,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 	const int M = batch * T;
 
 	if( batch > 1024 ) { setError( "encode: batch too large" ); return WH_E_INVALIDARG; }
-	const bool gated = ( g_tuning & TUNE_ENC_SERIAL ) && batch >= ENC_SERIAL_MIN_WINDOWS && g_liveContexts.load( std::memory_order_relaxed ) > 1;
+	const bool gated = ( g_tuning & TUNE_ENC_SERIAL ) && batch >= ENC_SERIAL_MIN_WINDOWS && liveContexts( m ).load( std::memory_order_relaxed ) > 1;
 	if( gated )
 	{
 		std::lock_guard<std::mutex> lk( g_encGateMx );
@@ -1585,7 +1587,11 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 		!( c->flags & WH_FLAG_DEBUG_CAPTURE ) && ( g_tuning & TUNE_DECODE_SMALL );
 	if( small )
 	{
-		const bool pfOn = ( g_tuning & TUNE_DECODE_PREFETCH ) != 0;
+#ifdef WH_PROBES
+		const bool pfOn = ( g_tuning & TUNE_DECODE_PREFETCH ) != 0;	   // measured slower: a probe build's switch only
+#else
+		const bool pfOn = false;
+#endif
 		// what a gemvSmall launch of N rows x K columns streams per workgroup (must mirror launchGemvSmall's row split)
 		auto gemvChunk = [ & ]( int N, int K ) -> int
 		{
@@ -2148,26 +2154,42 @@ int wh_decode_window_fetch( wh_context* c, int first, int count, wh_token_data* 
 		// enqueued anywhere -- an event wait + copy + synchronise costs the DECODE stream ~0.2 ms per step (measured, decode1_prof).
 		const size_t rows = (size_t)c->lastBatch;
 		const volatile int* const flag = c->mailFlag;
+		const TokenData* const data = c->mailData + (size_t)first * rows;
+		const size_t slot0 = (size_t)first * rows, nRec = rows * (size_t)count;
 		const auto t0 = std::chrono::steady_clock::now();
+		auto checksum = [ & ]( const TokenData& r ) -> int
+		{
+			int p, pt, ps;
+			memcpy( &p, &r.p, 4 ); memcpy( &pt, &r.pt, 4 ); memcpy( &ps, &r.ptsum, 4 );
+			return (int)( (unsigned)c->mailGen ^ (unsigned)r.id ^ ( (unsigned)r.tid * 0x9E3779B1u ) ^ (unsigned)p ^ ( (unsigned)pt * 3u ) ^ ( (unsigned)ps * 5u ) );
+		};
 		bool ready = false;
 		for( long spins = 0; !ready; spins++ )
 		{
 			ready = true;
-			for( size_t r = 0; r < rows * (size_t)count && ready; r++ )
-				ready = flag[ (size_t)first * rows + r ] == c->mailGen;
-			if( ready ) break;
+			for( size_t r = 0; r < nRec && ready; r++ ) ready = flag[ 2 * ( slot0 + r ) ] == c->mailGen;
+			if( ready )
+			{
+				// stamped: take the records and hold each against its checksum (a torn or early read fails it: poll on)
+				std::atomic_thread_fence( std::memory_order_acquire );
+				memcpy( out, data, sizeof( TokenData ) * nRec );
+				for( size_t r = 0; r < nRec && ready; r++ )
+				{
+					TokenData td;
+					memcpy( &td, (const char*)out + r * sizeof( TokenData ), sizeof( td ) );
+					ready = flag[ 2 * ( slot0 + r ) + 1 ] == checksum( td );
+				}
+				if( ready ) return 0;
+			}
 			if( ( spins & 255 ) == 255 )
 			{
-				// a stamp that does not arrive (a driver that does not make the mailbox visible) must not hang the caller
-				if( std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count() > 0.25 ) break;
-				std::this_thread::yield();
+				// a stamp that does not arrive (a driver that does not make the mailbox visible) must not hang the caller;
+				// a long wait (the encoder of a window runs ahead of its first sample) does not need a spinning core
+				const double waited = std::chrono::duration<double>( std::chrono::steady_clock::now() - t0 ).count();
+				if( waited > 0.25 ) break;
+				if( waited > 0.002 ) std::this_thread::sleep_for( std::chrono::microseconds( 20 ) );
+				else std::this_thread::yield();
 			}
-		}
-		if( ready )
-		{
-			std::atomic_thread_fence( std::memory_order_acquire );
-			memcpy( out, c->mailData + (size_t)first * rows, sizeof( TokenData ) * rows * (size_t)count );
-			return 0;
 		}
 	}
 	if( !c->copyStream ) WH_HIP( hipStreamCreateWithFlags( &c->copyStream, hipStreamNonBlocking ) );
