@@ -261,6 +261,7 @@ WH_API int wh_profile_read( wh_context* c, wh_profile_entry* out, int cap, int* 
 /* Test / parity access to internal state (the reference reaches these through its Tracing probe points,
  * Whisper/Whisper/WhisperContext.cpp:142-638). All outputs HOST FP32.
  *   what = "encode-out"  [batch][n_ctx][d]           (only valid right after wh_encode)
+ *          "exp-table"   [0x5000]: the model's copy of the reference's table_exp_f16 (ggml.c:1375-1385), entry i = fp16( expf( -|fp16 bits i| ) )
  *          "cross-k" / "cross-v"   layer, [batch][n_ctx][d] token-major like the reference's kvCross
  *          "self-k" / "self-v"     layer, [sequences][rows][d]
  * and, captured under WH_FLAG_DEBUG_CAPTURE by the wh_encode / wh_decode call that follows the flag:

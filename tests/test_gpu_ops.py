@@ -169,7 +169,9 @@ def test_flash_attention(batch, heads, T):
     L = binding.lib()
     # every kernel variant: two sweeps (default: unnormalised e into P.V, O / sum at the end), three sweeps (the reference's
     # fp16(e / sum) operand), and the scores kept in registers
-    for name, mask in (("two-sweep", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP),
+    results = {}
+    for name, mask in (("two-sweep", (binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP) & ~binding.TUNE_ATTN_ENC_TABLE),
+                       ("table", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE),
                        ("three-sweep", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_2SWEEP),
                        ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
         L.wh_debug_set_tuning(mask)
@@ -185,6 +187,29 @@ def test_flash_attention(batch, heads, T):
         # S differs by FP32 summation order only; that can flip the FP16 rounding of (S - max) for a few keys, each worth
         # <= 1.6 % of that key's probability, plus the final FP16 rounding of the output
         assert d.max() < 6e-3 and d.mean() < 2e-4
+        results[name] = got
+    # attentionEncT = the two-sweep kernel with the exponential looked up in the reference's own table (LDS) instead of computed by exp16:
+    # the scores are the same instruction sequence, so the outputs differ only where exp16 and the table differ (~1e-4 of the inputs,
+    # one FP16 ulp of e there) -- almost every output element is identical
+    same = float((results["table"] == results["two-sweep"]).mean())
+    dt = np.abs(results["table"] - results["two-sweep"]).max()
+    print("table kernel vs exp16 kernel: %.4f of the outputs identical, max difference %.2e" % (same, dt))
+    assert same > 0.9 and dt < 2e-3
+
+
+def test_exp_table_in_the_arena(golden):
+    """The model's copy of the reference's exponential table (ggml.c:1375-1385, what attentionEncT looks e up in): entry i must be the
+    reference's table_exp_f16 entry of the FP16 number -|bits i|, all 0x5000 of them, bit for bit; from 0x4C56 on they are 0."""
+    m = binding.HipModel.from_ggml(gf.synth_model("test-d128", seed=3))
+    ctx = binding.HipContext(m, 1)
+    got = ctx.debug_read("exp-table")
+    want = golden["table_exp"].view(np.float16)[0x8000:0x8000 + 0x5000].astype(np.float32)
+    assert np.array_equal(got, want)
+    assert got[0] == 1.0 and got[0x4C55] > 0.0 and not got[0x4C56:].any()
+    # and fp16( expf( x ) ) of everything the table does not hold is 0 as well: the clamp of the index is exact
+    assert not golden["table_exp"].view(np.float16)[0x8000 + 0x5000:0xFC01].astype(np.float32).any()
+    ctx.close()
+    m.close()
 
 
 def test_exp_table_exhaustive(golden):

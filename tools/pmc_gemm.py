@@ -53,30 +53,25 @@ def run(out):
 
 def summarize(out):
     raw = json.load(open(os.path.join(out, "raw.json")))
-    # group dispatches of a pass by duration: the four shapes differ by > 25 % in time (480 / 1250 / 1500 / 1600 us)
-    shapes = [("N=1024 K=1024", 2.0 * 168000 * 1024 * 1024), ("N=3072 K=1024", 2.0 * 168000 * 3072 * 1024), ("N=1024 K=4096", 2.0 * 168000 * 1024 * 4096), ("N=4096 K=1024", 2.0 * 168000 * 4096 * 1024)]
+    # the probe runs the shapes in the order of PROBE_SHAPES, 2 warm-up + 10 timed launches each: dispatch order identifies the shape
+    # (durations do not: a profiled pass jitters by +-20 %)
+    shapes = []
+    for sh in SHAPES.split(","):
+        M, N, K = (int(x) for x in sh.split("x"))
+        shapes.append(("N=%d K=%d" % (N, K), 2.0 * M * N * K))
     table = {s: {} for s, _ in shapes}
     by_pass = {}
     for k, v in raw.items():
-        by_pass.setdefault(k.split(":")[0], []).append(v)
+        p, disp = k.split(":")
+        by_pass.setdefault(p, []).append((int(disp), v))
     for p, rows in by_pass.items():
-        rows = [r for r in rows if r["ns"] > 0]
-        if not rows:
+        rows = [v for _, v in sorted(rows, key=lambda kv: kv[0])]
+        per = len(rows) // len(shapes)
+        if per * len(shapes) != len(rows) or per < 3:
+            print("pass", p, "has", len(rows), "launches of gemmTiled8: not", len(shapes), "equal groups")
             continue
-        durs = sorted(set(r["ns"] for r in rows))
-        # cluster: sort by duration, cut where the ratio of neighbours exceeds 1.12
-        clusters, cur = [], [durs[0]]
-        for d in durs[1:]:
-            if d > cur[-1] * 1.12:
-                clusters.append(cur); cur = [d]
-            else:
-                cur.append(d)
-        clusters.append(cur)
-        if len(clusters) != 4:
-            print("pass", p, "found", len(clusters), "duration clusters, expected 4:", [c[0] for c in clusters])
-            continue
-        for (sname, flops), cl in zip(shapes, clusters):
-            sel = [r for r in rows if cl[0] <= r["ns"] <= cl[-1]]
+        for i, (sname, flops) in enumerate(shapes):
+            sel = rows[i * per + 2:(i + 1) * per]          # without the two warm-up launches
             t = table[sname]
             for c in sel[0]:
                 if c == "ns":
@@ -89,7 +84,7 @@ def summarize(out):
         if "GRBM_GUI_ACTIVE" not in t:
             continue
         ns = t["ns@GRBM_GUI_ACTIVE"]
-        clk = t["GRBM_GUI_ACTIVE"] / ns
+        clk = t["GRBM_GUI_ACTIVE"] / 8.0 / ns       # the counter is the sum over the 8 XCDs' GRBMs (the vendor kernel reads 1.86-1.97 GHz this way)
         line = "%-14s %8.1f us  %7.1f TFLOP/s (profiled pass)  effective clock %.3f GHz" % (s, ns / 1e3, t["flops"] / ns / 1e3, clk)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in t:
             ns2 = t["ns@SQ_VALU_MFMA_BUSY_CYCLES"]

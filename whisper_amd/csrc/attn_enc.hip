@@ -559,6 +559,232 @@ namespace wh
 			}
 		}
 
+
+		// ---------------------------------------------------------------------------------------------------------------
+		// attentionEncT: attentionEncF<TWO = true> with the exponential as what it is in the reference -- a LOOKUP in table_exp_f16
+		// (Whisper/source/ggml.c:1375-1385; softmax of flash_attn_f16 :6001-6016). attentionEncF is bound by the VALU: its table-exact
+		// exp16 costs 14 issue slots per score (two converts, the hi / lo split of x log2 e, v_exp_f32 at quarter rate, the correction,
+		// the FP16 rounding) against 0.19 matrix-core cycles. Here a score costs
+		//     v_sub (s - max), v_cvt_pk_f16_f32 (two scores), and / v_pk_min_u16 (|bits| clamped to the first zero entry), two shifts
+		//     = 4 VALU slots, and ONE ds_read_u16 from the model's table in LDS (kernels.h EXP_TABLE_ENTRIES: the non-positive
+		//     arguments' 20480 entries, 40 KB) -- the LDS pipe is idle otherwise (4 fragment reads per 1024 scores).
+		// The result is the reference's e bit for bit (exp16 differs from the table in ~1e-4 of the inputs).
+		// 16 waves = 512 query rows share the K / V tiles AND the table: 104 KB of LDS, one 1024-thread workgroup per CU (the same
+		// 16 waves per CU attentionEncF runs as two workgroups).
+		constexpr int TQ = 512;
+		constexpr int T_TABLE_HALFS = EXP_TABLE_ENTRIES;
+		constexpr int T_LDS_BYTES = T_TABLE_HALFS * 2 + 4 * F_TILE * 2;
+
+		__global__ void __launch_bounds__( 1024, 4 ) attentionEncT( const f16* __restrict__ q, const f16* __restrict__ k,
+			const f16* __restrict__ vT, f16* __restrict__ out, const f16* __restrict__ expTab, int heads, int T, int Tpad, int nQ, int xcdRemap )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemT[];
+			f16* const ldsTab = (f16*)smemT;				  // [EXP_TABLE_ENTRIES] at LDS offset 0
+			f16* const ldsK = ldsTab + T_TABLE_HALFS;		  // [2][128][64], chunk-swizzled rows
+			f16* const ldsV = ldsK + 2 * F_TILE;			  // [2][8 key blocks][2 dd halves][64 lanes][8]
+			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+			typedef const __attribute__( ( address_space( 1 ) ) ) void* GlobalPtr;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int hi = lane >> 5;
+			const int c = lane & 31;
+			int bh, qb;
+			{
+				const int L = blockIdx.x;
+				if( xcdRemap )
+				{
+					const int kIdx = L >> 3;
+					bh = ( L & 7 ) + 8 * ( kIdx / nQ );
+					qb = kIdx % nQ;
+				}
+				else
+				{
+					bh = L / nQ;
+					qb = L - bh * nQ;
+				}
+			}
+			const f16* const Q = q + (long long)bh * T * HEAD_DIM;
+			const f16* const K = k + (long long)bh * T * HEAD_DIM;
+			const f16* const VT = vT + (long long)bh * HEAD_DIM * Tpad;
+			const int qRow = qb * TQ + wave * 32 + c;
+			const int nTiles = ( T + FK - 1 ) / FK;
+
+			// the table: 40 pieces of 1 KiB, lane-linear; needed from the second sweep on, so it lands under the first
+			for( int piece = wave; piece < T_TABLE_HALFS / 512; piece += 16 )
+				__builtin_amdgcn_global_load_lds( (GlobalPtr)( expTab + piece * 512 + lane * 8 ), (LdsPtr)( ldsTab + piece * 512 ), 16, 0, 0 );
+
+			f16x8 qf[ 4 ];
+			{
+				const int qr = qRow < T ? qRow : T - 1;
+	#pragma unroll
+				for( int kk = 0; kk < 4; kk++ )
+				{
+					qf[ kk ] = *(const f16x8*)( Q + (long long)qr * HEAD_DIM + kk * 16 + hi * 8 );
+	#pragma unroll
+					for( int j = 0; j < 8; j++ ) qf[ kk ][ j ] = qf[ kk ][ j ] * (f16)0.125f;
+				}
+			}
+			// K tile t -> LDS buffer: 16 pieces of 8 rows, one 1 KiB wave instruction per wave (swizzle on the SOURCE address)
+			auto issueK = [ & ]( int t, int buf )
+			{
+				const int row = wave * 8 + ( lane >> 3 );
+				const int cl = ( lane & 7 ) ^ ( ( row >> 1 ) & 7 );
+				int key = t * FK + row;
+				key = key < T ? key : T - 1;
+				__builtin_amdgcn_global_load_lds( (GlobalPtr)( K + (long long)key * HEAD_DIM + cl * 8 ), (LdsPtr)( ldsK + buf * F_TILE + wave * 512 ), 16, 0, 0 );
+			};
+			auto issueV = [ & ]( int t, int buf )
+			{
+				__builtin_amdgcn_global_load_lds( (GlobalPtr)( VT + (long long)t * F_TILE + wave * 512 + lane * 8 ), (LdsPtr)( ldsV + buf * F_TILE + wave * 512 ), 16, 0, 0 );
+			};
+			auto scores = [ & ]( const f16* kt, int st, int t ) -> f32x16
+			{
+				f32x16 acc;
+	#pragma unroll
+				for( int r = 0; r < 16; r++ ) acc[ r ] = 0.0f;
+				const int row = st * 32 + c;
+				const int sw = ( row >> 1 ) & 7;
+	#pragma unroll
+				for( int kk = 0; kk < 4; kk++ )
+				{
+					const f16x8 kf = *(const f16x8*)( kt + row * HEAD_DIM + ( ( ( kk * 2 + hi ) ^ sw ) << 3 ) );
+					acc = __builtin_amdgcn_mfma_f32_32x32x16_f16( kf, qf[ kk ], acc, 0, 0, 0 );
+				}
+				if( t == nTiles - 1 )
+				{
+					int limit = T - ( t * FK + st * 32 + 4 * hi );
+					asm volatile( "" : "+v"( limit ) );
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) acc[ r ] = ( r & 3 ) + 8 * ( r >> 2 ) < limit ? acc[ r ] : -3.0e38f;	  // fp16( -3e38 - max ) = -inf -> the zero entry
+				}
+				return acc;
+			};
+			auto sumP = [ & ]( const f16x8 ( &P )[ 2 ] ) -> float
+			{
+				typedef _Float16 h2 __attribute__( ( ext_vector_type( 2 ) ) );
+				const h2 ones = { (f16)1.0f, (f16)1.0f };
+				float part = 0.0f;
+	#pragma unroll
+				for( int h = 0; h < 2; h++ )
+	#pragma unroll
+					for( int j = 0; j < 8; j += 2 )
+						part = __builtin_amdgcn_fdot2( h2{ P[ h ][ j ], P[ h ][ j + 1 ] }, ones, part, false );
+				return part;
+			};
+
+			// ---- sweep 1: row maximum ----
+			float mx = -INFINITY;
+			issueK( 0, 0 );
+			for( int t = 0; t < nTiles; t++ )
+			{
+				const int buf = t & 1;
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				__syncthreads();
+				if( t + 1 < nTiles ) issueK( t + 1, buf ^ 1 );
+				const f16* const kt = ldsK + buf * F_TILE;
+	#pragma unroll
+				for( int st = 0; st < 4; st++ )
+				{
+					const f32x16 S = scores( kt, st, t );
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) mx = fmaxf( mx, S[ r ] );
+				}
+			}
+			mx = fmaxf( mx, __shfl_xor( mx, 32, 64 ) );
+
+			// ---- sweep 2: e = table[ |fp16( s - max )| ] straight into the B operand of O^T += V^T . e^T, row sum on the way ----
+			double sum = 0.0;
+			f32x16 O[ 2 ];
+	#pragma unroll
+			for( int a = 0; a < 2; a++ )
+	#pragma unroll
+				for( int r = 0; r < 16; r++ ) O[ a ][ r ] = 0.0f;
+			__syncthreads();
+			issueK( 0, 0 );
+			issueV( 0, 0 );
+			for( int t = 0; t < nTiles; t++ )
+			{
+				const int buf = t & 1;
+				asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				__syncthreads();
+				if( t + 1 < nTiles )
+				{
+					issueK( t + 1, buf ^ 1 );
+					issueV( t + 1, buf ^ 1 );
+				}
+				const f16* const kt = ldsK + buf * F_TILE;
+				const f16* const vt = ldsV + buf * F_TILE;
+	#pragma unroll
+				for( int st = 0; st < 4; st++ )
+				{
+					const f32x16 S = scores( kt, st, t );
+					f16x8 P[ 2 ];
+	#pragma unroll
+					for( int r = 0; r < 16; r += 2 )
+					{
+						typedef _Float16 h2 __attribute__( ( ext_vector_type( 2 ) ) );
+						typedef unsigned short u16x2 __attribute__( ( ext_vector_type( 2 ) ) );
+						const h2 hd = { (f16)( S[ r ] - mx ), (f16)( S[ r + 1 ] - mx ) };	  // the reference's fp16( s - max ) (ggml.c:6008)
+						u16x2 mag = __builtin_bit_cast( u16x2, __builtin_bit_cast( unsigned, hd ) & 0x7FFF7FFFu );
+						const u16x2 lim = { (unsigned short)EXP_TABLE_LIMIT, (unsigned short)EXP_TABLE_LIMIT };
+						mag = __builtin_elementwise_min( mag, lim );
+						P[ r >> 3 ][ r & 7 ] = ldsTab[ mag[ 0 ] ];
+						P[ r >> 3 ][ ( r & 7 ) + 1 ] = ldsTab[ mag[ 1 ] ];
+					}
+					sum += (double)sumP( P );
+	#pragma unroll
+					for( int half = 0; half < 2; half++ )
+					{
+						const int kb = st * 2 + half;
+	#pragma unroll
+						for( int ddt = 0; ddt < 2; ddt++ )
+						{
+							const f16x8 vf = *(const f16x8*)( vt + ( ( kb * 2 + ddt ) * 64 + lane ) * 8 );
+							O[ ddt ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( vf, P[ half ], O[ ddt ], 0, 0, 0 );
+						}
+					}
+				}
+			}
+			sum += __shfl_xor( sum, 32, 64 );
+			const float invSum = (float)( 1.0 / sum );
+	#pragma unroll
+			for( int a = 0; a < 2; a++ )
+	#pragma unroll
+				for( int r = 0; r < 16; r++ ) O[ a ][ r ] *= invSum;
+			if( qRow < T )
+			{
+				const int b = bh / heads, h = bh - b * heads;
+				f16* const o = out + ( (long long)b * T + qRow ) * ( heads * HEAD_DIM ) + h * HEAD_DIM;
+	#pragma unroll
+				for( int ddt = 0; ddt < 2; ddt++ )
+	#pragma unroll
+					for( int g4 = 0; g4 < 4; g4++ )
+					{
+						f16x4 pk;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) pk[ e ] = (f16)O[ ddt ][ 4 * g4 + e ];
+						*(f16x4*)( o + ddt * 32 + 8 * g4 + 4 * hi ) = pk;
+					}
+			}
+		}
+
+		int launchEncTable( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, const f16* expTab, hipStream_t stream )
+		{
+			static PerDeviceOnce once;
+			if( const int onceDev = once.needed(); onceDev >= 0 )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncT, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES ) );
+				once.mark( onceDev );
+			}
+			const int nQ = ( T + TQ - 1 ) / TQ, BH = batch * heads;
+			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
+			hipLaunchKernelGGL( attentionEncT, dim3( nQ * BH ), dim3( 1024 ), T_LDS_BYTES, stream, q, k, vT, out, expTab, heads, T, Tpad, nQ, xcdRemap );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+
 		int launchEncF( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream )
 		{
 			static PerDeviceOnce once;
@@ -598,13 +824,18 @@ namespace wh
 
 	int attentionInit() { return 0; }
 
-	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream )
+	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, const f16* expTab,
+		hipStream_t stream )
 	{
 		if( T <= 0 || T > 1536 || Tpad < ( ( T + 255 ) / 256 ) * 256 || ( Tpad & 7 ) != 0 )
 		{
 			setError( "attentionEnc: need 0 < T <= 1536 and Tpad >= roundup(T, 256)" );
 			return -1;
 		}
+		// the measured path (e unnormalised in FP16, O scaled by 1 / sum) with the exponential as a table lookup; the parity flag keeps
+		// the three-sweep kernel and the reference's fp16( e / sum ) operand
+		if( expTab && !exactP && ( g_tuning & TUNE_ATTN_ENC_TABLE ) && ( g_tuning & TUNE_ATTN_ENC_F ) && ( g_tuning & TUNE_ATTN_ENC_2SWEEP ) )
+			return launchEncTable( q, k, vT, out, batch, heads, T, Tpad, expTab, stream );
 		if( g_tuning & TUNE_ATTN_ENC_F ) return launchEncF( q, k, vT, out, batch, heads, T, Tpad, exactP, stream );
 		switch( ( T + 255 ) / 256 )
 		{

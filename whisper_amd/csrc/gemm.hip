@@ -2163,6 +2163,9 @@ namespace wh
 		switch( variant )
 		{
 		case 40: return launchTiled8<EPI_F32>( a, stream );	   // the production instance
+		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );	   // the 16-wave kernel of round 2 (products below gemmTiled8's threshold)
+		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
+		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );	   // register-staged 128x128x32: what wh_debug_probe checks every variant against
 #ifdef WH_PROBES
 		// Everything below exists for tools/*probe*: tile-shape experiments and ABLATIONS of the production kernels, several of them WRONG BY
 		// CONSTRUCTION (loads or fragment reads removed to see what the rest costs). The shipped objects do not contain them: build with
@@ -2183,10 +2186,8 @@ namespace wh
 		case 33: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2048 + 1024>( b, stream ); }   // ... with cycle stamps
 		case 35: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1024>( b, stream ); }   // correct results: cycle stamps into a.pe
 		case 38: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 192>( b, stream ); }
-		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
 		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
-		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, 1>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );
 		case 21: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 4>>( a, stream );
@@ -2205,7 +2206,6 @@ namespace wh
 		case 0: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 2>>( a, stream );
 		case 9: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );
 		case 1: return launchTiledT<EPI_F32, TileCfg<128, 128, 64, 2, 1>>( a, stream );
-		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );
 		case 3: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 1>>( a, stream );
 		case 4: return launchTiledT<EPI_F32, TileCfg<256, 128, 64, 2, 2>>( a, stream );
 		case 5: return launchTiledT<EPI_F32, TileCfg<256, 128, 32, 4, 1>>( a, stream );

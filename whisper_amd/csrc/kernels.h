@@ -34,6 +34,8 @@ namespace wh
 		TUNE_DECODE_SMALL = 16777216,	 // single-token steps of up to 4 sequences: the chip-wide launches of decode1.hip (gemvSmall, cross-attention over 8 key ranges)
 		TUNE_DECODE_PREFETCH = 33554432,	 // ... each carrying 256 workgroups that pull the next launch's weights into the L2 of the XCD that will read them
 										 // (measured round 3, medium shape, one sequence: 1216 vs 1129 us per token -- OFF)
+		TUNE_ATTN_ENC_TABLE = 268435456,	 // encoder attention: exp16 as a LOOKUP in the reference's own table held in LDS (1024-thread workgroups, 4 VALU slots + one
+										 // ds_read_u16 per score instead of 14 VALU slots); bit-exact table semantics
 		TUNE_ENC_SERIAL = 134217728,	 // several contexts in flight: their ENCODERS run one at a time (an event chain between the contexts' streams), so that a
 										 // batch's MFMA-bound encoder runs under the latency- and HBM-bound decode chain of its neighbours instead of next to their encoders
 		// Chosen from interleaved in-process runs on one MI355X (tools/ab_bench.py, WH_TUNING=<mask> python bench.py;
@@ -131,7 +133,11 @@ namespace wh
 	// ---------------------------------------------------------------------------------------------------------------
 	// encoder (unmasked) attention, all keys; q,k [bh][T][64], vT [bh][64][Tpad], out [b][T][H*64] FP16
 	// exactP: the P.V operand is the reference's fp16( e / sum ) (ggml.c:6035-6046) even when the two-sweep kernel is selected
-	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, hipStream_t stream );
+	// expTab: the model's table of fp16( expf( -|x| ) ) over the FP16 bit patterns 0 .. EXP_TABLE_ENTRIES-1 (null: the arithmetic exp16 kernels only)
+	constexpr int EXP_TABLE_ENTRIES = 0x5000;
+	constexpr int EXP_TABLE_LIMIT = 0x4C56;	   // first entry that is 0: fp16( expf( -17.34375 ) ); every larger magnitude maps here
+	int launchAttentionEnc( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, bool exactP, const f16* expTab,
+		hipStream_t stream );
 	int attentionInit();
 
 	struct DecAttnArgs

@@ -77,7 +77,7 @@ namespace
 	};
 	struct Layout
 	{
-		int64_t filters, dft, encPe, conv1w, conv1b, conv2w, conv2b, lnPostW, lnPostB;
+		int64_t filters, dft, expTab, encPe, conv1w, conv1b, conv2w, conv2b, lnPostW, lnPostB;
 		int64_t decPe, te, decLnW, decLnB, wcross, bcross;
 		std::vector<EncLayer> enc;
 		std::vector<DecLayer> dec;
@@ -92,6 +92,7 @@ namespace
 		const int64_t d = hp.n_audio_state, V = hp.n_vocab;
 		L.filters = take( 4ll * hp.n_mels * 201 );
 		L.dft = take( 8ll * 800 );
+		L.expTab = take( 2ll * EXP_TABLE_ENTRIES );
 		L.encPe = take( 4ll * hp.n_audio_ctx * d );
 		L.conv1w = take( 2ll * d * conv1Kpad( hp ) );
 		L.conv1b = take( 4 * d );
@@ -778,6 +779,22 @@ int wh_model_finalize( wh_model* m )
 		tw[ 400 + n ] = sin( ( 2.0 * M_PI * n ) / 400 );
 	}
 	WH_CHECK( upload( m, m->L.dft, tw.data(), 800 * 8 ) );
+	// The reference's exponential IS a table: table_exp_f16[ bits ] = fp16( expf( fp32( fp16 bits ) ) ), built once at start-up
+	// (Whisper/source/ggml.c:1375-1385, read at :5069-5080 and :6001-6016). The softmax only ever looks up non-positive arguments, and
+	// fp16( expf( x ) ) is 0 below -17.33: entry i here belongs to the FP16 number -|bits i|, i < 0x5000 (entries from 0x4C56 on are 0).
+	// Built with the host's expf like the reference builds its own -- all 20480 entries equal the reference's table
+	// (tests/test_gpu_ops.py::test_exp_table_in_the_arena). attentionEncT keeps it in LDS: 40 KB next to the K / V tiles.
+	{
+		std::vector<_Float16> tab( EXP_TABLE_ENTRIES );
+		for( uint32_t i = 0; i < (uint32_t)EXP_TABLE_ENTRIES; i++ )
+		{
+			const uint16_t bits = (uint16_t)( i | 0x8000u );
+			_Float16 h;
+			memcpy( &h, &bits, 2 );
+			tab[ i ] = (_Float16)expf( (float)h );
+		}
+		WH_CHECK( upload( m, m->L.expTab, tab.data(), EXP_TABLE_ENTRIES * 2 ) );
+	}
 	m->finalized = true;
 	return 0;
 }
@@ -1485,7 +1502,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 			WH_CHECK( gemmP( c, g, false ) );
 		}
 		WH_CHECK( profiled( c, KC_ATTN_ENC, 4.0 * batch * H * (double)T * T * HEAD_DIM, 2.0 * 4.0 * batch * H * (double)T * HEAD_DIM,
-			[ & ]() { return launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, ( c->flags & WH_FLAG_PARITY_PV ) != 0, st ); } ) );
+			[ & ]() { return launchAttentionEnc( c->q, c->k, c->vT, c->attn, batch, H, T, c->Tpad, ( c->flags & WH_FLAG_PARITY_PV ) != 0, m->at<f16>( L.expTab ), st ); } ) );
 		if( il == 0 ) WH_CHECK( capture( c, c->capEncKqv, c->attn, (int64_t)M * d, (int64_t)c->maxBatch * T * d ) );	// "enc-KQV"
 		{
 			GemmArgs g = plainGemm( c->attn, m->at<f16>( e.wo ), M, d, d );
@@ -2311,6 +2328,15 @@ int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* 
 	const int batch = c->lastEncBatch;
 	const int seqs = c->lastBatch;
 	const std::string w = what;
+	if( w == "exp-table" )
+	{
+		// the arena's copy of the reference's exponential table (non-positive arguments), as FP32 values
+		if( dstCapFloats < EXP_TABLE_ENTRIES ) return WH_E_BOUNDS;
+		std::vector<uint16_t> tmp( EXP_TABLE_ENTRIES );
+		WH_HIP( hipMemcpy( tmp.data(), c->m->at<f16>( c->m->L.expTab ), EXP_TABLE_ENTRIES * 2, hipMemcpyDeviceToHost ) );
+		for( int i = 0; i < EXP_TABLE_ENTRIES; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
+		return 0;
+	}
 	if( w == "encode-out" )
 	{
 		// the FP16 LayerNorm output that feeds the cross-attention projection
@@ -2402,7 +2428,31 @@ int wh_op_layer_norm( void* stream, const float* x, const float* w, const float*
 
 int wh_op_flash_attention( void* stream, const void* q, const void* k, const void* vT, void* out, int batch, int heads, int nCtx )
 {
-	return launchAttentionEnc( (const f16*)q, (const f16*)k, (const f16*)vT, (f16*)out, batch, heads, nCtx, roundUp( nCtx, 256 ), false, (hipStream_t)stream );
+	// no model here: the op-level entry keeps its own copy of the exponential's table per device (built like wh_model_finalize builds the arena's)
+	const f16* expTab = nullptr;
+	if( g_tuning & TUNE_ATTN_ENC_TABLE )
+	{
+		static std::mutex mx;
+		static f16* tabs[ 64 ] = {};
+		int dev = 0;
+		WH_HIP( hipGetDevice( &dev ) );
+		std::lock_guard<std::mutex> lk( mx );
+		if( !tabs[ dev & 63 ] )
+		{
+			std::vector<_Float16> tab( EXP_TABLE_ENTRIES );
+			for( uint32_t i = 0; i < (uint32_t)EXP_TABLE_ENTRIES; i++ )
+			{
+				const uint16_t bits = (uint16_t)( i | 0x8000u );
+				_Float16 h;
+				memcpy( &h, &bits, 2 );
+				tab[ i ] = (_Float16)expf( (float)h );
+			}
+			WH_HIP( hipMalloc( (void**)&tabs[ dev & 63 ], EXP_TABLE_ENTRIES * 2 ) );
+			WH_HIP( hipMemcpy( tabs[ dev & 63 ], tab.data(), EXP_TABLE_ENTRIES * 2, hipMemcpyHostToDevice ) );
+		}
+		expTab = tabs[ dev & 63 ];
+	}
+	return launchAttentionEnc( (const f16*)q, (const f16*)k, (const f16*)vT, (f16*)out, batch, heads, nCtx, roundUp( nCtx, 256 ), false, expTab, (hipStream_t)stream );
 }
 
 int wh_op_decoder_attention( void* stream, const void* qF16, const void* kCache, const void* vCache, void* outF16, int sequences, int heads,
