@@ -26,6 +26,10 @@ int32_t whisperc_tokenize( void* model, const char* text, int32_t* out, int cap 
  * flags = eFullParamsFlags bits (Translate 1, NoContext 2, SingleSegment 4, PrintSpecial 8 ...). */
 int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx /* < 0 keeps the default 16384 */ );
+/* The same with eSamplingStrategy::BeamSearch and beam_search.beam_width = beamWidth (1 .. 8; the reference declares the strategy,
+ * Whisper/API/sFullParams.h:10-13, and implements only Greedy): beamWidth hypotheses per window share one pass over its cross-attention K/V. */
+int32_t whisperc_run_full_beam( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, int beamWidth );
 /* iMediaFoundation::loadAudioFileData( WAV bytes: 16 kHz, mono/stereo, PCM16/float32 ) + iContext::runStreamed( params,
  * { progress callback }, reader ): the streaming entry the reference's CLI uses by default (Examples/main/main.cpp:305-311).
  * The values the progress sink received are copied to progressOut (first progressCap of them), their count to *progressCount. */

@@ -209,6 +209,19 @@ typedef struct wh_token_data
  * per call (same for all sequences). out: HOST [batch]. Exact ties resolve to the lower token id. */
 WH_API int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial, wh_token_data* out );
 
+/* Beam search on hypothesis groups (extension: the reference declares eSamplingStrategy::BeamSearch / beam_search.beam_width,
+ * Whisper/API/sFullParams.h:10-13, and implements only the greedy strategy). Data path of one step, for the sequences of a
+ * wh_context_create_hyp context:   wh_decode( tokens, batch, 1, nPast, NULL, NULL )  ->  wh_beam_candidates  ->  the host ranks
+ * parent score + log p over each window's candidates and keeps the best `hypotheses`  ->  wh_reorder_self_cache( parents )  ->  next wh_decode.
+ *   wh_beam_candidates: the `width` (1 .. 8) best continuations of every sequence from the probabilities of the last wh_decode, under
+ *     sampleBest's own rules (timestamp-vs-text sum rule, initial-timestamp cap, sot / solm / not skipped): candidate 0 IS wh_sample_best's
+ *     token, so width 1 is the greedy decoder. out: HOST [batch][width].
+ *   wh_reorder_self_cache: sequence j continues sequence parents[j] (same window): rows [0, rows) of the self-attention caches of all layers are
+ *     copied parents[j] -> j (through a scratch copy, so any permutation is safe; parents[j] == j costs nothing). The cross-attention K/V of a
+ *     window are shared by its hypotheses and never move. */
+WH_API int wh_beam_candidates( wh_context* c, int batch, int width, int forceTimestamp, int isInitial, wh_token_data* out );
+WH_API int wh_reorder_self_cache( wh_context* c, int batch, const int32_t* parents, int rows );
+
 /* The greedy loop of ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:597-673: decode -> sampleBest ->
  * feed the token back) kept on the device for nSteps tokens: firstTokens (HOST, [batch]) are fed at position nPast, each
  * step runs the decoder for one token per sequence, samples with the sampleBest rules and feeds the choice back, with

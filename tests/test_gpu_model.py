@@ -889,3 +889,47 @@ def test_encode_windows_equals_encode(hip_tiny, golden):
         assert np.array_equal(k[b], want[b][0]) and np.array_equal(v[b], want[b][1]), b
     ctx.close()
     one.close()
+
+
+def test_beam_candidates_and_cache_reorder(hip_tiny, golden, tiny_model):
+    """The data path of beam search on hypothesis groups (extension, whisper_hip.h): wh_beam_candidates gives every sequence's `width` best
+    continuations under sampleBest's rules -- candidate 0 IS wh_sample_best's token, probabilities do not increase, no token twice -- and
+    wh_reorder_self_cache makes sequence j continue sequence parents[j]: its self-attention cache rows are the parent's (every layer, any
+    permutation), and its next step computes what the parent's next step computes for the same token."""
+    sp = gf.special_tokens(tiny_model.hparams)
+    hp = tiny_model.hparams
+    hyp, windows = 5, 2
+    S = hyp * windows
+    mel = torch.from_numpy(golden["mel"]).cuda()
+    ctx = binding.HipContext(hip_tiny, windows, hypotheses=hyp)
+    ctx.encode(torch.stack([mel, torch.roll(mel, 100, 1)]))
+    prompt = np.array([[sp["sot"], sp["not_"], 300 + s] for s in range(S)], np.int32)       # every hypothesis its own third token
+    ctx.decode(prompt, 0, want_logits=False, want_probs=False)
+    for first in (True, False):
+        cand = ctx.beam_candidates(S, 5, force_timestamp=first, is_initial=first)
+        best = ctx.sample_best(S, first, first)
+        assert [int(x) for x in cand["id"][:, 0]] == [b["id"] for b in best]
+        assert np.allclose(cand["p"][:, 0], [b["p"] for b in best], rtol=0, atol=0)
+        assert (np.diff(cand["p"], axis=1) <= 0).all()
+        assert all(len(set(row)) == 5 for row in cand["id"])
+        assert not np.isin(cand["id"], [sp["sot"], sp["solm"], sp["not_"]]).any()
+    # one more token, so that position 3 differs between hypotheses too
+    toks = cand["id"][:, 1].astype(np.int32)[:, None]
+    ctx.decode(toks, 3, want_logits=False, want_probs=False)
+    rows = 4
+    before = [(ctx.debug_read("self-k", il, rows).copy(), ctx.debug_read("self-v", il, rows).copy()) for il in (0, hp.n_text_layer - 1)]
+    parents = np.array([2, 2, 0, 4, 1, 5 + 4, 5 + 0, 5 + 0, 5 + 3, 5 + 2], np.int32)      # a permutation with a cycle in window 0, a fan-out in window 1
+    # what every parent computes next for token 777 (before anything moves)
+    nxt = np.full((S, 1), 777, np.int32)
+    want_logits, _ = ctx.decode(nxt, rows)
+    # undo that step's cache row (position 4 is simply overwritten again below), reorder, repeat the step
+    ctx.reorder_self_cache(parents, rows)
+    after = [(ctx.debug_read("self-k", il, rows), ctx.debug_read("self-v", il, rows)) for il in (0, hp.n_text_layer - 1)]
+    for (bk, bv), (ak, av) in zip(before, after):
+        for j in range(S):
+            assert np.array_equal(ak[j], bk[parents[j]]) and np.array_equal(av[j], bv[parents[j]]), j
+    got_logits, _ = ctx.decode(nxt, rows)
+    for j in range(S):
+        assert np.array_equal(got_logits[j], want_logits[parents[j]]), j
+    ctx.reorder_self_cache(np.arange(S, dtype=np.int32), rows)                                # identity: nothing to do
+    ctx.close()

@@ -12,7 +12,7 @@ import pytest
 torch = pytest.importorskip("torch")
 
 from oracle import whisper_np as wn  # noqa: E402
-from whisper_amd import binding  # noqa: E402
+from whisper_amd import binding, ggml_format as gf  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

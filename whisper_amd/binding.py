@@ -30,7 +30,7 @@ TUNE_ATTN_ENC_TABLE = 268435456
 TUNE_DEFAULT = (TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD |
                 TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI |
                 TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS |
-                TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT)
+                TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE)
 
 # every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -40,7 +40,7 @@ EXPORTS = [
     "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
+    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -106,6 +106,8 @@ def lib():
         L.wh_encode_windows.argtypes = [vp, vp, i32]
         L.wh_decode.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.wh_sample_best.argtypes = [vp, i32, i32, i32, C.POINTER(TokenDataC)]
+        L.wh_beam_candidates.argtypes = [vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
+        L.wh_reorder_self_cache.argtypes = [vp, i32, vp, i32]
         L.wh_debug_read.argtypes = [vp, C.c_char_p, i32, i32, vp, i64]
         L.wh_decode_greedy.argtypes = [vp, i32, vp, i32, i32, i32, i32, C.POINTER(TokenDataC)]
         L.wh_decode_window_start.argtypes = [vp, i32, vp, i32, i32, i32, i32]
@@ -307,6 +309,18 @@ class HipContext:
         out = (TokenDataC * batch)()
         check(lib().wh_sample_best(self.handle, batch, int(force_timestamp), int(is_initial), out))
         return [dict(id=o.id, tid=o.tid, p=o.p, pt=o.pt, ptsum=o.ptsum) for o in out]
+
+    def beam_candidates(self, batch: int, width: int, force_timestamp: bool = False, is_initial: bool = False):
+        """The `width` best continuations of every sequence (candidate 0 = sample_best's token): dict of arrays [batch][width]."""
+        out = (TokenDataC * (batch * width))()
+        check(lib().wh_beam_candidates(self.handle, batch, width, int(force_timestamp), int(is_initial), out))
+        a = np.frombuffer(out, dtype=np.dtype([("id", "<i4"), ("tid", "<i4"), ("p", "<f4"), ("pt", "<f4"), ("ptsum", "<f4")])).reshape(batch, width)
+        return {k: a[k].copy() for k in a.dtype.names}
+
+    def reorder_self_cache(self, parents, rows: int):
+        """Sequence j continues sequence parents[j]: its self-attention cache rows [0, rows) are replaced by the parent's."""
+        p = np.ascontiguousarray(parents, np.int32)
+        check(lib().wh_reorder_self_cache(self.handle, len(p), p.ctypes.data_as(C.c_void_p), rows))
 
     def decode_greedy(self, first_tokens, n_past: int, n_steps: int, force_first_timestamp: bool = False,
                       first_is_initial: bool = False):

@@ -227,6 +227,93 @@ namespace wh
 				out[ blockIdx.x ] = r;
 			}
 		}
+		// ---- the `width` best continuations of a sequence under sampleBest's own rules (beam search on hypothesis groups) ----
+		// Candidate 0 IS ContextImpl::sampleBest's pick (timestamp-vs-text sum rule, initial-timestamp cap, the top tokens that are
+		// sot / solm / not skipped); candidates 1 .. width-1 are the next best tokens under the same mask, specials skipped as well.
+		// So a beam of width 1 is the greedy decoder. out: [sequences][width] TokenData (tid / pt / ptsum repeated).
+		__global__ void __launch_bounds__( 1024 ) beamCandidatesKernel( const float* __restrict__ probs, int nVocab, int tokenBeg,
+			int tokenSot, int tokenSolm, int tokenNot, int forceTimestamp, int isInitial, int width, TokenData* __restrict__ out )
+		{
+			__shared__ ArgMax sha[ 16 ];
+			__shared__ double shd[ 16 ];
+			const float* p = probs + (long long)blockIdx.x * nVocab;
+			const int tsEnd = isInitial ? min( tokenBeg + 101, nVocab ) : nVocab;
+			ArgMax tx = { -1.0f, 0x7fffffff }, ts = { -1.0f, 0x7fffffff };
+			double sumTs = 0.0;
+			for( int c = threadIdx.x; c < nVocab; c += 1024 )
+			{
+				const float v = p[ c ];
+				if( c < tokenBeg )
+					tx = better( tx, ArgMax{ v, c } );
+				else if( c < tsEnd )
+				{
+					ts = better( ts, ArgMax{ v, c } );
+					sumTs += (double)v;
+				}
+			}
+			tx = blockArgMax( tx, sha );
+			ts = blockArgMax( ts, sha );
+			sumTs = blockSumD<16>( sumTs, shd );
+			const bool onlyTs = ( sumTs > (double)fmaxf( tx.v, -1.0f ) ) || forceTimestamp;
+			const int lo = onlyTs ? tokenBeg : 0;
+			constexpr int MAXW = 8;
+			int taken[ MAXW + 3 ];
+			int nTaken = 0, found = 0;
+			// at most width + 3 rounds: the three specials may each cost one
+			for( int round = 0; round < width + 3 && found < width; round++ )
+			{
+				ArgMax best = { -INFINITY, 0x7fffffff };
+				for( int c = lo + threadIdx.x; c < nVocab; c += 1024 )
+				{
+					bool skip = c >= tsEnd && c >= tokenBeg;	  // masked by the initial-timestamp cap
+					for( int k = 0; k < nTaken; k++ ) skip = skip || ( taken[ k ] == c );
+					if( !skip ) best = better( best, ArgMax{ p[ c ], c } );
+				}
+				best = blockArgMax( best, sha );
+				taken[ nTaken++ ] = best.i;
+				const bool special = best.i == tokenSot || best.i == tokenSolm || best.i == tokenNot;
+				// sampleBest gives up after four rounds and takes the fourth token whatever it is: only candidate 0 can meet that rule
+				if( special && !( found == 0 && round == 3 ) ) continue;
+				if( threadIdx.x == 0 )
+				{
+					TokenData r;
+					r.id = ( best.i < 0 || best.i >= nVocab ) ? 0 : best.i;
+					r.tid = ts.v > -1.0f ? ts.i : 0;
+					r.p = best.v;
+					r.pt = (float)( (double)ts.v / ( sumTs + 1e-10 ) );
+					r.ptsum = (float)sumTs;
+					out[ (long long)blockIdx.x * width + found ] = r;
+				}
+				found++;
+			}
+			// fewer than `width` tokens under the mask (cannot happen with a real vocabulary): repeat the last one with probability 0
+			for( ; found < width; found++ )
+				if( threadIdx.x == 0 )
+				{
+					TokenData r = out[ (long long)blockIdx.x * width + ( found > 0 ? found - 1 : 0 ) ];
+					r.p = 0.0f;
+					out[ (long long)blockIdx.x * width + found ] = r;
+				}
+		}
+
+		// ---- self-attention cache rows of sequence parents[j] -> sequence j (beam search: hypotheses change lineage) ----
+		// Two launches through a scratch copy, so that a permutation (j <- p while p <- q) reads only rows nobody has overwritten:
+		// phase 0: scratch[ j ] = cache[ parents[ j ] ], phase 1: cache[ j ] = scratch[ j ]; sequences with parents[ j ] == j are skipped.
+		// grid (heads, sequences, layers x 2 (K, V)); rows x 128 bytes per block.
+		__global__ void __launch_bounds__( 256 ) reorderCacheKernel( f16* __restrict__ cacheK, f16* __restrict__ cacheV, f16* __restrict__ scratchK,
+			f16* __restrict__ scratchV, const int* __restrict__ parents, int heads, int seqStrideSeqs, int keyStride, int rows, int phase )
+		{
+			const int h = blockIdx.x, j = blockIdx.y, l = blockIdx.z >> 1, kv = blockIdx.z & 1;
+			const int p = parents[ j ];
+			if( p == j ) return;
+			f16* const cache = kv ? cacheV : cacheK;
+			f16* const scratch = kv ? scratchV : scratchK;
+			const long long layer = (long long)l * seqStrideSeqs * heads * keyStride * HEAD_DIM;
+			const f16* src = ( phase == 0 ? cache + layer + ( (long long)p * heads + h ) * keyStride * HEAD_DIM : scratch + layer + ( (long long)j * heads + h ) * keyStride * HEAD_DIM );
+			f16* dst = ( phase == 0 ? scratch : cache ) + layer + ( (long long)j * heads + h ) * keyStride * HEAD_DIM;
+			for( int i = threadIdx.x; i < rows * 8; i += 256 ) *(f16x8*)( dst + i * 8 ) = *(const f16x8*)( src + i * 8 );
+		}
+
 		// ---- logits row -> table softmax -> sampleBest in ONE kernel, the row held in registers -----------------------
 		// Used by the captured decode step: no host round trip between the logits product and the next token. Same
 		// arithmetic as softMaxRows followed by sampleBestKernel (p = exp16(x - max) * float(1 / double sum)).
@@ -418,6 +505,28 @@ namespace wh
 		hipLaunchKernelGGL( sampleBestKernel, dim3( rows ), dim3( 1024 ), 0, stream, probs, nVocab, tokenBeg, tokenSot, tokenSolm,
 			tokenNot, forceTimestamp, isInitial, out );
 		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchBeamCandidates( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
+		int forceTimestamp, int isInitial, int width, TokenData* out, hipStream_t stream )
+	{
+		if( width < 1 || width > 8 ) { setError( "beamCandidates: width must be 1 .. 8" ); return -1; }
+		hipLaunchKernelGGL( beamCandidatesKernel, dim3( rows ), dim3( 1024 ), 0, stream, probs, nVocab, tokenBeg, tokenSot, tokenSolm,
+			tokenNot, forceTimestamp, isInitial, width, out );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	int launchReorderCache( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, int layers, int sequences, int maxSeq,
+		int heads, int keyStride, int rows, hipStream_t stream )
+	{
+		for( int phase = 0; phase < 2; phase++ )
+		{
+			hipLaunchKernelGGL( reorderCacheKernel, dim3( heads, sequences, layers * 2 ), dim3( 256 ), 0, stream, cacheK, cacheV, scratchK, scratchV, parents,
+				heads, maxSeq, keyStride, rows, phase );
+			WH_HIP( hipGetLastError() );
+		}
 		return 0;
 	}
 

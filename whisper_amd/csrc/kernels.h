@@ -42,7 +42,7 @@ namespace wh
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT
+		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE
 	};
 	extern unsigned g_tuning;
 
@@ -248,6 +248,14 @@ namespace wh
 	// ContextImpl::sampleBest on the device
 	int launchSampleBest( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
 		int forceTimestamp, int isInitial, TokenData* out, hipStream_t stream );
+
+	// beam search on hypothesis groups: the `width` (<= 8) best continuations of every sequence under sampleBest's rules (candidate 0 = sampleBest's
+	// pick) -> out [rows][width]; and the self-attention cache rows [0, rows) of sequence parents[j] copied to sequence j (all layers, through a scratch
+	// copy of the caches)
+	int launchBeamCandidates( const float* probs, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
+		int forceTimestamp, int isInitial, int width, TokenData* out, hipStream_t stream );
+	int launchReorderCache( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, int layers, int sequences, int maxSeq,
+		int heads, int keyStride, int rows, hipStream_t stream );
 
 	// Device-resident state of the greedy loop: lets one captured hipGraph be replayed for every token. The POSITIONS live next to
 	// it as one int per sequence (wh_context::seqPos): the sequences of a lock-step batch may stand at different positions (streams

@@ -259,6 +259,8 @@ struct wh_context
 	int* melOffsetsDev = nullptr;
 	MelWindow* melWindowsDev = nullptr;
 	TokenData* tokDataDev = nullptr;
+	TokenData* beamCand = nullptr;			   // beam search: [maxSeq][8] candidates (allocated on first use)
+	f16 *selfKScratch = nullptr, *selfVScratch = nullptr;	   // beam search: the copy a cache reorder goes through (allocated on first use)
 	float* melScratch = nullptr;
 	// device-side greedy loop: the sampler's state and one position per sequence (the sequences of a lock-step batch may differ)
 	DecodeState* state = nullptr;
@@ -2255,6 +2257,45 @@ int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isInitial,
 	WH_HIP( hipMemcpyAsync( out, c->tokDataDev, sizeof( TokenData ) * batch, hipMemcpyDeviceToHost, c->stream ) );
 	WH_HIP( hipStreamSynchronize( c->stream ) );
 	return 0;
+}
+
+int wh_beam_candidates( wh_context* c, int batch, int width, int forceTimestamp, int isInitial, wh_token_data* out )
+{
+	if( !c || !out || batch <= 0 || batch > c->maxSeq || width < 1 || width > 8 ) { setError( "beam_candidates: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	const wh_hparams& hp = c->m->hp;
+	const SpecialIds sp = specialIds( hp );
+	if( !c->beamCand ) WH_CHECK( c->alloc( c->beamCand, (int64_t)c->maxSeq * 8, wh_context::DONT_CARE, "beamCand" ) );
+	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, ( 4.0 + width ) * 4.0 * batch * hp.n_vocab,
+		[ & ]() { return launchBeamCandidates( c->probs, batch, hp.n_vocab, sp.beg, sp.sot, sp.solm, sp.tnot, forceTimestamp, isInitial, width, c->beamCand, c->stream ); } ) );
+	WH_HIP( hipMemcpyAsync( out, c->beamCand, sizeof( TokenData ) * (size_t)batch * width, hipMemcpyDeviceToHost, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int wh_reorder_self_cache( wh_context* c, int batch, const int32_t* parents, int rows )
+{
+	if( !c || !parents || batch <= 0 || batch > c->maxSeq || rows < 0 ) { setError( "reorder_self_cache: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	const wh_hparams& hp = c->m->hp;
+	if( rows > hp.n_text_ctx ) { setError( "reorder_self_cache: more rows than n_text_ctx" ); return WH_E_BOUNDS; }
+	bool any = false;
+	for( int j = 0; j < batch; j++ )
+	{
+		if( parents[ j ] < 0 || parents[ j ] >= batch ) { setError( "reorder_self_cache: a parent is outside the batch" ); return WH_E_INVALIDARG; }
+		any = any || parents[ j ] != j;
+	}
+	if( !any || rows == 0 ) return 0;
+	const int64_t n = (int64_t)hp.n_text_layer * c->maxSeq * hp.n_text_ctx * hp.n_text_state;
+	if( !c->selfKScratch ) WH_CHECK( c->alloc( c->selfKScratch, n, wh_context::DONT_CARE, "selfKScratch" ) );
+	if( !c->selfVScratch ) WH_CHECK( c->alloc( c->selfVScratch, n, wh_context::DONT_CARE, "selfVScratch" ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );	   // the staging below may still be read by an earlier enqueue
+	int32_t* const st = c->pinned + wh_context::PIN_POS;
+	for( int j = 0; j < batch; j++ ) st[ j ] = parents[ j ];
+	WH_HIP( hipMemcpyAsync( c->tokDataDev, st, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, c->stream ) );	  // tokDataDev: [maxSeq] records of 20 bytes, free between samples
+	return profiled( c, KC_EMBED, 0.0, 4.0 * 2.0 * 2.0 * rows * hp.n_text_state * hp.n_text_layer * batch,
+		[ & ]() { return launchReorderCache( c->selfK, c->selfV, c->selfKScratch, c->selfVScratch, (const int*)c->tokDataDev, hp.n_text_layer, batch, c->maxSeq,
+			hp.n_text_head, hp.n_text_ctx, rows, c->stream ); } );
 }
 
 int wh_profile_enable( wh_context* c, int on )

@@ -33,6 +33,11 @@ namespace Whisper
 		std::vector<TokenData> tokens;
 		WindowScan( const sFullParams& p, const Vocabulary& v, int seek_, int seekEnd_, int nMax_ ) : params( p ), vocab( v ), seek( seek_ ), seekEnd( seekEnd_ ), nMax( nMax_ ) {}
 		int consumed() const { return i; }
+		// beam search: the window's result becomes that of the hypothesis that won (same window: same seek, bounds and parameters)
+		void adopt( const WindowScan& o )
+		{
+			i = o.i; hasTs = o.hasTs; seekDelta = o.seekDelta; resultLen = o.resultLen; failed = o.failed; over = o.over; tokens = o.tokens;
+		}
 		// Token i of the window. Returns true when the window is over: `failed`, or resultLen tokens stand and the next window
 		// starts seekDelta frames later.
 		bool feed( const TokenData& token )

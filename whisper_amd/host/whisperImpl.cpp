@@ -11,6 +11,7 @@
 #include "results.h"
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -112,6 +113,8 @@ namespace Whisper
 			std::shared_ptr<LoadedModel> model;
 			iModel* owner;	  // strong reference, like ContextImpl::modelPtr (ContextImpl.h:16)
 			wh_context* gpu = nullptr;
+			wh_context* gpuBeam = nullptr;	   // eSamplingStrategy::BeamSearch: one window x `beamSlots` hypotheses sharing its cross-attention K/V
+			int beamSlots = 0;
 			void* melDev = nullptr;
 			int64_t melCapacity = 0;
 			void* pcmDev = nullptr;
@@ -151,7 +154,9 @@ namespace Whisper
 			}
 			HRESULT fillResults( eResultFlags flags, ResultData& res ) const;
 			HRESULT runFullImpl( const sFullParams& params, const sProgressSink& progress );
-			HRESULT encodeWindow( int seek );
+			HRESULT encodeWindow( wh_context* ctx, int seek );
+			HRESULT beamContext( int width );
+			HRESULT decodeWindowBeam( const std::vector<int>& prompt, int width, WindowScan& scan, int& steps );
 
 		public:
 			ContextImpl( const std::shared_ptr<LoadedModel>& m, iModel* o ) : model( m ), owner( o )
@@ -163,6 +168,7 @@ namespace Whisper
 				if( gpu ) wh_context_bind( gpu );
 				if( melDev ) wh_buffer_free( melDev );
 				if( pcmDev ) wh_buffer_free( pcmDev );
+				if( gpuBeam ) wh_context_destroy( gpuBeam );
 				if( gpu ) wh_context_destroy( gpu );
 				if( owner ) owner->Release();
 			}
@@ -341,7 +347,7 @@ namespace Whisper
 		}
 
 		// ContextImpl::encode( iSpectrogram&, seek ) + MelInputTensor::create (MelInputTensor.cpp:8-63)
-		HRESULT ContextImpl::encodeWindow( int seek )
+		HRESULT ContextImpl::encodeWindow( wh_context* gpu, int seek )
 		{
 			const wh_hparams& hp = model->hp;
 			if( !mel.streamed )
@@ -432,6 +438,114 @@ namespace Whisper
 			}
 		};
 
+		// A context of one window x `slots` hypotheses (1, 2, 3, 4, 5 or 8 per window: wh_context_create_hyp)
+		HRESULT ContextImpl::beamContext( int width )
+		{
+			const int slots = width <= 5 ? width : 8;
+			if( gpuBeam && beamSlots == slots ) return S_OK;
+			if( gpuBeam ) { wh_context_destroy( gpuBeam ); gpuBeam = nullptr; }
+			CHECK_WH( wh_context_create_hyp( model->gpu, 1, slots, nullptr, &gpuBeam ) );
+			beamSlots = slots;
+			return S_OK;
+		}
+
+		// Beam search over one window (extension; the reference only declares the strategy). `width` hypotheses decode in lock step and
+		// share the window's cross-attention K/V (wh_context_create_hyp). A step: every live hypothesis proposes its `width` best
+		// continuations under sampleBest's own rules (wh_beam_candidates: candidate 0 is the greedy token), the pool is ranked by
+		// cumulative log-probability, the best `width` survive -- each either stays live (its parent's self-attention cache rows are
+		// copied into its slot, wh_reorder_self_cache) or, when the reference's stop rules end its window (WindowScan: EOT, a timestamp
+		// that goes back, end of audio, max_tokens ...), joins the finished list. The window's transcript is the finished hypothesis with
+		// the best log-probability per token; hypotheses the stop rules call failed count only if nothing else finished.
+		// Width 1 is the greedy decoder token for token (tests/test_host_api.py::test_beam_search).
+		HRESULT ContextImpl::decodeWindowBeam( const std::vector<int>& prompt, int width, WindowScan& result, int& steps )
+		{
+			const int B = beamSlots, n = (int)prompt.size();
+			struct Hyp
+			{
+				std::unique_ptr<WindowScan> scan;
+				double sum = 0.0;
+				int slot = 0;
+			};
+			std::vector<Hyp> live, finished;
+			std::vector<int32_t> tokens( (size_t)B * std::max( n, 1 ) ), parents( (size_t)B, 0 ), next( (size_t)B, 0 );
+			for( int b = 0; b < B; b++ ) std::copy( prompt.begin(), prompt.end(), tokens.begin() + (size_t)b * n );
+			CHECK_WH( wh_decode( gpuBeam, tokens.data(), B, n, 0, nullptr, nullptr ) );
+			std::vector<wh_token_data> cand( (size_t)B * width );
+			CHECK_WH( wh_beam_candidates( gpuBeam, B, width, 1, 1, cand.data() ) );
+			steps = 1;
+			// what a parent proposes: (parent index in `live`, candidate) ranked by parent score + log p; ties keep the parent's order
+			struct Prop { int parent, k; double score; };
+			auto expand = [ & ]( const std::vector<Hyp>& parentsHyp, const std::vector<Prop>& pool, std::vector<Hyp>& newLive )
+			{
+				int accepted = 0;
+				for( const Prop& pr : pool )
+				{
+					if( accepted >= width ) break;
+					const Hyp& par = parentsHyp[ (size_t)pr.parent ];
+					const wh_token_data& t = cand[ (size_t)par.slot * width + pr.k ];
+					Hyp h;
+					h.scan.reset( new WindowScan( *par.scan ) );
+					h.sum = pr.score;
+					h.slot = par.slot;	 // its cache rows live in the parent's slot until the reorder
+					TokenData td;
+					td.id = t.id; td.tid = t.tid; td.p = t.p; td.pt = t.pt; td.ptsum = t.ptsum;
+					const bool over = h.scan->feed( td );
+					accepted++;
+					if( over ) finished.push_back( std::move( h ) );
+					else newLive.push_back( std::move( h ) );
+				}
+			};
+			{
+				// the first sample: every slot holds the same prompt, slot 0 speaks for all
+				std::vector<Hyp> root( 1 );
+				root[ 0 ].scan.reset( new WindowScan( result ) );
+				root[ 0 ].slot = 0;
+				std::vector<Prop> pool;
+				for( int k = 0; k < width; k++ ) pool.push_back( Prop{ 0, k, log( std::max( (double)cand[ (size_t)k ].p, 1e-30 ) ) } );
+				std::stable_sort( pool.begin(), pool.end(), []( const Prop& a, const Prop& b ) { return a.score > b.score; } );
+				expand( root, pool, live );
+			}
+			for( int s = 0; !live.empty() && (int)finished.size() < width; s++ )
+			{
+				if( n + s >= model->hp.n_text_ctx ) break;	   // WindowScan's own bound (n_text_ctx / 2 - 4 tokens) fires first for every prompt the loop builds
+				// live hypothesis i moves to slot i; the idle slots repeat slot 0 and are ignored
+				for( int b = 0; b < B; b++ )
+				{
+					const Hyp& h = live[ (size_t)( b < (int)live.size() ? b : 0 ) ];
+					parents[ (size_t)b ] = h.slot;
+					next[ (size_t)b ] = h.scan->tokens.back().id;
+				}
+				// a hypothesis that stopped on a token WindowScan did not keep (a timestamp going back) never reaches this point: it is finished
+				CHECK_WH( wh_reorder_self_cache( gpuBeam, B, parents.data(), n + s ) );
+				for( size_t i = 0; i < live.size(); i++ ) live[ i ].slot = (int)i;
+				CHECK_WH( wh_decode( gpuBeam, next.data(), B, 1, n + s, nullptr, nullptr ) );
+				CHECK_WH( wh_beam_candidates( gpuBeam, B, width, 0, 0, cand.data() ) );
+				steps++;
+				std::vector<Prop> pool;
+				for( int i = 0; i < (int)live.size(); i++ )
+					for( int k = 0; k < width; k++ )
+						pool.push_back( Prop{ i, k, live[ (size_t)i ].sum + log( std::max( (double)cand[ (size_t)live[ (size_t)i ].slot * width + k ].p, 1e-30 ) ) } );
+				std::stable_sort( pool.begin(), pool.end(), []( const Prop& a, const Prop& b ) { return a.score > b.score; } );
+				std::vector<Hyp> newLive;
+				expand( live, pool, newLive );
+				live = std::move( newLive );
+			}
+			// hypotheses still live when the list filled up (or the context ran out) are candidates too: they end where they stand, as failed
+			// windows do when the loop's bound is reached
+			for( Hyp& h : live )
+			{
+				if( !h.scan->over ) h.scan->failed = h.scan->over = true;
+				finished.push_back( std::move( h ) );
+			}
+			const Hyp* best = nullptr;
+			auto perToken = []( const Hyp& h ) { return h.sum / (double)std::max<size_t>( 1, h.scan->tokens.size() ); };
+			for( const Hyp& h : finished )
+				if( !best || ( best->scan->failed && !h.scan->failed ) || ( best->scan->failed == h.scan->failed && perToken( h ) > perToken( *best ) ) ) best = &h;
+			if( !best ) return E_UNEXPECTED;
+			result.adopt( *best->scan );
+			return S_OK;
+		}
+
 		HRESULT ContextImpl::runFullImpl( const sFullParams& params, const sProgressSink& progress )
 		{
 			// the stream's rules (seek range, prompt carry-over, stop rules, segments, callbacks) live in hostLoop.h, shared with the
@@ -441,6 +555,20 @@ namespace Whisper
 			StreamRun run( params, vocab, hp, this, progress, resultAll, promptPast, &stamper );
 			const HRESULT hrBegin = run.begin( mel.length );
 			if( hrBegin != S_OK ) return hrBegin;
+			// eSamplingStrategy::BeamSearch (declared by the reference, implemented only here: sFullParams.h:10-13): beam_width hypotheses per
+			// window through decodeWindowBeam (width 1 included: there it must reproduce the greedy loop token for token). The Greedy strategy
+			// takes the device-side greedy loop.
+			int beamWidth = 0;
+			if( params.strategy == eSamplingStrategy::BeamSearch && params.beam_search.beam_width >= 1 )
+			{
+				beamWidth = params.beam_search.beam_width;
+				if( beamWidth > 8 )
+				{
+					logWarning( "runFull: beam_width %d is more than this build decodes in lock step; using 8", beamWidth );
+					beamWidth = 8;
+				}
+				CHECK( beamContext( beamWidth ) );
+			}
 			std::vector<int> prompt;
 			while( true )
 			{
@@ -451,7 +579,7 @@ namespace Whisper
 					// enqueued without a host sync: the decoder's launches line up behind the encoder's on the context's stream.
 					// With WHISPER_PROFILE=1 the two are separated so that the "Encode" block means what it means in the reference.
 					const auto t = Clock::now();
-					CHECK( encodeWindow( run.seek ) );
+					CHECK( encodeWindow( beamWidth >= 1 ? gpuBeam : gpu, run.seek ) );
 					if( gpuProfile ) CHECK_WH( wh_context_synchronize( gpu ) );
 					msEncode += msSince( t );
 					nEncode++;
@@ -459,6 +587,9 @@ namespace Whisper
 				const auto tDec = Clock::now();
 				WindowDecoder dec( gpu, hp.n_text_ctx );
 				WindowScan scan( run.fullParams(), vocab, run.seek, run.seekEnd(), run.maxTokens() );
+				if( beamWidth >= 1 )
+					CHECK( decodeWindowBeam( prompt, beamWidth, scan, dec.steps ) );
+				else
 				for( bool first = true; !scan.over; first = false )
 				{
 					TokenData token;
@@ -818,6 +949,27 @@ WHISPER_EXPORT int32_t whisperc_run_streamed( void* ctx, const void* wavBytes, u
 	hr = c->runStreamed( p, ps, reader );
 	reader->Release();
 	if( progressCount ) *progressCount = sink.n;
+	return hr;
+}
+// iContext::fullDefaultParams( BeamSearch ) + beam_search.beam_width = beamWidth (1 .. 8), then iContext::runFull
+WHISPER_EXPORT int32_t whisperc_run_full_beam( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, int beamWidth )
+{
+	if( !ctx || ( !pcm && nSamples ) ) return E_POINTER;
+	iContext* c = (iContext*)ctx;
+	sFullParams p;
+	CHECK( c->fullDefaultParams( eSamplingStrategy::BeamSearch, &p ) );
+	p.beam_search.beam_width = beamWidth;
+	p.flags = (eFullParamsFlags)flags;
+	p.language = makeLanguageKey( language ? language : "en" );
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	iAudioBuffer* buf = nullptr;
+	CHECK( createAudioBuffer( std::vector<float>( pcm, pcm + nSamples ), {}, &buf ) );
+	const HRESULT hr = c->runFull( p, buf );
+	buf->Release();
 	return hr;
 }
 // The same with the token-timestamp parameters of sFullParams (thold_pt, thold_ptsum, max_len; sFullParams.h:79-86)
