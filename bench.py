@@ -616,9 +616,47 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
             p[j::hyp, -1] = base[-1] + j
         return p
 
+    def beam_batch(c, mel_batch):
+        """BEAM SEARCH proper on one lock-step batch of k windows x hyp hypotheses (wh_beam_candidates / wh_reorder_self_cache): every step each
+        live hypothesis proposes its hyp best continuations under sampleBest's rules, a window's pool is ranked by cumulative log-probability and
+        its best hyp survive (their parents' self-attention cache rows move with them). Random weights never stop sensibly, so n_steps is
+        forced; returns the best hypothesis' ids per window [k][n_steps + 1]."""
+        k = mel_batch.shape[0]
+        S = k * hyp
+        c.encode(mel_batch, sync=False)
+        c.decode(np.tile(base, (S, 1)), 0, want_logits=False, want_probs=False)
+        cand = c.beam_candidates(S, hyp, True, True)
+        ids0, p0 = cand["id"][::hyp], cand["p"][::hyp]                      # every hypothesis of a window holds the same prompt: the first speaks
+        score = np.log(np.maximum(p0, 1e-30)).astype(np.float64)           # [k][hyp]
+        tok = ids0.astype(np.int32)                                         # [k][hyp]
+        parents = (np.arange(k)[:, None] * hyp + np.zeros((1, hyp), np.int64)).astype(np.int32)
+        hist = tok[:, :, None]
+        for s_ in range(n_steps):
+            c.reorder_self_cache(parents.reshape(-1), len(base) + s_)
+            c.decode(tok.reshape(-1, 1), len(base) + s_, want_logits=False, want_probs=False)
+            cand = c.beam_candidates(S, hyp)
+            pool = score[:, :, None] + np.log(np.maximum(cand["p"].reshape(k, hyp, hyp), 1e-30))
+            flat = pool.reshape(k, hyp * hyp)
+            order = np.argsort(-flat, axis=1, kind="stable")[:, :hyp]
+            par_local, cidx = order // hyp, order % hyp
+            score = np.take_along_axis(flat, order, axis=1)
+            tok = np.take_along_axis(cand["id"].reshape(k, hyp * hyp), order, axis=1).astype(np.int32)
+            parents = (np.arange(k)[:, None] * hyp + par_local).astype(np.int32)
+            hist = np.concatenate([np.take_along_axis(hist, par_local[:, :, None], axis=1), tok[:, :, None]], axis=2)
+        best = np.argmax(score, axis=1)
+        return hist[np.arange(k), best]
+
     def transcribe(lb, le):
         outs, pending = [], []
         idx = list(range(lb - b, le - b, per))
+        if hyp > 1:
+            # host-ranked steps: one batch at a time per context; the contexts still alternate
+            for n, i0 in enumerate(idx):
+                k = min(per, le - b - i0)
+                best = beam_batch(ctxs[n % len(ctxs)], mels[i0:i0 + k])
+                outs.append(np.concatenate([best] * hyp, axis=1))      # one row of hyp * (n_steps + 1) ints per window, like the greedy layout
+            ids = np.concatenate(outs, axis=0) if outs else np.zeros((0, hyp * (n_steps + 1)), np.int32)
+            return ids.reshape(le - lb, hyp * (n_steps + 1))
         for n, i0 in enumerate(idx):
             c = ctxs[n % len(ctxs)]
             while len(pending) >= len(ctxs):
@@ -659,9 +697,11 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "ggml-%s shape (random weights), %d x 30 s synthetic mel chunks (U(-1,1), seed = chunk index) resident in HBM, contiguous "
-                               "shards over %d rank(s), lock-step batches of %d windows x %d hypotheses sharing one pass over the cross-attention K/V, "
+                               "shards over %d rank(s), lock-step batches of %d windows x %d hypotheses sharing one pass over the cross-attention K/V%s, "
                                "%d contexts in flight, %d-token prompt + %d greedy steps per sequence; token ids gathered on rank 0"
-                               % (args.model, n_chunks, world, per, hyp, len(ctxs), N_PROMPT, n_steps),
+                               % (args.model, n_chunks, world, per, hyp, " (beam search: every step the pool of hyp x hyp continuations of a window is ranked by cumulative "
+                                  "log-probability on the host, the best hyp survive, parents' self-attention cache rows move with them)" if hyp > 1 else "",
+                                  len(ctxs), N_PROMPT, n_steps),
                    "model": "ggml-" + args.model, "chunks": n_chunks, "hypotheses": hyp, "windows_per_batch": per,
                    "parallelism": "dp%d (independent windows; RCCL weight broadcast outside the timed region: %s; no collective in the step)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
         "rtf": round(elapsed / (args.steps * n_chunks * 30.0), 6), "roofline": None, "cpu_baseline": None,

@@ -44,7 +44,7 @@ import json
 d=json.load(open("$out/bench.json"))
 print({k:d[k] for k in ("value","ms_per_step","steps")})
 print(json.dumps(d["roofline"])[:2200])
-for k in ("single_stream","large_v2","parity"): print(k, d.get(k))
+for k in ("through_boundary","single_stream","large_v2","parity"): print(k, d.get(k))
 PY
 fi
 if has prof; then
