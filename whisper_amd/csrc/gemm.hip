@@ -2005,6 +2005,10 @@ namespace wh
 				// 64 rows per workgroup read each weight row once per 64 rows, but N / ROWS x ceil(M / 64) workgroups must still
 				// cover the chip: below 256 of them, 32 rows per workgroup (twice the workgroups, each with half the activation
 				// traffic) measured 5.8 vs 7.8 us (N = K = 1024) and 14.1 vs 22.0 us (N = 1024, K = 4096) at 112 rows
+				// TUNE_GEMV_MT8 (A/B): ALL rows in one workgroup when N / ROWS alone fills the chip (the MLP up-projection, N = 4096): the weights are
+				// streamed once instead of once per 64 rows; 4 fragment slots instead of 8 keep 8 x 4 activation fragments at 128 registers
+				if constexpr( NW == 4 )
+					if( a.M > 64 && ( a.N + ROWS - 1 ) / ROWS >= 256 && ( g_tuning & TUNE_GEMV_MT8 ) ) return launchGemvK<EPI, PRO, ROWS, NW, 4, 8>( a, stream );
 				const int wgs = ( a.N + ROWS - 1 ) / ROWS * ( ( a.M + 63 ) / 64 );
 				if( wgs < 256 && ( g_tuning & TUNE_GEMV_ROWGROUPS ) ) return launchGemvK<EPI, PRO, ROWS, NW, 8, 2>( a, stream );
 				return launchGemvK<EPI, PRO, ROWS, NW, 8, 4>( a, stream );

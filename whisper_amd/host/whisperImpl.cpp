@@ -505,8 +505,30 @@ namespace Whisper
 				std::stable_sort( pool.begin(), pool.end(), []( const Prop& a, const Prop& b ) { return a.score > b.score; } );
 				expand( root, pool, live );
 			}
-			for( int s = 0; !live.empty() && (int)finished.size() < width; s++ )
+			// The search goes on while a live hypothesis could still win: a finished list that is full ends it only once every live
+			// hypothesis has fallen below the best finished one (a cumulative log-probability only ever decreases). Low-probability
+			// continuations that end their window at once (an EOT proposed with p ~ 1e-5) fill the list early and must not stop the
+			// hypothesis that is still being transcribed.
+			auto keepSearching = [ & ]() -> bool
 			{
+				if( live.empty() ) return false;
+				if( (int)finished.size() < width ) return true;
+				double bestFinished = -1e300, bestLive = -1e300;
+				for( const Hyp& h : finished )
+					if( !h.scan->failed ) bestFinished = std::max( bestFinished, h.sum );
+				for( const Hyp& h : live ) bestLive = std::max( bestLive, h.sum );
+				return bestLive >= bestFinished;
+			};
+			auto perToken = []( const Hyp& h ) { return h.sum / (double)std::max<size_t>( 1, h.scan->tokens.size() ); };
+			for( int s = 0; keepSearching(); s++ )
+			{
+				// the finished list keeps its best `width` entries (successful windows first, then log-probability per token)
+				if( (int)finished.size() > 2 * width )
+				{
+					std::stable_sort( finished.begin(), finished.end(), [ & ]( const Hyp& a, const Hyp& b )
+						{ return a.scan->failed != b.scan->failed ? !a.scan->failed : perToken( a ) > perToken( b ); } );
+					finished.resize( (size_t)width );
+				}
 				if( n + s >= model->hp.n_text_ctx ) break;	   // WindowScan's own bound (n_text_ctx / 2 - 4 tokens) fires first for every prompt the loop builds
 				// live hypothesis i moves to slot i; the idle slots repeat slot 0 and are ignored
 				for( int b = 0; b < B; b++ )
@@ -538,7 +560,6 @@ namespace Whisper
 				finished.push_back( std::move( h ) );
 			}
 			const Hyp* best = nullptr;
-			auto perToken = []( const Hyp& h ) { return h.sum / (double)std::max<size_t>( 1, h.scan->tokens.size() ); };
 			for( const Hyp& h : finished )
 				if( !best || ( best->scan->failed && !h.scan->failed ) || ( best->scan->failed == h.scan->failed && perToken( h ) > perToken( *best ) ) ) best = &h;
 			if( !best ) return E_UNEXPECTED;
