@@ -18,7 +18,7 @@ the --inflight contexts (plan_batches: 32 passes = 16 + 16, 20 passes = 10 + 10;
 Objects next to the contract fields:
   roofline      dominant kernel class: algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on
                 the launch stream (one batch at a time) minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per
-                launch from the committed PMC pass (profiles/r03_pmc.json). Two classes take turns at the top, so both are in
+                launch from the committed PMC pass (profiles/r04_pmc.json; counters cannot be collected inside a timed run). Two classes take turns at the top, so both are in
                 every line: `mfma_kernel` (the encoder's matrix-core product) and `hbm_kernel` (the decode step's
                 cross-attention); the top level repeats the larger. `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured
   cpu_baseline  the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample, same run
@@ -57,7 +57,9 @@ PUBLISHED_AUDIO_S_PER_S = {"medium": 13.30, "large-v2": 7.22, "large": 7.22}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
 MFMA_CLASSES = ("gemmTiled", "attentionEnc")
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
+if not os.path.exists(PMC_JSON):
+    PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
 BCAST_NOTE = {}        # model kind -> what the weight broadcast of this run was (ranks, bytes, seconds, GB/s)
 EMPTY_KERNEL_US = 1.9
 METRIC = "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU"
@@ -444,7 +446,7 @@ def roofline_from(kernels, batch_ms_timed, lone_ms, n_batches=1):
             if name in pmc.get("kernels", {}):
                 k = pmc["kernels"][name]
                 e["traffic"] = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
-                e["traffic_source"] = "%s: %s" % (os.path.relpath(PMC_JSON, ROOT), pmc.get("note", ""))
+                e["traffic_source"] = "committed counters, NOT measured in this run -- %s: %s" % (os.path.relpath(PMC_JSON, ROOT), pmc.get("note", ""))
                 e["traffic_over_algorithmic"] = round(e["traffic"] / max(k.get("algorithmic_bytes_per_launch", c["bytes"] / c["calls"]), 1.0), 3)
         except (ValueError, KeyError):
             pass
@@ -893,10 +895,10 @@ def main():
             # the like-for-like ratio is single_stream.vs_baseline
             "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, "
-                                   "%d clip pass(es) per lock-step batch, %d batches in flight on separate HIP streams; pinned host PCM -> H2D -> GPU mel + encoder + "
+            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, the %d clip passes of the timed region dealt "
+                                   "into lock-step batches of %s clips (at most %d), %d batches in flight on separate HIP streams; pinned host PCM -> H2D -> GPU mel + encoder + "
                                    "%d-token prompt + %d greedy steps per window, device-side sampling (captured hipGraph per token); span = first H2D byte to "
-                                   "last token id on the host" % (args.model, audio_seconds, B, C, args.inflight, N_PROMPT, N_GREEDY),
+                                   "last token id on the host" % (args.model, audio_seconds, B, args.steps, batch_plan, C, args.inflight, N_PROMPT, N_GREEDY),
                        "model": "ggml-" + args.model, "task": "translate" if args.workload == "v3stream" else "transcribe",
                        "baseline": "BASELINE.md section 1 publishes one sequential clip on a GTX 1080Ti (13.30 audio-s/s medium): compared in single_stream, not here",
                        "windows_per_clip": B, "clips_per_batch": C, "batch_plan": batch_plan, "batches_in_flight": args.inflight, "decode_steps_per_window": N_GREEDY + 1,

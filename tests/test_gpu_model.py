@@ -331,7 +331,10 @@ def test_hypotheses_share_cross_attention(hip_tiny, golden):
                                        # one stream (1 .. 4 sequences): the chip-wide launches of decode1.hip against the batch kernels;
                                        # their prefetch workgroups on / off must not change a bit
                                        ("TUNE_DECODE_SMALL", 1), ("TUNE_DECODE_SMALL", 2), ("TUNE_DECODE_SMALL", 3), ("TUNE_DECODE_SMALL", 4),
-                                       ("TUNE_DECODE_PREFETCH", 1), ("TUNE_DECODE_PREFETCH", 3)])
+                                       ("TUNE_DECODE_PREFETCH", 1), ("TUNE_DECODE_PREFETCH", 3),
+                                       # 65 .. 128 rows, N / 16 >= 256 (the MLP up-projection at d = 128: N = 512 -- too narrow; the test model
+                                       # never takes the variant, the medium-shape model of test_gemv_all_rows_variant does)
+                                       ("TUNE_GEMV_MT8", 100)])
 def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
     """Decode steps with a fusion switched on against the same steps with the separate launches (tuning bit off):
     LayerNorm + cross-attention query inside the attention kernel; LayerNorm + per-head QKV + cache append + self-attention
@@ -933,3 +936,32 @@ def test_beam_candidates_and_cache_reorder(hip_tiny, golden, tiny_model):
         assert np.array_equal(got_logits[j], want_logits[parents[j]]), j
     ctx.reorder_self_cache(np.arange(S, dtype=np.int32), rows)                                # identity: nothing to do
     ctx.close()
+
+
+@pytest.mark.parametrize("M", [65, 100, 112, 128])
+def test_gemv_all_rows_variant(M):
+    """TUNE_GEMV_MT8: the 65 .. 128-row decode product with ALL rows in one workgroup (weights streamed once), against the default
+    row-grouped kernel on the MLP up-projection's shape (N = 4096, K = 1024, GELU epilogue) and a plain FP32 product: the same MFMA
+    tiles and the same K split, so the results are identical bit for bit."""
+    rng = np.random.default_rng(M)
+    N, K = 4096, 1024
+    a = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ad, wd, bd = (torch.from_numpy(x).cuda() for x in (a, w, bias))
+    L = binding.lib()
+    outs = {}
+    for name, mask in (("default", binding.TUNE_DEFAULT & ~binding.TUNE_GEMV_MT8), ("mt8", binding.TUNE_DEFAULT | binding.TUNE_GEMV_MT8)):
+        L.wh_debug_set_tuning(mask)
+        try:
+            o16 = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+            binding.check(L.wh_op_mul_mat_gelu(None, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), o16.data_ptr(), M, N, K))
+            o32 = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+            binding.check(L.wh_op_mul_mat(None, ad.data_ptr(), wd.data_ptr(), bd.data_ptr(), None, o32.data_ptr(), M, N, K))
+            torch.cuda.synchronize()
+            outs[name] = (o16.cpu().numpy(), o32.cpu().numpy())
+        finally:
+            L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+    want = a.astype(np.float32) @ w.astype(np.float32).T + bias
+    assert np.abs(outs["mt8"][1] - want).max() < 2e-3
+    assert np.array_equal(outs["default"][0], outs["mt8"][0]) and np.array_equal(outs["default"][1], outs["mt8"][1])
