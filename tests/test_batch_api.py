@@ -194,3 +194,48 @@ def test_batch_caller_cpp(tmp_path):
     print(r.stdout[-3000:])
     assert r.returncode == 0
     assert "BATCH_CALLER_OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_batch_stress_random_lengths_and_flags(tmp_path):
+    """Many streams of random lengths (0.4 s .. 70 s; some too short, some exactly at window boundaries) on an audio-conditioned model, few slots,
+    small chunks, with and without the extra queued chunk (sBatchSetup.flags bit 0): slots are refilled all the time, windows of a round end at
+    different tokens, a group runs half empty at the tail. Every stream must equal its sequential runFull; the same under TokenTimestamps (token
+    times and vlen are host-side post-processing of the same tokens) and SingleSegment."""
+    mg = _generator()
+    path = str(tmp_path / "cond.bin")
+    gf.write_model(path, mg.model_for(10))
+    m = api.Model(path)
+    base = np.concatenate([mg.pcm_for("long"), mg.pcm_for("mixed")])             # 99 s of material
+    rng = np.random.default_rng(21)
+    pcms = []
+    for s in [0.4, 30.0, 60.0, 0.99, 1.5] + [float(x) for x in rng.uniform(2.0, 70.0, 18)]:
+        n = int(s * 16000)
+        off = int(rng.integers(0, len(base) - n))
+        pcms.append(np.ascontiguousarray(base[off:off + n]))
+    ctx = m.create_context()
+
+    def sequential(flags):
+        out = []
+        for pcm in pcms:
+            hr = ctx.run_full(pcm, flags=flags, prompt=[1000], n_max_text_ctx=0)
+            segs = ctx.results()
+            out.append((hr, [(s["t0"], s["t1"], s["text"], [(t["id"], t["t0"], t["t1"], round(t["vlen"], 4)) for t in s["tokens"]]) for s in segs]))
+        return out
+
+    def batched(runner, flags):
+        hr, got, per = runner.run(pcms, flags=flags, prompt=[1000], n_max_text_ctx=0)
+        assert hr == 0
+        return [(per[i], [(s["t0"], s["t1"], s["text"], [(t["id"], t["t0"], t["t1"], round(t["vlen"], 4)) for t in s["tokens"]]) for s in got[i]]) for i in range(len(pcms))]
+
+    for flags in (api.NO_CONTEXT, api.NO_CONTEXT | api.TOKEN_TIMESTAMPS, api.NO_CONTEXT | api.SINGLE_SEGMENT):
+        want = sequential(flags)
+        assert sum(len(w) for _, w in want) > 20
+        for slots, groups, chunk, fl in ((4, 2, 2, 0), (3, 1, 5, 1), (16, 2, 0, 0)):
+            runner = m.create_batch_runner(max_slots=slots, groups=groups, greedy_chunk=chunk, flags=fl)
+            got = batched(runner, flags)
+            for i in range(len(pcms)):
+                assert got[i] == want[i], (flags, slots, groups, chunk, fl, i, len(pcms[i]) / 16000.0)
+            runner.close()
+    ctx.close()
+    m.close()

@@ -171,7 +171,7 @@ def test_flash_attention(batch, heads, T):
     # fp16(e / sum) operand), and the scores kept in registers
     results = {}
     for name, mask in (("two-sweep", (binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP) & ~binding.TUNE_ATTN_ENC_TABLE),
-                       ("table", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE),
+                       ("table", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
                        ("three-sweep", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_2SWEEP),
                        ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
         L.wh_debug_set_tuning(mask)

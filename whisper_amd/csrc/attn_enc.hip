@@ -834,7 +834,10 @@ namespace wh
 		}
 		// the measured path (e unnormalised in FP16, O scaled by 1 / sum) with the exponential as a table lookup; the parity flag keeps
 		// the three-sweep kernel and the reference's fp16( e / sum ) operand
-		if( expTab && !exactP && ( g_tuning & TUNE_ATTN_ENC_TABLE ) && ( g_tuning & TUNE_ATTN_ENC_F ) && ( g_tuning & TUNE_ATTN_ENC_2SWEEP ) )
+		// (its 1024-thread workgroups take 512 query rows each: a single window is 48 of them on 256 CUs, where attentionEncF's 96 half-size
+		// workgroups finish sooner -- the table kernel runs once its grid covers the chip)
+		if( expTab && !exactP && ( g_tuning & TUNE_ATTN_ENC_TABLE ) && ( g_tuning & TUNE_ATTN_ENC_F ) && ( g_tuning & TUNE_ATTN_ENC_2SWEEP ) &&
+			( ( ( T + TQ - 1 ) / TQ ) * batch * heads >= 256 || ( g_tuning & TUNE_ATTN_ENC_TABLE_ANY ) ) )
 			return launchEncTable( q, k, vT, out, batch, heads, T, Tpad, expTab, stream );
 		if( g_tuning & TUNE_ATTN_ENC_F ) return launchEncF( q, k, vT, out, batch, heads, T, Tpad, exactP, stream );
 		switch( ( T + 255 ) / 256 )

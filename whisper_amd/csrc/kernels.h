@@ -36,6 +36,7 @@ namespace wh
 										 // (measured round 3, medium shape, one sequence: 1216 vs 1129 us per token -- OFF)
 		TUNE_ATTN_ENC_TABLE = 268435456,	 // encoder attention: exp16 as a LOOKUP in the reference's own table held in LDS (1024-thread workgroups, 4 VALU slots + one
 										 // ds_read_u16 per score instead of 14 VALU slots); bit-exact table semantics
+		TUNE_ATTN_ENC_TABLE_ANY = 1073741824,	 // ... whatever the grid (tests: small shapes through the table kernel)
 		TUNE_GEMV_MT8 = 536870912,		 // 65 .. 128 decode rows, N / 16 >= 256: all rows in one workgroup (weights streamed once), 4 fragment slots
 		TUNE_ENC_SERIAL = 134217728,	 // several contexts in flight: their ENCODERS run one at a time (an event chain between the contexts' streams), so that a
 										 // batch's MFMA-bound encoder runs under the latency- and HBM-bound decode chain of its neighbours instead of next to their encoders

@@ -483,6 +483,14 @@ namespace Whisper
 			{
 				if( !results || ( count && !streams ) ) return E_POINTER;
 				if( count == 0 ) return S_OK;
+				// the lock-step batch decodes greedily (one sequence per stream); beam search is iContext::runFull's (hypotheses of ONE window in lock step)
+				bool beam = params.strategy == eSamplingStrategy::BeamSearch;
+				for( uint32_t i = 0; i < count; i++ ) beam = beam || ( streams[ i ].params && streams[ i ].params->strategy == eSamplingStrategy::BeamSearch );
+				if( beam )
+				{
+					logError( "runFullBatch: eSamplingStrategy::BeamSearch is not available in a lock-step batch; use iContext::runFull" );
+					return E_NOTIMPL;
+				}
 				// streams dealt evenly: no more groups than hold two streams each, every group the same number of slots
 				const uint32_t useGroups = std::max<uint32_t>( 1, std::min<uint32_t>( nGroups, count / 2 ) );
 				const uint32_t slots = std::max<uint32_t>( 1, std::min<uint32_t>( maxSlots, ( count + useGroups - 1 ) / useGroups ) );
