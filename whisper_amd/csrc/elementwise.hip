@@ -431,6 +431,194 @@ namespace wh
 			}
 		}
 
+		// ---- the same sampler for the few rows of ONE stream, spread over the chip -------------------------------------
+		// softMaxSampleKernel gives a row to one workgroup: 207 KB of logits and 52 k exponentials on ONE CU = 41 us of the ~1.1 ms a
+		// single-stream token takes. Here a row is cut into SP_G slices: (1) slice maxima, (2) e = exp16( x - global max ), slice sums,
+		// slice argmaxima and top-4 lists, (3) one wave per row merges the SP_G records and applies sampleBest's rules. Same values:
+		// p = e * float( 1 / double sum ) for every number that leaves the sampler; the timestamp sum adds the same products in another order
+		// (double). e (unnormalised) is left in `eOut`.
+		constexpr int SP_G = 64;
+		struct SamplePart
+		{
+			double sumE;
+			ArgMax tx, ts;
+			ArgMax topAll[ 4 ], topTs[ 4 ];
+		};
+		__global__ void __launch_bounds__( 256 ) sampleSpreadMax( const float* __restrict__ logits, int nVocab, float* __restrict__ partMax )
+		{
+			__shared__ float sh[ 4 ];
+			const int row = blockIdx.y, g = blockIdx.x;
+			const int per = ( nVocab + SP_G - 1 ) / SP_G;
+			const int c0 = g * per, c1 = min( c0 + per, nVocab );
+			const float* x = logits + (long long)row * nVocab;
+			float m = -INFINITY;
+			for( int c = c0 + threadIdx.x; c < c1; c += 256 ) m = fmaxf( m, x[ c ] );
+			m = waveReduceMax( m );
+			if( ( threadIdx.x & 63 ) == 0 ) sh[ threadIdx.x >> 6 ] = m;
+			__syncthreads();
+			if( threadIdx.x == 0 ) partMax[ row * SP_G + g ] = fmaxf( fmaxf( sh[ 0 ], sh[ 1 ] ), fmaxf( sh[ 2 ], sh[ 3 ] ) );
+		}
+		__device__ __forceinline__ ArgMax block4ArgMax( ArgMax a, ArgMax* sh )
+		{
+#pragma unroll
+			for( int o = 32; o > 0; o >>= 1 )
+			{
+				ArgMax b;
+				b.v = __shfl_xor( a.v, o, 64 );
+				b.i = __shfl_xor( a.i, o, 64 );
+				a = better( a, b );
+			}
+			if( ( threadIdx.x & 63 ) == 0 ) sh[ threadIdx.x >> 6 ] = a;
+			__syncthreads();
+			const ArgMax r = better( better( sh[ 0 ], sh[ 1 ] ), better( sh[ 2 ], sh[ 3 ] ) );
+			__syncthreads();
+			return r;
+		}
+		__global__ void __launch_bounds__( 256 ) sampleSpreadExp( const float* __restrict__ logits, int nVocab, int tokenBeg, const float* __restrict__ partMax,
+			const DecodeState* __restrict__ state, float* __restrict__ eOut, SamplePart* __restrict__ parts )
+		{
+			__shared__ ArgMax sha[ 4 ];
+			__shared__ double shd[ 4 ];
+			const int row = blockIdx.y, g = blockIdx.x;
+			const int per = ( nVocab + SP_G - 1 ) / SP_G;
+			const int c0 = g * per, c1 = min( c0 + per, nVocab );
+			const float* x = logits + (long long)row * nVocab;
+			const int tsEnd = state->isInitial ? min( tokenBeg + 101, nVocab ) : nVocab;
+			float m = partMax[ row * SP_G + ( threadIdx.x & ( SP_G - 1 ) ) ];
+			m = waveReduceMax( m );
+			constexpr int PER_T = 4;	   // ceil( 51866 / 64 / 256 )
+			float v[ PER_T ];
+			double s = 0.0;
+			ArgMax tx = { -1.0f, 0x7fffffff }, ts = { -1.0f, 0x7fffffff };
+#pragma unroll
+			for( int j = 0; j < PER_T; j++ )
+			{
+				const int c = c0 + threadIdx.x + j * 256;
+				float e = -1.0f;	   // below every real e: never wins an argmax
+				if( c < c1 )
+				{
+					const float xv = x[ c ];
+					e = ( xv == -INFINITY ) ? 0.0f : exp16( xv - m );
+					eOut[ (long long)row * nVocab + c ] = e;
+					s += (double)e;
+					if( c < tokenBeg ) tx = better( tx, ArgMax{ e, c } );
+					else if( c < tsEnd ) ts = better( ts, ArgMax{ e, c } );
+				}
+				v[ j ] = e;
+			}
+			s = waveReduceSumD( s );
+			if( ( threadIdx.x & 63 ) == 0 ) shd[ threadIdx.x >> 6 ] = s;
+			tx = block4ArgMax( tx, sha );	   // (its barriers also publish shd)
+			ts = block4ArgMax( ts, sha );
+			SamplePart p;
+			p.sumE = ( shd[ 0 ] + shd[ 1 ] ) + ( shd[ 2 ] + shd[ 3 ] );
+			p.tx = tx; p.ts = ts;
+			// the slice's four best tokens among all that may be sampled, and among its timestamps: whichever list the row needs is merged later
+			for( int list = 0; list < 2; list++ )
+			{
+				float w[ PER_T ];
+#pragma unroll
+				for( int j = 0; j < PER_T; j++ )
+				{
+					const int c = c0 + threadIdx.x + j * 256;
+					const bool ok = c < c1 && !( c >= tsEnd && c >= tokenBeg ) && ( list == 0 || c >= tokenBeg );
+					w[ j ] = ok ? v[ j ] : -2.0f;
+				}
+				for( int round = 0; round < 4; round++ )
+				{
+					ArgMax best = { -2.0f, 0x7fffffff };
+#pragma unroll
+					for( int j = 0; j < PER_T; j++ ) best = better( best, ArgMax{ w[ j ], c0 + (int)threadIdx.x + j * 256 } );
+					best = block4ArgMax( best, sha );
+					if( best.v < 0.0f ) best.i = 0x7fffffff;	   // the slice has fewer than `round + 1` such tokens
+					( list == 0 ? p.topAll : p.topTs )[ round ] = best;
+#pragma unroll
+					for( int j = 0; j < PER_T; j++ )
+						if( c0 + (int)threadIdx.x + j * 256 == best.i ) w[ j ] = -2.0f;
+				}
+			}
+			if( threadIdx.x == 0 ) parts[ row * SP_G + g ] = p;
+		}
+		__global__ void __launch_bounds__( 64 ) sampleSpreadFinal( const SamplePart* __restrict__ parts, const float* __restrict__ e, int nVocab, int tokenBeg,
+			int tokenSot, int tokenSolm, int tokenNot, const DecodeState* __restrict__ state, TokenData* __restrict__ out, int* __restrict__ nextTokens,
+			const SampleMailbox mail )
+		{
+			static_assert( SP_G == 64, "one lane per slice" );
+			const int row = blockIdx.x, lane = threadIdx.x;
+			const SamplePart p = parts[ row * SP_G + lane ];
+			const int forceTimestamp = state->forceTimestamp;
+			const int tsEnd = state->isInitial ? min( tokenBeg + 101, nVocab ) : nVocab;
+			const double sum = waveReduceSumD( p.sumE );
+			const float inv = (float)( 1.0 / sum );
+			auto waveBest = [ & ]( ArgMax a ) -> ArgMax
+			{
+#pragma unroll
+				for( int o = 32; o > 0; o >>= 1 )
+				{
+					ArgMax b;
+					b.v = __shfl_xor( a.v, o, 64 );
+					b.i = __shfl_xor( a.i, o, 64 );
+					a = better( a, b );
+				}
+				return a;
+			};
+			ArgMax tx = waveBest( p.tx ), ts = waveBest( p.ts );
+			tx.v = tx.v < 0.0f ? -1.0f : tx.v * inv;
+			ts.v = ts.v < 0.0f ? -1.0f : ts.v * inv;
+			// the timestamp probabilities once more, as the products the one-workgroup sampler adds
+			double sumTs = 0.0;
+			for( int c = tokenBeg + lane; c < tsEnd; c += 64 ) sumTs += (double)( e[ (long long)row * nVocab + c ] * inv );
+			sumTs = waveReduceSumD( sumTs );
+			const bool onlyTs = ( sumTs > (double)fmaxf( tx.v, -1.0f ) ) || forceTimestamp;
+			// merge the slices' lists: every round the best head wins and its lane moves on
+			ArgMax mine[ 4 ];
+#pragma unroll
+			for( int k = 0; k < 4; k++ ) mine[ k ] = onlyTs ? p.topTs[ k ] : p.topAll[ k ];
+			int cursor = 0;
+			ArgMax pick = { -INFINITY, 0 };
+			for( int round = 0; round < 4; round++ )
+			{
+				ArgMax head = { -2.0f, 0x7fffffff };
+#pragma unroll
+				for( int k = 0; k < 4; k++ )
+					if( k == cursor ) head = mine[ k ];
+				if( head.i == 0x7fffffff ) head.v = -2.0f;
+				const ArgMax best = waveBest( head );
+				if( best.i == head.i && head.i != 0x7fffffff ) cursor++;
+				pick = best;
+				const bool special = best.i == tokenSot || best.i == tokenSolm || best.i == tokenNot;
+				if( !special ) break;
+			}
+			if( lane == 0 )
+			{
+				if( pick.i < 0 || pick.i >= nVocab ) { pick.i = 0; pick.v = 0.0f; }
+				TokenData r;
+				r.id = pick.i;
+				r.tid = ts.v > -1.0f ? ts.i : 0;
+				r.p = pick.v * inv;
+				r.pt = (float)( (double)ts.v / ( sumTs + 1e-10 ) );
+				r.ptsum = (float)sumTs;
+				const long long slot = (long long)state->step * gridDim.x + blockIdx.x;
+				out[ slot ] = r;
+				nextTokens[ blockIdx.x ] = pick.i;
+				const int gen = state->gen;
+				if( mail.data && gen != 0 )
+				{
+					int* const md = (int*)( mail.data + slot );
+					__hip_atomic_store( md + 0, r.id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					__hip_atomic_store( md + 1, r.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					__hip_atomic_store( md + 2, __float_as_int( r.p ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					__hip_atomic_store( md + 3, __float_as_int( r.pt ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					__hip_atomic_store( md + 4, __float_as_int( r.ptsum ), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					const int check = (int)( (unsigned)gen ^ (unsigned)r.id ^ ( (unsigned)r.tid * 0x9E3779B1u ) ^ (unsigned)__float_as_int( r.p ) ^
+						( (unsigned)__float_as_int( r.pt ) * 3u ) ^ ( (unsigned)__float_as_int( r.ptsum ) * 5u ) );
+					__hip_atomic_store( mail.flag + 2 * slot + 1, check, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+					__hip_atomic_store( mail.flag + 2 * slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM );
+				}
+			}
+		}
+
 		__global__ void advanceStateKernel( DecodeState* state, int* seqPos, int rows )
 		{
 			const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,6 +728,21 @@ namespace wh
 		}
 		hipLaunchKernelGGL( softMaxSampleKernel, dim3( rows ), dim3( 1024 ), 0, stream, logits, probsOut, nVocab, tokenBeg, tokenSot, tokenSolm,
 			tokenNot, state, out, nextTokens, mail );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	size_t sampleSpreadScratchBytes( int rows ) { return (size_t)rows * SP_G * ( sizeof( SamplePart ) + sizeof( float ) ); }
+	int launchSoftMaxSampleSpread( const float* logits, float* eOut, int rows, int nVocab, int tokenBeg, int tokenSot, int tokenSolm, int tokenNot,
+		const DecodeState* state, TokenData* out, int* nextTokens, SampleMailbox mail, void* scratch, hipStream_t stream )
+	{
+		if( nVocab > SP_G * 256 * 4 || rows < 1 || !scratch || !eOut ) { setError( "softMaxSampleSpread: bad argument" ); return -1; }
+		SamplePart* const parts = (SamplePart*)scratch;
+		float* const partMax = (float*)( parts + (size_t)rows * SP_G );
+		hipLaunchKernelGGL( sampleSpreadMax, dim3( SP_G, rows ), dim3( 256 ), 0, stream, logits, nVocab, partMax );
+		hipLaunchKernelGGL( sampleSpreadExp, dim3( SP_G, rows ), dim3( 256 ), 0, stream, logits, nVocab, tokenBeg, partMax, state, eOut, parts );
+		hipLaunchKernelGGL( sampleSpreadFinal, dim3( rows ), dim3( 64 ), 0, stream, parts, eOut, nVocab, tokenBeg, tokenSot, tokenSolm, tokenNot, state, out,
+			nextTokens, mail );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

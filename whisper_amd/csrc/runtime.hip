@@ -259,6 +259,7 @@ struct wh_context
 	int* melOffsetsDev = nullptr;
 	MelWindow* melWindowsDev = nullptr;
 	TokenData* tokDataDev = nullptr;
+	uint8_t* sampleScratch = nullptr;		   // TUNE_SAMPLE_SPREAD: slice records of the spread sampler (allocated on first use, before any capture)
 	TokenData* beamCand = nullptr;			   // beam search: [maxSeq][8] candidates (allocated on first use)
 	f16 *selfKScratch = nullptr, *selfVScratch = nullptr;	   // beam search: the copy a cache reorder goes through (allocated on first use)
 	float* melScratch = nullptr;
@@ -1900,6 +1901,23 @@ static int uploadDecodeState( wh_context* c, int batch, const DecodeState& s, co
 	return 0;
 }
 
+// logits -> table softmax -> sampleBest -> token data + next token: one workgroup per row, or -- for the few rows of one stream -- every row cut
+// into 64 slices over the chip (three small launches, ~12 us instead of 41 on one CU)
+static int sampleStep( wh_context* c, int batch, hipStream_t st )
+{
+	const wh_hparams& hp = c->m->hp;
+	const SpecialIds sp = specialIds( hp );
+	const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
+	if( batch <= SMALL_MAX_ROWS && ( g_tuning & TUNE_SAMPLE_SPREAD ) )
+	{
+		if( !c->sampleScratch ) WH_CHECK( c->alloc( c->sampleScratch, (int64_t)sampleSpreadScratchBytes( SMALL_MAX_ROWS ), wh_context::DONT_CARE, "sampleScratch" ) );
+		return profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
+			[ & ]() { return launchSoftMaxSampleSpread( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, c->sampleScratch, st ); } );
+	}
+	return profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
+		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, st ); } );
+}
+
 // One greedy token on the device: decoder graph -> softmax + sampleBest -> advance the device-resident state.
 static int greedyStep( wh_context* c, int batch )
 {
@@ -1907,8 +1925,7 @@ static int greedyStep( wh_context* c, int batch )
 	const SpecialIds sp = specialIds( hp );
 	const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
 	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
-	WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
-		[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, c->stream ); } ) );
+	WH_CHECK( sampleStep( c, batch, c->stream ) );
 	return launchAdvanceState( c->state, c->seqPos, batch, c->stream );
 }
 
@@ -2073,8 +2090,7 @@ static int windowStart( wh_context* c, int batch, const int32_t* promptTokens, c
 	{
 		const SpecialIds sp = specialIds( hp );
 		const int sot = sp.sot, solm = sp.solm, tnot = sp.tnot, beg = sp.beg;
-		WH_CHECK( profiled( c, KC_SAMPLE, 12.0 * batch * hp.n_vocab, 8.0 * batch * hp.n_vocab,
-			[ & ]() { return launchSoftMaxSample( c->logits, c->probs, batch, hp.n_vocab, beg, sot, solm, tnot, c->state, c->greedyOut, c->tokensDev, c->mailDev, st ); } ) );
+		WH_CHECK( sampleStep( c, batch, st ) );
 		WH_CHECK( launchAdvanceState( c->state, c->seqPos, batch, st ) );
 	}
 	if( useGraph )
