@@ -968,19 +968,20 @@ def test_gemv_all_rows_variant(M):
 
 
 @pytest.mark.parametrize("batch", [1, 2, 4])
-def test_spread_sampler_equals_the_one_workgroup_sampler(golden, golden_e2e, batch):
-    """TUNE_SAMPLE_SPREAD: for the few rows of one stream the sampler's row is cut into 64 slices over the chip (slice maxima -> exponentials,
-    slice sums / argmaxima / top-4 lists -> one wave merges them and applies sampleBest's rules, ContextImpl.cpp:71-157) instead of one workgroup
-    on one CU. Same numbers: token ids, timestamp ids and p identical; pt / ptsum add the same products in another order (double). Two models:
-    random weights (every sample a timestamp by the sum rule) and the peaked one of the jfk.wav fixture (text tokens, the forced first timestamp)."""
-    sp = gf.special_tokens(gf.hparams_for("test-d128"))
-    peaked = gf.synth_model("test-d128", seed=1234, attn_sharpness=2.0)
-    te = peaked.tensors["decoder.token_embedding.weight"].astype(np.float32) * float(golden_e2e["greedy_gain"][0])
-    peaked.tensors["decoder.token_embedding.weight"] = te.astype(np.float16)
+def test_spread_sampler_equals_the_one_workgroup_sampler(golden, batch):
+    """TUNE_SAMPLE_SPREAD (measured, not the default): for the few rows of one stream the sampler's row is cut into 64 slices over the chip
+    (slice maxima -> exponentials, slice sums / argmaxima / top-4 lists -> one wave merges them and applies sampleBest's rules,
+    ContextImpl.cpp:71-157) instead of one workgroup on one CU. Same numbers: token ids, timestamp ids and p identical; pt / ptsum add the same
+    products in another order (double). Two models: random weights (every sample a timestamp by the sum rule) and an audio-conditioned one
+    (text tokens between timestamps, the forced first timestamp)."""
     mel = torch.from_numpy(golden["mel"]).cuda()
     mels = torch.stack([torch.roll(mel, 53 * b, 1) for b in range(batch)])
     L = binding.lib()
-    for model in (gf.synth_model("test-d128", seed=77), peaked):
+    hp_ml = gf.hparams_for("test-d128-ml")
+    cond = gf.conditioned_model(gf.conditioned_layout(hp_ml), 4, kind="test-d128-ml", seed=10)
+    for model, text in ((gf.synth_model("test-d128", seed=77), False), (cond, True)):
+        sp = gf.special_tokens(model.hparams)
+        prompt = [sp["prev"], sp["sot"], sp["sot"] + 1, sp["transcribe"]] if text else [sp["sot"]]
         m = binding.HipModel.from_ggml(model)
         res = {}
         for name, mask in (("spread", binding.TUNE_DEFAULT | binding.TUNE_SAMPLE_SPREAD), ("one", binding.TUNE_DEFAULT & ~binding.TUNE_SAMPLE_SPREAD)):
@@ -988,7 +989,7 @@ def test_spread_sampler_equals_the_one_workgroup_sampler(golden, golden_e2e, bat
             try:
                 ctx = binding.HipContext(m, batch)
                 ctx.encode(mels)
-                ctx.decode_window_start(np.array([[sp["sot"]]] * batch, np.int32), 14, force_first_timestamp=True, first_is_initial=True)
+                ctx.decode_window_start(np.array([prompt] * batch, np.int32), 14, force_first_timestamp=True, first_is_initial=True)
                 res[name] = ctx.decode_window_fetch_data(0, 15)
                 ctx.close()
             finally:
@@ -996,5 +997,6 @@ def test_spread_sampler_equals_the_one_workgroup_sampler(golden, golden_e2e, bat
         a, b = res["spread"], res["one"]
         assert np.array_equal(a["id"], b["id"]) and np.array_equal(a["tid"], b["tid"]) and np.array_equal(a["p"], b["p"])
         assert np.allclose(a["pt"], b["pt"], rtol=1e-6, atol=0) and np.allclose(a["ptsum"], b["ptsum"], rtol=1e-6, atol=0)
-        assert (a["id"] < sp["beg"]).any() or model is not peaked      # the peaked model samples text tokens too
+        if text:
+            assert (a["id"] < sp["eot"]).any() and (a["id"] > sp["beg"]).any()
         m.close()

@@ -33,7 +33,7 @@ TUNE_SAMPLE_SPREAD = 2147483648
 TUNE_DEFAULT = (TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD |
                 TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI |
                 TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS |
-                TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE | TUNE_SAMPLE_SPREAD)
+                TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE)
 
 # every symbol include/whisper_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

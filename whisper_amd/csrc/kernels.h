@@ -38,6 +38,7 @@ namespace wh
 										 // ds_read_u16 per score instead of 14 VALU slots); bit-exact table semantics
 		TUNE_ATTN_ENC_TABLE_ANY = 1073741824,	 // ... whatever the grid (tests: small shapes through the table kernel)
 		TUNE_SAMPLE_SPREAD = 2147483648u,	 // up to 4 sequences: the sampler's row cut into 64 slices over the chip (3 launches) instead of one workgroup per row
+										 // (measured round 4, one stream through runFull: 417.9 / 419.5 without, 418.5 / 417.1 audio-s/s with -- nothing; OFF)
 		TUNE_GEMV_MT8 = 536870912,		 // 65 .. 128 decode rows, N / 16 >= 256: all rows in one workgroup (weights streamed once), 4 fragment slots
 		TUNE_ENC_SERIAL = 134217728,	 // several contexts in flight: their ENCODERS run one at a time (an event chain between the contexts' streams), so that a
 										 // batch's MFMA-bound encoder runs under the latency- and HBM-bound decode chain of its neighbours instead of next to their encoders
@@ -45,7 +46,7 @@ namespace wh
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE | TUNE_SAMPLE_SPREAD
+		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE
 	};
 	extern unsigned g_tuning;
 
