@@ -226,8 +226,41 @@ def gpu_parity_record(hip_model, hp, pcm_window, prompt, path):
     ctx.close()
     t = truth_yardstick()
     if t is not None:
+        if hp.n_text_state == 1024 and hp.n_text_layer == 24:
+            tm = truth_medium(hip_model)
+            if tm is not None:
+                t["medium_shape"] = tm
         rec["truth"] = np.asarray(json.dumps(t))
     np.savez(path, **rec)
+
+
+def truth_medium(hip_model):
+    """The same yardstick at the MEASURED shape: tests/golden/truth_medium.npz holds the float64 no-rounding logits of this very model (seed 1) on
+    the bench's window for the prompt and three teacher-forced steps, and how far the reference's CPU path (8 threads) is from them
+    (tests/golden/make_golden_truth_medium.py). Returns the HIP path's distance next to the reference's."""
+    import torch
+    from whisper_amd import binding
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "truth_medium.npz"))
+    except OSError:
+        return None
+    stats = json.loads(str(g["stats"]))
+    ctx = binding.HipContext(hip_model, 1)
+    ctx.encode(torch.from_numpy(g["mel"]).cuda())
+    steps = [[int(t) for t in g["prompt"]]] + [[int(t)] for t in g["extra"]]
+    out = {"model": "ggml-medium shape (the bench's model), window 0, prompt + 3 teacher-forced steps", "gpu_vs_truth_max": 0.0, "gpu_vs_truth_mean": 0.0,
+           "ref8_vs_truth_max": max(s["ref8_vs_truth_max"] for s in stats), "ref8_vs_truth_mean": max(s["ref8_vs_truth_mean"] for s in stats), "top1_equal_exact": 0}
+    n_past = 0
+    for i, toks in enumerate(steps):
+        gl, _ = ctx.decode(np.asarray([toks], np.int32), n_past)
+        n_past += len(toks)
+        d = np.abs(gl[0].astype(np.float64) - g["truth_logits%d" % i].astype(np.float64))
+        out["gpu_vs_truth_max"] = max(out["gpu_vs_truth_max"], float(d.max()))
+        out["gpu_vs_truth_mean"] = max(out["gpu_vs_truth_mean"], float(d.mean()))
+        out["top1_equal_exact"] += int(int(np.argmax(gl[0])) == stats[i]["truth_top1"])
+    out["top1_equal_exact"] = "%d/%d" % (out["top1_equal_exact"], len(steps))
+    ctx.close()
+    return out
 
 
 def truth_yardstick():
