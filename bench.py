@@ -190,6 +190,8 @@ def cpu_baseline_worker(model_path, model_kind, pcm_path, prompt, n_threads, par
         par.update({"ref1_vs_ref%d_max" % n_threads: b_max, "ref1_vs_ref%d_mean" % n_threads: b_mean, "gpu_vs_ref1_max": g1_max})
         if "truth" in g.files:
             par["truth_d128"] = json.loads(str(g["truth"]))
+            if "medium_shape" in par["truth_d128"]:
+                par["truth_medium"] = par["truth_d128"].pop("medium_shape")
         par.update({"steps": len(ids), "logits_max_abs_diff": worst_max, "logits_mean_abs_diff": worst_mean,
                     "logit_span_min": min(spans), "top1_agreement": "%d/%d" % (agree, len(ids)),
                     "note": "teacher-forced by the GPU's own greedy ids; the reference's decoder result itself moves by ~5e-2 between 1 and "
