@@ -294,6 +294,44 @@ def test_mul_mat_fragment_prefetch_is_bit_identical(M, N, K):
         assert torch.equal(o, outs[0])
 
 
+@pytest.mark.parametrize("M,N,K", [(16500, 4608, 1024), (17000, 5120, 192), (16384 + 77, 4672, 256), (16400, 1256, 128), (16400, 1250, 128),
+                                   (33000, 1024, 4096)])
+def test_mul_mat_4wave_kernel_equals_8wave(M, N, K):
+    """gemmTiled4 (one wave per SIMD, 128 x 128 outputs per wave, a hand-pipelined K loop with one barrier per K tile) against
+    gemmTiled8: the same MFMAs in the same order per output, so FP32 (bias + residual) and FP16 GELU outputs must agree bit for
+    bit -- whole and ragged tiles, the shortest K loop (two K tiles), N % 8 != 0 (the element-wise epilogue), several launches
+    (a missing wait or a buffer overwritten too early is intermittent), and against the float64 product."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + 7)
+    a = torch.randn((M, K), generator=g, device="cuda").half()
+    w = (0.05 * torch.randn((N, K), generator=g, device="cuda")).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    res = torch.randn((M, N), generator=g, device="cuda")
+    want = _torch_ref_mul_mat(a, w, bias, res)
+    L = binding.lib()
+    outs, gelus = [], []
+    try:
+        for mask in (binding.TUNE_DEFAULT & ~binding.TUNE_GEMM_4WAVE, binding.TUNE_DEFAULT | binding.TUNE_GEMM_4WAVE):
+            L.wh_debug_set_tuning(mask)
+            for rep in range(3):
+                out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+                binding.check(L.wh_op_mul_mat(None, ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), M, N, K))
+                outs.append(out)
+                o16 = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+                binding.check(L.wh_op_mul_mat_gelu(None, ptr(a), ptr(w), ptr(bias), ptr(o16), M, N, K))
+                gelus.append(o16)
+    finally:
+        L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+    torch.cuda.synchronize()
+    d = (outs[-1].double() - want).abs()
+    print("mul_mat 4-wave %dx%dx%d maxdiff %.3e" % (M, N, K, float(d.max())))
+    assert bool(torch.isfinite(outs[-1]).all())
+    assert float(d.max()) < 2e-5 * max(1.0, np.sqrt(K / 128))
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    for o in gelus[1:]:
+        assert torch.equal(o, gelus[0])
+
+
 def test_mul_mat_gelu_big_tiles(golden):
     """The same instance with the FP16 GELU epilogue (EPI_F16_GELU, the encoder's MLP up-projection)."""
     M, N, K = 16390, 4608, 512

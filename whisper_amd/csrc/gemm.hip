@@ -1458,6 +1458,720 @@ namespace wh
 				if( !more ) break;
 			}
 		}
+
+		// ---------------------------------------------------------------------------------------------------------------
+		// gemmTiled4 (round 4): the encoder product with ONE wave per SIMD. profiles/r04_gemm_counters.txt: gemmTiled8's waves own
+		// 128 x 64 outputs, so every fragment read feeds half the MFMAs it could (24 ds_read_b128 per 32 MFMAs), the LDS pipe of a
+		// CU is ~75 % busy under a full-rate matrix pipe and the chip clocks lower for it. Here FOUR waves (2 x 2) own 128 x 128
+		// each = 4 x 4 tiles of v_mfma_f32_32x32x16_f16: 256 accumulator registers (the AGPR half of a 512-register wave), 8
+		// fragment reads per 16 MFMAs, half the LDS traffic per FLOP. With a single wave per SIMD nothing overlaps by
+		// itself, so the K loop is a software pipeline written out by hand:
+		//   * a K tile (64) is four substeps of 16 MFMAs; the fragments of substep s+1 are read (8 x ds_read_b128, second
+		//     register set) while the MFMAs of substep s issue -- interleaved 1 read : 2 MFMAs by sched_group_barrier;
+		//   * ONE s_barrier per K tile, before the LAST substep: by then a wave has read everything it needs from the current
+		//     buffer (the last substep's fragments are in registers) and waited for its own LDS-DMA pieces of the next tile
+		//     (vmcnt(0)), so after the barrier the next K tile is complete in the other buffer and the current buffer is dead:
+		//     the first fragments of the next K tile are read under the last substep's MFMAs and the DMA of the tile after
+		//     next starts into the dead buffer. A DMA piece has a whole K tile (~2k cycles) to land; the matrix pipe sees
+		//     the barrier only as the skew between four waves that run the same instruction stream;
+		//   * the stream of K tiles is FLAT across output tiles (persistent workgroup, the band walk of gemmTiled8): the
+		//     producer side (tile coordinates, per-lane source offsets) runs two K tiles ahead of the consumer and simply
+		//     moves on to the next output tile; the epilogue of a tile runs between two K tiles with the next output tile's
+		//     first K tile already in LDS and its second one in flight;
+		//   * a tile's first substep multiplies into the constant 0 instead of clearing 256 registers.
+		// LDS: two 64 KiB K-tile buffers (A rows, then W rows, 128-byte rows, 16-byte chunks XOR-swizzled exactly as gemmTiled8)
+		// + 4 KiB of epilogue staging per wave = 144 KiB. Wave w stages rows 64 w .. 64 w + 63 of both operand tiles.
+		// An accumulator register of gemmTiled4 read where the epilogue uses it. Written as assembly so that the register allocator keeps
+		// the 256 accumulators in the AGPR half of the file until then: left to itself it copies half of them into VGPRs at the end of
+		// the K loop, spills the K loop's own state to scratch to make room, and every scratch reload then waits for ALL stores in
+		// flight (vmcnt(0)). The MFMAs that wrote the accumulators are dozens of instructions behind the first read (the caller
+		// computes the next tile's offsets in between and pads with s_nop): no hazard the compiler would have had to see.
+		__device__ __forceinline__ f32x16 accReadTile( const f32x16& t )
+		{
+			f32x16 v;
+	#pragma unroll
+			for( int r = 0; r < 16; r++ )
+			{
+				float x;
+				asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( x ) : "a"( t[ r ] ) );
+				v[ r ] = x;
+			}
+			return v;
+		}
+
+		// Epilogue of an INTERIOR 128 x 128 wave tile of gemmTiled4 (whole tile inside M x N; the launcher has checked what a.wideEpi == 2
+		// promises below). One wave per SIMD: nothing hides a stall, so this path has no bounds checks, no divisions per row, no
+		// branches, and an order of memory operations that never waits for a store:
+		//   * the tile leaves in UNITS of 32 rows x 128 bytes (FP32: one MFMA tile; FP16: two side by side) through 4 KiB of LDS per
+		//     wave: 16 / 32 column-wise writes per lane, then 4 x (ds_read_b128 -> 16-byte row store), 8 lanes per 128-byte row;
+		//     LDS operations of a wave execute in order, so one buffer is enough and nothing but the data dependence is waited for;
+		//   * software pipeline over the units, in program order: reads of unit k issued | residual rows of unit k + 1 requested |
+		//     unit k + 1 converted and written to LDS (the GELU arithmetic sits here, under the LDS round trip of unit k) | unit k
+		//     stored. A residual load is always older than the stores issued after it: waiting for it never waits for a store;
+		//   * addresses are a scalar base per unit + one 32-bit offset per lane and row (16 registers for the 16 rows a lane stores,
+		//     computed once per tile); a row past the end of its segment (sequence / conv batch) adds one constant: the wave's 128
+		//     rows cross at most one boundary (segments are at least 128 rows long).
+		// Same arithmetic per element as tileEpilogue / epilogueBlock32x64 (bit-identical outputs).
+		template<int EPI, bool HASRES, int ABL = 0>
+		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ 4 ], int mW, int nW, int lane, unsigned char* stage )
+		{
+			static_assert( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV, "fast epilogue" );
+			constexpr bool F32OUT = EPI == EPI_F32;
+			constexpr bool HEADS = EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV;
+			constexpr int UNITS = F32OUT ? 16 : 8;
+			// (opaque copy: what follows is a few VALU instructions per tile; hoisted out of the tile loop it would live in scratch)
+			asm volatile( "" : "+v"( lane ) );
+			const int hi = lane >> 5, cl = lane & 31, rl = lane >> 3, ch = lane & 7;
+			float bias[ 4 ];
+	#pragma unroll
+			for( int j = 0; j < 4; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
+
+			// ---- rows (wave-uniform): segment length, position of the tile's first row in its segment, byte offset of that row
+			int seg, segPos;
+			unsigned rowBytes, crossBytes;
+			long long firstRowBytes;
+			if constexpr( HEADS )
+			{
+				seg = a.T;
+				const int b = mW / a.T;
+				segPos = mW - b * a.T;
+				rowBytes = 128u;
+				crossBytes = (unsigned)( a.H - 1 ) * (unsigned)a.T * 128u;
+				firstRowBytes = ( (long long)b * a.H * a.T + segPos ) * 128;
+			}
+			else
+			{
+				constexpr int ES = F32OUT ? 4 : 2;
+				const int b = a.Mb > 0 ? mW / a.Mb : 0;
+				seg = a.Mb > 0 ? a.Mb : 0x7fffffff;
+				segPos = mW - b * ( a.Mb > 0 ? a.Mb : 0 );
+				rowBytes = (unsigned)a.ldc * ES;
+				crossBytes = (unsigned)( ( a.cBatchStride - (long long)a.Mb * a.ldc ) * ES );
+				firstRowBytes = ( (long long)b * a.cBatchStride + (long long)segPos * a.ldc ) * ES;
+			}
+			seg = __builtin_amdgcn_readfirstlane( seg );
+			segPos = __builtin_amdgcn_readfirstlane( segPos );
+			rowBytes = __builtin_amdgcn_readfirstlane( rowBytes );
+			crossBytes = __builtin_amdgcn_readfirstlane( crossBytes );
+			unsigned voff[ 4 ][ 4 ];
+	#pragma unroll
+			for( int i = 0; i < 4; i++ )
+	#pragma unroll
+				for( int it = 0; it < 4; it++ )
+				{
+					const int r = 32 * i + 8 * it + rl;
+					voff[ i ][ it ] = (unsigned)r * rowBytes + ( segPos + r >= seg ? crossBytes : 0u ) + (unsigned)ch * 16u;
+				}
+
+			// ---- columns (wave-uniform): what the wave's 128 columns are, base address of unit k
+			int sel = 0;
+			long long colBytes = 0;	   // byte offset of the wave tile's first column block
+			if constexpr( EPI == EPI_F32 ) colBytes = (long long)nW * 4;
+			if constexpr( EPI == EPI_F16_GELU ) colBytes = (long long)nW * 2;
+			if constexpr( EPI == EPI_QKV_ENC )
+			{
+				const int d = a.H * HEAD_DIM;
+				sel = __builtin_amdgcn_readfirstlane( nW / d );
+				colBytes = (long long)( ( nW - sel * d ) >> 6 ) * a.T * 128;
+			}
+			if constexpr( EPI == EPI_CROSS_KV )
+			{
+				const int d = a.H * HEAD_DIM;
+				const int layer = __builtin_amdgcn_readfirstlane( nW / ( 2 * d ) );
+				const int c2 = nW - layer * 2 * d;
+				sel = c2 >= d ? 1 : 0;
+				colBytes = ( (long long)layer * a.B * a.H + ( ( sel ? c2 - d : c2 ) >> 6 ) ) * a.T * 128;
+			}
+			unsigned char* outBase;
+			if constexpr( EPI == EPI_F32 ) outBase = (unsigned char*)a.out32;
+			if constexpr( EPI == EPI_F16_GELU ) outBase = (unsigned char*)a.out16;
+			if constexpr( EPI == EPI_QKV_ENC ) outBase = (unsigned char*)( sel == 0 ? a.q : a.k );
+			if constexpr( EPI == EPI_CROSS_KV ) outBase = (unsigned char*)( sel ? a.v : a.k );
+			outBase += firstRowBytes + colBytes;
+			const unsigned char* resBase = HASRES ? (const unsigned char*)a.res + firstRowBytes + colBytes : nullptr;
+			// bytes from the wave tile's first unit to unit k: FP32 unit k = MFMA tile (k >> 2, k & 3); FP16 unit k = tiles (k >> 1, 2 (k & 1)), (.., + 1)
+			const long long headBytes = HEADS ? (long long)a.T * 128 : 128;
+
+			auto writeUnit = [ & ]( auto kc )
+			{
+				constexpr int k = decltype( kc )::value;
+				if constexpr( F32OUT )
+				{
+					constexpr int i = k >> 2, j = k & 3;
+	#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+						float x;
+						asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( x ) : "a"( acc[ i ][ j ][ r ] ) );
+						*(float*)( stage + row * 128 + cl * 4 ) = x + bias[ j ];
+					}
+				}
+				else
+				{
+					constexpr int i = k >> 1, jp = k & 1;
+	#pragma unroll
+					for( int jj = 0; jj < 2; jj++ )
+	#pragma unroll
+						for( int r = 0; r < 16; r++ )
+						{
+							const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+							float v;
+							asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( v ) : "a"( acc[ i ][ 2 * jp + jj ][ r ] ) );
+							f16 hv;
+							if constexpr( EPI == EPI_F16_GELU )
+								hv = gelu16( v + bias[ 2 * jp + jj ] );
+							else if constexpr( EPI == EPI_QKV_ENC )
+								hv = (f16)( v + bias[ 2 * jp + jj ] );
+							else
+								hv = sel ? (f16)( v + bias[ 2 * jp + jj ] ) : (f16)( v * a.scale );
+							*(f16*)( stage + row * 128 + ( jj * 32 + cl ) * 2 ) = hv;
+						}
+				}
+			};
+			auto ldsFence = [ & ]()
+			{
+				// compile-time only: the column-wise writes and the row-wise reads of the staging area use different types
+				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+			};
+			auto unitBytes = [ & ]( int k ) -> long long { return F32OUT ? (long long)( k & 3 ) * 128 : (long long)( k & 1 ) * headBytes; };
+			auto loadRes = [ & ]( auto kc, f32x4( &ex )[ 4 ] )
+			{
+				constexpr int k = decltype( kc )::value;
+				if constexpr( HASRES )
+				{
+					constexpr int i = F32OUT ? k >> 2 : k >> 1;
+					const unsigned char* const b = resBase + unitBytes( k );
+	#pragma unroll
+					for( int it = 0; it < 4; it++ ) ex[ it ] = *(const f32x4*)( b + voff[ i ][ it ] );
+				}
+			};
+			auto readUnit = [ & ]( f32x4( &dv )[ 4 ] )
+			{
+	#pragma unroll
+				for( int it = 0; it < 4; it++ ) dv[ it ] = *(const f32x4*)( stage + ( it * 8 + rl ) * 128 + ch * 16 );
+			};
+			auto storeUnit = [ & ]( auto kc, const f32x4( &dv )[ 4 ], const f32x4( &ex )[ 4 ] )
+			{
+				constexpr int k = decltype( kc )::value;
+				constexpr int i = F32OUT ? k >> 2 : k >> 1;
+				unsigned char* const b = outBase + unitBytes( k );
+	#pragma unroll
+				for( int it = 0; it < 4; it++ )
+				{
+					f32x4 o = dv[ it ];
+					if constexpr( HASRES )
+					{
+	#pragma unroll
+						for( int e = 0; e < 4; e++ ) o[ e ] = dv[ it ][ e ] + ex[ it ][ e ];
+					}
+					if constexpr( ( ABL & 1 ) != 0 )
+						asm volatile( "" ::"v"( o ) );	   // probe: everything but the global stores
+					else
+						*(f32x4*)( b + voff[ i ][ it ] ) = o;
+				}
+			};
+
+			f32x4 ex[ 2 ][ 4 ], dv[ 4 ];
+			loadRes( std::integral_constant<int, 0>{}, ex[ 0 ] );
+			writeUnit( std::integral_constant<int, 0>{} );
+			ldsFence();
+			__builtin_amdgcn_sched_barrier( 0 );
+			auto step = [ & ]( auto kc )
+			{
+				constexpr int k = decltype( kc )::value;
+				readUnit( dv );
+				ldsFence();
+				__builtin_amdgcn_sched_barrier( 0 );
+				if constexpr( k + 1 < UNITS )
+				{
+					loadRes( std::integral_constant<int, k + 1>{}, ex[ ( k + 1 ) & 1 ] );
+					writeUnit( std::integral_constant<int, k + 1>{} );
+					ldsFence();
+					__builtin_amdgcn_sched_barrier( 0 );
+				}
+				storeUnit( kc, dv, ex[ k & 1 ] );
+				__builtin_amdgcn_sched_barrier( 0 );
+			};
+			step( std::integral_constant<int, 0>{} );
+			step( std::integral_constant<int, 1>{} );
+			step( std::integral_constant<int, 2>{} );
+			step( std::integral_constant<int, 3>{} );
+			step( std::integral_constant<int, 4>{} );
+			step( std::integral_constant<int, 5>{} );
+			step( std::integral_constant<int, 6>{} );
+			step( std::integral_constant<int, 7>{} );
+			if constexpr( UNITS == 16 )
+			{
+				step( std::integral_constant<int, 8>{} );
+				step( std::integral_constant<int, 9>{} );
+				step( std::integral_constant<int, 10>{} );
+				step( std::integral_constant<int, 11>{} );
+				step( std::integral_constant<int, 12>{} );
+				step( std::integral_constant<int, 13>{} );
+				step( std::integral_constant<int, 14>{} );
+				step( std::integral_constant<int, 15>{} );
+			}
+		}
+
+		// The V third of the encoder's Q/K/V product, interior wave tile of gemmTiled4: fragment-major V (vFragIndex) straight from the
+		// accumulators, no LDS. A lane of a 32x32 accumulator tile holds one dimension and, per register group g, the 4 consecutive keys
+		// t .. t + 3 (t % 4 == 0: T % 4 == 0, launcher) -- one 8-byte half of a 16-byte fragment; the other half (keys t + 8 ..) is the
+		// lane's group g + 1 or g - 1 and follows within a few instructions, so the L2 sees whole lines. Per lane 16 offsets (4 row tiles x 4 groups),
+		// computed once per tile; the dimension block (+ 1 KiB) is an immediate, the head a scalar base. Same values as epilogueBlockV32x64.
+		__device__ __forceinline__ void epilogueFastV4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ 4 ], int mW, int nW, int lane )
+		{
+			asm volatile( "" : "+v"( lane ) );
+			const int hi = lane >> 5, cl = lane & 31;
+			const int d = a.H * HEAD_DIM;
+			float bias[ 4 ];
+	#pragma unroll
+			for( int j = 0; j < 4; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
+			const int b = __builtin_amdgcn_readfirstlane( mW / a.T );
+			const int segPos = mW - b * a.T;
+			const unsigned headBytes = (unsigned)HEAD_DIM * (unsigned)a.Tpad * 2u;
+			const unsigned seqBytes = (unsigned)a.H * headBytes;
+			unsigned char* const base = (unsigned char*)a.v + (long long)b * seqBytes + (long long)( ( nW - 2 * d ) >> 6 ) * headBytes;
+			unsigned voff[ 4 ][ 4 ];
+	#pragma unroll
+			for( int i = 0; i < 4; i++ )
+	#pragma unroll
+				for( int g = 0; g < 4; g++ )
+				{
+					int t = segPos + 32 * i + 8 * g + 4 * hi;
+					const bool cross = t >= a.T;
+					t = cross ? t - a.T : t;
+					voff[ i ][ g ] = ( cross ? seqBytes : 0u ) + (unsigned)( ( ( ( t >> 4 ) * 128 + ( ( t >> 2 ) & 1 ) * 32 + cl ) * 8 + ( ( t >> 3 ) & 1 ) * 4 ) * 2 );
+				}
+	#pragma unroll
+			for( int i = 0; i < 4; i++ )
+			{
+	#pragma unroll
+				for( int j = 0; j < 4; j++ )
+				{
+					unsigned char* const bj = base + ( j >> 1 ) * (long long)headBytes + ( j & 1 ) * 1024;
+	#pragma unroll
+					for( int g = 0; g < 4; g++ )
+					{
+						f16x4 pk;
+	#pragma unroll
+						for( int e = 0; e < 4; e++ )
+						{
+							float x;
+							asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( x ) : "a"( acc[ i ][ j ][ 4 * g + e ] ) );
+							pk[ e ] = (f16)( x + bias[ j ] );
+						}
+						*(f16x4*)( bj + voff[ i ][ g ] ) = pk;
+					}
+				}
+				__builtin_amdgcn_sched_barrier( 0 );
+			}
+		}
+
+		struct Cfg4
+		{
+			static constexpr int BM = 256, BN = 256, BK = 64, NT = 256, TI = 4, TJ = 4;
+			static constexpr int A_BYTES = BM * BK * 2, STAGE_BYTES = ( BM + BN ) * BK * 2;	   // 32 KiB, 64 KiB
+			static constexpr int EPI_OFFSET = 2 * STAGE_BYTES;
+			static constexpr int EPI_PER_WAVE = 4096;
+			static constexpr int LDS_BYTES = EPI_OFFSET + 4 * EPI_PER_WAVE;
+		};
+
+		// SCH (measurement variants, all correct): bit 0 = the DMA pieces of a K tile spread 3 / 3 / 2 over three substeps (else 4 / 4
+		// over two), bit 1 = no sched_group_barrier interleave (the compiler's own order inside a substep), bit 2 = 1 read : 1 MFMA at
+		// the head of a substep instead of 1 : 2 throughout
+		template<int EPI, bool WIDE, int SCH = 0>
+		__global__ void __launch_bounds__( 256, 1 ) gemmTiled4( const GemmArgs a )
+		{
+			using C = Cfg4;
+			constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smem[];
+			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+			const int wr = wave >> 1, wc = wave & 1;
+
+			// ---- this workgroup's tiles (as gemmTiled8): XCD x = workgroup id % 8 owns a contiguous range of the band-walk order
+			const int tilesM = ( a.M + BM - 1 ) / BM, tilesN = ( a.N + BN - 1 ) / BN;
+			const int nTiles = tilesM * tilesN;
+			int linFirst, linEnd, linStep;
+			{
+				const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+				const int q = nTiles >> 3, r = nTiles & 7;
+				const int start = xcd < r ? xcd * ( q + 1 ) : r * ( q + 1 ) + ( xcd - r ) * q;
+				linEnd = start + ( xcd < r ? q + 1 : q );
+				linFirst = start + idx;
+				linStep = ( gridDim.x + 7 - xcd ) >> 3;
+			}
+			auto tileCoords = [ & ]( int lin, int& tm, int& tn )
+			{
+				if( a.groupM > 1 )
+				{
+					const int perBand = a.groupM * tilesN;
+					const int band = lin / perBand;
+					const int first = band * a.groupM;
+					const int rows = min( tilesM - first, a.groupM );
+					const int r = lin - band * perBand;
+					tm = first + r % rows;
+					tn = r / rows;
+				}
+				else
+				{
+					tm = lin / tilesN;
+					tn = lin - tm * tilesN;
+				}
+			};
+			if( linFirst >= linEnd ) return;
+
+			// ---- producer side: LDS-DMA sources. A tile is 32 pieces of 8 rows x 128 bytes; wave w owns pieces 8 w .. 8 w + 7 of the A
+			// tile and of the W tile, issued as 4 + 4 pairs. Lane l of a piece lands at row l / 8, physical chunk l % 8, which must hold
+			// logical chunk (l % 8) ^ ((row >> 1) & 7); offA / offW = byte offset of that chunk from a.A / a.W at k = 0.
+			// pOff* = the output tile the producer is in, nOff* = the workgroup's tile after that one (computed outside the K loop: the
+			// producer changes tiles in the middle of the consumer's K loop and then only copies 16 registers).
+			unsigned pOffA[ 4 ][ 2 ], pOffW[ 4 ][ 2 ], nOffA[ 4 ][ 2 ], nOffW[ 4 ][ 2 ];
+			auto tileOffsets = [ & ]( int lin, unsigned( &offA )[ 4 ][ 2 ], unsigned( &offW )[ 4 ][ 2 ] )
+			{
+				int tm, tn;
+				tileCoords( lin, tm, tn );
+				// No branch and no division per row: rows past M / N repeat the last one, a tile crosses at most one segment boundary of A
+				// (segments of at least 256 rows, launcher), and everything fits 32 bits (launcher)
+				const int mFirst = tm * BM, nFirst = tn * BN;
+				const int mMax = a.M - 1 - mFirst, nMax = a.N - 1 - nFirst;
+				int laneV = lane;
+				asm volatile( "" : "+v"( laneV ) );	   // (not hoisted out of the tile loop into scratch)
+				const int rIn = laneV >> 3, cPhys = laneV & 7;
+				const bool segd = a.Mb > 0 && a.Mb < a.M;
+				const int b0 = segd ? mFirst / a.Mb : 0;
+				const int t0 = mFirst - b0 * ( segd ? a.Mb : 0 );
+				const int segLeft = segd ? a.Mb - t0 : 0x7fffffff;
+				const unsigned aBase = (unsigned)( ( (long long)b0 * a.aBatchStride + (long long)t0 * a.lda ) * 2 );
+				const unsigned crossA = segd ? (unsigned)( ( a.aBatchStride - (long long)a.Mb * a.lda ) * 2 ) : 0u;
+				const unsigned wBase = (unsigned)( (long long)nFirst * a.K * 2 );
+	#pragma unroll
+				for( int q = 0; q < 4; q++ )
+	#pragma unroll
+					for( int i = 0; i < 2; i++ )
+					{
+						const int row = ( wave * 8 + q * 2 + i ) * 8 + rIn;
+						const unsigned c16 = (unsigned)( cPhys ^ ( ( row >> 1 ) & 7 ) ) * 16u;
+						const int rm = min( row, mMax );
+						offA[ q ][ i ] = aBase + (unsigned)rm * (unsigned)( a.lda * 2 ) + ( rm >= segLeft ? crossA : 0u ) + c16;
+						const int rn = min( row, nMax );
+						offW[ q ][ i ] = wBase + (unsigned)rn * (unsigned)( a.K * 2 ) + c16;
+					}
+			};
+			const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)smem );
+			const unsigned pieceBase = ldsBase + (unsigned)wave * 8192u;
+			const int nk = a.K / BK;	  // >= 2 (launcher)
+			int pKt = 0;
+			unsigned pBufOff = 0;	  // byte offset of the buffer the producer's K tile goes to
+			auto dmaA = [ & ]( auto qc )
+			{
+				constexpr int q = decltype( qc )::value;
+				ldsDmaPair( a.A + pKt * BK, pOffA[ q ][ 0 ], pOffA[ q ][ 1 ], pieceBase + pBufOff + q * 2048 );
+			};
+			auto dmaW = [ & ]( auto qc )
+			{
+				constexpr int q = decltype( qc )::value;
+				ldsDmaPair( a.W + pKt * BK, pOffW[ q ][ 0 ], pOffW[ q ][ 1 ], pieceBase + pBufOff + C::A_BYTES + q * 2048 );
+			};
+			using Q0 = std::integral_constant<int, 0>;
+			using Q1 = std::integral_constant<int, 1>;
+			using Q2 = std::integral_constant<int, 2>;
+			using Q3 = std::integral_constant<int, 3>;
+			// the producer's next K tile: the one after in this output tile, or K tile 0 of the workgroup's next output tile. Past the
+			// workgroup's last tile it keeps issuing (valid addresses of an earlier tile, buffers nobody reads): no branch in the K loop
+			auto advanceProducer = [ & ]( unsigned bufOff )
+			{
+				pBufOff = bufOff;
+				if( ++pKt < nk ) return;
+				pKt = 0;
+	#pragma unroll
+				for( int q = 0; q < 4; q++ )
+	#pragma unroll
+					for( int i = 0; i < 2; i++ )
+					{
+						pOffA[ q ][ i ] = nOffA[ q ][ i ];
+						pOffW[ q ][ i ] = nOffW[ q ][ i ];
+					}
+			};
+			// Which of a K tile's 8 pairs (0..3 = A, 4..7 = W; A first: its rows are the ones that may come from HBM) goes out after chunk c
+			// of substep s (s = 3: the last substep of K tile g - 2, s = 0 / 1: the first two of g - 1); -1 = none
+			auto dmaAfter = [ & ]( auto sc, auto cc )
+			{
+				constexpr int s = decltype( sc )::value, c = decltype( cc )::value;
+				if constexpr( ( SCH & 256 ) != 0 ) return;
+				constexpr int pair = ( SCH & 1 ) == 0 ? ( s == 3 ? c : s == 0 ? 4 + c : -1 )
+													  : ( s == 3 ? ( c < 3 ? c : -1 ) : s == 0 ? ( c < 3 ? 3 + c : -1 ) : s == 1 ? ( c < 2 ? 6 + c : -1 ) : -1 );
+				if constexpr( pair >= 4 )
+					dmaW( std::integral_constant<int, ( pair >= 4 ? pair - 4 : 0 )>{} );
+				else if constexpr( pair >= 0 )
+					dmaA( std::integral_constant<int, ( pair >= 0 && pair < 4 ? pair : 0 )>{} );
+			};
+
+			// ---- consumer side: lane l reads row l & 31 of a 32-row tile, logical chunk 2 ks + (l >> 5), stored at chunk ^ ((row >> 1) & 7)
+			const int x0 = ( lane >> 5 ) ^ ( ( lane >> 1 ) & 7 );
+			unsigned aAddr[ 4 ], wAddr[ 4 ];	 // byte offsets inside a K-tile buffer, per k-substep
+	#pragma unroll
+			for( int ks = 0; ks < 4; ks++ )
+			{
+				const unsigned laneK = (unsigned)( ( lane & 31 ) * 128 + ( ( x0 ^ ( ks << 1 ) ) << 4 ) );
+				aAddr[ ks ] = (unsigned)( wr * 128 * 128 ) + laneK;
+				wAddr[ ks ] = (unsigned)( C::A_BYTES + wc * 128 * 128 ) + laneK;
+			}
+			f32x16 acc[ 4 ][ 4 ];
+	#pragma unroll
+			for( int i = 0; i < 4; i++ )
+	#pragma unroll
+				for( int j = 0; j < 4; j++ )
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
+			f16x8 fa[ 2 ][ 4 ], fb[ 2 ][ 4 ];
+			// One substep (index s of its K tile) = four chunks of 4 MFMAs (A row tile c x the four W tiles) from register set SET; the
+			// fragments of the NEXT substep (k-substep ksNext of the buffer at bufOff) go to set SET ^ 1: the W fragments with chunk 0,
+			// the A fragments with chunk 1, so that every read has at least 8 MFMAs (256 matrix-pipe cycles) to come back. Nothing
+			// crosses a chunk boundary (sched_barrier): a DMA pair issued there sits between two groups of MFMAs in the stream.
+			auto substep = [ & ]( auto sc, auto setc, auto zeroc, unsigned bufOff, int ksNext )
+			{
+				constexpr int SET = decltype( setc )::value;
+				constexpr bool ZERO = decltype( zeroc )::value;
+				const unsigned char* const pa = smem + bufOff + aAddr[ ksNext ];
+				const unsigned char* const pw = smem + bufOff + wAddr[ ksNext ];
+				auto chunk = [ & ]( auto cc )
+				{
+					constexpr int c = decltype( cc )::value;
+					constexpr int RD = ( SCH & 4 ) ? 2 : 4;	   // reads per chunk: 4 + 4 + 0 + 0 or 2 + 2 + 2 + 2
+					if constexpr( ( SCH & 4 ) == 0 )
+					{
+						if constexpr( c == 0 )
+						{
+	#pragma unroll
+							for( int j = 0; j < 4; j++ ) fb[ SET ^ 1 ][ j ] = *(const f16x8*)( pw + j * 4096 );
+						}
+						if constexpr( c == 1 )
+						{
+	#pragma unroll
+							for( int i = 0; i < 4; i++ ) fa[ SET ^ 1 ][ i ] = *(const f16x8*)( pa + i * 4096 );
+						}
+					}
+					else
+					{
+						if constexpr( c < 2 )
+						{
+	#pragma unroll
+							for( int j = 0; j < 2; j++ ) fb[ SET ^ 1 ][ 2 * c + j ] = *(const f16x8*)( pw + ( 2 * c + j ) * 4096 );
+						}
+						else
+						{
+	#pragma unroll
+							for( int i = 0; i < 2; i++ ) fa[ SET ^ 1 ][ 2 * ( c - 2 ) + i ] = *(const f16x8*)( pa + ( 2 * ( c - 2 ) + i ) * 4096 );
+						}
+					}
+					auto mfmaOne = [ & ]( int j )
+					{
+						if constexpr( ZERO )
+						{
+							const f32x16 z = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+							acc[ c ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ SET ][ c ], fb[ SET ][ j ], z, 0, 0, 0 );
+						}
+						else
+							acc[ c ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ SET ][ c ], fb[ SET ][ j ], acc[ c ][ j ], 0, 0, 0 );
+					};
+					if constexpr( ( SCH & 8 ) != 0 )
+					{
+						// STAGGERED: wave w issues its pair behind MFMA w of the chunk, so that the four waves of the CU (which run the same
+						// stream between two barriers) do not queue up at the CU's one vector-memory issue path
+	#pragma unroll
+						for( int j = 0; j < 4; j++ )
+						{
+							mfmaOne( j );
+							__builtin_amdgcn_sched_barrier( 0 );
+							if( wave == j ) dmaAfter( sc, cc );
+							__builtin_amdgcn_sched_barrier( 0 );
+						}
+						return;
+					}
+	#pragma unroll
+					for( int j = 0; j < 4; j++ ) mfmaOne( j );
+					if constexpr( ( SCH & 2 ) == 0 && ( ( SCH & 4 ) != 0 || c < 2 ) )
+					{
+						// MFMA first, then a read behind each MFMA
+	#pragma unroll
+						for( int k = 0; k < RD; k++ )
+						{
+							__builtin_amdgcn_sched_group_barrier( 0x008, 1, 0 );
+							__builtin_amdgcn_sched_group_barrier( 0x100, 1, 0 );
+						}
+						if constexpr( RD < 4 ) __builtin_amdgcn_sched_group_barrier( 0x008, 4 - RD, 0 );
+					}
+					__builtin_amdgcn_sched_barrier( 0 );
+					dmaAfter( sc, cc );
+					__builtin_amdgcn_sched_barrier( 0 );
+				};
+				chunk( std::integral_constant<int, 0>{} );
+				chunk( std::integral_constant<int, 1>{} );
+				chunk( std::integral_constant<int, 2>{} );
+				chunk( std::integral_constant<int, 3>{} );
+			};
+			using S0 = std::integral_constant<int, 0>;
+			using S1 = std::integral_constant<int, 1>;
+			using P0 = std::integral_constant<int, 0>;
+			using P1 = std::integral_constant<int, 1>;
+			using P2 = std::integral_constant<int, 2>;
+			using P3 = std::integral_constant<int, 3>;
+			using ZN = std::integral_constant<bool, false>;
+			using ZY = std::integral_constant<bool, true>;
+
+			unsigned bufOff = 0;
+			// one K tile of the consumer; the fragments of its first substep are in register set 0
+			auto kTile = [ & ]( auto zeroc )
+			{
+				substep( P0{}, S0{}, zeroc, bufOff, 1 );
+				substep( P1{}, S1{}, ZN{}, bufOff, 2 );
+				// substep 2; then every fragment of this buffer is in registers and this wave's pieces of the next K tile must have landed
+				substep( P2{}, S0{}, ZN{}, bufOff, 3 );
+				asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
+				WH_BAR();
+				// substep 3: the next K tile is complete in the other buffer, this buffer is dead
+				advanceProducer( bufOff );
+				bufOff ^= (unsigned)C::STAGE_BYTES;
+				substep( P3{}, S1{}, ZN{}, bufOff, 0 );
+			};
+
+			auto epilogue = [ & ]( int tmD, int tnD )
+			{
+				if constexpr( ( SCH & 512 ) != 0 )
+				{
+	#pragma unroll
+					for( int i = 0; i < 4; i++ )
+	#pragma unroll
+						for( int j = 0; j < 4; j++ ) asm volatile( "" ::"a"( acc[ i ][ j ] ) );
+					return;
+				}
+				if constexpr( WIDE )
+				{
+					unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
+					const int mW = tmD * BM + wr * 128, nW = tnD * BN + wc * 128;
+					bool isV = false;
+					if constexpr( EPI == EPI_QKV_ENC ) isV = nW >= 2 * a.H * HEAD_DIM;	   // 2 d is a multiple of 256: a tile is V or it is not
+					const bool interior = a.wideEpi == 2 && ( tmD + 1 ) * BM <= a.M && ( tnD + 1 ) * BN <= a.N;
+					if constexpr( EPI == EPI_QKV_ENC )
+					{
+						if( isV && interior )
+						{
+							epilogueFastV4( a, acc, mW, nW, lane );
+							return;
+						}
+					}
+					if( !isV && interior )
+					{
+						if constexpr( EPI == EPI_F32 )
+						{
+							if( a.res )
+								epilogueFast4<EPI, true>( a, acc, mW, nW, lane, stage );
+							else
+								epilogueFast4<EPI, false, ( SCH & 1024 ) ? 1 : 0>( a, acc, mW, nW, lane, stage );
+						}
+						else
+							epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
+						return;
+					}
+					// edge tiles (and launches without the fast path's promises): the general block epilogues of gemmTiled8
+					int laneS = lane;
+					asm volatile( "" : "+v"( laneS ) );
+	#pragma unroll
+					for( int i = 0; i < 4; i++ )
+	#pragma unroll
+						for( int jp = 0; jp < 2; jp++ )
+						{
+							const int m0 = mW + i * 32, n0 = nW + jp * 64;
+							if constexpr( EPI == EPI_QKV_ENC )
+							{
+								// fragment-major V straight from the registers (the launcher guarantees T % 4 == 0 for this instance)
+								if( isV )
+								{
+									const f32x16 c0 = accReadTile( acc[ i ][ 2 * jp ] ), c1 = accReadTile( acc[ i ][ 2 * jp + 1 ] );
+									epilogueBlockV32x64( a, c0, c1, m0, n0, laneS );
+									__builtin_amdgcn_sched_barrier( 0 );
+									continue;
+								}
+							}
+							const f32x16 c0 = accReadTile( acc[ i ][ 2 * jp ] ), c1 = accReadTile( acc[ i ][ 2 * jp + 1 ] );
+							epilogueBlock32x64<EPI>( a, c0, c1, m0, n0, laneS, stage );
+							__builtin_amdgcn_sched_barrier( 0 );
+						}
+				}
+				else
+				{
+					// element-wise stores (N % 8 != 0 and the like): a copy of the tile in VGPRs, most of it through scratch -- correct, not fast
+					f32x16 cp[ 4 ][ 4 ];
+	#pragma unroll
+					for( int i = 0; i < 4; i++ )
+	#pragma unroll
+						for( int j = 0; j < 4; j++ ) cp[ i ][ j ] = accReadTile( acc[ i ][ j ] );
+					tileEpilogue<EPI, Cfg4>( a, cp, tmD, tnD, wr, wc, lane );
+				}
+			};
+
+			if constexpr( ( SCH & 2048 ) != 0 )
+			{
+				// probe: the workgroups of an XCD start a quarter tile apart, so that the epilogues of the chip (its store bursts) do not coincide
+				const int phase = ( blockIdx.x >> 3 ) & 3;
+				for( int i = 0; i < phase * nk; i++ ) __builtin_amdgcn_s_sleep( 16 );
+			}
+			// ---- prologue: K tile 0 of the first output tile completely, then the first part of K tile 1
+			int lin = linFirst;
+			tileOffsets( lin, pOffA, pOffW );
+			if( lin + linStep < linEnd )
+				tileOffsets( lin + linStep, nOffA, nOffW );
+			else
+			{
+	#pragma unroll
+				for( int q = 0; q < 4; q++ )
+	#pragma unroll
+					for( int i = 0; i < 2; i++ ) nOffA[ q ][ i ] = nOffW[ q ][ i ] = 0;
+			}
+			dmaA( Q0{} );
+			dmaA( Q1{} );
+			dmaA( Q2{} );
+			dmaA( Q3{} );
+			dmaW( Q0{} );
+			dmaW( Q1{} );
+			dmaW( Q2{} );
+			dmaW( Q3{} );
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			WH_BAR();
+			advanceProducer( C::STAGE_BYTES );
+			dmaA( Q0{} );
+			dmaA( Q1{} );
+			dmaA( Q2{} );
+			if constexpr( ( SCH & 1 ) == 0 ) dmaA( Q3{} );
+	#pragma unroll
+			for( int i = 0; i < 4; i++ ) fa[ 0 ][ i ] = *(const f16x8*)( smem + aAddr[ 0 ] + i * 4096 );
+	#pragma unroll
+			for( int j = 0; j < 4; j++ ) fb[ 0 ][ j ] = *(const f16x8*)( smem + wAddr[ 0 ] + j * 4096 );
+			__builtin_amdgcn_sched_barrier( 0 );
+
+			for( ;; )
+			{
+				kTile( ZY{} );
+				for( int kt = 1; kt < nk; kt++ ) kTile( ZN{} );
+				// the producer is in the next output tile now (nk >= 2): the offsets of the one after it, before the epilogue's loads and stores
+				if( lin + 2 * linStep < linEnd ) tileOffsets( lin + 2 * linStep, nOffA, nOffW );
+				int tm, tn;
+				tileCoords( lin, tm, tn );
+				asm volatile( "s_nop 15\n\ts_nop 15" ::: "memory" );	   // the last MFMA's 16 passes are over before the first accumulator is read
+				epilogue( tm, tn );
+				lin += linStep;
+				if( lin >= linEnd ) break;
+			}
+			// the producer ran ahead: nothing of it may land after the workgroup has given its LDS back
+			asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+		}
 #undef WH_BAR
 
 		// ---- skinny: M <= 32 ----
@@ -2161,12 +2875,86 @@ namespace wh
 		return wide ? launchTiled8K<EPI, true>( b, stream ) : launchTiled8K<EPI, false>( b, stream );
 	}
 
+	template<int EPI, bool WIDE, int SCH = 0>
+	static int launchTiled4K( const GemmArgs& b, hipStream_t stream )
+	{
+		static PerDeviceOnce once;
+		static int cusOfDevice[ 64 ];
+		int dev = 0;
+		if( hipGetDevice( &dev ) != hipSuccess ) dev = 0;
+		if( const int onceDev = once.needed(); onceDev >= 0 )
+		{
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled4<EPI, WIDE, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg4::LDS_BYTES ) );
+			int cus = 0;
+			WH_HIP( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, dev ) );
+			cusOfDevice[ onceDev ] = cus;
+			once.mark( onceDev );
+		}
+		// persistent: one workgroup per CU (512 registers per lane: one wave per SIMD), each walks its share of the tiles
+		const int tilesM = ( b.M + Cfg4::BM - 1 ) / Cfg4::BM, tilesN = ( b.N + Cfg4::BN - 1 ) / Cfg4::BN;
+		int cus = cusOfDevice[ dev & 63 ] > 0 ? cusOfDevice[ dev & 63 ] : 256;
+		if( b.cuLimit > 0 && b.cuLimit < cus ) cus = b.cuLimit;
+		const int grid = tilesM * tilesN < cus ? tilesM * tilesN : cus;
+		hipLaunchKernelGGL( ( gemmTiled4<EPI, WIDE, SCH> ), dim3( grid ), dim3( Cfg4::NT ), Cfg4::LDS_BYTES, stream, b );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	// the 4-wave 256x256x64 kernel; preconditions of the LDS-transposed epilogue as launchTiled8, plus T % 4 == 0 for the V columns of the encoder's Q/K/V product
+	template<int EPI, int SCH = 0>
+	static int launchTiled4( const GemmArgs& a, hipStream_t stream )
+	{
+		GemmArgs b = a;
+		static const int groupEnv = []() { const char* e = getenv( "WH_GEMM_GROUP_M" ); const int v = e ? atoi( e ) : 0; return v >= 1 && v <= 64 ? v : 0; }();
+		if( b.groupM == 0 ) b.groupM = groupEnv ? groupEnv : ( ( g_tuning & TUNE_GEMM_GROUP_M ) ? 4 : 1 );
+		bool wide = false;
+		if( g_tuning & TUNE_GEMM_WIDE_EPI )
+		{
+			const bool al16 = ( a.N % 8 ) == 0 && ( a.ldc % 8 ) == 0 && ( a.cBatchStride % 8 ) == 0;
+			switch( EPI )
+			{
+			case EPI_F32: wide = al16 && ( ( (size_t)a.out32 | (size_t)a.res ) % 16 ) == 0; break;
+			case EPI_CONV2: wide = al16 && ( ( (size_t)a.out32 | (size_t)a.pe ) % 16 ) == 0; break;
+			case EPI_F16_GELU: wide = al16 && ( (size_t)a.out16 % 16 ) == 0; break;
+			case EPI_QKV_ENC: wide = ( a.N % 64 ) == 0 && ( a.T % 4 ) == 0 && ( ( (size_t)a.q | (size_t)a.k | (size_t)a.v ) % 16 ) == 0; break;
+			case EPI_CROSS_KV: wide = ( a.N % 64 ) == 0 && ( ( (size_t)a.k | (size_t)a.v ) % 16 ) == 0; break;
+			default: break;
+			}
+		}
+		b.wideEpi = wide ? 1 : 0;
+		if( wide )
+		{
+			// what epilogueFast4 relies on: a wave's 128 rows cross at most one segment boundary, and everything it adds per lane fits 32 bits
+			bool fast = true;
+			if( EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV )
+				fast = a.T >= 128 && ( a.H * HEAD_DIM ) % 128 == 0 && (long long)( a.H - 1 ) * a.T * 128 < ( 1ll << 31 );
+			else
+			{
+				const int es = EPI == EPI_F32 ? 4 : 2;
+				fast = (long long)a.ldc * es * 128 < ( 1ll << 31 );
+				if( a.Mb > 0 && a.Mb < a.M )
+				{
+					const long long cross = ( a.cBatchStride - (long long)a.Mb * a.ldc ) * es;
+					fast = fast && a.Mb >= 128 && cross >= 0 && cross + (long long)a.ldc * es * 128 < ( 1ll << 31 );
+				}
+			}
+			if( fast ) b.wideEpi = 2;
+		}
+		return wide ? launchTiled4K<EPI, true, SCH>( b, stream ) : launchTiled4K<EPI, false, SCH>( b, stream );
+	}
+
 	// Tile-shape experiments on the plain FP32 epilogue (tools/gemm_probe.py): variant -> configuration
 	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream )
 	{
 		switch( variant )
 		{
-		case 40: return launchTiled8<EPI_F32>( a, stream );	   // the production instance
+		case 40: return launchTiled8<EPI_F32>( a, stream );	   // the 8-wave persistent kernel (round 3)
+		case 50: return launchTiled4<EPI_F32>( a, stream );	   // the 4-wave persistent kernel (round 4)
+		case 60: return launchTiled4<EPI_F32, 256>( a, stream );	   // ablations (60 .. 69, wrong results, not checked): no LDS-DMA in the K loop
+		case 61: return launchTiled4<EPI_F32, 512>( a, stream );	   // ... no epilogue
+		case 62: return launchTiled4<EPI_F32, 768>( a, stream );	   // ... neither
+		case 63: return launchTiled4<EPI_F32, 1024>( a, stream );	   // ... the epilogue without its global stores
+		case 57: return launchTiled4<EPI_F32, 2048>( a, stream );	   // correct: workgroups start a quarter tile apart
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );	   // the 16-wave kernel of round 2 (products below gemmTiled8's threshold)
 		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );	   // register-staged 128x128x32: what wh_debug_probe checks every variant against
@@ -2262,7 +3050,11 @@ namespace wh
 		const long long aBytes = 2ll * ( a.Mb > 0 && a.Mb < a.M ? ( (long long)( a.M / a.Mb ) + 1 ) * a.aBatchStride + (long long)a.Mb * a.lda : (long long)a.M * a.lda ) + 2ll * a.K;
 		const bool fits32 = aBytes < ( 1ll << 32 ) && 2ll * a.N * a.K < ( 1ll << 32 );
 		const bool w8 = big && fits32 && ( g_tuning & TUNE_GEMM_8WAVE ) != 0;
+		// gemmTiled4 on top: at least two K tiles, A segments of at least a tile's 256 rows with a non-negative gap
+		const bool w4 = w8 && a.K >= 128 && ( g_tuning & TUNE_GEMM_4WAVE ) != 0 &&
+			( a.Mb <= 0 || a.Mb >= a.M || ( a.Mb >= 256 && a.aBatchStride >= (long long)a.Mb * a.lda ) );
 #define WH_TILED( E )                                                    \
+	if( w4 ) return launchTiled4<E>( a, stream );                        \
 	if( w8 ) return launchTiled8<E>( a, stream );                        \
 	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
 	if( pf ) return launchTiledT<E, CfgGlPf>( a, stream );               \

@@ -8,6 +8,7 @@ namespace wh
 	enum eTuning : unsigned
 	{
 		TUNE_GEMV_ROWS4 = 2,	 // 4 weight rows per workgroup for small-N / large-K gemv (else 16)
+		TUNE_GEMM_4WAVE = 4,	 // ... of those, one wave per SIMD: 4 waves x (128 x 128), 256 accumulator registers, a hand-pipelined K loop with one barrier per K tile (gemmTiled4)
 		TUNE_GEMM_8WAVE = 16,	 // big tiled GEMMs: 8 waves x (128 x 64), four phases per K tile, wave rows one barrier apart, counted vmcnt (gemmTiled8)
 		TUNE_GEMM_BIG = 8,		 // 256x256x64 tiles for large tiled GEMMs (else 128x128x32 everywhere)
 		TUNE_GEMV_SMALLREG = 32,	 // 8-slot gemv instance when a wave's K slice fits (fewer registers, same loads in flight)

@@ -2703,7 +2703,7 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 		if( stamps ) (void)hipFree( stamps );
 		// every variant is checked against the production path on the same operands: a pipeline that races is fast and wrong
 		// (variants 31 .. 39 are ablations, wrong by construction)
-		if( rc == 0 && ( variant == 34 || ( !( variant >= 31 && variant <= 39 ) && !( variant >= 41 && variant <= 49 ) ) ) )
+		if( rc == 0 && ( variant == 34 || ( !( variant >= 31 && variant <= 39 ) && !( variant >= 41 && variant <= 49 ) && !( variant >= 60 && variant <= 69 ) ) ) )
 		{
 			void* ref = nullptr;
 			int* diff = nullptr;
