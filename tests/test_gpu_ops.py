@@ -294,11 +294,12 @@ def test_mul_mat_fragment_prefetch_is_bit_identical(M, N, K):
         assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("M,N,K", [(16500, 4608, 1024), (17000, 5120, 192), (16384 + 77, 4672, 256), (16400, 1256, 128), (16400, 1250, 128),
+@pytest.mark.parametrize("M,N,K", [(16500, 4608, 1024), (17000, 5120, 192), (16384 + 77, 4672, 256), (16400, 1256, 256), (16400, 1250, 320),
                                    (33000, 1024, 4096)])
 def test_mul_mat_4wave_kernel_equals_8wave(M, N, K):
-    """gemmTiled4 (one wave per SIMD, 128 x 128 outputs per wave, a hand-pipelined K loop with one barrier per K tile) against
-    gemmTiled8: the same MFMAs in the same order per output, so FP32 (bias + residual) and FP16 GELU outputs must agree bit for
+    """gemmTiled4 (one wave per SIMD, 128 x 128 outputs per wave, a hand-pipelined K loop with one barrier per K tile) and gemmTiled8
+    with the lean interior-tile epilogue (TUNE_GEMM_FAST_EPI) against gemmTiled8 with the general block epilogues: the same MFMAs in the
+    same order per output and the same arithmetic per element, so FP32 (bias + residual) and FP16 GELU outputs must agree bit for
     bit -- whole and ragged tiles, the shortest K loop (two K tiles), N % 8 != 0 (the element-wise epilogue), several launches
     (a missing wait or a buffer overwritten too early is intermittent), and against the float64 product."""
     g = torch.Generator(device="cuda").manual_seed(M + N + 7)
@@ -310,7 +311,8 @@ def test_mul_mat_4wave_kernel_equals_8wave(M, N, K):
     L = binding.lib()
     outs, gelus = [], []
     try:
-        for mask in (binding.TUNE_DEFAULT & ~binding.TUNE_GEMM_4WAVE, binding.TUNE_DEFAULT | binding.TUNE_GEMM_4WAVE):
+        base = binding.TUNE_DEFAULT & ~(binding.TUNE_GEMM_4WAVE | binding.TUNE_GEMM_FAST_EPI)
+        for mask in (base, base | binding.TUNE_GEMM_4WAVE, base | binding.TUNE_GEMM_FAST_EPI):
             L.wh_debug_set_tuning(mask)
             for rep in range(3):
                 out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")

@@ -22,6 +22,7 @@ WH_FLAG_DEBUG_CAPTURE = 4
 # kernel-variant switches (whisper_amd/csrc/kernels.h eTuning); TUNE_DEFAULT is what the library starts with
 TUNE_GEMM_8WAVE = 16
 TUNE_GEMM_4WAVE = 4
+TUNE_GEMM_FAST_EPI = 1
 TUNE_GEMV_ROWS4, TUNE_GEMM_BIG, TUNE_GEMV_SMALLREG, TUNE_GEMM_GL, TUNE_LN_SEPARATE_BIGM, TUNE_ATTN_XCD = 2, 8, 32, 64, 128, 256
 TUNE_ATTN_DEC_G, TUNE_FUSE_CROSS_Q, TUNE_GEMM_GROUP_M, TUNE_FUSE_SELF_BLOCK, TUNE_GEMV_LN_BLOCK, TUNE_GEMV_K8 = 512, 1024, 2048, 4096, 8192, 16384
 TUNE_SPLIT_STREAMS, TUNE_ATTN_ENC_F, TUNE_GEMM_WIDE_EPI, TUNE_GEMM_FRAGPF, TUNE_ATTN_ENC_2SWEEP = 32768, 65536, 131072, 262144, 524288
@@ -31,7 +32,7 @@ TUNE_ATTN_ENC_TABLE = 268435456
 TUNE_GEMV_MT8 = 536870912
 TUNE_ATTN_ENC_TABLE_ANY = 1073741824
 TUNE_SAMPLE_SPREAD = 2147483648
-TUNE_DEFAULT = (TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD |
+TUNE_DEFAULT = (TUNE_GEMM_FAST_EPI | TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD |
                 TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI |
                 TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS |
                 TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE)

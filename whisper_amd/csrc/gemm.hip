@@ -1107,6 +1107,10 @@ namespace wh
 			}
 		}
 
+		// the interior-tile epilogue of both persistent kernels (defined with gemmTiled4 below)
+		template<int EPI, bool HASRES, int ABL = 0, int FIRST = 0, int LAST = 16, int TJ = 4, bool AGPR = true>
+		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ TJ ], int mW, int nW, int lane, unsigned char* stage );
+
 		// ABL (probe only, wrong results by construction): 1 = no LDS-DMA inside the K loop, 2 = fragments read from LDS for the first K tile
 		// only, 4 = no MFMAs, 16 = every tile reads the first A tile (operands stay in L2), 32 = no epilogue stores
 		template<int EPI, bool WIDE, int ABL = 0>
@@ -1415,6 +1419,32 @@ namespace wh
 				else
 				{
 					bool direct = !WIDE;
+					bool fastDone = false;
+					if constexpr( ABL == 0 && WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
+					{
+						// interior tiles: the lean epilogue written for gemmTiled4 (no bounds checks, no divisions per row, residual rows requested a unit
+						// ahead of the stores); a.wideEpi == 2 = the launcher has checked what it relies on
+						const int mW = tmDone * BM + wr * 128, nW = tnDone * BN + wc * 64;
+						const bool isV = EPI == EPI_QKV_ENC && nW >= 2 * a.H * HEAD_DIM;
+						if( a.wideEpi == 2 && !isV && ( tmDone + 1 ) * BM <= a.M && ( tnDone + 1 ) * BN <= a.N )
+						{
+							unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
+							if constexpr( EPI == EPI_F32 )
+							{
+								if( a.res )
+									epilogueFast4<EPI, true, 0, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
+								else
+									epilogueFast4<EPI, false, 0, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
+							}
+							else
+								epilogueFast4<EPI, false, 0, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
+							fastDone = true;
+						}
+					}
+					if( fastDone )
+					{
+					}
+					else
 					if constexpr( WIDE && EPI == EPI_QKV_ENC )
 					{
 						// fragment-major V: straight from the registers (groups of 4 consecutive keys; T % 4 != 0 keeps the element-wise path)
@@ -1429,7 +1459,10 @@ namespace wh
 							}
 						}
 					}
-					if( direct )
+					if( fastDone )
+					{
+					}
+					else if( direct )
 						tileEpilogue<EPI, Cfg8>( a, acc, tmDone, tnDone, wr, wc, lane );
 					else if( !( WIDE && EPI == EPI_QKV_ENC && ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM ) )
 					{
@@ -1512,19 +1545,21 @@ namespace wh
 		//     computed once per tile); a row past the end of its segment (sequence / conv batch) adds one constant: the wave's 128
 		//     rows cross at most one boundary (segments are at least 128 rows long).
 		// Same arithmetic per element as tileEpilogue / epilogueBlock32x64 (bit-identical outputs).
-		template<int EPI, bool HASRES, int ABL = 0>
-		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ 4 ], int mW, int nW, int lane, unsigned char* stage )
+		// TJ = MFMA tiles per wave in N: 4 (gemmTiled4: 128 x 128 per wave) or 2 (gemmTiled8: 128 x 64); AGPR = the accumulators are read as assembly (gemmTiled4)
+		template<int EPI, bool HASRES, int ABL, int FIRST, int LAST, int TJ, bool AGPR>
+		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ TJ ], int mW, int nW, int lane, unsigned char* stage )
 		{
 			static_assert( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV, "fast epilogue" );
 			constexpr bool F32OUT = EPI == EPI_F32;
 			constexpr bool HEADS = EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV;
-			constexpr int UNITS = F32OUT ? 16 : 8;
+			constexpr int UNITS = F32OUT ? 4 * TJ : 2 * TJ;
+			constexpr int JP = TJ / 2;
 			// (opaque copy: what follows is a few VALU instructions per tile; hoisted out of the tile loop it would live in scratch)
 			asm volatile( "" : "+v"( lane ) );
 			const int hi = lane >> 5, cl = lane & 31, rl = lane >> 3, ch = lane & 7;
-			float bias[ 4 ];
+			float bias[ TJ ];
 	#pragma unroll
-			for( int j = 0; j < 4; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
+			for( int j = 0; j < TJ; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
 
 			// ---- rows (wave-uniform): segment length, position of the tile's first row in its segment, byte offset of that row
 			int seg, segPos;
@@ -1589,7 +1624,7 @@ namespace wh
 			if constexpr( EPI == EPI_CROSS_KV ) outBase = (unsigned char*)( sel ? a.v : a.k );
 			outBase += firstRowBytes + colBytes;
 			const unsigned char* resBase = HASRES ? (const unsigned char*)a.res + firstRowBytes + colBytes : nullptr;
-			// bytes from the wave tile's first unit to unit k: FP32 unit k = MFMA tile (k >> 2, k & 3); FP16 unit k = tiles (k >> 1, 2 (k & 1)), (.., + 1)
+			// bytes from the wave tile's first unit to unit k: FP32 unit k = MFMA tile (k / TJ, k % TJ); FP16 unit k = tiles (k / JP, 2 (k % JP)), (.., + 1)
 			const long long headBytes = HEADS ? (long long)a.T * 128 : 128;
 
 			auto writeUnit = [ & ]( auto kc )
@@ -1597,19 +1632,22 @@ namespace wh
 				constexpr int k = decltype( kc )::value;
 				if constexpr( F32OUT )
 				{
-					constexpr int i = k >> 2, j = k & 3;
+					constexpr int i = k / TJ, j = k % TJ;
 	#pragma unroll
 					for( int r = 0; r < 16; r++ )
 					{
 						const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
 						float x;
-						asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( x ) : "a"( acc[ i ][ j ][ r ] ) );
+						if constexpr( AGPR )
+							asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( x ) : "a"( acc[ i ][ j ][ r ] ) );
+						else
+							x = acc[ i ][ j ][ r ];
 						*(float*)( stage + row * 128 + cl * 4 ) = x + bias[ j ];
 					}
 				}
 				else
 				{
-					constexpr int i = k >> 1, jp = k & 1;
+					constexpr int i = k / JP, jp = k % JP;
 	#pragma unroll
 					for( int jj = 0; jj < 2; jj++ )
 	#pragma unroll
@@ -1617,7 +1655,10 @@ namespace wh
 						{
 							const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
 							float v;
-							asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( v ) : "a"( acc[ i ][ 2 * jp + jj ][ r ] ) );
+							if constexpr( AGPR )
+								asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( v ) : "a"( acc[ i ][ 2 * jp + jj ][ r ] ) );
+							else
+								v = acc[ i ][ 2 * jp + jj ][ r ];
 							f16 hv;
 							if constexpr( EPI == EPI_F16_GELU )
 								hv = gelu16( v + bias[ 2 * jp + jj ] );
@@ -1636,13 +1677,13 @@ namespace wh
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
 			};
-			auto unitBytes = [ & ]( int k ) -> long long { return F32OUT ? (long long)( k & 3 ) * 128 : (long long)( k & 1 ) * headBytes; };
+			auto unitBytes = [ & ]( int k ) -> long long { return F32OUT ? (long long)( k % TJ ) * 128 : (long long)( k % JP ) * headBytes; };
 			auto loadRes = [ & ]( auto kc, f32x4( &ex )[ 4 ] )
 			{
 				constexpr int k = decltype( kc )::value;
 				if constexpr( HASRES )
 				{
-					constexpr int i = F32OUT ? k >> 2 : k >> 1;
+					constexpr int i = F32OUT ? k / TJ : k / JP;
 					const unsigned char* const b = resBase + unitBytes( k );
 	#pragma unroll
 					for( int it = 0; it < 4; it++ ) ex[ it ] = *(const f32x4*)( b + voff[ i ][ it ] );
@@ -1656,7 +1697,7 @@ namespace wh
 			auto storeUnit = [ & ]( auto kc, const f32x4( &dv )[ 4 ], const f32x4( &ex )[ 4 ] )
 			{
 				constexpr int k = decltype( kc )::value;
-				constexpr int i = F32OUT ? k >> 2 : k >> 1;
+				constexpr int i = F32OUT ? k / TJ : k / JP;
 				unsigned char* const b = outBase + unitBytes( k );
 	#pragma unroll
 				for( int it = 0; it < 4; it++ )
@@ -1674,37 +1715,42 @@ namespace wh
 				}
 			};
 
-			f32x4 ex[ 2 ][ 4 ], dv[ 4 ];
-			loadRes( std::integral_constant<int, 0>{}, ex[ 0 ] );
-			writeUnit( std::integral_constant<int, 0>{} );
-			ldsFence();
-			__builtin_amdgcn_sched_barrier( 0 );
-			auto step = [ & ]( auto kc )
+			// units FIRST .. min( LAST, UNITS ) - 1 (gemmTiled4 keeps the rest of an FP16 tile in registers and stores it under the next tile's K loop)
+			constexpr int U0 = FIRST, U1 = LAST < UNITS ? LAST : UNITS;
+			if constexpr( U0 < U1 )
 			{
-				constexpr int k = decltype( kc )::value;
-				readUnit( dv );
+				f32x4 ex[ 2 ][ 4 ], dv[ 4 ];
+				loadRes( std::integral_constant<int, U0>{}, ex[ U0 & 1 ] );
+				writeUnit( std::integral_constant<int, U0>{} );
 				ldsFence();
 				__builtin_amdgcn_sched_barrier( 0 );
-				if constexpr( k + 1 < UNITS )
+				auto step = [ & ]( auto kc )
 				{
-					loadRes( std::integral_constant<int, k + 1>{}, ex[ ( k + 1 ) & 1 ] );
-					writeUnit( std::integral_constant<int, k + 1>{} );
-					ldsFence();
-					__builtin_amdgcn_sched_barrier( 0 );
-				}
-				storeUnit( kc, dv, ex[ k & 1 ] );
-				__builtin_amdgcn_sched_barrier( 0 );
-			};
-			step( std::integral_constant<int, 0>{} );
-			step( std::integral_constant<int, 1>{} );
-			step( std::integral_constant<int, 2>{} );
-			step( std::integral_constant<int, 3>{} );
-			step( std::integral_constant<int, 4>{} );
-			step( std::integral_constant<int, 5>{} );
-			step( std::integral_constant<int, 6>{} );
-			step( std::integral_constant<int, 7>{} );
-			if constexpr( UNITS == 16 )
-			{
+					constexpr int k = decltype( kc )::value;
+					if constexpr( k >= U0 && k < U1 )
+					{
+						readUnit( dv );
+						ldsFence();
+						__builtin_amdgcn_sched_barrier( 0 );
+						if constexpr( k + 1 < U1 )
+						{
+							loadRes( std::integral_constant<int, k + 1>{}, ex[ ( k + 1 ) & 1 ] );
+							writeUnit( std::integral_constant<int, k + 1>{} );
+							ldsFence();
+							__builtin_amdgcn_sched_barrier( 0 );
+						}
+						storeUnit( kc, dv, ex[ k & 1 ] );
+						__builtin_amdgcn_sched_barrier( 0 );
+					}
+				};
+				step( std::integral_constant<int, 0>{} );
+				step( std::integral_constant<int, 1>{} );
+				step( std::integral_constant<int, 2>{} );
+				step( std::integral_constant<int, 3>{} );
+				step( std::integral_constant<int, 4>{} );
+				step( std::integral_constant<int, 5>{} );
+				step( std::integral_constant<int, 6>{} );
+				step( std::integral_constant<int, 7>{} );
 				step( std::integral_constant<int, 8>{} );
 				step( std::integral_constant<int, 9>{} );
 				step( std::integral_constant<int, 10>{} );
@@ -1830,9 +1876,8 @@ namespace wh
 			// ---- producer side: LDS-DMA sources. A tile is 32 pieces of 8 rows x 128 bytes; wave w owns pieces 8 w .. 8 w + 7 of the A
 			// tile and of the W tile, issued as 4 + 4 pairs. Lane l of a piece lands at row l / 8, physical chunk l % 8, which must hold
 			// logical chunk (l % 8) ^ ((row >> 1) & 7); offA / offW = byte offset of that chunk from a.A / a.W at k = 0.
-			// pOff* = the output tile the producer is in, nOff* = the workgroup's tile after that one (computed outside the K loop: the
-			// producer changes tiles in the middle of the consumer's K loop and then only copies 16 registers).
-			unsigned pOffA[ 4 ][ 2 ], pOffW[ 4 ][ 2 ], nOffA[ 4 ][ 2 ], nOffW[ 4 ][ 2 ];
+			// pOff* = the output tile the producer is in (recomputed, branch-free, when it moves on to the workgroup's next tile in the middle of the consumer's K loop)
+			unsigned pOffA[ 4 ][ 2 ], pOffW[ 4 ][ 2 ];
 			auto tileOffsets = [ & ]( int lin, unsigned( &offA )[ 4 ][ 2 ], unsigned( &offW )[ 4 ][ 2 ] )
 			{
 				int tm, tn;
@@ -1867,7 +1912,7 @@ namespace wh
 			const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)smem );
 			const unsigned pieceBase = ldsBase + (unsigned)wave * 8192u;
 			const int nk = a.K / BK;	  // >= 2 (launcher)
-			int pKt = 0;
+			int pKt = 0, pLin = linFirst;
 			unsigned pBufOff = 0;	  // byte offset of the buffer the producer's K tile goes to
 			auto dmaA = [ & ]( auto qc )
 			{
@@ -1890,21 +1935,28 @@ namespace wh
 				pBufOff = bufOff;
 				if( ++pKt < nk ) return;
 				pKt = 0;
-	#pragma unroll
-				for( int q = 0; q < 4; q++ )
-	#pragma unroll
-					for( int i = 0; i < 2; i++ )
-					{
-						pOffA[ q ][ i ] = nOffA[ q ][ i ];
-						pOffW[ q ][ i ] = nOffW[ q ][ i ];
-					}
+				pLin += linStep;
+				if( pLin < linEnd ) tileOffsets( pLin, pOffA, pOffW );
 			};
 			// Which of a K tile's 8 pairs (0..3 = A, 4..7 = W; A first: its rows are the ones that may come from HBM) goes out after chunk c
 			// of substep s (s = 3: the last substep of K tile g - 2, s = 0 / 1: the first two of g - 1); -1 = none
-			auto dmaAfter = [ & ]( auto sc, auto cc )
+			// pos: 0 = a K tile in the middle of an output tile, 1 = the FIRST one (its W pieces went out before the epilogue: nothing in substep 0),
+			// 2 = the LAST one (substep 3 issues the next K tile's A AND W pieces: everything the first barrier after the epilogue waits for is then older
+			// than the epilogue's stores, and the wait can leave those in flight)
+			auto dmaAfter = [ & ]( auto sc, auto cc, auto posc )
 			{
-				constexpr int s = decltype( sc )::value, c = decltype( cc )::value;
+				constexpr int s = decltype( sc )::value, c = decltype( cc )::value, pos = decltype( posc )::value;
 				if constexpr( ( SCH & 256 ) != 0 ) return;
+				if constexpr( ( SCH & 1 ) == 0 && ( SCH & 16384 ) == 0 )
+				{
+					if constexpr( pos == 1 && s == 0 ) return;
+					if constexpr( pos == 2 && s == 3 )
+					{
+						dmaA( cc );
+						dmaW( cc );
+						return;
+					}
+				}
 				constexpr int pair = ( SCH & 1 ) == 0 ? ( s == 3 ? c : s == 0 ? 4 + c : -1 )
 													  : ( s == 3 ? ( c < 3 ? c : -1 ) : s == 0 ? ( c < 3 ? 3 + c : -1 ) : s == 1 ? ( c < 2 ? 6 + c : -1 ) : -1 );
 				if constexpr( pair >= 4 )
@@ -1935,7 +1987,7 @@ namespace wh
 			// fragments of the NEXT substep (k-substep ksNext of the buffer at bufOff) go to set SET ^ 1: the W fragments with chunk 0,
 			// the A fragments with chunk 1, so that every read has at least 8 MFMAs (256 matrix-pipe cycles) to come back. Nothing
 			// crosses a chunk boundary (sched_barrier): a DMA pair issued there sits between two groups of MFMAs in the stream.
-			auto substep = [ & ]( auto sc, auto setc, auto zeroc, unsigned bufOff, int ksNext )
+			auto substep = [ & ]( auto sc, auto setc, auto zeroc, auto posc, unsigned bufOff, int ksNext, auto&& hook )
 			{
 				constexpr int SET = decltype( setc )::value;
 				constexpr bool ZERO = decltype( zeroc )::value;
@@ -1990,9 +2042,11 @@ namespace wh
 						{
 							mfmaOne( j );
 							__builtin_amdgcn_sched_barrier( 0 );
-							if( wave == j ) dmaAfter( sc, cc );
+							if( wave == j ) dmaAfter( sc, cc, posc );
 							__builtin_amdgcn_sched_barrier( 0 );
 						}
+						hook( cc );
+						__builtin_amdgcn_sched_barrier( 0 );
 						return;
 					}
 	#pragma unroll
@@ -2009,7 +2063,8 @@ namespace wh
 						if constexpr( RD < 4 ) __builtin_amdgcn_sched_group_barrier( 0x008, 4 - RD, 0 );
 					}
 					__builtin_amdgcn_sched_barrier( 0 );
-					dmaAfter( sc, cc );
+					dmaAfter( sc, cc, posc );
+					hook( cc );
 					__builtin_amdgcn_sched_barrier( 0 );
 				};
 				chunk( std::integral_constant<int, 0>{} );
@@ -2026,24 +2081,224 @@ namespace wh
 			using ZN = std::integral_constant<bool, false>;
 			using ZY = std::integral_constant<bool, true>;
 
-			unsigned bufOff = 0;
-			// one K tile of the consumer; the fragments of its first substep are in register set 0
-			auto kTile = [ & ]( auto zeroc )
+			// ---- the PENDING tile (FP16 outputs only: GELU, Q / K, cross K / V). A CU stores ~16 bytes per cycle, so the 128 KiB of a tile take
+			// ~4 us to leave, and vmcnt counts loads and stores in ONE in-order queue: a wave that has just issued its 64 stores finds them
+			// in front of every LDS-DMA piece it waits for at the next K tile's barrier. So the finished tile is only CONVERTED at the end
+			// of its K loop -- bias / scale / GELU, packed into 128 VGPRs (the accumulators are free again) -- and leaves during the NEXT
+			// tile's K loop, one unit (32 rows x 128 bytes per wave) per K tile: 32 ds_write_b16 under substep 1, the four row reads and
+			// 16-byte stores under substep 2, and the barrier waits with vmcnt(4): everything older than those four stores, i.e. every
+			// DMA piece, and the stores themselves have a whole K tile to complete. Needs nk >= 8 (else the tile leaves at once).
+			constexpr bool F16OUT = EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV;
+			constexpr bool DEFER = WIDE && F16OUT && ( SCH & 4096 ) != 0;	   // measured slower in the model (profiles/r04_gemm4_probe.txt): off
+			constexpr int NP = DEFER ? 8 : 1;
+			// IMM: the tile's first units (row tile 0) do not wait: the registers of 8 units + the K loop's own do not fit 256
+			constexpr int IMM = 4;
+			constexpr int PI0 = IMM / 2;		 // first row tile that waits
+			f16x2 pend[ DEFER ? 4 - PI0 : 1 ][ DEFER ? 4 : 1 ][ NP ];	 // [ i - PI0 ][ j ][ r / 2 ]: accumulator registers r, r + 1 of MFMA tile (i, j)
+			int pendNext = 8;					 // next unit to leave (8 = nothing pending)
+			unsigned char* pdBase = nullptr;	 // first row, first column block of the pending wave tile
+			unsigned pdHeadBytes = 0, pdRowBytes = 0, pdCrossBytes = 0;
+			int pdSeg = 0x7fffffff, pdSegPos = 0;
+			unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
+			auto ldsFence = [ & ]()
 			{
-				substep( P0{}, S0{}, zeroc, bufOff, 1 );
-				substep( P1{}, S1{}, ZN{}, bufOff, 2 );
-				// substep 2; then every fragment of this buffer is in registers and this wave's pieces of the next K tile must have landed
-				substep( P2{}, S0{}, ZN{}, bufOff, 3 );
-				asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
+				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+			};
+			// group G (0..3) of unit U's 32 column-wise LDS writes: MFMA tile (U >> 1, 2 (U & 1) + (G >> 1)), registers 8 (G & 1) .. + 7
+			auto pendWrite = [ & ]( auto uc, auto gc )
+			{
+				constexpr int U = decltype( uc )::value, G = decltype( gc )::value;
+				if constexpr( DEFER && U >= IMM )
+				{
+					constexpr int i = U >> 1, jj = G >> 1, j = 2 * ( U & 1 ) + jj;
+					// (a marker that differs per unit: identical arms would be merged into ONE with a run-time index into `pend`, which then lives in scratch)
+					asm volatile( "; pending unit %0, group %1" ::"n"( U ), "n"( G ) );
+					const int hi = lane >> 5, cl = lane & 31;
+	#pragma unroll
+					for( int q = 0; q < 8; q++ )
+					{
+						constexpr int r0 = 8 * ( G & 1 );
+						const int r = r0 + q;
+						const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
+						*(f16*)( stage + row * 128 + ( jj * 32 + cl ) * 2 ) = pend[ i - PI0 ][ j ][ r >> 1 ][ r & 1 ];
+					}
+					asm volatile( "; end of pending unit %0, group %1" ::"n"( U ), "n"( G ) );	  // (common code is sunk from the END of the arms)
+				}
+			};
+			auto pendRead = [ & ]( int it0, f32x4& d0, f32x4& d1 )
+			{
+				const int rl = lane >> 3, ch = lane & 7;
+				d0 = *(const f32x4*)( stage + ( it0 * 8 + rl ) * 128 + ch * 16 );
+				d1 = *(const f32x4*)( stage + ( ( it0 + 1 ) * 8 + rl ) * 128 + ch * 16 );
+			};
+			auto pendStore = [ & ]( int u, int it0, const f32x4& d0, const f32x4& d1 )
+			{
+				const int rl = lane >> 3, ch = lane & 7;
+				unsigned char* const b = pdBase + (long long)( u & 1 ) * pdHeadBytes;
+				const int r0 = 32 * ( u >> 1 ) + 8 * it0 + rl, r1 = r0 + 8;
+				const unsigned v0 = (unsigned)r0 * pdRowBytes + ( pdSegPos + r0 >= pdSeg ? pdCrossBytes : 0u ) + (unsigned)ch * 16u;
+				const unsigned v1 = (unsigned)r1 * pdRowBytes + ( pdSegPos + r1 >= pdSeg ? pdCrossBytes : 0u ) + (unsigned)ch * 16u;
+				*(f32x4*)( b + v0 ) = d0;
+				*(f32x4*)( b + v1 ) = d1;
+			};
+			using G0 = std::integral_constant<int, 0>;
+			using G1 = std::integral_constant<int, 1>;
+			using G2 = std::integral_constant<int, 2>;
+			using G3 = std::integral_constant<int, 3>;
+
+			unsigned bufOff = 0;
+			auto noHook = [ & ]( auto ) {};
+			// one K tile of the consumer; the fragments of its first substep are in register set 0. flushU = the pending tile's unit that leaves under it (-1: none)
+			// uc = the pending tile's unit that leaves under this K tile (a compile-time constant: it selects registers; -1 = none), and only
+			// if something is pending (a run-time, wave-uniform flag: the hooks between the chunks branch on it, nothing else does --
+			// the accumulators must never meet at the end of alternative paths, the allocator would copy all 256 of them around)
+			int postEpi = 0;	 // VMEM operations the last epilogue issued after the DMA pieces of the K tile that follows it (0 / 32 / 63: see the wait below)
+			auto kTile = [ & ]( auto zeroc, auto uc, bool pendActive, auto posc )
+			{
+				constexpr int U = decltype( uc )::value;
+				constexpr int pos = decltype( posc )::value;
+				constexpr bool FL = DEFER && U >= 0;
+				substep( P0{}, S0{}, zeroc, posc, bufOff, 1, noHook );
+				// substep 1: the pending unit's 32 column-wise LDS writes, 8 behind each chunk
+				substep( P1{}, S1{}, ZN{}, posc, bufOff, 2, [ & ]( auto cc )
+				{
+					if constexpr( FL )
+					{
+						if( pendActive )
+						{
+							pendWrite( uc, cc );
+							if constexpr( decltype( cc )::value == 3 ) ldsFence();
+						}
+					}
+				} );
+				// substep 2: the unit's rows back from LDS and out; then every fragment of this buffer is in registers and this wave's
+				// pieces of the next K tile must have landed
+				f32x4 d0, d1;
+				substep( P2{}, S0{}, ZN{}, posc, bufOff, 3, [ & ]( auto cc )
+				{
+					if constexpr( FL )
+					{
+						constexpr int c = decltype( cc )::value;
+						if( pendActive )
+						{
+							if constexpr( c == 0 ) pendRead( 0, d0, d1 );
+							if constexpr( c == 1 )
+							{
+								pendStore( U, 0, d0, d1 );
+								pendRead( 2, d0, d1 );
+							}
+							if constexpr( c == 3 )
+							{
+								pendStore( U, 2, d0, d1 );
+								ldsFence();
+							}
+						}
+					}
+				} );
+				if( FL && pendActive )
+					asm volatile( "s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory" );
+				else if( pos == 1 && !DEFER && ( SCH & 16384 ) == 0 && postEpi >= 63 )
+					// the first K tile after an epilogue: its successor's pieces are all OLDER than the epilogue's loads and stores (vmcnt is one
+					// in-order queue), so they have landed as soon as no more than those are in flight -- the stores go on draining under this
+					// K tile and the next (a CU stores ~16 bytes per cycle: 4 .. 7 us for a tile's 128 .. 256 KiB)
+					asm volatile( "s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory" );
+				else if( pos == 1 && !DEFER && ( SCH & 16384 ) == 0 && postEpi >= 32 )
+					asm volatile( "s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory" );
+				else
+					asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
 				WH_BAR();
 				// substep 3: the next K tile is complete in the other buffer, this buffer is dead
 				advanceProducer( bufOff );
 				bufOff ^= (unsigned)C::STAGE_BYTES;
-				substep( P3{}, S1{}, ZN{}, bufOff, 0 );
+				substep( P3{}, S1{}, ZN{}, posc, bufOff, 0, noHook );
+			};
+			// accumulators -> the pending registers (the arithmetic of epilogueFast4::writeUnit), and where the tile goes
+			auto pendConvert = [ & ]( int mW, int nW )
+			{
+				if constexpr( DEFER )
+				{
+					int laneV = lane;
+					asm volatile( "" : "+v"( laneV ) );
+					const int cl = laneV & 31;
+					const int d = a.H * HEAD_DIM;
+					int sel = 0;
+					long long colBytes = 0, firstRowBytes = 0;
+					if constexpr( EPI == EPI_F16_GELU )
+					{
+						const int b = a.Mb > 0 ? mW / a.Mb : 0;
+						pdSeg = a.Mb > 0 ? a.Mb : 0x7fffffff;
+						pdSegPos = mW - b * ( a.Mb > 0 ? a.Mb : 0 );
+						pdRowBytes = (unsigned)a.ldc * 2u;
+						pdCrossBytes = (unsigned)( ( a.cBatchStride - (long long)a.Mb * a.ldc ) * 2 );
+						firstRowBytes = ( (long long)b * a.cBatchStride + (long long)pdSegPos * a.ldc ) * 2;
+						colBytes = (long long)nW * 2;
+						pdHeadBytes = 128u;
+						pdBase = (unsigned char*)a.out16;
+					}
+					else
+					{
+						const int b = mW / a.T;
+						pdSeg = a.T;
+						pdSegPos = mW - b * a.T;
+						pdRowBytes = 128u;
+						pdCrossBytes = (unsigned)( a.H - 1 ) * (unsigned)a.T * 128u;
+						firstRowBytes = ( (long long)b * a.H * a.T + pdSegPos ) * 128;
+						pdHeadBytes = (unsigned)a.T * 128u;
+						if constexpr( EPI == EPI_QKV_ENC )
+						{
+							sel = nW / d;
+							colBytes = (long long)( ( nW - sel * d ) >> 6 ) * a.T * 128;
+							pdBase = (unsigned char*)( sel == 0 ? a.q : a.k );
+						}
+						else
+						{
+							const int layer = nW / ( 2 * d );
+							const int c2 = nW - layer * 2 * d;
+							sel = c2 >= d ? 1 : 0;
+							colBytes = ( (long long)layer * a.B * a.H + ( ( sel ? c2 - d : c2 ) >> 6 ) ) * a.T * 128;
+							pdBase = (unsigned char*)( sel ? a.v : a.k );
+						}
+					}
+					pdBase += firstRowBytes + colBytes;
+					pdSeg = __builtin_amdgcn_readfirstlane( pdSeg );
+					pdSegPos = __builtin_amdgcn_readfirstlane( pdSegPos );
+					pdRowBytes = __builtin_amdgcn_readfirstlane( pdRowBytes );
+					pdCrossBytes = __builtin_amdgcn_readfirstlane( pdCrossBytes );
+					pdHeadBytes = __builtin_amdgcn_readfirstlane( pdHeadBytes );
+					sel = __builtin_amdgcn_readfirstlane( sel );
+	#pragma unroll
+					for( int j = 0; j < 4; j++ )
+					{
+						const float bias = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
+	#pragma unroll
+						for( int i = PI0; i < 4; i++ )
+						{
+	#pragma unroll
+							for( int r = 0; r < 16; r++ )
+							{
+								float v;
+								asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( v ) : "a"( acc[ i ][ j ][ r ] ) );
+								f16 hv;
+								if constexpr( EPI == EPI_F16_GELU )
+									hv = gelu16( v + bias );
+								else if constexpr( EPI == EPI_QKV_ENC )
+									hv = (f16)( v + bias );
+								else
+									hv = sel ? (f16)( v + bias ) : (f16)( v * a.scale );
+								pend[ i - PI0 ][ j ][ r >> 1 ][ r & 1 ] = hv;
+							}
+							__builtin_amdgcn_sched_barrier( 0 );
+						}
+					}
+					pendNext = IMM;
+				}
 			};
 
-			auto epilogue = [ & ]( int tmD, int tnD )
+			auto epilogue = [ & ]( int tmD, int tnD, bool lastTile )
 			{
+				postEpi = 0;
 				if constexpr( ( SCH & 512 ) != 0 )
 				{
 	#pragma unroll
@@ -2054,7 +2309,6 @@ namespace wh
 				}
 				if constexpr( WIDE )
 				{
-					unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
 					const int mW = tmD * BM + wr * 128, nW = tnD * BN + wc * 128;
 					bool isV = false;
 					if constexpr( EPI == EPI_QKV_ENC ) isV = nW >= 2 * a.H * HEAD_DIM;	   // 2 d is a multiple of 256: a tile is V or it is not
@@ -2064,6 +2318,7 @@ namespace wh
 						if( isV && interior )
 						{
 							epilogueFastV4( a, acc, mW, nW, lane );
+							postEpi = 64;
 							return;
 						}
 					}
@@ -2076,8 +2331,20 @@ namespace wh
 							else
 								epilogueFast4<EPI, false, ( SCH & 1024 ) ? 1 : 0>( a, acc, mW, nW, lane, stage );
 						}
+						else if constexpr( DEFER )
+						{
+							if( lastTile )
+								epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
+							else
+							{
+								// the first units leave now, the rest waits in registers for the next tile's K loop
+								epilogueFast4<EPI, false, 0, 0, IMM>( a, acc, mW, nW, lane, stage );
+								pendConvert( mW, nW );
+							}
+						}
 						else
 							epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
+						postEpi = EPI == EPI_F32 ? 64 : 32;
 						return;
 					}
 					// edge tiles (and launches without the fast path's promises): the general block epilogues of gemmTiled8
@@ -2126,15 +2393,6 @@ namespace wh
 			// ---- prologue: K tile 0 of the first output tile completely, then the first part of K tile 1
 			int lin = linFirst;
 			tileOffsets( lin, pOffA, pOffW );
-			if( lin + linStep < linEnd )
-				tileOffsets( lin + linStep, nOffA, nOffW );
-			else
-			{
-	#pragma unroll
-				for( int q = 0; q < 4; q++ )
-	#pragma unroll
-					for( int i = 0; i < 2; i++ ) nOffA[ q ][ i ] = nOffW[ q ][ i ] = 0;
-			}
 			dmaA( Q0{} );
 			dmaA( Q1{} );
 			dmaA( Q2{} );
@@ -2150,22 +2408,49 @@ namespace wh
 			dmaA( Q1{} );
 			dmaA( Q2{} );
 			if constexpr( ( SCH & 1 ) == 0 ) dmaA( Q3{} );
+			if constexpr( !DEFER && ( SCH & 1 ) == 0 && ( SCH & 16384 ) == 0 )
+			{
+				dmaW( Q0{} );
+				dmaW( Q1{} );
+				dmaW( Q2{} );
+				dmaW( Q3{} );
+			}
 	#pragma unroll
 			for( int i = 0; i < 4; i++ ) fa[ 0 ][ i ] = *(const f16x8*)( smem + aAddr[ 0 ] + i * 4096 );
 	#pragma unroll
 			for( int j = 0; j < 4; j++ ) fb[ 0 ][ j ] = *(const f16x8*)( smem + wAddr[ 0 ] + j * 4096 );
 			__builtin_amdgcn_sched_barrier( 0 );
 
+			using UN = std::integral_constant<int, -1>;
+			using KM = std::integral_constant<int, 0>;
+			using KF = std::integral_constant<int, 1>;
+			using KL = std::integral_constant<int, 2>;
 			for( ;; )
 			{
-				kTile( ZY{} );
-				for( int kt = 1; kt < nk; kt++ ) kTile( ZN{} );
-				// the producer is in the next output tile now (nk >= 2): the offsets of the one after it, before the epilogue's loads and stores
-				if( lin + 2 * linStep < linEnd ) tileOffsets( lin + 2 * linStep, nOffA, nOffW );
+				if constexpr( DEFER )
+				{
+					// the pending tile's units IMM .. 7 leave under this tile's first K tiles (nk >= 8 - IMM: launcher)
+					const bool pa = pendNext < 8;
+					kTile( ZY{}, std::integral_constant<int, IMM>{}, pa, KM{} );
+					kTile( ZN{}, std::integral_constant<int, IMM + 1>{}, pa, KM{} );
+					if constexpr( IMM + 2 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 2 < 8 ? IMM + 2 : -1 )>{}, pa, KM{} );
+					if constexpr( IMM + 3 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 3 < 8 ? IMM + 3 : -1 )>{}, pa, KM{} );
+					if constexpr( IMM + 4 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 4 < 8 ? IMM + 4 : -1 )>{}, pa, KM{} );
+					if constexpr( IMM + 5 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 5 < 8 ? IMM + 5 : -1 )>{}, pa, KM{} );
+					pendNext = 8;
+					for( int kt = 8 - IMM; kt < nk; kt++ ) kTile( ZN{}, UN{}, false, KM{} );
+				}
+				else
+				{
+					// first, middle, last: three instances in a row (nk >= 2), never alternatives
+					kTile( ZY{}, UN{}, false, KF{} );
+					for( int kt = 1; kt + 1 < nk; kt++ ) kTile( ZN{}, UN{}, false, KM{} );
+					kTile( ZN{}, UN{}, false, KL{} );
+				}
 				int tm, tn;
 				tileCoords( lin, tm, tn );
 				asm volatile( "s_nop 15\n\ts_nop 15" ::: "memory" );	   // the last MFMA's 16 passes are over before the first accumulator is read
-				epilogue( tm, tn );
+				epilogue( tm, tn, lin + linStep >= linEnd );
 				lin += linStep;
 				if( lin >= linEnd ) break;
 			}
@@ -2824,6 +3109,24 @@ namespace wh
 		return launchTiledK<EPI, C, false>( b, stream );
 	}
 
+	// What epilogueFast4 relies on (interior tiles of the two persistent kernels): a wave's 128 rows cross at most one segment boundary, and
+	// everything it adds per lane fits 32 bits
+	template<int EPI>
+	static bool fastEpilogueOk( const GemmArgs& a )
+	{
+		if( EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV )
+			return a.T >= 128 && ( a.H * HEAD_DIM ) % 128 == 0 && (long long)( a.H - 1 ) * a.T * 128 < ( 1ll << 31 );
+		if( EPI != EPI_F32 && EPI != EPI_F16_GELU ) return false;
+		const int es = EPI == EPI_F32 ? 4 : 2;
+		bool fast = (long long)a.ldc * es * 128 < ( 1ll << 31 );
+		if( a.Mb > 0 && a.Mb < a.M )
+		{
+			const long long cross = ( a.cBatchStride - (long long)a.Mb * a.ldc ) * es;
+			fast = fast && a.Mb >= 128 && cross >= 0 && cross + (long long)a.ldc * es * 128 < ( 1ll << 31 );
+		}
+		return fast;
+	}
+
 	template<int EPI, bool WIDE, int ABL = 0>
 	static int launchTiled8K( const GemmArgs& b, hipStream_t stream )
 	{
@@ -2872,6 +3175,7 @@ namespace wh
 			}
 		}
 		b.wideEpi = wide ? 1 : 0;
+		if( wide && ( g_tuning & TUNE_GEMM_FAST_EPI ) && ( EPI != EPI_QKV_ENC || ( a.T % 4 ) == 0 ) && fastEpilogueOk<EPI>( a ) ) b.wideEpi = 2;
 		return wide ? launchTiled8K<EPI, true>( b, stream ) : launchTiled8K<EPI, false>( b, stream );
 	}
 
@@ -2922,24 +3226,7 @@ namespace wh
 			}
 		}
 		b.wideEpi = wide ? 1 : 0;
-		if( wide )
-		{
-			// what epilogueFast4 relies on: a wave's 128 rows cross at most one segment boundary, and everything it adds per lane fits 32 bits
-			bool fast = true;
-			if( EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV )
-				fast = a.T >= 128 && ( a.H * HEAD_DIM ) % 128 == 0 && (long long)( a.H - 1 ) * a.T * 128 < ( 1ll << 31 );
-			else
-			{
-				const int es = EPI == EPI_F32 ? 4 : 2;
-				fast = (long long)a.ldc * es * 128 < ( 1ll << 31 );
-				if( a.Mb > 0 && a.Mb < a.M )
-				{
-					const long long cross = ( a.cBatchStride - (long long)a.Mb * a.ldc ) * es;
-					fast = fast && a.Mb >= 128 && cross >= 0 && cross + (long long)a.ldc * es * 128 < ( 1ll << 31 );
-				}
-			}
-			if( fast ) b.wideEpi = 2;
-		}
+		if( wide && fastEpilogueOk<EPI>( a ) ) b.wideEpi = 2;
 		return wide ? launchTiled4K<EPI, true, SCH>( b, stream ) : launchTiled4K<EPI, false, SCH>( b, stream );
 	}
 
@@ -2954,7 +3241,7 @@ namespace wh
 		case 61: return launchTiled4<EPI_F32, 512>( a, stream );	   // ... no epilogue
 		case 62: return launchTiled4<EPI_F32, 768>( a, stream );	   // ... neither
 		case 63: return launchTiled4<EPI_F32, 1024>( a, stream );	   // ... the epilogue without its global stores
-		case 57: return launchTiled4<EPI_F32, 2048>( a, stream );	   // correct: workgroups start a quarter tile apart
+		case 51: return launchTiled4<EPI_F32, 16384>( a, stream );	   // correct: without the early W pieces / the counted wait after the epilogue
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );	   // the 16-wave kernel of round 2 (products below gemmTiled8's threshold)
 		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );	   // register-staged 128x128x32: what wh_debug_probe checks every variant against
@@ -3051,7 +3338,7 @@ namespace wh
 		const bool fits32 = aBytes < ( 1ll << 32 ) && 2ll * a.N * a.K < ( 1ll << 32 );
 		const bool w8 = big && fits32 && ( g_tuning & TUNE_GEMM_8WAVE ) != 0;
 		// gemmTiled4 on top: at least two K tiles, A segments of at least a tile's 256 rows with a non-negative gap
-		const bool w4 = w8 && a.K >= 128 && ( g_tuning & TUNE_GEMM_4WAVE ) != 0 &&
+		const bool w4 = w8 && a.K >= 256 && ( g_tuning & TUNE_GEMM_4WAVE ) != 0 &&	   // (K >= 256: the FP16 epilogues leave under the next tile's first four K tiles)
 			( a.Mb <= 0 || a.Mb >= a.M || ( a.Mb >= 256 && a.aBatchStride >= (long long)a.Mb * a.lda ) );
 #define WH_TILED( E )                                                    \
 	if( w4 ) return launchTiled4<E>( a, stream );                        \

@@ -9,6 +9,7 @@ namespace wh
 	{
 		TUNE_GEMV_ROWS4 = 2,	 // 4 weight rows per workgroup for small-N / large-K gemv (else 16)
 		TUNE_GEMM_4WAVE = 4,	 // ... of those, one wave per SIMD: 4 waves x (128 x 128), 256 accumulator registers, a hand-pipelined K loop with one barrier per K tile (gemmTiled4)
+		TUNE_GEMM_FAST_EPI = 1,	 // gemmTiled8: interior tiles leave through gemmTiled4's lean epilogue (no bounds checks / divisions per row, residual a unit ahead of the stores)
 		TUNE_GEMM_8WAVE = 16,	 // big tiled GEMMs: 8 waves x (128 x 64), four phases per K tile, wave rows one barrier apart, counted vmcnt (gemmTiled8)
 		TUNE_GEMM_BIG = 8,		 // 256x256x64 tiles for large tiled GEMMs (else 128x128x32 everywhere)
 		TUNE_GEMV_SMALLREG = 32,	 // 8-slot gemv instance when a wave's K slice fits (fewer registers, same loads in flight)
@@ -47,7 +48,7 @@ namespace wh
 		// profiles/r01_ab_variants.txt). Retired after measuring slower, ms per clip pass: 8-wave
 		// LayerNorm prologue (+3.4, spills), 4-row workgroups for K = d (+0.5), cross-attention split over 4 workgroups with
 		// the combine in the next gemv's prologue (+6.7), all of a head's K/V requested up front (+1.5).
-		TUNE_DEFAULT = TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE
+		TUNE_DEFAULT = TUNE_GEMM_FAST_EPI | TUNE_GEMM_8WAVE | TUNE_GEMV_ROWS4 | TUNE_GEMV_SMALLREG | TUNE_GEMM_BIG | TUNE_GEMM_GL | TUNE_LN_SEPARATE_BIGM | TUNE_ATTN_XCD | TUNE_ATTN_DEC_G | TUNE_FUSE_CROSS_Q | TUNE_GEMM_GROUP_M | TUNE_FUSE_SELF_BLOCK | TUNE_GEMV_K8 | TUNE_ATTN_ENC_F | TUNE_GEMM_WIDE_EPI | TUNE_GEMM_FRAGPF | TUNE_ATTN_ENC_2SWEEP | TUNE_GEMV_ALLROWS | TUNE_GEMV_ROWGROUPS | TUNE_SELF_MFMA | TUNE_MEL_MFMA | TUNE_DECODE_SMALL | TUNE_ATTN_DEC_NT | TUNE_ATTN_ENC_TABLE
 	};
 	extern unsigned g_tuning;
 
