@@ -49,6 +49,7 @@ PY
 fi
 if has prof; then
   echo "== rocprof bench"; date
+  rm -rf /tmp/prof_bench
   cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python $R/bench.py --no-roofline --no-cpu-baseline --no-single-stream --no-large --no-boundary > $R/$out/bench_prof.json 2> $R/$out/bench_prof.err
   cd $R
   f=$(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1); cp $f $out/bench_kernel_stats.csv 2>/dev/null

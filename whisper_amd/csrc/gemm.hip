@@ -1493,27 +1493,39 @@ namespace wh
 		}
 
 		// ---------------------------------------------------------------------------------------------------------------
-		// gemmTiled4 (round 4): the encoder product with ONE wave per SIMD. profiles/r04_gemm_counters.txt: gemmTiled8's waves own
-		// 128 x 64 outputs, so every fragment read feeds half the MFMAs it could (24 ds_read_b128 per 32 MFMAs), the LDS pipe of a
-		// CU is ~75 % busy under a full-rate matrix pipe and the chip clocks lower for it. Here FOUR waves (2 x 2) own 128 x 128
-		// each = 4 x 4 tiles of v_mfma_f32_32x32x16_f16: 256 accumulator registers (the AGPR half of a 512-register wave), 8
-		// fragment reads per 16 MFMAs, half the LDS traffic per FLOP. With a single wave per SIMD nothing overlaps by
-		// itself, so the K loop is a software pipeline written out by hand:
-		//   * a K tile (64) is four substeps of 16 MFMAs; the fragments of substep s+1 are read (8 x ds_read_b128, second
-		//     register set) while the MFMAs of substep s issue -- interleaved 1 read : 2 MFMAs by sched_group_barrier;
+		// gemmTiled4 (round 4): the encoder product with ONE wave per SIMD -- the tile shape of the vendor library's kernel for these
+		// shapes (profiles/r04_gemm_counters.txt). gemmTiled8's waves own 128 x 64 outputs, so every fragment read feeds half the MFMAs
+		// it could (24 ds_read_b128 per 32 MFMAs). Here FOUR waves (2 x 2) own 128 x 128 each = 4 x 4 tiles of
+		// v_mfma_f32_32x32x16_f16: 256 accumulator registers (the AGPR half of a 512-register wave), 8 fragment reads per 16 MFMAs,
+		// half the LDS traffic per FLOP. With a single wave per SIMD nothing overlaps by itself, so the K loop is a software pipeline
+		// written out by hand:
+		//   * a K tile (64) is four substeps of 16 MFMAs in chunks of 4 (one A row tile x the four W tiles); the fragments of substep
+		//     s + 1 are read (8 x ds_read_b128, second register set) behind the first 8 MFMAs of substep s, one read per MFMA
+		//     (sched_group_barrier), and nothing crosses a chunk boundary (sched_barrier);
 		//   * ONE s_barrier per K tile, before the LAST substep: by then a wave has read everything it needs from the current
 		//     buffer (the last substep's fragments are in registers) and waited for its own LDS-DMA pieces of the next tile
-		//     (vmcnt(0)), so after the barrier the next K tile is complete in the other buffer and the current buffer is dead:
+		//     (vmcnt), so after the barrier the next K tile is complete in the other buffer and the current buffer is dead:
 		//     the first fragments of the next K tile are read under the last substep's MFMAs and the DMA of the tile after
-		//     next starts into the dead buffer. A DMA piece has a whole K tile (~2k cycles) to land; the matrix pipe sees
-		//     the barrier only as the skew between four waves that run the same instruction stream;
+		//     next starts into the dead buffer, one pair of 1 KiB pieces behind each chunk of substeps 3 and 0. A piece has a whole
+		//     K tile (~2k cycles) to land; the matrix pipe sees the barrier only as the skew between four waves that run the same stream;
 		//   * the stream of K tiles is FLAT across output tiles (persistent workgroup, the band walk of gemmTiled8): the
-		//     producer side (tile coordinates, per-lane source offsets) runs two K tiles ahead of the consumer and simply
-		//     moves on to the next output tile; the epilogue of a tile runs between two K tiles with the next output tile's
-		//     first K tile already in LDS and its second one in flight;
-		//   * a tile's first substep multiplies into the constant 0 instead of clearing 256 registers.
+		//     producer side (tile coordinates, per-lane source offsets, recomputed without a branch or a division per row) runs two
+		//     K tiles ahead of the consumer and simply moves on to the next output tile; the epilogue of a tile runs between two K
+		//     tiles with the next output tile's first two K tiles requested before its first store;
+		//   * a tile's first substep multiplies into the constant 0 instead of clearing 256 registers;
+		//   * ONE instance of every K tile position (first / middle / last) in a row and the epilogue outside the K loop: accumulators
+		//     that meet at the end of alternative paths (a switch, a peeled variant) are 256 registers the allocator copies around.
 		// LDS: two 64 KiB K-tile buffers (A rows, then W rows, 128-byte rows, 16-byte chunks XOR-swizzled exactly as gemmTiled8)
 		// + 4 KiB of epilogue staging per wave = 144 KiB. Wave w stages rows 64 w .. 64 w + 63 of both operand tiles.
+		//
+		// MEASURED (MI355X, profiles/r04_gemm4_probe.txt): correct (bit-identical to gemmTiled8) and +7 .. 15 % on the plain FP32 probe
+		// (168000 x 4096 x 1024: 930 against 850 TFLOP/s), but inside the model it is level with gemmTiled8 (GEMM class -2 % .. +0.3 %:
+		// Q/K/V -5 %, GELU and cross-K/V +4 .. 5 %), so TUNE_GEMM_4WAVE is OFF. What it did settle, by ablation: without LDS-DMA and
+		// without epilogue the K loop runs at 1500 TFLOP/s; the DMA costs 18 % of that whatever its placement (staggered over the waves,
+		// spread over 2 or 3 substeps: the same) -- it is the CU's L2 -> LDS path, ~19 bytes per cycle under the MFMAs (26 alone), and a
+		// 256 x 256 x 64 tile needs 64 KiB per 2048 matrix-pipe cycles = 32; the epilogue costs another 25 %: 2.5 us of instructions and
+		// 4 .. 7 us in which the tile's 128 .. 256 KiB drain at the ~16 bytes per cycle a CU stores, with the next tile's DMA queued
+		// behind them. Its lean epilogue, which does not depend on the wave shape, is what gemmTiled8 now uses (TUNE_GEMM_FAST_EPI).
 		// An accumulator register of gemmTiled4 read where the epilogue uses it. Written as assembly so that the register allocator keeps
 		// the 256 accumulators in the AGPR half of the file until then: left to itself it copies half of them into VGPRs at the end of
 		// the K loop, spills the K loop's own state to scratch to make room, and every scratch reload then waits for ALL stores in
@@ -1825,9 +1837,10 @@ namespace wh
 			static constexpr int LDS_BYTES = EPI_OFFSET + 4 * EPI_PER_WAVE;
 		};
 
-		// SCH (measurement variants, all correct): bit 0 = the DMA pieces of a K tile spread 3 / 3 / 2 over three substeps (else 4 / 4
-		// over two), bit 1 = no sched_group_barrier interleave (the compiler's own order inside a substep), bit 2 = 1 read : 1 MFMA at
-		// the head of a substep instead of 1 : 2 throughout
+		// SCH (probe builds; 0 = the instance that ships): 1 = the DMA pieces of a K tile spread 3 / 3 / 2 over three substeps (else 4 / 4 over
+		// two), 2 = the compiler's own order inside a chunk, 4 = 2 fragment reads per chunk instead of 4 + 4 + 0 + 0, 16384 = no early W
+		// pieces / counted wait after the epilogue (all correct); ablations with WRONG results: 256 = no LDS-DMA in the K loop, 512 = no
+		// epilogue, 1024 = the epilogue without its global stores
 		template<int EPI, bool WIDE, int SCH = 0>
 		__global__ void __launch_bounds__( 256, 1 ) gemmTiled4( const GemmArgs a )
 		{
@@ -2033,22 +2046,6 @@ namespace wh
 						else
 							acc[ c ][ j ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( fa[ SET ][ c ], fb[ SET ][ j ], acc[ c ][ j ], 0, 0, 0 );
 					};
-					if constexpr( ( SCH & 8 ) != 0 )
-					{
-						// STAGGERED: wave w issues its pair behind MFMA w of the chunk, so that the four waves of the CU (which run the same
-						// stream between two barriers) do not queue up at the CU's one vector-memory issue path
-	#pragma unroll
-						for( int j = 0; j < 4; j++ )
-						{
-							mfmaOne( j );
-							__builtin_amdgcn_sched_barrier( 0 );
-							if( wave == j ) dmaAfter( sc, cc, posc );
-							__builtin_amdgcn_sched_barrier( 0 );
-						}
-						hook( cc );
-						__builtin_amdgcn_sched_barrier( 0 );
-						return;
-					}
 	#pragma unroll
 					for( int j = 0; j < 4; j++ ) mfmaOne( j );
 					if constexpr( ( SCH & 2 ) == 0 && ( ( SCH & 4 ) != 0 || c < 2 ) )
@@ -2081,130 +2078,27 @@ namespace wh
 			using ZN = std::integral_constant<bool, false>;
 			using ZY = std::integral_constant<bool, true>;
 
-			// ---- the PENDING tile (FP16 outputs only: GELU, Q / K, cross K / V). A CU stores ~16 bytes per cycle, so the 128 KiB of a tile take
-			// ~4 us to leave, and vmcnt counts loads and stores in ONE in-order queue: a wave that has just issued its 64 stores finds them
-			// in front of every LDS-DMA piece it waits for at the next K tile's barrier. So the finished tile is only CONVERTED at the end
-			// of its K loop -- bias / scale / GELU, packed into 128 VGPRs (the accumulators are free again) -- and leaves during the NEXT
-			// tile's K loop, one unit (32 rows x 128 bytes per wave) per K tile: 32 ds_write_b16 under substep 1, the four row reads and
-			// 16-byte stores under substep 2, and the barrier waits with vmcnt(4): everything older than those four stores, i.e. every
-			// DMA piece, and the stores themselves have a whole K tile to complete. Needs nk >= 8 (else the tile leaves at once).
-			constexpr bool F16OUT = EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV;
-			constexpr bool DEFER = WIDE && F16OUT && ( SCH & 4096 ) != 0;	   // measured slower in the model (profiles/r04_gemm4_probe.txt): off
-			constexpr int NP = DEFER ? 8 : 1;
-			// IMM: the tile's first units (row tile 0) do not wait: the registers of 8 units + the K loop's own do not fit 256
-			constexpr int IMM = 4;
-			constexpr int PI0 = IMM / 2;		 // first row tile that waits
-			f16x2 pend[ DEFER ? 4 - PI0 : 1 ][ DEFER ? 4 : 1 ][ NP ];	 // [ i - PI0 ][ j ][ r / 2 ]: accumulator registers r, r + 1 of MFMA tile (i, j)
-			int pendNext = 8;					 // next unit to leave (8 = nothing pending)
-			unsigned char* pdBase = nullptr;	 // first row, first column block of the pending wave tile
-			unsigned pdHeadBytes = 0, pdRowBytes = 0, pdCrossBytes = 0;
-			int pdSeg = 0x7fffffff, pdSegPos = 0;
 			unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
-			auto ldsFence = [ & ]()
-			{
-				__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-			};
-			// group G (0..3) of unit U's 32 column-wise LDS writes: MFMA tile (U >> 1, 2 (U & 1) + (G >> 1)), registers 8 (G & 1) .. + 7
-			auto pendWrite = [ & ]( auto uc, auto gc )
-			{
-				constexpr int U = decltype( uc )::value, G = decltype( gc )::value;
-				if constexpr( DEFER && U >= IMM )
-				{
-					constexpr int i = U >> 1, jj = G >> 1, j = 2 * ( U & 1 ) + jj;
-					// (a marker that differs per unit: identical arms would be merged into ONE with a run-time index into `pend`, which then lives in scratch)
-					asm volatile( "; pending unit %0, group %1" ::"n"( U ), "n"( G ) );
-					const int hi = lane >> 5, cl = lane & 31;
-	#pragma unroll
-					for( int q = 0; q < 8; q++ )
-					{
-						constexpr int r0 = 8 * ( G & 1 );
-						const int r = r0 + q;
-						const int row = ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi;
-						*(f16*)( stage + row * 128 + ( jj * 32 + cl ) * 2 ) = pend[ i - PI0 ][ j ][ r >> 1 ][ r & 1 ];
-					}
-					asm volatile( "; end of pending unit %0, group %1" ::"n"( U ), "n"( G ) );	  // (common code is sunk from the END of the arms)
-				}
-			};
-			auto pendRead = [ & ]( int it0, f32x4& d0, f32x4& d1 )
-			{
-				const int rl = lane >> 3, ch = lane & 7;
-				d0 = *(const f32x4*)( stage + ( it0 * 8 + rl ) * 128 + ch * 16 );
-				d1 = *(const f32x4*)( stage + ( ( it0 + 1 ) * 8 + rl ) * 128 + ch * 16 );
-			};
-			auto pendStore = [ & ]( int u, int it0, const f32x4& d0, const f32x4& d1 )
-			{
-				const int rl = lane >> 3, ch = lane & 7;
-				unsigned char* const b = pdBase + (long long)( u & 1 ) * pdHeadBytes;
-				const int r0 = 32 * ( u >> 1 ) + 8 * it0 + rl, r1 = r0 + 8;
-				const unsigned v0 = (unsigned)r0 * pdRowBytes + ( pdSegPos + r0 >= pdSeg ? pdCrossBytes : 0u ) + (unsigned)ch * 16u;
-				const unsigned v1 = (unsigned)r1 * pdRowBytes + ( pdSegPos + r1 >= pdSeg ? pdCrossBytes : 0u ) + (unsigned)ch * 16u;
-				*(f32x4*)( b + v0 ) = d0;
-				*(f32x4*)( b + v1 ) = d1;
-			};
-			using G0 = std::integral_constant<int, 0>;
-			using G1 = std::integral_constant<int, 1>;
-			using G2 = std::integral_constant<int, 2>;
-			using G3 = std::integral_constant<int, 3>;
 
 			unsigned bufOff = 0;
 			auto noHook = [ & ]( auto ) {};
-			// one K tile of the consumer; the fragments of its first substep are in register set 0. flushU = the pending tile's unit that leaves under it (-1: none)
-			// uc = the pending tile's unit that leaves under this K tile (a compile-time constant: it selects registers; -1 = none), and only
-			// if something is pending (a run-time, wave-uniform flag: the hooks between the chunks branch on it, nothing else does --
-			// the accumulators must never meet at the end of alternative paths, the allocator would copy all 256 of them around)
-			int postEpi = 0;	 // VMEM operations the last epilogue issued after the DMA pieces of the K tile that follows it (0 / 32 / 63: see the wait below)
-			auto kTile = [ & ]( auto zeroc, auto uc, bool pendActive, auto posc )
+			// One K tile of the consumer; the fragments of its first substep are in register set 0. There is ONE instance of every K tile position
+			// (first / middle / last) in a row, never alternatives: accumulators that meet at the end of alternative paths are 256 registers
+			// the allocator then copies around.
+			int postEpi = 0;	 // VMEM operations the last epilogue issued after the DMA pieces of the K tile that follows it (0 / 32 / 64: see the wait below)
+			auto kTile = [ & ]( auto zeroc, auto posc )
 			{
-				constexpr int U = decltype( uc )::value;
 				constexpr int pos = decltype( posc )::value;
-				constexpr bool FL = DEFER && U >= 0;
 				substep( P0{}, S0{}, zeroc, posc, bufOff, 1, noHook );
-				// substep 1: the pending unit's 32 column-wise LDS writes, 8 behind each chunk
-				substep( P1{}, S1{}, ZN{}, posc, bufOff, 2, [ & ]( auto cc )
-				{
-					if constexpr( FL )
-					{
-						if( pendActive )
-						{
-							pendWrite( uc, cc );
-							if constexpr( decltype( cc )::value == 3 ) ldsFence();
-						}
-					}
-				} );
-				// substep 2: the unit's rows back from LDS and out; then every fragment of this buffer is in registers and this wave's
-				// pieces of the next K tile must have landed
-				f32x4 d0, d1;
-				substep( P2{}, S0{}, ZN{}, posc, bufOff, 3, [ & ]( auto cc )
-				{
-					if constexpr( FL )
-					{
-						constexpr int c = decltype( cc )::value;
-						if( pendActive )
-						{
-							if constexpr( c == 0 ) pendRead( 0, d0, d1 );
-							if constexpr( c == 1 )
-							{
-								pendStore( U, 0, d0, d1 );
-								pendRead( 2, d0, d1 );
-							}
-							if constexpr( c == 3 )
-							{
-								pendStore( U, 2, d0, d1 );
-								ldsFence();
-							}
-						}
-					}
-				} );
-				if( FL && pendActive )
-					asm volatile( "s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory" );
-				else if( pos == 1 && !DEFER && ( SCH & 16384 ) == 0 && postEpi >= 63 )
+				substep( P1{}, S1{}, ZN{}, posc, bufOff, 2, noHook );
+				// substep 2; then every fragment of this buffer is in registers and this wave's pieces of the next K tile must have landed
+				substep( P2{}, S0{}, ZN{}, posc, bufOff, 3, noHook );
+				if( pos == 1 && ( SCH & 16384 ) == 0 && postEpi >= 63 )
 					// the first K tile after an epilogue: its successor's pieces are all OLDER than the epilogue's loads and stores (vmcnt is one
 					// in-order queue), so they have landed as soon as no more than those are in flight -- the stores go on draining under this
-					// K tile and the next (a CU stores ~16 bytes per cycle: 4 .. 7 us for a tile's 128 .. 256 KiB)
+					// K tile and the next
 					asm volatile( "s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory" );
-				else if( pos == 1 && !DEFER && ( SCH & 16384 ) == 0 && postEpi >= 32 )
+				else if( pos == 1 && ( SCH & 16384 ) == 0 && postEpi >= 32 )
 					asm volatile( "s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory" );
 				else
 					asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
@@ -2213,87 +2107,6 @@ namespace wh
 				advanceProducer( bufOff );
 				bufOff ^= (unsigned)C::STAGE_BYTES;
 				substep( P3{}, S1{}, ZN{}, posc, bufOff, 0, noHook );
-			};
-			// accumulators -> the pending registers (the arithmetic of epilogueFast4::writeUnit), and where the tile goes
-			auto pendConvert = [ & ]( int mW, int nW )
-			{
-				if constexpr( DEFER )
-				{
-					int laneV = lane;
-					asm volatile( "" : "+v"( laneV ) );
-					const int cl = laneV & 31;
-					const int d = a.H * HEAD_DIM;
-					int sel = 0;
-					long long colBytes = 0, firstRowBytes = 0;
-					if constexpr( EPI == EPI_F16_GELU )
-					{
-						const int b = a.Mb > 0 ? mW / a.Mb : 0;
-						pdSeg = a.Mb > 0 ? a.Mb : 0x7fffffff;
-						pdSegPos = mW - b * ( a.Mb > 0 ? a.Mb : 0 );
-						pdRowBytes = (unsigned)a.ldc * 2u;
-						pdCrossBytes = (unsigned)( ( a.cBatchStride - (long long)a.Mb * a.ldc ) * 2 );
-						firstRowBytes = ( (long long)b * a.cBatchStride + (long long)pdSegPos * a.ldc ) * 2;
-						colBytes = (long long)nW * 2;
-						pdHeadBytes = 128u;
-						pdBase = (unsigned char*)a.out16;
-					}
-					else
-					{
-						const int b = mW / a.T;
-						pdSeg = a.T;
-						pdSegPos = mW - b * a.T;
-						pdRowBytes = 128u;
-						pdCrossBytes = (unsigned)( a.H - 1 ) * (unsigned)a.T * 128u;
-						firstRowBytes = ( (long long)b * a.H * a.T + pdSegPos ) * 128;
-						pdHeadBytes = (unsigned)a.T * 128u;
-						if constexpr( EPI == EPI_QKV_ENC )
-						{
-							sel = nW / d;
-							colBytes = (long long)( ( nW - sel * d ) >> 6 ) * a.T * 128;
-							pdBase = (unsigned char*)( sel == 0 ? a.q : a.k );
-						}
-						else
-						{
-							const int layer = nW / ( 2 * d );
-							const int c2 = nW - layer * 2 * d;
-							sel = c2 >= d ? 1 : 0;
-							colBytes = ( (long long)layer * a.B * a.H + ( ( sel ? c2 - d : c2 ) >> 6 ) ) * a.T * 128;
-							pdBase = (unsigned char*)( sel ? a.v : a.k );
-						}
-					}
-					pdBase += firstRowBytes + colBytes;
-					pdSeg = __builtin_amdgcn_readfirstlane( pdSeg );
-					pdSegPos = __builtin_amdgcn_readfirstlane( pdSegPos );
-					pdRowBytes = __builtin_amdgcn_readfirstlane( pdRowBytes );
-					pdCrossBytes = __builtin_amdgcn_readfirstlane( pdCrossBytes );
-					pdHeadBytes = __builtin_amdgcn_readfirstlane( pdHeadBytes );
-					sel = __builtin_amdgcn_readfirstlane( sel );
-	#pragma unroll
-					for( int j = 0; j < 4; j++ )
-					{
-						const float bias = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
-	#pragma unroll
-						for( int i = PI0; i < 4; i++ )
-						{
-	#pragma unroll
-							for( int r = 0; r < 16; r++ )
-							{
-								float v;
-								asm volatile( "v_accvgpr_read_b32 %0, %1" : "=v"( v ) : "a"( acc[ i ][ j ][ r ] ) );
-								f16 hv;
-								if constexpr( EPI == EPI_F16_GELU )
-									hv = gelu16( v + bias );
-								else if constexpr( EPI == EPI_QKV_ENC )
-									hv = (f16)( v + bias );
-								else
-									hv = sel ? (f16)( v + bias ) : (f16)( v * a.scale );
-								pend[ i - PI0 ][ j ][ r >> 1 ][ r & 1 ] = hv;
-							}
-							__builtin_amdgcn_sched_barrier( 0 );
-						}
-					}
-					pendNext = IMM;
-				}
 			};
 
 			auto epilogue = [ & ]( int tmD, int tnD, bool lastTile )
@@ -2330,17 +2143,6 @@ namespace wh
 								epilogueFast4<EPI, true>( a, acc, mW, nW, lane, stage );
 							else
 								epilogueFast4<EPI, false, ( SCH & 1024 ) ? 1 : 0>( a, acc, mW, nW, lane, stage );
-						}
-						else if constexpr( DEFER )
-						{
-							if( lastTile )
-								epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
-							else
-							{
-								// the first units leave now, the rest waits in registers for the next tile's K loop
-								epilogueFast4<EPI, false, 0, 0, IMM>( a, acc, mW, nW, lane, stage );
-								pendConvert( mW, nW );
-							}
 						}
 						else
 							epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
@@ -2408,7 +2210,7 @@ namespace wh
 			dmaA( Q1{} );
 			dmaA( Q2{} );
 			if constexpr( ( SCH & 1 ) == 0 ) dmaA( Q3{} );
-			if constexpr( !DEFER && ( SCH & 1 ) == 0 && ( SCH & 16384 ) == 0 )
+			if constexpr( ( SCH & 1 ) == 0 && ( SCH & 16384 ) == 0 )
 			{
 				dmaW( Q0{} );
 				dmaW( Q1{} );
@@ -2421,32 +2223,15 @@ namespace wh
 			for( int j = 0; j < 4; j++ ) fb[ 0 ][ j ] = *(const f16x8*)( smem + wAddr[ 0 ] + j * 4096 );
 			__builtin_amdgcn_sched_barrier( 0 );
 
-			using UN = std::integral_constant<int, -1>;
 			using KM = std::integral_constant<int, 0>;
 			using KF = std::integral_constant<int, 1>;
 			using KL = std::integral_constant<int, 2>;
 			for( ;; )
 			{
-				if constexpr( DEFER )
-				{
-					// the pending tile's units IMM .. 7 leave under this tile's first K tiles (nk >= 8 - IMM: launcher)
-					const bool pa = pendNext < 8;
-					kTile( ZY{}, std::integral_constant<int, IMM>{}, pa, KM{} );
-					kTile( ZN{}, std::integral_constant<int, IMM + 1>{}, pa, KM{} );
-					if constexpr( IMM + 2 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 2 < 8 ? IMM + 2 : -1 )>{}, pa, KM{} );
-					if constexpr( IMM + 3 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 3 < 8 ? IMM + 3 : -1 )>{}, pa, KM{} );
-					if constexpr( IMM + 4 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 4 < 8 ? IMM + 4 : -1 )>{}, pa, KM{} );
-					if constexpr( IMM + 5 < 8 ) kTile( ZN{}, std::integral_constant<int, ( IMM + 5 < 8 ? IMM + 5 : -1 )>{}, pa, KM{} );
-					pendNext = 8;
-					for( int kt = 8 - IMM; kt < nk; kt++ ) kTile( ZN{}, UN{}, false, KM{} );
-				}
-				else
-				{
-					// first, middle, last: three instances in a row (nk >= 2), never alternatives
-					kTile( ZY{}, UN{}, false, KF{} );
-					for( int kt = 1; kt + 1 < nk; kt++ ) kTile( ZN{}, UN{}, false, KM{} );
-					kTile( ZN{}, UN{}, false, KL{} );
-				}
+				// first, middle, last (nk >= 2)
+				kTile( ZY{}, KF{} );
+				for( int kt = 1; kt + 1 < nk; kt++ ) kTile( ZN{}, KM{} );
+				kTile( ZN{}, KL{} );
 				int tm, tn;
 				tileCoords( lin, tm, tn );
 				asm volatile( "s_nop 15\n\ts_nop 15" ::: "memory" );	   // the last MFMA's 16 passes are over before the first accumulator is read
@@ -3237,15 +3022,15 @@ namespace wh
 		{
 		case 40: return launchTiled8<EPI_F32>( a, stream );	   // the 8-wave persistent kernel (round 3)
 		case 50: return launchTiled4<EPI_F32>( a, stream );	   // the 4-wave persistent kernel (round 4)
+		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );	   // the 16-wave kernel of round 2 (products below gemmTiled8's threshold)
+		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
+		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );	   // register-staged 128x128x32: what wh_debug_probe checks every variant against
+#ifdef WH_PROBES
 		case 60: return launchTiled4<EPI_F32, 256>( a, stream );	   // ablations (60 .. 69, wrong results, not checked): no LDS-DMA in the K loop
 		case 61: return launchTiled4<EPI_F32, 512>( a, stream );	   // ... no epilogue
 		case 62: return launchTiled4<EPI_F32, 768>( a, stream );	   // ... neither
 		case 63: return launchTiled4<EPI_F32, 1024>( a, stream );	   // ... the epilogue without its global stores
 		case 51: return launchTiled4<EPI_F32, 16384>( a, stream );	   // correct: without the early W pieces / the counted wait after the epilogue
-		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );	   // the 16-wave kernel of round 2 (products below gemmTiled8's threshold)
-		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
-		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );	   // register-staged 128x128x32: what wh_debug_probe checks every variant against
-#ifdef WH_PROBES
 		// Everything below exists for tools/*probe*: tile-shape experiments and ABLATIONS of the production kernels, several of them WRONG BY
 		// CONSTRUCTION (loads or fragment reads removed to see what the rest costs). The shipped objects do not contain them: build with
 		// WH_PROBES=1 python -m whisper_amd.build --force to get them back.
