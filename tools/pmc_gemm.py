@@ -16,11 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUPS = [["GRBM_GUI_ACTIVE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"], ["SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
           ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"], ["FETCH_SIZE"], ["WRITE_SIZE"]]
 SHAPES = "168000x4096x1024,168000x1024x1024,168000x1024x4096,168000x3072x1024"
+# PMC_VARIANT=50 PMC_KERNEL=gemmTiled4: the same passes over the 4-wave kernel (profiles/r04_gemm4_probe.txt)
+VARIANT = os.environ.get("PMC_VARIANT", "40")
+KERNEL = os.environ.get("PMC_KERNEL", "gemmTiled8")
 
 
 def run(out):
     os.makedirs(out, exist_ok=True)
-    env = dict(os.environ, PROBE_VARIANTS="40", PROBE_ROUNDS="1", PROBE_SHAPES=SHAPES, TMPDIR="/tmp")
+    env = dict(os.environ, PROBE_VARIANTS=VARIANT, PROBE_ROUNDS="1", PROBE_SHAPES=SHAPES, TMPDIR="/tmp")
     # un-profiled timing of the same command first (a profiled pass clocks lower: never compare the two)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm8_probe.py")], env=env, stdout=subprocess.PIPE, text=True, cwd="/tmp")
     open(os.path.join(out, "unprofiled.txt"), "w").write(r.stdout)
@@ -33,11 +36,11 @@ def run(out):
         dur = {}
         for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
             for row in csv.DictReader(open(path)):
-                if "gemmTiled8" in row["Kernel_Name"]:
+                if KERNEL in row["Kernel_Name"]:
                     dur[row["Dispatch_Id"]] = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(path)):
-                if "gemmTiled8" not in row["Kernel_Name"]:
+                if KERNEL not in row["Kernel_Name"]:
                     continue
                 # the probe runs the shapes in order, 10 timed + 1 warm-up launches each: key by grid/dispatch order is fragile, key by duration bucket instead
                 ns = dur.get(row["Dispatch_Id"], 0)

@@ -3123,7 +3123,9 @@ namespace wh
 		const bool fits32 = aBytes < ( 1ll << 32 ) && 2ll * a.N * a.K < ( 1ll << 32 );
 		const bool w8 = big && fits32 && ( g_tuning & TUNE_GEMM_8WAVE ) != 0;
 		// gemmTiled4 on top: at least two K tiles, A segments of at least a tile's 256 rows with a non-negative gap
-		const bool w4 = w8 && a.K >= 256 && ( g_tuning & TUNE_GEMM_4WAVE ) != 0 &&	   // (K >= 256: the FP16 epilogues leave under the next tile's first four K tiles)
+		// WH_GEMM_4WAVE_EPIS: bit mask of epilogues that take gemmTiled4 without the tuning bit (A/B runs)
+		static const int epis4 = []() { const char* e = getenv( "WH_GEMM_4WAVE_EPIS" ); return e ? atoi( e ) : 0; }();
+		const bool w4 = w8 && a.K >= 256 && ( ( g_tuning & TUNE_GEMM_4WAVE ) != 0 || ( ( epis4 >> a.epi ) & 1 ) != 0 ) &&	   // (K >= 256: the FP16 epilogues leave under the next tile's first four K tiles)
 			( a.Mb <= 0 || a.Mb >= a.M || ( a.Mb >= 256 && a.aBatchStride >= (long long)a.Mb * a.lda ) );
 #define WH_TILED( E )                                                    \
 	if( w4 ) return launchTiled4<E>( a, stream );                        \
