@@ -530,6 +530,39 @@ def test_large_v2_shape_against_the_reference(ref_lib_available, tmp_path):
     full_shape_against_the_reference("large-v2", tmp_path)
 
 
+def test_encoder_is_bit_identical_under_the_gemm_variants():
+    """The encoder products' epilogues that only the model reaches at their full size -- head-split Q / K, fragment-major V, the cross-K/V caches of
+    all decoder layers, conv1's segmented FP16 GELU output -- through gemmTiled8 with the general block epilogues, gemmTiled8 with the lean
+    interior-tile epilogue (TUNE_GEMM_FAST_EPI, the default) and gemmTiled4 (TUNE_GEMM_4WAVE): the same MFMAs in the same order and the same
+    arithmetic per element, so the cross-attention caches of an 11-window batch (M = 16500 rows, ragged last tile row; every encoder layer is
+    upstream of them) must agree bit for bit."""
+    import bench
+    model = gf.synth_model("medium", seed=3)
+    hp = model.hparams
+    m = binding.HipModel.from_ggml(model)
+    del model
+    n_win = 11
+    ctx = binding.HipContext(m, n_win)
+    pcm_dev = torch.from_numpy(bench.synth_pcm(n_win, seed=7)).cuda()
+    mels = torch.stack([ctx.mel_spectrogram(pcm_dev[b]) for b in range(n_win)])
+    L = binding.lib()
+    base = binding.TUNE_DEFAULT & ~(binding.TUNE_GEMM_4WAVE | binding.TUNE_GEMM_FAST_EPI)
+    got = []
+    try:
+        for mask in (base, base | binding.TUNE_GEMM_FAST_EPI, base | binding.TUNE_GEMM_4WAVE):
+            L.wh_debug_set_tuning(mask)
+            ctx.encode(mels)
+            got.append([(ctx.debug_read("cross-k", il).copy(), ctx.debug_read("cross-v", il).copy()) for il in (0, hp.n_text_layer // 2, hp.n_text_layer - 1)])
+    finally:
+        L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+    assert np.isfinite(got[0][0][0]).all() and float(np.abs(got[0][0][1]).max()) > 0.1
+    for other in got[1:]:
+        for (k0, v0), (k1, v1) in zip(got[0], other):
+            assert np.array_equal(k0, k1) and np.array_equal(v0, v1)
+    ctx.close()
+    m.close()
+
+
 def test_decoder_batch_invariance_and_kv_consistency(hip_tiny, golden):
     """(1) every sequence of a lock-step batch gets the result of a batch of one; (2) feeding the prompt token by token
     through the KV cache gives the same last-row logits as one multi-token step (same kernels, same order)."""
