@@ -1,0 +1,91 @@
+// What clock does the chip hold under back-to-back MFMAs on random FP16 data, for the two FP16 shapes? (nothing but MFMAs: 4 waves per CU, one per
+// SIMD, 8 independent accumulator chains per wave; operands random / zero). TFLOP/s here = matrix-pipe rate x clock: the ratio to 2.5 PF @ 2.4 GHz is the clock.
+// hipcc --offload-arch=gfx950 -O2 tools/mfma_power_probe.hip -o whisper_amd/lib/mfma-power-probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef _Float16 f16;
+typedef __attribute__( ( ext_vector_type( 8 ) ) ) _Float16 f16x8;
+typedef __attribute__( ( ext_vector_type( 16 ) ) ) float f32x16;
+typedef __attribute__( ( ext_vector_type( 4 ) ) ) float f32x4;
+
+template<int SHAPE>
+__global__ void __launch_bounds__( 256 ) k( const f16x8* in, float* out, int iters )
+{
+	const int t = blockIdx.x * 256 + threadIdx.x;
+	f16x8 a[ 4 ], b[ 4 ];
+	for( int i = 0; i < 4; i++ )
+	{
+		a[ i ] = in[ ( t * 8 + i ) & 0xffff ];
+		b[ i ] = in[ ( t * 8 + 4 + i ) & 0xffff ];
+	}
+	if constexpr( SHAPE == 32 )
+	{
+		f32x16 c[ 8 ];
+		for( int i = 0; i < 8; i++ )
+			for( int r = 0; r < 16; r++ ) c[ i ][ r ] = 0.0f;
+		for( int it = 0; it < iters; it++ )
+#pragma unroll
+			for( int i = 0; i < 8; i++ ) c[ i ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( a[ i & 3 ], b[ ( i >> 1 ) & 3 ], c[ i ], 0, 0, 0 );
+		float s = 0;
+		for( int i = 0; i < 8; i++ )
+			for( int r = 0; r < 16; r++ ) s += c[ i ][ r ];
+		out[ t ] = s;
+	}
+	else
+	{
+		f32x4 c[ 16 ];
+		for( int i = 0; i < 16; i++ )
+			for( int r = 0; r < 4; r++ ) c[ i ][ r ] = 0.0f;
+		for( int it = 0; it < iters; it++ )
+#pragma unroll
+			for( int i = 0; i < 16; i++ ) c[ i ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( a[ i & 3 ], b[ ( i >> 2 ) & 3 ], c[ i ], 0, 0, 0 );
+		float s = 0;
+		for( int i = 0; i < 16; i++ )
+			for( int r = 0; r < 4; r++ ) s += c[ i ][ r ];
+		out[ t ] = s;
+	}
+}
+
+template<int SHAPE>
+static double run( const f16x8* in, float* out, int iters )
+{
+	hipEvent_t e0, e1;
+	hipEventCreate( &e0 ); hipEventCreate( &e1 );
+	hipLaunchKernelGGL( k<SHAPE>, dim3( 256 ), dim3( 256 ), 0, 0, in, out, iters / 10 );
+	hipDeviceSynchronize();
+	hipEventRecord( e0, 0 );
+	hipLaunchKernelGGL( k<SHAPE>, dim3( 256 ), dim3( 256 ), 0, 0, in, out, iters );
+	hipEventRecord( e1, 0 );
+	hipEventSynchronize( e1 );
+	float ms = 0;
+	hipEventElapsedTime( &ms, e0, e1 );
+	const double perIter = SHAPE == 32 ? 8.0 * 2 * 32 * 32 * 16 : 16.0 * 2 * 16 * 16 * 32;
+	return perIter * iters * 1024.0 / ( ms * 1e-3 ) / 1e12;	  // 1024 waves
+}
+
+int main()
+{
+	const int n = 65536;
+	f16x8* h = (f16x8*)malloc( n * 16 );
+	f16x8 *dRand, *dZero; float* out;
+	hipMalloc( &dRand, n * 16 ); hipMalloc( &dZero, n * 16 ); hipMalloc( &out, 256 * 256 * 4 );
+	uint32_t seed = 1;
+	for( int i = 0; i < n; i++ )
+		for( int j = 0; j < 8; j++ )
+		{
+			seed = seed * 1664525u + 1013904223u;
+			h[ i ][ j ] = (f16)( ( (int)( seed >> 16 ) - 32768 ) / 32768.0f );
+		}
+	hipMemcpy( dRand, h, n * 16, hipMemcpyHostToDevice );
+	hipMemset( dZero, 0, n * 16 );
+	const int iters = 200000;
+	for( int rep = 0; rep < 2; rep++ )
+	{
+		const double r32 = run<32>( dRand, out, iters ), r16 = run<16>( dRand, out, iters );
+		const double z32 = run<32>( dZero, out, iters ), z16 = run<16>( dZero, out, iters );
+		printf( "MFMA only, 1024 waves: 32x32x16 random %.0f TF (%.2f GHz)  16x16x32 random %.0f TF (%.2f GHz)   32x32x16 zeros %.0f TF (%.2f GHz)  16x16x32 zeros %.0f TF (%.2f GHz)\n",
+			r32, r32 / 2500 * 2.4, r16, r16 / 2500 * 2.4, z32, z32 / 2500 * 2.4, z16, z16 / 2500 * 2.4 );
+	}
+	return 0;
+}
