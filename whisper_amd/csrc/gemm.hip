@@ -2000,7 +2000,7 @@ namespace wh
 			// fragments of the NEXT substep (k-substep ksNext of the buffer at bufOff) go to set SET ^ 1: the W fragments with chunk 0,
 			// the A fragments with chunk 1, so that every read has at least 8 MFMAs (256 matrix-pipe cycles) to come back. Nothing
 			// crosses a chunk boundary (sched_barrier): a DMA pair issued there sits between two groups of MFMAs in the stream.
-			auto substep = [ & ]( auto sc, auto setc, auto zeroc, auto posc, unsigned bufOff, int ksNext, auto&& hook )
+			auto substep = [ & ]( auto sc, auto setc, auto zeroc, auto posc, unsigned bufOff, int ksNext )
 			{
 				constexpr int SET = decltype( setc )::value;
 				constexpr bool ZERO = decltype( zeroc )::value;
@@ -2061,7 +2061,6 @@ namespace wh
 					}
 					__builtin_amdgcn_sched_barrier( 0 );
 					dmaAfter( sc, cc, posc );
-					hook( cc );
 					__builtin_amdgcn_sched_barrier( 0 );
 				};
 				chunk( std::integral_constant<int, 0>{} );
@@ -2081,7 +2080,6 @@ namespace wh
 			unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
 
 			unsigned bufOff = 0;
-			auto noHook = [ & ]( auto ) {};
 			// One K tile of the consumer; the fragments of its first substep are in register set 0. There is ONE instance of every K tile position
 			// (first / middle / last) in a row, never alternatives: accumulators that meet at the end of alternative paths are 256 registers
 			// the allocator then copies around.
@@ -2089,10 +2087,10 @@ namespace wh
 			auto kTile = [ & ]( auto zeroc, auto posc )
 			{
 				constexpr int pos = decltype( posc )::value;
-				substep( P0{}, S0{}, zeroc, posc, bufOff, 1, noHook );
-				substep( P1{}, S1{}, ZN{}, posc, bufOff, 2, noHook );
+				substep( P0{}, S0{}, zeroc, posc, bufOff, 1 );
+				substep( P1{}, S1{}, ZN{}, posc, bufOff, 2 );
 				// substep 2; then every fragment of this buffer is in registers and this wave's pieces of the next K tile must have landed
-				substep( P2{}, S0{}, ZN{}, posc, bufOff, 3, noHook );
+				substep( P2{}, S0{}, ZN{}, posc, bufOff, 3 );
 				if( pos == 1 && ( SCH & 16384 ) == 0 && postEpi >= 63 )
 					// the first K tile after an epilogue: its successor's pieces are all OLDER than the epilogue's loads and stores (vmcnt is one
 					// in-order queue), so they have landed as soon as no more than those are in flight -- the stores go on draining under this
@@ -2106,7 +2104,7 @@ namespace wh
 				// substep 3: the next K tile is complete in the other buffer, this buffer is dead
 				advanceProducer( bufOff );
 				bufOff ^= (unsigned)C::STAGE_BYTES;
-				substep( P3{}, S1{}, ZN{}, posc, bufOff, 0, noHook );
+				substep( P3{}, S1{}, ZN{}, posc, bufOff, 0 );
 			};
 
 			auto epilogue = [ & ]( int tmD, int tnD, bool lastTile )
