@@ -48,20 +48,20 @@ __global__ void __launch_bounds__( 256 ) k( const f16x8* in, float* out, int ite
 }
 
 template<int SHAPE>
-static double run( const f16x8* in, float* out, int iters )
+static double run( const f16x8* in, float* out, int iters, int wgs = 256 )
 {
 	hipEvent_t e0, e1;
 	hipEventCreate( &e0 ); hipEventCreate( &e1 );
-	hipLaunchKernelGGL( k<SHAPE>, dim3( 256 ), dim3( 256 ), 0, 0, in, out, iters / 10 );
+	hipLaunchKernelGGL( k<SHAPE>, dim3( wgs ), dim3( 256 ), 0, 0, in, out, iters / 10 );
 	hipDeviceSynchronize();
 	hipEventRecord( e0, 0 );
-	hipLaunchKernelGGL( k<SHAPE>, dim3( 256 ), dim3( 256 ), 0, 0, in, out, iters );
+	hipLaunchKernelGGL( k<SHAPE>, dim3( wgs ), dim3( 256 ), 0, 0, in, out, iters );
 	hipEventRecord( e1, 0 );
 	hipEventSynchronize( e1 );
 	float ms = 0;
 	hipEventElapsedTime( &ms, e0, e1 );
 	const double perIter = SHAPE == 32 ? 8.0 * 2 * 32 * 32 * 16 : 16.0 * 2 * 16 * 16 * 32;
-	return perIter * iters * 1024.0 / ( ms * 1e-3 ) / 1e12;	  // 1024 waves
+	return perIter * iters * 4.0 * wgs / ( ms * 1e-3 ) / 1e12;	  // 4 waves per workgroup
 }
 
 int main()
@@ -69,7 +69,7 @@ int main()
 	const int n = 65536;
 	f16x8* h = (f16x8*)malloc( n * 16 );
 	f16x8 *dRand, *dZero; float* out;
-	hipMalloc( &dRand, n * 16 ); hipMalloc( &dZero, n * 16 ); hipMalloc( &out, 256 * 256 * 4 );
+	hipMalloc( &dRand, n * 16 ); hipMalloc( &dZero, n * 16 ); hipMalloc( &out, 1024 * 256 * 4 );
 	uint32_t seed = 1;
 	for( int i = 0; i < n; i++ )
 		for( int j = 0; j < 8; j++ )
@@ -86,6 +86,13 @@ int main()
 		const double z32 = run<32>( dZero, out, iters ), z16 = run<16>( dZero, out, iters );
 		printf( "MFMA only, 1024 waves: 32x32x16 random %.0f TF (%.2f GHz)  16x16x32 random %.0f TF (%.2f GHz)   32x32x16 zeros %.0f TF (%.2f GHz)  16x16x32 zeros %.0f TF (%.2f GHz)\n",
 			r32, r32 / 2500 * 2.4, r16, r16 / 2500 * 2.4, z32, z32 / 2500 * 2.4, z16, z16 / 2500 * 2.4 );
+	}
+	// two and four waves per SIMD (512 / 1024 workgroups): the 16x16x32 form needs more than one wave per SIMD to issue back to back
+	for( int wgs = 512; wgs <= 1024; wgs *= 2 )
+	{
+		const double r32 = run<32>( dRand, out, iters / 2, wgs ), r16 = run<16>( dRand, out, iters / 2, wgs );
+		const double z32 = run<32>( dZero, out, iters / 2, wgs ), z16 = run<16>( dZero, out, iters / 2, wgs );
+		printf( "MFMA only, %d waves: 32x32x16 random %.0f TF  16x16x32 random %.0f TF   32x32x16 zeros %.0f TF  16x16x32 zeros %.0f TF\n", 4 * wgs, r32, r16, z32, z16 );
 	}
 	return 0;
 }
