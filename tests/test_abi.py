@@ -80,3 +80,21 @@ def test_product_never_touches_the_oracle():
         # every import sits inside cpu_baseline_worker / cpu_baseline
         head = bench[:u]
         assert head.rfind("def cpu_baseline") > head.rfind("def main") and head.rfind("def cpu_baseline") > head.rfind("def run_passes")
+
+
+def test_tuning_bits_of_the_binding_match_the_library_header():
+    """whisper_amd/binding.py mirrors csrc/kernels.h eTuning by hand; tests restore binding.TUNE_DEFAULT after an A/B, so a bit that is in one default
+    and not in the other would silently change what the rest of a test session measures."""
+    import re
+    from whisper_amd import binding
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "whisper_amd", "csrc", "kernels.h")).read()
+    body = text[text.index("enum eTuning"):]
+    body = body[:body.index("};")]
+    values = {}
+    for name, expr in re.findall(r"^\s*(TUNE_[A-Z0-9_]+)\s*=\s*([^,/\n]+?)\s*,?\s*(?://.*)?$", body, re.M):
+        expr = re.sub(r"(\d+)u\b", r"\1", expr)
+        values[name] = eval(expr, {}, values)
+    assert "TUNE_DEFAULT" in values and len(values) > 25
+    for name, v in values.items():
+        assert hasattr(binding, name), name + " is missing in binding.py"
+        assert getattr(binding, name) == v, (name, getattr(binding, name), v)
