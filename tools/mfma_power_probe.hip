@@ -47,6 +47,80 @@ __global__ void __launch_bounds__( 256 ) k( const f16x8* in, float* out, int ite
 	}
 }
 
+// The same MFMA stream with the OTHER traffic of a GEMM K loop beside it, at gemmTiled4's ratio per 16 MFMAs: 4 LDS-DMA pieces of 1 KiB from an L2-resident
+// buffer (MODE & 1) and / or 8 ds_read_b128 fragment reads (MODE & 2). Two workgroups per CU (two waves per SIMD) so that issue stalls of one wave are covered by the
+// other and a lower rate means a lower CLOCK (power), not an idle matrix pipe.
+template<int MODE>
+__global__ void __launch_bounds__( 256, 2 ) kMix( const f16x8* in, const unsigned char* l2buf, unsigned l2mask, float* out, int iters )
+{
+	extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char lds[];	  // 64 KiB
+	typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+	const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane( threadIdx.x >> 6 );
+	f16x8 a[ 4 ], b[ 4 ];
+	for( int i = 0; i < 4; i++ )
+	{
+		a[ i ] = in[ ( t * 8 + i ) & 0xffff ];
+		b[ i ] = in[ ( t * 8 + 4 + i ) & 0xffff ];
+	}
+	for( int i = threadIdx.x; i < 4096; i += 256 ) ( (f16x8*)lds )[ i ] = in[ ( i + blockIdx.x * 17 ) & 0xffff ];
+	__syncthreads();
+	f32x16 c[ 8 ];
+	for( int i = 0; i < 8; i++ )
+		for( int r = 0; r < 16; r++ ) c[ i ][ r ] = 0.0f;
+	const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)lds ) + wave * 16384;
+	unsigned off = ( blockIdx.x * 65536u + wave * 16384u + lane * 16u ) & l2mask;
+	f16x8 fr[ 8 ];
+	for( int i = 0; i < 8; i++ ) fr[ i ] = a[ i & 3 ];
+	for( int it = 0; it < iters; it++ )
+	{
+		if constexpr( ( MODE & 1 ) != 0 )
+		{
+#pragma unroll
+			for( int p = 0; p < 4; p++ )
+			{
+				const unsigned dst = ldsBase + ( ( it * 4 + p ) & 15 ) * 1024;
+				const unsigned o = ( off + p * 1024u ) & l2mask;
+				unsigned keep;
+				asm volatile( "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0" : "=&s"( keep ) : "s"( (const void*)l2buf ), "v"( o ), "s"( dst ) : "memory" );
+			}
+			off = ( off + 4096u * 61u ) & l2mask;
+			asm volatile( "s_waitcnt vmcnt(8)" ::: "memory" );
+		}
+		if constexpr( ( MODE & 2 ) != 0 )
+		{
+#pragma unroll
+			for( int p = 0; p < 8; p++ ) fr[ p ] = *(const f16x8*)( lds + ( ( ( it * 8 + p ) * 1024 + lane * 16 + wave * 16384 ) & 65535 ) );
+		}
+#pragma unroll
+		for( int i = 0; i < 8; i++ ) c[ i ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( ( MODE & 2 ) ? fr[ i ] : a[ i & 3 ], b[ ( i >> 1 ) & 3 ], c[ i ], 0, 0, 0 );
+#pragma unroll
+		for( int i = 0; i < 8; i++ ) c[ i ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( a[ i & 3 ], ( MODE & 2 ) ? fr[ 7 - i ] : b[ ( i >> 1 ) & 3 ], c[ i ], 0, 0, 0 );
+	}
+	asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+	float s = 0;
+	for( int i = 0; i < 8; i++ )
+		for( int r = 0; r < 16; r++ ) s += c[ i ][ r ];
+	out[ t ] = s;
+}
+
+template<int MODE>
+static double runMix( const f16x8* in, const unsigned char* l2buf, float* out, int iters )
+{
+	hipEvent_t e0, e1;
+	hipEventCreate( &e0 ); hipEventCreate( &e1 );
+	hipFuncSetAttribute( (const void*)kMix<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 );
+	const unsigned mask = ( 4u << 20 ) - 1;
+	hipLaunchKernelGGL( kMix<MODE>, dim3( 512 ), dim3( 256 ), 65536, 0, in, l2buf, mask, out, iters / 10 );
+	hipDeviceSynchronize();
+	hipEventRecord( e0, 0 );
+	hipLaunchKernelGGL( kMix<MODE>, dim3( 512 ), dim3( 256 ), 65536, 0, in, l2buf, mask, out, iters );
+	hipEventRecord( e1, 0 );
+	hipEventSynchronize( e1 );
+	float ms = 0;
+	hipEventElapsedTime( &ms, e0, e1 );
+	return 16.0 * 2 * 32 * 32 * 16 * iters * 2048.0 / ( ms * 1e-3 ) / 1e12;
+}
+
 template<int SHAPE>
 static double run( const f16x8* in, float* out, int iters, int wgs = 256 )
 {
@@ -93,6 +167,15 @@ int main()
 		const double r32 = run<32>( dRand, out, iters / 2, wgs ), r16 = run<16>( dRand, out, iters / 2, wgs );
 		const double z32 = run<32>( dZero, out, iters / 2, wgs ), z16 = run<16>( dZero, out, iters / 2, wgs );
 		printf( "MFMA only, %d waves: 32x32x16 random %.0f TF  16x16x32 random %.0f TF   32x32x16 zeros %.0f TF  16x16x32 zeros %.0f TF\n", 4 * wgs, r32, r16, z32, z16 );
+	}
+	// the other traffic of a K loop beside the MFMAs (random operands, 2048 waves)
+	unsigned char* l2buf;
+	hipMalloc( &l2buf, 4u << 20 );
+	for( int i = 0; i < 64; i++ ) hipMemcpy( l2buf + i * 65536, dRand, 65536, hipMemcpyDeviceToDevice );
+	for( int rep = 0; rep < 2; rep++ )
+	{
+		const double m0 = runMix<0>( dRand, l2buf, out, iters / 4 ), m1 = runMix<1>( dRand, l2buf, out, iters / 4 ), m2 = runMix<2>( dRand, l2buf, out, iters / 4 ), m3 = runMix<3>( dRand, l2buf, out, iters / 4 );
+		printf( "16 MFMAs per iteration, 2048 waves, random: alone %.0f TF | + 4 KiB of LDS-DMA from L2 %.0f | + 8 ds_read_b128 %.0f | + both %.0f\n", m0, m1, m2, m3 );
 	}
 	return 0;
 }
