@@ -254,3 +254,67 @@ def read_wav_mono16(path: str) -> np.ndarray:
         if w.getnchannels() == 2:
             a = a.reshape(-1, 2).mean(axis=1)
     return a / 32768.0
+
+
+# ---- the reference's streaming spectrogram (oracle/_ref/libmelstreamer_ref.so: Whisper/Whisper/MelStreamer.cpp + melSpectrogram.cpp
+# compiled unmodified, oracle/melstreamer_harness.cpp) ----
+MELSTREAMER_LIB_PATH = os.path.join(_HERE, "_ref", "libmelstreamer_ref.so")
+_ms_lib = None
+
+
+def melstreamer_available() -> bool:
+    return os.path.exists(MELSTREAMER_LIB_PATH)
+
+
+def _melstreamer_lib():
+    global _ms_lib
+    if _ms_lib is None:
+        L = C.CDLL(MELSTREAMER_LIB_PATH)
+        L.ms_create.restype = C.c_void_p
+        L.ms_create.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_longlong, C.c_int, C.c_int]
+        L.ms_length.restype = C.c_longlong
+        L.ms_length.argtypes = [C.c_void_p]
+        L.ms_make_buffer.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, _f32p]
+        L.ms_destroy.argtypes = [C.c_void_p]
+        _ms_lib = L
+    return _ms_lib
+
+
+class RefMelStreamer:
+    """The reference's iSpectrogram of iContext::runStreamed over PCM in memory: threads <= 1 = MelStreamerSimple (FFTs on demand),
+    threads >= 2 = MelStreamerThread (a background thread keeps a queue of frames full; what runStreamed picks for cpuThreads > 1,
+    ContextImpl.misc.cpp:404-413). make_buffer(off, len) = makeBuffer + makeTransposedBuffer: [80][len] frames of the stream
+    normalised on the window's own maximum. `block` = samples per delivery of the in-memory "source reader"; with anything but one
+    chunk per delivery the reference reads stale memory at the end of a stream whose length is not a multiple of 160 samples
+    (oracle/melstreamer_harness.cpp, "the end of a stream")."""
+
+    def __init__(self, pcm: np.ndarray, filters: np.ndarray, threads: int = 1, block: int = 160):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        flt = np.ascontiguousarray(filters, np.float32)
+        assert flt.shape == (80, 201)
+        self._h = _melstreamer_lib().ms_create(flt.reshape(-1), 80, 201, pcm if len(pcm) else np.zeros(1, np.float32), len(pcm), threads, block)
+        if not self._h:
+            raise RuntimeError("ms_create failed")
+
+    @property
+    def length(self) -> int:
+        """PcmReader::getLength(): whole 160-sample chunks."""
+        return int(_melstreamer_lib().ms_length(self._h))
+
+    def make_buffer(self, off: int, length: int) -> np.ndarray:
+        out = np.zeros((80, length), np.float32)
+        hr = _melstreamer_lib().ms_make_buffer(self._h, off, length, out)
+        if hr < 0:
+            raise RuntimeError("MelStreamer::makeBuffer failed: HRESULT 0x%08x" % (hr & 0xFFFFFFFF))
+        return out
+
+    def close(self):
+        if self._h:
+            _melstreamer_lib().ms_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -119,10 +119,13 @@ def log_mel_spectrogram(pcm, filters, n_fft=400, hop=160):
 
 class MelStreamerNP:
     """MelStreamer::makeBuffer + makeTransposedBuffer (Whisper/Whisper/MelStreamer.cpp:189-245, :125-187), what
-    iContext::runStreamed feeds the encoder with. The reference's CPU model has no streamer, so this restatement (not a
-    reference run) is the pin for that row: frames [off, off + len) of the stream; frames the reader has no 160-sample chunk for
-    are 0 BEFORE normalisation; maximum over the window with a floor of 1e-20; when a request ends at the frame the previous
-    one ended at, the previous maximum is re-used; clamp and (x + 4) * 0.25 in FP32."""
+    iContext::runStreamed feeds the encoder with: frames [off, off + len) of the stream; frames the reader has no 160-sample chunk
+    for are 0 BEFORE normalisation; maximum over the window with a floor of 1e-20; when a request ends at the frame the previous
+    one ended at, the previous maximum is re-used; clamp and (x + 4) * 0.25 in FP32. Pinned on outputs of the reference's own
+    MelStreamer.cpp / melSpectrogram.cpp compiled unmodified (oracle/Makefile -> _ref/libmelstreamer_ref.so; fixture
+    tests/golden/ref_melstreamer.npz; tests/test_oracle.py::test_melstreamer_restatement_pinned_on_the_reference). These are
+    MelStreamerSimple's semantics; MelStreamerThread returns zeros for the partial last chunk's frame too, which lies past the
+    length runStreamed clamps its requests to."""
 
     def __init__(self, pcm, filters):
         self.pcm = np.asarray(pcm, F32)

@@ -20,6 +20,7 @@ from oracle import whisper_np as wn  # noqa: E402
 from whisper_amd import binding, ggml_format as gf  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # about 2x the measured end-to-end differences on the d = 128 test model (max 2.3e-3, mean 4.2e-4 against the 8-thread reference;
 # the reference itself sits 1.7-2.0e-3 / 3.5e-4 from exact arithmetic, see test_decoder_fast_path)
@@ -840,6 +841,50 @@ def test_streamed_mel_window(hip_tiny, golden, tiny_model):
     ref_short.n_chunks = 1100
     assert np.abs(short - ref_short.make_buffer(1000, 150)).max() < 2e-5
     ctx.close()
+
+
+def test_streamed_mel_window_against_the_reference(hip_tiny, tiny_model):
+    """SURVEY.md 8 row f1 on the HIP path: wh_mel_spectrogram_window against outputs of the REFERENCE's streaming spectrogram
+    (Whisper/Whisper/MelStreamer.cpp + melSpectrogram.cpp compiled unmodified; tests/golden/ref_melstreamer.npz, generated by
+    tests/golden/make_golden_melstreamer.py) on the request sequence iContext::runStreamed makes over a 63917-sample stream: fresh
+    maximum, re-used maximum (the request ends where the last one ended, MelStreamer.cpp:158-172), window-local maxima, and a
+    request past the stream's length (MelStreamerSimple: the partial chunk's frame is computed, frames after it are zero before
+    normalisation). Bound: the reference's FP32 FFT against the FP64 matrix-core transform, as in row a1 (5e-4 max, 5e-6 mean);
+    the live streamer, when oracle/_ref carries it, must give the fixture's bits."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_melstreamer", os.path.join(ROOT, "tests", "golden", "make_golden_melstreamer.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_melstreamer.npz")))
+    pcm = mg.clip()
+    assert len(pcm) == int(g["n_samples"])
+    ctx = binding.HipContext(hip_tiny, 1)
+    dev = torch.from_numpy(pcm).cuda()
+    last_end = None
+    for i, (off, ln) in enumerate(g["requests"]):
+        off, ln = int(off), int(ln)
+        reuse = last_end == off + ln           # the host loop's rule (whisperImpl.cpp encodeWindow; MelStreamer.cpp:158-166)
+        if not reuse:
+            last_end = off + ln
+        got = ctx.mel_spectrogram_window(dev, off, ln, reuse_previous_max=reuse).cpu().numpy()
+        want = g["window%d" % i]
+        d = report("streamed mel window vs the reference's MelStreamer off=%d len=%d reuse=%d" % (off, ln, reuse), got, want)
+        assert got.shape == want.shape and d.max() < 5e-4 and d.mean() < 5e-6
+        if i < 2:       # requests 0 and 1 are clamped at (the stream's maximum - 8): the floor says which maximum was used
+            assert abs(float(got.min()) - float(want.min())) < 5e-6
+    off, ln = (int(x) for x in g["past_end"])
+    got = ctx.mel_spectrogram_window(dev, off, ln).cpu().numpy()
+    want = g["past_end_simple"]
+    d = report("streamed mel window past the stream's end", got, want)
+    assert d.max() < 5e-4
+    n_chunks = (len(pcm) + 159) // 160
+    assert np.array_equal(got[:, n_chunks - off:], want[:, n_chunks - off:])       # zero frames: one constant, the same one
+    ctx.close()
+    from oracle import ref
+    if ref.melstreamer_available():
+        st = ref.RefMelStreamer(pcm, tiny_model.filters, threads=2)
+        assert np.array_equal(st.make_buffer(0, 399), g["window0"])
+        st.close()
 
 
 @pytest.mark.parametrize("batch", [3, 6, 12, 37])

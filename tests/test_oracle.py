@@ -9,11 +9,14 @@ implementation whose FP32 summation order differs from ggml's accumulates FP16 r
 table arguments); measured restatement-vs-reference noise on this model: encoder output max 2e-3 / mean 3e-4, logits
 max 2e-3 / mean 4e-4 (|logit| <= 2.5). The end-to-end bounds below are 2.5x that floor.
 """
+import os
 import numpy as np
 import pytest
 
 from oracle import whisper_np as wn
 from whisper_amd import ggml_format as gf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 E2E_MAX, E2E_MEAN = 4e-3, 8e-4   # same bounds as tests/test_gpu_model.py
 
@@ -129,6 +132,67 @@ def test_streamed_spectrogram_restatement(golden, tiny_model):
     st.n_chunks = 1000
     c = st.make_buffer(900, 200)          # frames 1000.. have no chunk: zero before normalisation
     assert np.all(c[:, 100:] == c[0, 100]) and c.shape == (80, 200)
+
+
+def _melstreamer_fixture():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_melstreamer", os.path.join(ROOT, "tests", "golden", "make_golden_melstreamer.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg, dict(np.load(os.path.join(ROOT, "tests", "golden", "ref_melstreamer.npz")))
+
+
+def test_melstreamer_restatement_pinned_on_the_reference(tiny_model):
+    """MelStreamerNP against outputs of the REFERENCE's streaming spectrogram (Whisper/Whisper/MelStreamer.cpp +
+    melSpectrogram.cpp compiled unmodified, oracle/Makefile; fixture tests/golden/ref_melstreamer.npz from make_golden_melstreamer.py):
+    the request sequence of iContext::runStreamed on a 63917-sample stream (399 chunks + a partial one) with a quiet tail -- a fresh
+    maximum, the re-used maximum of a request that ends where the last one ended, window-local maxima, and a request past the
+    stream's length (partial chunk's frame computed, frames after it zero before normalisation). Values: the reference's FP32
+    split-radix FFT against float64 (max 1.3e-4, mean 3e-7 measured; the whole-buffer path of row a1 shows the same noise);
+    the clamp floor (which maximum was used) and the positions of the zero frames must agree exactly."""
+    mg, g = _melstreamer_fixture()
+    pcm = mg.clip()
+    assert len(pcm) == int(g["n_samples"])
+    st = wn.MelStreamerNP(pcm, tiny_model.filters)
+    assert st.length == 399 and st.n_chunks == 400
+    floors = []
+    for i, (off, ln) in enumerate(g["requests"]):
+        want = g["window%d" % i]
+        got = st.make_buffer(int(off), int(ln))
+        d = np.abs(got - want)
+        assert got.shape == want.shape and d.max() < 4e-4 and d.mean() < 2e-6, (i, d.max(), d.mean())
+        if i < 2:       # requests 0 and 1 are clamped at (the stream's maximum - 8): the floor says which maximum was used
+            assert abs(float(got.min()) - float(want.min())) < 2e-6
+        floors.append(float(want.min()))
+    # request 1 ends where request 0 ended: the stream-wide maximum is re-used although the window itself is quiet;
+    # request 2 ends elsewhere: its own maximum (nothing is clamped any more, the floor is the data's)
+    assert floors[1] == floors[0] and floors[2] < floors[0] - 0.3
+    off, ln = (int(x) for x in g["past_end"])
+    got, want = st.make_buffer(off, ln), g["past_end_simple"]
+    assert np.abs(got - want).max() < 4e-4
+    tail = want[:, st.n_chunks - off:]
+    assert tail.size and np.all(tail == tail[0, 0]) and np.array_equal(got[:, st.n_chunks - off:], tail)
+    # the reference's two streamers differ only past the length runStreamed clamps its requests to (MelInputTensor.cpp:37-39)
+    differs = np.where(np.abs(g["past_end_simple"] - g["past_end_thread"]).max(axis=0) > 0)[0]
+    assert list(differs) == [st.length - off]
+
+
+def test_live_melstreamer_if_present(tiny_model):
+    """When oracle/_ref/libmelstreamer_ref.so is built: the reference's streamers (on demand / background thread) reproduce the
+    committed fixture bit for bit."""
+    from oracle import ref
+    if not ref.melstreamer_available():
+        pytest.skip("oracle/_ref/libmelstreamer_ref.so not built (needs /root/reference)")
+    mg, g = _melstreamer_fixture()
+    pcm = mg.clip()
+    for threads in (1, 3):
+        st = ref.RefMelStreamer(pcm, tiny_model.filters, threads=threads)
+        assert st.length == 399
+        for i, (off, ln) in enumerate(g["requests"]):
+            assert np.array_equal(st.make_buffer(int(off), int(ln)), g["window%d" % i])
+        past = st.make_buffer(*(int(x) for x in g["past_end"]))
+        assert np.array_equal(past, g["past_end_simple" if threads == 1 else "past_end_thread"])
+        st.close()
 
 
 def test_truth_model_orders_the_references(golden, golden_e2e):
