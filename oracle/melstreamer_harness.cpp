@@ -1,7 +1,8 @@
 // oracle/melstreamer_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
 // Flat C entry points over the reference's streaming spectrogram, compiled UNMODIFIED from /root/reference by oracle/Makefile
-// (Whisper/Whisper/MelStreamer.cpp + melSpectrogram.cpp, MF/AudioBuffer.cpp) into oracle/_ref/libmelstreamer_ref.so:
-// the oracle of SURVEY.md section 8 row f1 (iContext::runStreamed's per-window spectrogram, MelStreamer.cpp:125-187).
+// (Whisper/Whisper/MelStreamer.cpp + Spectrogram.cpp + melSpectrogram.cpp, MF/AudioBuffer.cpp) into oracle/_ref/libmelstreamer_ref.so:
+// the oracle of SURVEY.md section 8 row f1 (iContext::runStreamed's per-window spectrogram, MelStreamer.cpp:125-187) and, for row a1,
+// the whole-buffer spectrogram of the GPU model's runFull (Spectrogram::pcmToMel, Spectrogram.cpp:64-122).
 //
 // What this file supplies is what those sources link against and Windows / Media Foundation would provide:
 //   * PcmReader's three methods (declared in the reference's MF/PcmReader.h, defined in MF/PcmReader.cpp over IMFSourceReader):
@@ -22,6 +23,7 @@
 //   * the logger's functions and setCurrentThreadName.
 #include "stdafx.h"
 #include "Whisper/MelStreamer.h"
+#include "Whisper/Spectrogram.h"
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -104,6 +106,19 @@ HRESULT ThreadPoolWork::parallelFor( int threadsCount ) noexcept
 	return S_OK;
 }
 
+// the free function of Utils/parallelFor.h (Spectrogram::pcmToMel with threads >= 2, Spectrogram.cpp:86-93)
+HRESULT Whisper::parallelFor( pfnParallelForCallback pfn, int threadsCount, void* ctx )
+{
+	std::vector<std::thread> ts;
+	std::vector<HRESULT> hrs( (size_t)threadsCount, S_OK );
+	for( int i = 1; i < threadsCount; i++ ) ts.emplace_back( [ pfn, ctx, i, &hrs ]() { hrs[ i ] = pfn( i, ctx ); } );
+	hrs[ 0 ] = pfn( 0, ctx );
+	for( auto& t : ts ) t.join();
+	for( HRESULT hr : hrs )
+		if( FAILED( hr ) ) return hr;
+	return S_OK;
+}
+
 void setCurrentThreadName( const char* ) {}
 
 static void vlog( const char* level, const char8_t* fmt, va_list ap )
@@ -136,6 +151,21 @@ namespace
 		HRESULT COMLIGHTCALL getDuration( int64_t& rdi ) const override { rdi = (int64_t)source->count * 10000000 / SAMPLE_RATE; return S_OK; }
 		HRESULT COMLIGHTCALL getReader( IMFSourceReader** pp ) const override { source->AddRef(); *pp = source; return S_OK; }
 		HRESULT COMLIGHTCALL requestedStereo() const override { return S_FALSE; }
+	};
+	// iAudioBuffer over PCM the caller owns (what iContext::runFull receives)
+	struct MemoryBuffer : iAudioBuffer
+	{
+		const float* const pcm;
+		const uint32_t count;
+		MemoryBuffer( const float* p, uint32_t n ) : pcm( p ), count( n ) {}
+		virtual ~MemoryBuffer() {}
+		HRESULT COMLIGHTCALL QueryInterface( REFIID, void** ) override { return E_NOINTERFACE; }
+		uint32_t COMLIGHTCALL AddRef() override { return 1; }
+		uint32_t COMLIGHTCALL Release() override { return 1; }
+		uint32_t COMLIGHTCALL countSamples() const override { return count; }
+		const float* COMLIGHTCALL getPcmMono() const override { return pcm; }
+		const float* COMLIGHTCALL getPcmStereo() const override { return nullptr; }
+		HRESULT COMLIGHTCALL getTime( int64_t& rdi ) const override { rdi = 0; return S_OK; }
 	};
 	struct Streamer
 	{
@@ -185,6 +215,26 @@ __attribute__( ( visibility( "default" ) ) ) int ms_make_buffer( void* h, long l
 	const HRESULT hr = ( (Streamer*)h )->mel->makeBuffer( (size_t)offset, (size_t)length, &buffer, stride );
 	if( FAILED( hr ) ) return (int)hr;
 	for( size_t j = 0; j < N_MEL; j++ ) memcpy( out + j * (size_t)length, buffer + j * stride, (size_t)length * 4 );
+	return (int)hr;
+}
+// Spectrogram::pcmToMel (Spectrogram.cpp:64-122): the whole buffer, normalised on its global maximum; out = N_MEL rows of nSamples / 160 floats
+__attribute__( ( visibility( "default" ) ) ) int ms_pcm_to_mel( const float* filters, int nMel, int nFft, const float* pcm, long long nSamples, int threads, float* out )
+{
+	if( nMel != (int)N_MEL || nFft != 1 + (int)FFT_SIZE / 2 ) return (int)E_INVALIDARG;
+	Filters f;
+	f.n_mel = (uint32_t)nMel;
+	f.n_fft = (uint32_t)nFft;
+	f.data.assign( filters, filters + (size_t)nMel * nFft );
+	MemoryBuffer buffer( pcm, (uint32_t)nSamples );
+	Spectrogram mel;
+	HRESULT hr = mel.pcmToMel( &buffer, f, threads );
+	if( FAILED( hr ) ) return (int)hr;
+	iSpectrogram& is = mel;
+	const float* p = nullptr;
+	size_t stride = 0;
+	hr = is.makeBuffer( 0, is.getLength(), &p, stride );
+	if( FAILED( hr ) ) return (int)hr;
+	for( size_t j = 0; j < N_MEL; j++ ) memcpy( out + j * is.getLength(), p + j * stride, is.getLength() * 4 );
 	return (int)hr;
 }
 __attribute__( ( visibility( "default" ) ) ) void ms_destroy( void* h )

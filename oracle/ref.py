@@ -276,8 +276,20 @@ def _melstreamer_lib():
         L.ms_length.argtypes = [C.c_void_p]
         L.ms_make_buffer.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, _f32p]
         L.ms_destroy.argtypes = [C.c_void_p]
+        L.ms_pcm_to_mel.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_longlong, C.c_int, _f32p]
         _ms_lib = L
     return _ms_lib
+
+
+def spectrogram_pcm_to_mel(pcm: np.ndarray, filters: np.ndarray, threads: int = 1) -> np.ndarray:
+    """Spectrogram::pcmToMel of the reference's GPU model (Whisper/Whisper/Spectrogram.cpp:64-122): [80][len(pcm) // 160]."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    flt = np.ascontiguousarray(filters, np.float32)
+    out = np.zeros((80, len(pcm) // 160), np.float32)
+    hr = _melstreamer_lib().ms_pcm_to_mel(flt.reshape(-1), 80, 201, pcm, len(pcm), threads, out)
+    if hr < 0:
+        raise RuntimeError("Spectrogram::pcmToMel failed: HRESULT 0x%08x" % (hr & 0xFFFFFFFF))
+    return out
 
 
 class RefMelStreamer:

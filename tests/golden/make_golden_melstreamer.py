@@ -1,5 +1,5 @@
 """Generates tests/golden/ref_melstreamer.npz from the REFERENCE's streaming spectrogram -- Whisper/Whisper/MelStreamer.cpp +
-melSpectrogram.cpp + MF/AudioBuffer.cpp compiled unmodified into oracle/_ref/libmelstreamer_ref.so (oracle/Makefile; needs
+melSpectrogram.cpp + MF/AudioBuffer.cpp, and Spectrogram.cpp (`whole`: Spectrogram::pcmToMel of the GPU model's runFull) compiled unmodified into oracle/_ref/libmelstreamer_ref.so (oracle/Makefile; needs
 /root/reference, so it runs in the build container only; the fixture travels).
 
     python tests/golden/make_golden_melstreamer.py
@@ -56,6 +56,12 @@ def main():
     other = ref.RefMelStreamer(pcm, filters, threads=1, block=4096).make_buffer(0, 399)
     assert np.array_equal(other[:, :397], out["window0"][:, :397])
     out["stale_end_block4096"] = other[:, 397:]
+    # row a1 on the file SURVEY.md section 8 cites for the GPU model: Spectrogram::pcmToMel (Spectrogram.cpp:64-122), the whole buffer
+    # normalised on its global maximum; 1 thread and 4 must agree bit for bit (frames are independent)
+    whole = ref.spectrogram_pcm_to_mel(pcm, filters, threads=1)
+    assert np.array_equal(whole, ref.spectrogram_pcm_to_mel(pcm, filters, threads=4))
+    # a stream of one window: the streamer's buffer IS the whole-buffer spectrogram, bit for bit -- window0 serves as both
+    assert np.array_equal(whole, out["window0"])
     path = os.path.join(HERE, "ref_melstreamer.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -872,6 +872,11 @@ def test_streamed_mel_window_against_the_reference(hip_tiny, tiny_model):
         assert got.shape == want.shape and d.max() < 5e-4 and d.mean() < 5e-6
         if i < 2:       # requests 0 and 1 are clamped at (the stream's maximum - 8): the floor says which maximum was used
             assert abs(float(got.min()) - float(want.min())) < 5e-6
+    # window0 is also Spectrogram::pcmToMel of the reference's GPU model (Spectrogram.cpp:64-122, asserted equal by the generator):
+    # row a1's whole-buffer kernel against the file SURVEY.md 8(a1) names
+    whole = ctx.mel_spectrogram(dev).cpu().numpy()
+    d = report("whole-buffer mel vs the reference's Spectrogram::pcmToMel", whole, g["window0"])
+    assert whole.shape == (80, 399) and d.max() < 5e-4 and d.mean() < 5e-6
     off, ln = (int(x) for x in g["past_end"])
     got = ctx.mel_spectrogram_window(dev, off, ln).cpu().numpy()
     want = g["past_end_simple"]

@@ -164,6 +164,11 @@ def test_melstreamer_restatement_pinned_on_the_reference(tiny_model):
         if i < 2:       # requests 0 and 1 are clamped at (the stream's maximum - 8): the floor says which maximum was used
             assert abs(float(got.min()) - float(want.min())) < 2e-6
         floors.append(float(want.min()))
+    # window0 is also Spectrogram::pcmToMel of the GPU model's runFull (Spectrogram.cpp:64-122; the generator asserts the two equal bit
+    # for bit): the whole-buffer restatement of row a1 against the file SURVEY.md 8(a1) cites, next to whisper.cpp's (test_mel_*)
+    whole = wn.log_mel_spectrogram(pcm, tiny_model.filters)
+    d = np.abs(whole - g["window0"])
+    assert whole.shape == (80, 399) and d.max() < 4e-4 and d.mean() < 2e-6
     # request 1 ends where request 0 ended: the stream-wide maximum is re-used although the window itself is quiet;
     # request 2 ends elsewhere: its own maximum (nothing is clamped any more, the floor is the data's)
     assert floors[1] == floors[0] and floors[2] < floors[0] - 0.3
@@ -190,6 +195,7 @@ def test_live_melstreamer_if_present(tiny_model):
         assert st.length == 399
         for i, (off, ln) in enumerate(g["requests"]):
             assert np.array_equal(st.make_buffer(int(off), int(ln)), g["window%d" % i])
+        assert np.array_equal(ref.spectrogram_pcm_to_mel(pcm, tiny_model.filters, threads=threads), g["window0"])
         past = st.make_buffer(*(int(x) for x in g["past_end"]))
         assert np.array_equal(past, g["past_end_simple" if threads == 1 else "past_end_thread"])
         st.close()
