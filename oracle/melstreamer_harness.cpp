@@ -190,14 +190,7 @@ __attribute__( ( visibility( "default" ) ) ) void* ms_create( const float* filte
 		s->filters.data.assign( filters, filters + (size_t)nMel * nFft );
 		s->pcm.assign( pcm, pcm + nSamples );
 		s->reader.reset( new MemoryReader( s->pcm.data(), s->pcm.size(), (size_t)block ) );
-		if( threads >= 2 )
-		{
-			s->mel.reset( new MelStreamerThread( s->filters, s->profiler, s->reader.get(), threads ) );
-			// The reference has a start-up race: makeBuffer() that runs before the new thread has set threadStatus = Working sees
-			// NotStarted, falls through its wait loop (MelStreamer.cpp:436-452; the assert is compiled out of release builds) and
-			// returns zeros for every frame not produced yet. A caller on Windows loses that race rarely; the oracle must never.
-			std::this_thread::sleep_for( std::chrono::milliseconds( 50 ) );
-		}
+		if( threads >= 2 ) s->mel.reset( new MelStreamerThread( s->filters, s->profiler, s->reader.get(), threads ) );	// (start-up race: shim/melstreamer/stdafx.h CreateThread)
 		else s->mel.reset( new MelStreamerSimple( s->filters, s->profiler, s->reader.get() ) );
 		return s;
 	}

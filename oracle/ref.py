@@ -330,3 +330,126 @@ class RefMelStreamer:
             self.close()
         except Exception:
             pass
+
+
+# ---- the reference's GPU-model iContext over its own CPU arithmetic (oracle/_ref/libcontextimpl_ref.so: Whisper/Whisper/ContextImpl.cpp +
+# ContextImpl.misc.cpp + Languages.cpp compiled unmodified, the D3D compute context replaced by whisper.cpp; oracle/contextimpl_harness.cpp) ----
+CONTEXTIMPL_LIB_PATH = os.path.join(_HERE, "_ref", "libcontextimpl_ref.so")
+_ci_lib = None
+
+FLAG_TRANSLATE, FLAG_NO_CONTEXT, FLAG_SINGLE_SEGMENT, FLAG_PRINT_SPECIAL, FLAG_TOKEN_TIMESTAMPS = 1, 2, 4, 8, 0x100    # eFullParamsFlags (API/sFullParams.h:22-35)
+
+
+def contextimpl_available() -> bool:
+    return os.path.exists(CONTEXTIMPL_LIB_PATH) and available()
+
+
+class _CiParams(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("language", C.c_uint32), ("cpuThreads", C.c_int32), ("n_max_text_ctx", C.c_int32), ("offset_ms", C.c_int32),
+                ("duration_ms", C.c_int32), ("max_tokens", C.c_int32), ("max_len", C.c_int32), ("thold_pt", C.c_float), ("thold_ptsum", C.c_float),
+                ("prompt_tokens", C.POINTER(C.c_int32)), ("prompt_n_tokens", C.c_int32), ("mediaTime", C.c_int64)]
+
+
+def _contextimpl_lib():
+    global _ci_lib
+    if _ci_lib is None:
+        C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L = C.CDLL(CONTEXTIMPL_LIB_PATH)
+        L.ci_create.restype = C.c_void_p
+        L.ci_create.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int, C.c_int]
+        L.ci_destroy.argtypes = [C.c_void_p]
+        L.ci_last_error.restype = C.c_char_p
+        for n in ("ci_run_full", "ci_run_streamed"):
+            getattr(L, n).argtypes = [C.c_void_p, C.POINTER(_CiParams), _f32p, C.c_int]
+        L.ci_counts.argtypes = [C.c_void_p, _i32p]
+        L.ci_progress.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")]
+        L.ci_segment.restype = C.c_char_p
+        L.ci_segment.argtypes = [C.c_void_p, C.c_int, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"),
+                                 np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")]
+        L.ci_token.restype = C.c_char_p
+        L.ci_token.argtypes = [C.c_void_p, C.c_int, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), _f32p, _i32p]
+        L.ci_language_id.argtypes = [C.c_char_p]
+        _ci_lib = L
+    return _ci_lib
+
+
+def language_key(code: str) -> int:
+    """makeLanguageKey (API/sFullParams.h:117-132)."""
+    k = 0
+    for i, ch in enumerate(code.encode()[:4]):
+        k |= ch << (8 * i)
+    return k
+
+
+class RefContextImpl:
+    """The reference's ContextImpl (runFull / runStreamed / getResults of its GPU model) computing with the reference's CPU model.
+    run_full / run_streamed return (HRESULT, segments); a segment = dict(t0, t1 [100 ns ticks incl. the media time offset], text, tokens=[dict(id,
+    text, t0, t1, p, pt, ptsum, vlen, flags)]). self.progress = what the progress sink saw (runStreamed), self.new_segment = (calls, sum of n_new)."""
+
+    def __init__(self, model_path: str, filters: np.ndarray, encoder_threads: int = 4):
+        flt = np.ascontiguousarray(filters, np.float32)
+        assert flt.shape == (80, 201)
+        lib().ref_set_log_level(0)
+        self._h = _contextimpl_lib().ci_create(model_path.encode(), flt.reshape(-1), 80, 201, encoder_threads)
+        if not self._h:
+            raise RuntimeError("ci_create failed for " + model_path)
+        self.progress, self.new_segment = [], (0, 0)
+
+    def _params(self, lang, flags, cpu_threads, n_max_text_ctx, offset_ms, duration_ms, max_tokens, max_len, thold_pt, thold_ptsum, prompt, media_time):
+        p = _CiParams()
+        p.flags, p.language, p.cpuThreads, p.n_max_text_ctx = flags, language_key(lang), cpu_threads, n_max_text_ctx
+        p.offset_ms, p.duration_ms, p.max_tokens, p.max_len, p.thold_pt, p.thold_ptsum = offset_ms, duration_ms, max_tokens, max_len, thold_pt, thold_ptsum
+        self._prompt = (C.c_int32 * max(1, len(prompt or [])))(*(prompt or [0]))
+        p.prompt_tokens = C.cast(self._prompt, C.POINTER(C.c_int32)) if prompt else None
+        p.prompt_n_tokens = len(prompt or [])
+        p.mediaTime = media_time
+        return p
+
+    def _results(self):
+        L = _contextimpl_lib()
+        cnt = np.zeros(4, np.int32)
+        n_prog = L.ci_counts(self._h, cnt)
+        prog = np.zeros(max(1, n_prog), np.float64)
+        L.ci_progress(self._h, prog)
+        self.progress, self.new_segment = [float(x) for x in prog[:n_prog]], (int(cnt[2]), int(cnt[3]))
+        segs = []
+        for i in range(int(cnt[0])):
+            t, ft = np.zeros(2, np.int64), np.zeros(2, np.uint32)
+            text = L.ci_segment(self._h, i, t, ft)
+            toks = []
+            for j in range(int(ft[0]), int(ft[0] + ft[1])):
+                tt, pr, idf = np.zeros(2, np.int64), np.zeros(4, np.float32), np.zeros(2, np.int32)
+                s = L.ci_token(self._h, j, tt, pr, idf)
+                toks.append(dict(id=int(idf[0]), flags=int(idf[1]), text=(s or b"").decode(errors="replace"), t0=int(tt[0]), t1=int(tt[1]),
+                                 p=float(pr[0]), pt=float(pr[1]), ptsum=float(pr[2]), vlen=float(pr[3])))
+            segs.append(dict(t0=int(t[0]), t1=int(t[1]), text=(text or b"").decode(errors="replace"), tokens=toks))
+        return segs
+
+    def _run(self, fn, pcm, lang="en", flags=0, cpu_threads=4, n_max_text_ctx=-1, offset_ms=0, duration_ms=0, max_tokens=0, max_len=0,
+             thold_pt=-1.0, thold_ptsum=-1.0, prompt=None, media_time=0):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        p = self._params(lang, flags, cpu_threads, n_max_text_ctx, offset_ms, duration_ms, max_tokens, max_len, thold_pt, thold_ptsum, prompt, media_time)
+        hr = fn(self._h, C.byref(p), pcm if len(pcm) else np.zeros(1, np.float32), len(pcm))
+        if hr < 0:
+            return hr & 0xFFFFFFFF, []
+        return hr, self._results()
+
+    def run_full(self, pcm, **kw):
+        return self._run(_contextimpl_lib().ci_run_full, pcm, **kw)
+
+    def run_streamed(self, pcm, **kw):
+        return self._run(_contextimpl_lib().ci_run_streamed, pcm, **kw)
+
+    def last_error(self) -> str:
+        return (_contextimpl_lib().ci_last_error() or b"").decode(errors="replace")
+
+    def close(self):
+        if self._h:
+            _contextimpl_lib().ci_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

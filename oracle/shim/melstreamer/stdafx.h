@@ -19,6 +19,7 @@
 #include <string.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -90,6 +91,12 @@ inline HANDLE CreateThread( void*, size_t, DWORD ( *proc )( void* ), void* arg, 
 		t->done = true;
 		t->cv.notify_all();
 	} );
+	// MelStreamerThread has a start-up race: a makeBuffer() that runs before the new thread has set threadStatus = Working sees
+	// NotStarted, falls through its wait loop (MelStreamer.cpp:436-452; the assert is compiled out of release builds) and returns zeros
+	// for every frame not produced yet. On Windows the caller spends its first hundred microseconds in D3D calls and the thread wins;
+	// here nothing stands between the constructor and the first makeBuffer(), so thread creation is made "slow": the oracle must
+	// never lose that race.
+	std::this_thread::sleep_for( std::chrono::milliseconds( 30 ) );
 	return t;
 }
 inline DWORD WaitForSingleObject( HANDLE h, DWORD ms )
@@ -106,14 +113,16 @@ inline int GetExitCodeThread( HANDLE h, DWORD* code )
 	*code = t->done ? t->code : 259u;	// STILL_ACTIVE
 	return 1;
 }
-// The record outlives the handle when the thread is still asleep (see above): a finished thread is joined, any other detached.
+// The record outlives the handle when the thread is still asleep (see above): a finished thread is joined, any other detached --
+// after a patient wait: ~MelStreamerThread gives a working thread 100 ms to see `shuttingDown` (MelStreamer.cpp:478-493) and then
+// lets go of it while it may still touch the object; a thread that is merely slow must not outlive the stack frame here.
 inline void CloseHandle( HANDLE h )
 {
 	ShimThread* t = (ShimThread*)h;
 	bool done;
 	{
-		std::lock_guard<std::mutex> lk( t->mx );
-		done = t->done;
+		std::unique_lock<std::mutex> lk( t->mx );
+		done = t->cv.wait_for( lk, std::chrono::seconds( 3 ), [ t ] { return t->done; } );
 	}
 	if( done ) { t->thread.join(); delete t; }
 	else t->thread.detach();
@@ -156,6 +165,35 @@ public:
 	operator HANDLE() const { return h; }
 };
 
+// ATL's hash map as Languages.cpp uses it: SetAt, Lookup returning a node with m_value (atlcoll.h)
+#include <unordered_map>
+template<class K, class V>
+class CAtlMap
+{
+public:
+	struct CPair { K m_key; V m_value; };
+private:
+	std::unordered_map<K, CPair> map;
+public:
+	CAtlMap( unsigned = 17, float = 0.75f, float = 0.25f, float = 2.25f, unsigned = 10 ) {}
+	void SetAt( const K& k, const V& v ) { map[ k ] = CPair{ k, v }; }
+	const CPair* Lookup( const K& k ) const
+	{
+		const auto it = map.find( k );
+		return it == map.end() ? nullptr : &it->second;
+	}
+};
+
+// ---- what ContextImpl.misc.cpp asks the system: processor counts (sysinfoapi.h) and Media Foundation's 64-bit a * b / c ----
+#include <climits>
+#define __declspec( x )
+struct SYSTEM_INFO { DWORD dwNumberOfProcessors; };
+inline void GetSystemInfo( SYSTEM_INFO* si ) { si->dwNumberOfProcessors = std::max( 1u, std::thread::hardware_concurrency() ); }
+enum LOGICAL_PROCESSOR_RELATIONSHIP { RelationProcessorCore = 0 };
+struct SYSTEM_LOGICAL_PROCESSOR_INFORMATION { uint64_t ProcessorMask; LOGICAL_PROCESSOR_RELATIONSHIP Relationship; uint64_t pad[ 2 ]; };
+inline int GetLogicalProcessorInformation( SYSTEM_LOGICAL_PROCESSOR_INFORMATION*, DWORD* n ) { *n = 0; return 1; }
+inline long long MFllMulDiv( long long a, long long b, long long c, long long d ) { return (long long)( ( (__int128)a * b + d ) / c ); }
+
 // ---- DirectXMath (DirectXMathVector.inl XMVectorSinCos, DirectXMathMisc.inl XMScalarSinCos): see the header comment ----
 namespace DirectX
 {
@@ -175,4 +213,8 @@ namespace DirectX
 }
 
 #include "Utils/Logger.h"		// oracle/shim/Utils/Logger.h: logError ... with C linkage (defined in the harness)
+extern "C" {
+void logErrorHr( long hr, const char8_t* fmt, ... );	  // Utils/Logger.h:9, :12 of the reference
+void logWarningHr( long hr, const char8_t* fmt, ... );
+}
 #include "Utils/miscUtils.h"	// the reference's own: CHECK, check(), setCurrentThreadName (through the tree of oracle/Makefile)
