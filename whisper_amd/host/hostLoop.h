@@ -12,8 +12,11 @@ namespace Whisper
 {
 	// The reference ships TWO host loops that differ in two rules: its CPU model (Whisper/source/whisper.cpp:2765-3120, the oracle
 	// every parity test is pinned to) drops the past prompt when < 5 s of audio remain and retries a failed window once without it;
-	// its GPU model's port (Whisper/Whisper/ContextImpl.cpp:452-793) does neither. The default follows the CPU path, because that is
-	// what north_star asks token ids to match; whisperc_set_host_loop_rules( 1 ) selects the GPU model's behaviour.
+	// its GPU model's port (Whisper/Whisper/ContextImpl.cpp:452-793) does neither -- and its token-level timestamps start from 0
+	// instead of "unknown" (see finishWindow). The default follows the CPU path, because that is what north_star asks token ids to
+	// match; whisperc_set_host_loop_rules( 1 ) selects the GPU model's behaviour. Both are pinned on the reference's own code:
+	// whisper_full (tests/golden/ref_hostloop.json) and ContextImpl.cpp compiled unmodified (ref_hostloop_contextimpl.json), on the
+	// CPU (tests/test_hostloop_cpu.py: these objects over the reference's CPU model) and through libWhisper.so (tests/test_host_api.py).
 	enum struct eHostLoopRules : int { ReferenceCpu = 0, ContextImpl = 1 };
 	extern eHostLoopRules g_hostLoopRules;
 
@@ -221,7 +224,12 @@ namespace Whisper
 					uint32_t nNew = 1;
 					if( params.flag( eFullParamsFlags::TokenTimestamps ) && stamper && stamper->ready() )
 					{
-						// whisper.cpp:3063-3069 / ContextImpl.cpp:741-749
+						// whisper.cpp:3063-3069 / ContextImpl.cpp:741-749. The GPU model's sampler starts a token's times at 0
+						// (`sTokenData result = { 0 }`, ContextImpl.cpp:77) where whisper.cpp starts them at -1 = unknown
+						// (whisper.cpp:1880-1882), and its port of the algorithm still tests `t1 < 0` (ContextImpl.cpp:306): there the
+						// proportional split of the unknown intervals never runs. Under its rules the same happens here.
+						if( g_hostLoopRules == eHostLoopRules::ContextImpl )
+							for( TokenData& t : resultAll.back().tokens ) t.t0 = t.t1 = 0;
 						stamper->compute( resultAll.back(), vocab, params.thold_pt, params.thold_ptsum );
 						if( params.max_len > 0 ) nNew = (uint32_t)TokenTimestamper::wrapLast( resultAll, vocab, params.max_len );
 					}
