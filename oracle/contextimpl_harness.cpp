@@ -308,7 +308,9 @@ static HRESULT makeParams( Instance& inst, const CiParams& c, sFullParams& p )
 static HRESULT fetch( Instance& inst )
 {
 	iContext* ctx = inst.context;
-	return ctx->getResults( (eResultFlags)( (uint32_t)eResultFlags::Timestamps | (uint32_t)eResultFlags::Tokens | (uint32_t)eResultFlags::NewObject ), &inst.result );
+	// without eResultFlags::NewObject: the context's own result object, strings left in place. (With it makeResults MOVES the segments' strings
+	// into the new object, ContextImpl.misc.cpp:244-248: a second getResults( NewObject ) finds empty texts.)
+	return ctx->getResults( (eResultFlags)( (uint32_t)eResultFlags::Timestamps | (uint32_t)eResultFlags::Tokens ), &inst.result );
 }
 CI_API int ci_run_full( void* h, const CiParams* c, const float* pcm, int nSamples )
 {
@@ -339,6 +341,14 @@ CI_API int ci_run_streamed( void* h, const CiParams* c, const float* pcm, int nS
 	if( FAILED( hr ) ) return hr;
 	const HRESULT hr2 = fetch( inst );
 	return FAILED( hr2 ) ? hr2 : hr;
+}
+// getResults again with other eResultFlags (Tokens = 1, Timestamps = 2): the context's own result object, refilled
+CI_API int ci_get_results( void* h, uint32_t flags )
+{
+	Instance& inst = *(Instance*)h;
+	inst.result = nullptr;
+	iContext* ctx = inst.context;
+	return ctx->getResults( (eResultFlags)flags, &inst.result );
 }
 CI_API int ci_counts( void* h, int32_t* out4 )
 {

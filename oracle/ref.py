@@ -369,6 +369,7 @@ def _contextimpl_lib():
         L.ci_token.restype = C.c_char_p
         L.ci_token.argtypes = [C.c_void_p, C.c_int, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), _f32p, _i32p]
         L.ci_language_id.argtypes = [C.c_char_p]
+        L.ci_get_results.argtypes = [C.c_void_p, C.c_uint32]
         _ci_lib = L
     return _ci_lib
 
@@ -405,7 +406,14 @@ class RefContextImpl:
         p.mediaTime = media_time
         return p
 
-    def _results(self):
+    def results(self, flags: int):
+        """iContext::getResults with these eResultFlags (Tokens = 1, Timestamps = 2) on the transcript of the last run."""
+        hr = _contextimpl_lib().ci_get_results(self._h, flags)
+        if hr < 0:
+            raise RuntimeError("getResults failed: 0x%08x" % (hr & 0xFFFFFFFF))
+        return self._results(with_tokens=bool(flags & 1))
+
+    def _results(self, with_tokens=True):
         L = _contextimpl_lib()
         cnt = np.zeros(4, np.int32)
         n_prog = L.ci_counts(self._h, cnt)
@@ -417,12 +425,12 @@ class RefContextImpl:
             t, ft = np.zeros(2, np.int64), np.zeros(2, np.uint32)
             text = L.ci_segment(self._h, i, t, ft)
             toks = []
-            for j in range(int(ft[0]), int(ft[0] + ft[1])):
+            for j in range(int(ft[0]), int(ft[0] + ft[1])) if with_tokens else []:
                 tt, pr, idf = np.zeros(2, np.int64), np.zeros(4, np.float32), np.zeros(2, np.int32)
                 s = L.ci_token(self._h, j, tt, pr, idf)
                 toks.append(dict(id=int(idf[0]), flags=int(idf[1]), text=(s or b"").decode(errors="replace"), t0=int(tt[0]), t1=int(tt[1]),
                                  p=float(pr[0]), pt=float(pr[1]), ptsum=float(pr[2]), vlen=float(pr[3])))
-            segs.append(dict(t0=int(t[0]), t1=int(t[1]), text=(text or b"").decode(errors="replace"), tokens=toks))
+            segs.append(dict(t0=int(t[0]), t1=int(t[1]), text=(text or b"").decode(errors="replace"), tokens=toks, first_token=int(ft[0]), count_tokens=int(ft[1])))
         return segs
 
     def _run(self, fn, pcm, lang="en", flags=0, cpu_threads=4, n_max_text_ctx=-1, offset_ms=0, duration_ms=0, max_tokens=0, max_len=0,

@@ -100,8 +100,29 @@ def main():
         print(c["name"], "hr", hr, "->", len(segs), "segments", [(s["t0"] // 100000, s["t1"] // 100000) for s in segs][:10], "min p %.3f" % worst,
               "progress", (streamed or {}).get("progress"))
         out.append(rec)
+    # iContext::getResults / makeResults (ContextImpl.misc.cpp:196-300) under every combination of eResultFlags, with a buffer whose media time
+    # is not zero: what the POD structures of API/TranscribeStructs.h carry then (times scaled to 100 ns ticks + the media time, zero without
+    # Timestamps; no token array without Tokens, firstToken / countTokens all the same; eTokenFlags::Special from token_eot on)
+    c = [x for x in cases() if x["name"] == "translate_de"][0]
+    model = gf.scripted_model(c["script"], c["prompt_len"])
+    n = int(16000 * c["seconds"])
+    pcm = (0.05 * np.random.default_rng(PCM_SEED + 1).standard_normal(n)).astype(np.float32)
+    media_time = 76543210
+    variants = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        gf.write_model(path, model)
+        ci = ref.RefContextImpl(path, model.filters, encoder_threads=4)
+        hr, _ = ci.run_full(pcm, cpu_threads=4, lang="de", flags=flags_of(c["flags"]), prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"], media_time=media_time)
+        assert hr == 0
+        for rf in (0, 1, 2, 3):
+            variants[str(rf)] = [dict(t0=s["t0"], t1=s["t1"], text=s["text"], first_token=s["first_token"], count_tokens=s["count_tokens"],
+                                      tokens=[dict(id=t["id"], flags=t["flags"], t0=t["t0"], t1=t["t1"], text=t["text"]) for t in s["tokens"]])
+                                 for s in ci.results(rf)]
+        ci.close()
+    results = dict(case="translate_de", pcm_seed=PCM_SEED + 1, n_samples=n, media_time=media_time, by_flags=variants)
     with open(os.path.join(HERE, "ref_hostloop_contextimpl.json"), "w") as f:
-        json.dump(dict(cases=out), f, indent=1)
+        json.dump(dict(cases=out, results=results), f, indent=1)
 
 
 if __name__ == "__main__":

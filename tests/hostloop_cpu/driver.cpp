@@ -9,6 +9,7 @@
 // Built by tests/test_hostloop_cpu.py into tests/_build/ (g++, a few seconds); the window loop below is the shape of
 // ContextImpl::runFullImpl / whisperImpl.cpp's runFullImpl: nextWindow -> encode -> decode + sample until WindowScan says stop -> finishWindow.
 #include "hostLoop.h"
+#include "results.h"
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -73,9 +74,11 @@ struct HlParams
 	const int32_t* prompt_tokens;
 	int32_t prompt_n_tokens;
 	int32_t withProgress;
+	uint32_t resultFlags;	 // eResultFlags of the "pods" section (iContext::getResults through results.h fillResultData)
+	int64_t mediaTime;		 // iAudioBuffer::getTime
 };
 
-// Returns the HRESULT of the run; hl_result() = {"segments":[{"t0","t1","text","tokens":[{"id","tid","p","pt","ptsum","t0","t1","vlen"}]}],"progress":[..],"new_segment":[calls,sum]}
+// Returns the HRESULT of the run; hl_result() = {"pods":[...] (see below),"segments":[{"t0","t1","text","tokens":[{"id","tid","p","pt","ptsum","t0","t1","vlen"}]}],"progress":[..],"new_segment":[calls,sum]}
 extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_run( const char* modelPath, int rules, const HlParams* hp, const float* pcm, int nSamples, int threads )
 {
 	g_out.clear();
@@ -161,6 +164,25 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_run( const char* 
 			const TokenData& t = s.tokens[ j ];
 			o << ( j ? "," : "" ) << "{\"id\":" << t.id << ",\"tid\":" << t.tid << ",\"p\":" << t.p << ",\"pt\":" << t.pt << ",\"ptsum\":" << t.ptsum
 			  << ",\"t0\":" << t.t0 << ",\"t1\":" << t.t1 << ",\"vlen\":" << t.vlen << "}";
+		}
+		o << "]}";
+	}
+	// the same transcript as iContext::getResults hands it out: the product's own conversion into the reference's POD layout
+	ResultData pods;
+	fillResultData( resultAll, vocab, hp->mediaTime, (eResultFlags)hp->resultFlags, pods );
+	o << "],\"pods\":[";
+	for( size_t i = 0; i < pods.segments.size(); i++ )
+	{
+		const sSegment& s = pods.segments[ i ];
+		o << ( i ? "," : "" ) << "{\"t0\":" << s.time.begin.ticks << ",\"t1\":" << s.time.end.ticks << ",\"first_token\":" << s.firstToken << ",\"count_tokens\":" << s.countTokens << ",\"text\":";
+		jsonString( o, s.text );
+		o << ",\"tokens\":[";
+		for( uint32_t j = 0; j < s.countTokens && s.firstToken + j < pods.tokens.size(); j++ )
+		{
+			const sToken& t = pods.tokens[ s.firstToken + j ];
+			o << ( j ? "," : "" ) << "{\"id\":" << t.id << ",\"flags\":" << (uint32_t)t.flags << ",\"t0\":" << t.time.begin.ticks << ",\"t1\":" << t.time.end.ticks << ",\"text\":";
+			jsonString( o, t.text ? t.text : "" );
+			o << "}";
 		}
 		o << "]}";
 	}

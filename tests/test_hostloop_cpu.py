@@ -25,7 +25,7 @@ REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 HIP_DIR = os.path.join(ROOT, "whisper_amd", "lib")
 SOURCES = [os.path.join(ROOT, "tests", "hostloop_cpu", "driver.cpp"), os.path.join(ROOT, "whisper_amd", "host", "support.cpp"),
            os.path.join(ROOT, "whisper_amd", "host", "tokenTimestamps.cpp")]
-HEADERS = [os.path.join(ROOT, "whisper_amd", "host", h) for h in ("hostLoop.h", "hostCommon.h")] + \
+HEADERS = [os.path.join(ROOT, "whisper_amd", "host", h) for h in ("hostLoop.h", "hostCommon.h", "results.h")] + \
           [os.path.join(ROOT, "include", h) for h in ("whisperApi.h", "whisper_hip.h")]
 
 FLAG_TRANSLATE, FLAG_NO_CONTEXT, FLAG_SINGLE_SEGMENT, FLAG_TOKEN_TIMESTAMPS = 1, 2, 4, 0x100
@@ -34,7 +34,8 @@ FLAG_TRANSLATE, FLAG_NO_CONTEXT, FLAG_SINGLE_SEGMENT, FLAG_TOKEN_TIMESTAMPS = 1,
 class HlParams(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("language", C.c_uint32), ("n_max_text_ctx", C.c_int32), ("offset_ms", C.c_int32), ("duration_ms", C.c_int32),
                 ("max_tokens", C.c_int32), ("max_len", C.c_int32), ("thold_pt", C.c_float), ("thold_ptsum", C.c_float),
-                ("prompt_tokens", C.POINTER(C.c_int32)), ("prompt_n_tokens", C.c_int32), ("withProgress", C.c_int32)]
+                ("prompt_tokens", C.POINTER(C.c_int32)), ("prompt_n_tokens", C.c_int32), ("withProgress", C.c_int32), ("resultFlags", C.c_uint32),
+                ("mediaTime", C.c_int64)]
 
 
 @pytest.fixture(scope="module")
@@ -65,7 +66,7 @@ def language_key(code):
     return k
 
 
-def run_case(L, tmp_path, c, pcm, rules, with_progress=False):
+def run_case(L, tmp_path, c, pcm, rules, with_progress=False, result_flags=3, media_time=0):
     model = gf.scripted_model(c["script"], c["prompt_len"])
     path = str(tmp_path / (c["name"] + ".bin"))
     gf.write_model(path, model)
@@ -81,6 +82,7 @@ def run_case(L, tmp_path, c, pcm, rules, with_progress=False):
     p.prompt_tokens = C.cast(arr, C.POINTER(C.c_int32)) if prompt else None
     p.prompt_n_tokens = len(prompt)
     p.withProgress = int(with_progress)
+    p.resultFlags, p.mediaTime = result_flags, media_time
     pcm = np.ascontiguousarray(pcm, np.float32)
     hr = L.hl_run(path.encode(), rules, C.byref(p), pcm, len(pcm), 4)
     assert hr >= 0, "hl_run failed: 0x%08x" % (hr & 0xFFFFFFFF)
@@ -137,3 +139,23 @@ def test_contextimpl_rules(driver, tmp_path):
             key = lambda r: [(s["t0"], s["t1"], [t["id"] for t in s["tokens"]]) for s in r["segments"]]      # noqa: E731
             differ += key(other) != key(got)
     assert differ == 2
+
+
+def test_result_pods_under_every_flag(driver, tmp_path):
+    """results.h fillResultData (what iContext::getResults hands out) against the reference's makeResults (ContextImpl.misc.cpp:196-300) for
+    every combination of eResultFlags, with a media time that is not zero: tick scaling + media time, zero times without Timestamps, no token
+    array without Tokens but firstToken / countTokens all the same, eTokenFlags::Special from token_eot on, the token's text."""
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_hostloop_contextimpl.json")))
+    r = G["results"]
+    c = [x for x in G["cases"] if x["name"] == r["case"]][0]
+    pcm = (0.05 * np.random.default_rng(r["pcm_seed"]).standard_normal(r["n_samples"])).astype(np.float32)
+    for rf, want in r["by_flags"].items():
+        hr, got = run_case(driver, tmp_path, c, pcm, rules=1, result_flags=int(rf), media_time=r["media_time"])
+        assert hr == 0 and len(got["pods"]) == len(want)
+        for g, w in zip(got["pods"], want):
+            assert {k: g[k] for k in ("t0", "t1", "text", "first_token", "count_tokens")} == {k: w[k] for k in ("t0", "t1", "text", "first_token", "count_tokens")}, (rf, g, w)
+            assert g["tokens"] == w["tokens"], (rf, g["tokens"][:3], w["tokens"][:3])
+    # whisper_full's rules: a token whose times were never computed reports 0, not the media time
+    hr, got = run_case(driver, tmp_path, c, pcm, rules=0, result_flags=3, media_time=r["media_time"])
+    assert hr == 0 and all(t["t0"] == 0 and t["t1"] == 0 for s in got["pods"] for t in s["tokens"])
+    assert got["pods"][0]["t0"] == r["by_flags"]["3"][0]["t0"]

@@ -2,6 +2,7 @@
 // the transcript a stream built (hostLoop.h). Shared by iContext::getResults and Whisper::runFullBatch.
 #pragma once
 #include "hostCommon.h"
+#include "hostLoop.h"
 
 namespace Whisper
 {
@@ -36,6 +37,15 @@ namespace Whisper
 		res.tokens.resize( tc );
 		size_t soFar = 0;
 		auto ticks = []( int64_t t10ms ) { return (uint64_t)( t10ms * 100000 ); };	 // 10 ms -> 100 ns
+		// A token whose times were never computed (no TokenTimestamps flag) reports 0. Under the GPU model's rules a token's times START
+		// at 0 instead of "unknown" (hostLoop.h), so makeResults reports the media time for it (ContextImpl.misc.cpp:277-283); pinned on
+		// the reference's own makeResults, tests/golden/ref_hostloop_contextimpl.json "results".
+		const bool fromZero = g_hostLoopRules == eHostLoopRules::ContextImpl;
+		auto tokenTicks = [ & ]( int64_t t10ms ) -> uint64_t
+		{
+			if( !withTimes || ( t10ms < 0 && !fromZero ) ) return 0;
+			return ticks( std::max<int64_t>( t10ms, 0 ) ) + (uint64_t)mediaTimeOffset;
+		};
 		for( size_t i = 0; i < resultAll.size(); i++ )
 		{
 			const Segment& src = resultAll[ i ];
@@ -52,8 +62,8 @@ namespace Whisper
 					const TokenData& t = src.tokens[ j ];
 					sToken& o = res.tokens[ soFar + j ];
 					o.text = vocab.string( t.id );
-					o.time.begin.ticks = ( withTimes && t.t0 >= 0 ) ? ticks( t.t0 ) + (uint64_t)mediaTimeOffset : 0;
-					o.time.end.ticks = ( withTimes && t.t1 >= 0 ) ? ticks( t.t1 ) + (uint64_t)mediaTimeOffset : 0;
+					o.time.begin.ticks = tokenTicks( t.t0 );
+					o.time.end.ticks = tokenTicks( t.t1 );
 					o.probability = t.p; o.probabilityTimestamp = t.pt; o.ptsum = t.ptsum; o.vlen = t.vlen;
 					o.id = t.id;
 					o.flags = t.id >= vocab.token_eot ? eTokenFlags::Special : eTokenFlags::None;
