@@ -100,6 +100,35 @@ def main():
         print(c["name"], "hr", hr, "->", len(segs), "segments", [(s["t0"] // 100000, s["t1"] // 100000) for s in segs][:10], "min p %.3f" % worst,
               "progress", (streamed or {}).get("progress"))
         out.append(rec)
+    # Numerics through the GPU model's host loop: the audio-CONDITIONED models of make_golden_runfull.py (tokens and timestamps depend on the
+    # audio: a wrong logit moves a timestamp, the timestamp moves the next window's seek) through ContextImpl::runFull at 1, 4 and 8 decoder
+    # threads -- the transcript must not depend on the thread count, as there -- next to whisper_full's transcript of the same case.
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_runfull", os.path.join(HERE, "make_golden_runfull.py"))
+    rf_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rf_mod)
+    wf = {c["name"]: c for c in json.load(open(os.path.join(HERE, "ref_runfull_conditioned.json")))["cases"]}
+    conditioned = []
+    for name, c in wf.items():
+        pcm = rf_mod.pcm_for(c["pcm"])
+        model = rf_mod.model_for(c["seed"])
+        res = {}
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "m.bin")
+            gf.write_model(path, model)
+            for nt in (1, 4, 8):
+                ci = ref.RefContextImpl(path, model.filters, encoder_threads=nt)
+                hr, segs = ci.run_full(pcm, cpu_threads=nt, lang="en", flags=ref.FLAG_NO_CONTEXT, prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"])
+                assert hr == 0
+                res[nt] = [dict(t0=s["t0"], t1=s["t1"], text=s["text"], tokens=[t["id"] for t in s["tokens"]], probs=[round(t["p"], 5) for t in s["tokens"]]) for s in segs]
+                ci.close()
+        strip = lambda r: [(s["t0"], s["t1"], s["tokens"]) for s in r]          # noqa: E731
+        assert strip(res[1]) == strip(res[4]) == strip(res[8]), name
+        same = strip(res[4]) == [(s["t0"] * 100000, s["t1"] * 100000, s["tokens"]) for s in c["segments"]]
+        print("conditioned", name, "->", len(res[4]), "segments;", "the same transcript as whisper_full" if same else "DIFFERS from whisper_full (rules)")
+        conditioned.append(dict(name=name, pcm=c["pcm"], seed=c["seed"], n_samples=len(pcm), prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"],
+                                same_as_whisper_full=same, min_logit_margin=c["min_logit_margin"], segments=res[4]))
+
     # iContext::getResults / makeResults (ContextImpl.misc.cpp:196-300) under every combination of eResultFlags, with a buffer whose media time
     # is not zero: what the POD structures of API/TranscribeStructs.h carry then (times scaled to 100 ns ticks + the media time, zero without
     # Timestamps; no token array without Tokens, firstToken / countTokens all the same; eTokenFlags::Special from token_eot on)
@@ -122,7 +151,7 @@ def main():
         ci.close()
     results = dict(case="translate_de", pcm_seed=PCM_SEED + 1, n_samples=n, media_time=media_time, by_flags=variants)
     with open(os.path.join(HERE, "ref_hostloop_contextimpl.json"), "w") as f:
-        json.dump(dict(cases=out, results=results), f, indent=1)
+        json.dump(dict(cases=out, conditioned=conditioned, results=results), f, indent=1)
 
 
 if __name__ == "__main__":

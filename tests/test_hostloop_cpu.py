@@ -66,15 +66,15 @@ def language_key(code):
     return k
 
 
-def run_case(L, tmp_path, c, pcm, rules, with_progress=False, result_flags=3, media_time=0):
-    model = gf.scripted_model(c["script"], c["prompt_len"])
+def run_case(L, tmp_path, c, pcm, rules, with_progress=False, result_flags=3, media_time=0, model=None):
+    model = model if model is not None else gf.scripted_model(c["script"], c["prompt_len"])
     path = str(tmp_path / (c["name"] + ".bin"))
     gf.write_model(path, model)
-    fl = c["flags"]
+    fl = c.get("flags", dict(no_context=True))
     p = HlParams()
     p.flags = (FLAG_NO_CONTEXT if fl.get("no_context") else 0) | (FLAG_SINGLE_SEGMENT if fl.get("single_segment") else 0) | \
               (FLAG_TRANSLATE if fl.get("translate") else 0) | (FLAG_TOKEN_TIMESTAMPS if fl.get("token_timestamps") else 0)
-    p.language = language_key(c["lang"])
+    p.language = language_key(c.get("lang", "en"))
     p.n_max_text_ctx, p.max_tokens, p.max_len = c["n_max_text_ctx"], fl.get("max_tokens", 0), fl.get("max_len", 0)
     p.thold_pt = p.thold_ptsum = -1.0
     prompt = c["prompt"] or []
@@ -159,3 +159,33 @@ def test_result_pods_under_every_flag(driver, tmp_path):
     hr, got = run_case(driver, tmp_path, c, pcm, rules=0, result_flags=3, media_time=r["media_time"])
     assert hr == 0 and all(t["t0"] == 0 and t["t1"] == 0 for s in got["pods"] for t in s["tokens"])
     assert got["pods"][0]["t0"] == r["by_flags"]["3"][0]["t0"]
+
+
+@pytest.mark.parametrize("rules", [0, 1])
+def test_audio_conditioned_models(driver, tmp_path, rules):
+    """Numerics in the loop: models whose tokens AND timestamps depend on the audio (ggml_format.conditioned_model; a wrong logit moves a
+    timestamp, the timestamp moves the next window). rules 0 against whisper_full (ref_runfull_conditioned.json), rules 1 against the
+    reference's ContextImpl::runFull over the same arithmetic (ref_hostloop_contextimpl.json "conditioned": thread-count independent, and on
+    these cases the same transcript as whisper_full's). Three of the six cases (the GPU tests run all of them)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_runfull", os.path.join(ROOT, "tests", "golden", "make_golden_runfull.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if rules == 0:
+        cases = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_runfull_conditioned.json")))["cases"]
+        scale = 100000
+    else:
+        cases = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_hostloop_contextimpl.json")))["conditioned"]
+        scale = 1
+    ran = 0
+    for c in cases:
+        if c["name"] not in ("jfk_s10", "mixed_s10", "jfk_s11"):
+            continue
+        hr, got = run_case(driver, tmp_path, c, mod.pcm_for(c["pcm"]), rules=rules, model=mod.model_for(c["seed"]))
+        want = c["segments"]
+        assert hr == 0 and len(got["pods"]) == len(want), (c["name"], len(got["pods"]), len(want))
+        for g, w in zip(got["pods"], want):
+            assert (g["t0"], g["t1"], g["text"]) == (w["t0"] * scale, w["t1"] * scale, w["text"]), (c["name"], g, w)
+            assert [t["id"] for t in g["tokens"]] == w["tokens"]
+        ran += 1
+    assert ran == 3
