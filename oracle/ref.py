@@ -59,6 +59,7 @@ def lib():
         L.ref_is_multilingual.argtypes = [C.c_void_p]
         L.ref_full.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_int]
+        L.ref_full_range.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ref_full_token_timestamps.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                                 C.c_float, C.c_float, C.c_int]
         L.ref_full_token_data.argtypes = [C.c_void_p, C.c_int, C.c_int, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"),
@@ -204,6 +205,23 @@ class RefWhisper:
                 tokens=[self.L.ref_full_token_id(self.ctx, i, j) for j in range(nt)],
                 probs=[self.L.ref_full_token_p(self.ctx, i, j) for j in range(nt)]))
         return segs
+
+    def full_range(self, pcm: np.ndarray, lang: str = "en", flags: int = 1, max_tokens: int = 0, prompt: Optional[Sequence[int]] = None,
+                   n_max_text_ctx: int = -1, offset_ms: int = 0, duration_ms: int = 0):
+        """whisper_full on a range of the audio. flags: 1 no_context, 2 single_segment, 4 translate, 8 print_special."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        rc = self.L.ref_full_range(self.ctx, pcm if len(pcm) else np.zeros(1, np.float32), len(pcm), self.n_threads, lang.encode(), flags, max_tokens,
+                                   pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx, offset_ms, duration_ms)
+        segs = []
+        if rc != 0:
+            return rc, segs
+        for i in range(self.L.ref_full_n_segments(self.ctx)):
+            nt = self.L.ref_full_n_tokens(self.ctx, i)
+            segs.append(dict(t0=self.L.ref_full_segment_t0(self.ctx, i), t1=self.L.ref_full_segment_t1(self.ctx, i),
+                             text=self.L.ref_full_segment_text(self.ctx, i).decode(errors="replace"),
+                             tokens=[self.L.ref_full_token_id(self.ctx, i, j) for j in range(nt)]))
+        return rc, segs
 
     def full_token_timestamps(self, pcm: np.ndarray, lang: str = "en", no_context: bool = True, prompt: Optional[Sequence[int]] = None,
                               n_max_text_ctx: int = -1, thold_pt: float = 0.01, thold_ptsum: float = 0.01, max_len: int = 0):

@@ -211,6 +211,28 @@ int ref_full( whisper_context* ctx, const float* pcm, int nSamples, int nThreads
 	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
 	return whisper_full( ctx, p, pcm, nSamples );
 }
+// the same with a range of the audio (offset_ms / duration_ms, whisper.cpp:2786-2787) and print_special
+int ref_full_range( whisper_context* ctx, const float* pcm, int nSamples, int nThreads, const char* lang, int flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, int offsetMs, int durationMs )
+{
+	whisper_full_params p = whisper_full_default_params( WHISPER_SAMPLING_GREEDY );
+	p.n_threads = nThreads;
+	p.print_progress = false;
+	p.print_realtime = false;
+	p.print_timestamps = false;
+	p.print_special = ( flags & 8 ) != 0;
+	p.language = lang;
+	p.no_context = ( flags & 1 ) != 0;
+	p.single_segment = ( flags & 2 ) != 0;
+	p.translate = ( flags & 4 ) != 0;
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	p.offset_ms = offsetMs;
+	p.duration_ms = durationMs;
+	return whisper_full( ctx, p, pcm, nSamples );
+}
 // whisper_full with token-level timestamps (whisper.cpp:2803-2808, 3063-3069): thold_pt / thold_ptsum / max_len as given
 int ref_full_token_timestamps( whisper_context* ctx, const float* pcm, int nSamples, int nThreads, const char* lang, int flags,
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, float tholdPt, float tholdPtsum, int maxLen )

@@ -21,6 +21,7 @@ void ref_set_log_level( int lvl );
 void ref_hparams( void* ctx, int32_t* out11 );
 int ref_pcm_to_mel( void* ctx, const float* pcm, int n, int nThreads );
 int ref_mel_len( void* ctx );
+int ref_set_mel( void* ctx, const float* mel, int nLen, int nMel );
 int ref_encode( void* ctx, int melOffset, int nThreads );
 int ref_decode( void* ctx, const int32_t* tokens, int nTokens, int nPast, int nThreads );
 void ref_sample_best( void* ctx, int32_t* id, int32_t* tid, float* p, float* pt, float* ptsum );
@@ -76,6 +77,8 @@ struct HlParams
 	int32_t withProgress;
 	uint32_t resultFlags;	 // eResultFlags of the "pods" section (iContext::getResults through results.h fillResultData)
 	int64_t mediaTime;		 // iAudioBuffer::getTime
+	const float* mel;		 // optional: the whole-buffer spectrogram [80][melLen] to run on (else whisper.cpp's own of the PCM)
+	int32_t melLen;
 };
 
 // Returns the HRESULT of the run; hl_result() = {"pods":[...] (see below),"segments":[{"t0","t1","text","tokens":[{"id","tid","p","pt","ptsum","t0","t1","vlen"}]}],"progress":[..],"new_segment":[calls,sum]}
@@ -115,8 +118,12 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_run( const char* 
 	StreamRun run( p, vocab, hparams, nullptr, sink, resultAll, promptPast, &stamper );
 
 	// the whole-buffer spectrogram, as iContext::runFull makes it before the loop
-	if( nSamples > 0 && 0 != ref_pcm_to_mel( cpu, pcm, nSamples, threads ) ) { ref_free( cpu ); return E_FAIL; }
-	const int64_t melLen = nSamples > 0 ? ref_mel_len( cpu ) : 0;
+	if( hp->mel )
+	{
+		if( 0 != ref_set_mel( cpu, hp->mel, hp->melLen, hparams.n_mels ) ) { ref_free( cpu ); return E_FAIL; }
+	}
+	else if( nSamples > 0 && 0 != ref_pcm_to_mel( cpu, pcm, nSamples, threads ) ) { ref_free( cpu ); return E_FAIL; }
+	const int64_t melLen = hp->mel ? hp->melLen : ( nSamples > 0 ? ref_mel_len( cpu ) : 0 );
 	hr = run.begin( melLen );
 	if( hr == S_OK )
 	{

@@ -35,7 +35,7 @@ class HlParams(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("language", C.c_uint32), ("n_max_text_ctx", C.c_int32), ("offset_ms", C.c_int32), ("duration_ms", C.c_int32),
                 ("max_tokens", C.c_int32), ("max_len", C.c_int32), ("thold_pt", C.c_float), ("thold_ptsum", C.c_float),
                 ("prompt_tokens", C.POINTER(C.c_int32)), ("prompt_n_tokens", C.c_int32), ("withProgress", C.c_int32), ("resultFlags", C.c_uint32),
-                ("mediaTime", C.c_int64)]
+                ("mediaTime", C.c_int64), ("mel", C.POINTER(C.c_float)), ("melLen", C.c_int32)]
 
 
 @pytest.fixture(scope="module")
@@ -66,14 +66,18 @@ def language_key(code):
     return k
 
 
-def run_case(L, tmp_path, c, pcm, rules, with_progress=False, result_flags=3, media_time=0, model=None):
+def run_case(L, tmp_path, c, pcm, rules, with_progress=False, result_flags=3, media_time=0, model=None, mel=None):
     model = model if model is not None else gf.scripted_model(c["script"], c["prompt_len"])
     path = str(tmp_path / (c["name"] + ".bin"))
     gf.write_model(path, model)
     fl = c.get("flags", dict(no_context=True))
     p = HlParams()
     p.flags = (FLAG_NO_CONTEXT if fl.get("no_context") else 0) | (FLAG_SINGLE_SEGMENT if fl.get("single_segment") else 0) | \
-              (FLAG_TRANSLATE if fl.get("translate") else 0) | (FLAG_TOKEN_TIMESTAMPS if fl.get("token_timestamps") else 0)
+              (FLAG_TRANSLATE if fl.get("translate") else 0) | (FLAG_TOKEN_TIMESTAMPS if fl.get("token_timestamps") else 0) | (8 if fl.get("print_special") else 0)
+    p.offset_ms, p.duration_ms = c.get("offset_ms", 0), c.get("duration_ms", 0)
+    if mel is not None:
+        mel = np.ascontiguousarray(mel, np.float32)
+        p.mel, p.melLen = mel.ctypes.data_as(C.POINTER(C.c_float)), mel.shape[1]
     p.language = language_key(c.get("lang", "en"))
     p.n_max_text_ctx, p.max_tokens, p.max_len = c["n_max_text_ctx"], fl.get("max_tokens", 0), fl.get("max_len", 0)
     p.thold_pt = p.thold_ptsum = -1.0
@@ -189,3 +193,88 @@ def test_audio_conditioned_models(driver, tmp_path, rules):
             assert [t["id"] for t in g["tokens"]] == w["tokens"]
         ran += 1
     assert ran == 3
+
+
+def _fuzz_cases(n):
+    """Seeded parameter combinations: model kind x flags x prompt x text context x range of the audio x audio length."""
+    rng = np.random.default_rng(2026)
+    hp = gf.hparams_for("test-d128-ml")
+    sp = gf.special_tokens(hp)
+    beg, eot = sp["beg"], sp["eot"]
+    script = [beg, 300, 301, 302, beg + 120, beg + 120, 400, 401, 402, beg + 250, beg + 250, 500, 501, beg + 360, eot]
+    out = []
+    for i in range(n):
+        kind = ("scripted", "conditioned", "scripted", "conditioned", "random-ml", "scripted", "conditioned", "random-en")[i % 8]
+        seconds = 0.6 if i == 5 else float(rng.choice([3.0, 8.0, 11.0, 20.0, 33.0, 45.0]))
+        c = dict(name="fuzz%d" % i, kind=kind, seed=int(rng.integers(1, 1000)), seconds=seconds,
+                 lang="en" if kind == "random-en" else str(rng.choice(["en", "de", "ja"])),
+                 flags=dict(no_context=bool(rng.integers(0, 2)), single_segment=bool(rng.integers(0, 5) == 0), translate=bool(rng.integers(0, 3) == 0),
+                            print_special=bool(rng.integers(0, 3) == 0), max_tokens=int(rng.choice([0, 0, 0, 7, 40]))),
+                 prompt=[None, [1000], [1000], [1000, 1001, 1002, 1003, 1004]][int(rng.integers(0, 4))],
+                 n_max_text_ctx=int(rng.choice([-1, 0, 0, 1, 5, 64])),
+                 offset_ms=int(rng.choice([0, 0, 0, 1500, 7000])), duration_ms=int(rng.choice([0, 0, 0, 9000, 15000])), script=script, prompt_len=4)
+        out.append(c)
+    return out
+
+
+def _fuzz_model(c):
+    if c["kind"] == "scripted":
+        return gf.scripted_model(c["script"], c["prompt_len"])
+    if c["kind"] == "conditioned":
+        return gf.conditioned_model(gf.conditioned_layout(gf.hparams_for("test-d128-ml")), 4, kind="test-d128-ml", seed=c["seed"])
+    return gf.synth_model("test-d128-ml" if c["kind"] == "random-ml" else "test-d128", seed=c["seed"])
+
+
+def test_differential_against_the_reference_host_loops(driver, tmp_path):
+    """Differential test of the host logic against the reference's two host loops RUN LIVE on the same arithmetic: 16 seeded combinations of
+    model (scripted, audio-conditioned, random weights: whatever tokens come out, both sides see the same ones) x flags (no_context,
+    single_segment, translate, print_special, max_tokens) x initial prompt x n_max_text_ctx (prompts of varying length carried over) x
+    offset_ms / duration_ms x audio length (incl. < 1 s) x language. rules 0 = whisper_full (Whisper/source/whisper.cpp), rules 1 =
+    ContextImpl::runFull (Whisper/Whisper/ContextImpl.cpp compiled unmodified) fed the GPU model's own spectrogram (Spectrogram.cpp).
+    Same CPU model, same thread count on both sides, so the transcripts must be IDENTICAL: ids, texts, times."""
+    from oracle import ref
+    if not (ref.contextimpl_available() and ref.melstreamer_available()):
+        pytest.skip("oracle/_ref is not complete (needs /root/reference)")
+    jfk = np.load(os.path.join(ROOT, "tests", "golden", "ref_test_d128.npz"))["pcm16"].astype(np.float32) / 32768.0
+    seen = dict(segments=0, empty=0, short=0, rules_differ=0)
+    for c in _fuzz_cases(16):
+        model = _fuzz_model(c)
+        n = int(16000 * c["seconds"])
+        pcm = np.resize(jfk, n).astype(np.float32) * (0.3 + 0.7 * (c["seed"] % 7) / 7.0)
+        path = str(tmp_path / (c["name"] + ".bin"))
+        gf.write_model(path, model)
+        fl = c["flags"]
+        # ---- rules 0: whisper_full
+        w = ref.RefWhisper(path, n_threads=4, log_level=0)
+        rc, want0 = w.full_range(pcm, lang=c["lang"], flags=int(fl["no_context"]) | (int(fl["single_segment"]) << 1) | (int(fl["translate"]) << 2) | (int(fl["print_special"]) << 3),
+                                 max_tokens=fl["max_tokens"], prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"], offset_ms=c["offset_ms"], duration_ms=c["duration_ms"])
+        w.close()
+        hr0, got0 = run_case(driver, tmp_path, c, pcm, rules=0, model=model)
+        if rc != 0:
+            assert hr0 < 0 or hr0 == 1, (c, rc, hr0)      # whisper_full refuses (unknown language ...): so must the host loop
+            key0 = None
+        else:
+            key0 = [(s["t0"], s["t1"], s["text"], [t["id"] for t in s["tokens"]]) for s in (got0["segments"] if got0 else [])]
+            assert key0 == [(s["t0"], s["t1"], s["text"], s["tokens"]) for s in want0], (c, "rules 0")
+        # ---- rules 1: ContextImpl::runFull on Spectrogram::pcmToMel's spectrogram
+        ci = ref.RefContextImpl(path, model.filters, encoder_threads=4)
+        hr_ref, want1 = ci.run_full(pcm, cpu_threads=4, lang=c["lang"],
+                                    flags=(ref.FLAG_NO_CONTEXT if fl["no_context"] else 0) | (ref.FLAG_SINGLE_SEGMENT if fl["single_segment"] else 0) |
+                                    (ref.FLAG_TRANSLATE if fl["translate"] else 0) | (ref.FLAG_PRINT_SPECIAL if fl["print_special"] else 0),
+                                    max_tokens=fl["max_tokens"], prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"], offset_ms=c["offset_ms"], duration_ms=c["duration_ms"])
+        ci.close()
+        mel = ref.spectrogram_pcm_to_mel(pcm, model.filters, threads=2)
+        hr1, got1 = run_case(driver, tmp_path, c, pcm, rules=1, model=model, mel=mel)
+        if hr_ref > 1:
+            assert hr1 == hr_ref - (1 << 32) or hr1 < 0, (c, hex(hr_ref), hr1)
+            continue
+        assert hr1 == hr_ref, (c, hr1, hr_ref)
+        key1 = [(s["t0"] * 100000, s["t1"] * 100000, s["text"], [t["id"] for t in s["tokens"]]) for s in (got1["segments"] if got1 else [])]
+        assert key1 == [(s["t0"], s["t1"], s["text"], [t["id"] for t in s["tokens"]]) for s in want1], (c, "rules 1")
+        seen["segments"] += len(key1)
+        seen["empty"] += not key1
+        seen["short"] += hr_ref == 1
+        if key0 is not None:
+            seen["rules_differ"] += [(a, b, i) for a, b, _, i in key0] != [(a // 100000, b // 100000, i) for a, b, _, i in key1]
+    print("differential:", seen)
+    assert seen["segments"] >= 30 and seen["short"] >= 1 and seen["rules_differ"] >= 1
