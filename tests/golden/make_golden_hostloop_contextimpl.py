@@ -124,10 +124,27 @@ def main():
                 ci.close()
         strip = lambda r: [(s["t0"], s["t1"], s["tokens"]) for s in r]          # noqa: E731
         assert strip(res[1]) == strip(res[4]) == strip(res[8]), name
+        # iContext::runStreamed on the same recording (row f1 end to end): the spectrogram comes window by window from the reference's MelStreamer,
+        # normalised on the window's own maximum, so the logits are NOT runFull's. Both streamers (cpuThreads 1: on demand, 4 / 8: background
+        # thread) and all thread counts must agree among themselves.
+        streamed = {}
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "m.bin")
+            gf.write_model(path, model)
+            for nt in (1, 4, 8):
+                ci = ref.RefContextImpl(path, model.filters, encoder_threads=nt)
+                hr, segs = ci.run_streamed(pcm, cpu_threads=nt, lang="en", flags=ref.FLAG_NO_CONTEXT, prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"])
+                assert hr == 0
+                streamed[nt] = [dict(t0=s["t0"], t1=s["t1"], text=s["text"], tokens=[t["id"] for t in s["tokens"]], probs=[round(t["p"], 5) for t in s["tokens"]]) for s in segs]
+                progress = ci.progress
+                ci.close()
+        assert strip(streamed[1]) == strip(streamed[4]) == strip(streamed[8]), (name, "runStreamed")
+        print("conditioned", name, "runStreamed ->", len(streamed[4]), "segments;", "the same transcript as runFull" if strip(streamed[4]) == strip(res[4]) else "DIFFERS from runFull (window-local normalisation)")
         same = strip(res[4]) == [(s["t0"] * 100000, s["t1"] * 100000, s["tokens"]) for s in c["segments"]]
         print("conditioned", name, "->", len(res[4]), "segments;", "the same transcript as whisper_full" if same else "DIFFERS from whisper_full (rules)")
         conditioned.append(dict(name=name, pcm=c["pcm"], seed=c["seed"], n_samples=len(pcm), prompt=c["prompt"], n_max_text_ctx=c["n_max_text_ctx"],
-                                same_as_whisper_full=same, min_logit_margin=c["min_logit_margin"], segments=res[4]))
+                                same_as_whisper_full=same, min_logit_margin=c["min_logit_margin"], segments=res[4],
+                                streamed=dict(segments=streamed[4], progress=progress, same_as_run_full=strip(streamed[4]) == strip(res[4]))))
 
     # iContext::getResults / makeResults (ContextImpl.misc.cpp:196-300) under every combination of eResultFlags, with a buffer whose media time
     # is not zero: what the POD structures of API/TranscribeStructs.h carry then (times scaled to 100 ns ticks + the media time, zero without
