@@ -278,3 +278,66 @@ def test_differential_against_the_reference_host_loops(driver, tmp_path):
             seen["rules_differ"] += [(a, b, i) for a, b, _, i in key0] != [(a // 100000, b // 100000, i) for a, b, _, i in key1]
     print("differential:", seen)
     assert seen["segments"] >= 30 and seen["short"] >= 1 and seen["rules_differ"] >= 1
+
+
+def test_token_timestamps_differential(driver, tmp_path):
+    """tokenTimestamps.cpp (TokenTimestamper: the energy-based token times and the max_len wrap) against BOTH reference implementations run
+    live on the same tokens: whisper.cpp's whisper_exp_compute_token_level_timestamps / whisper_wrap_segment (rules 0) and ContextImpl's port
+    (rules 1: times start from 0, the proportional split never runs -- hostLoop.h) -- on speech (jfk.wav) and on a speech / silence / noise mix,
+    thresholds 0.01 and 0.5, max_len 0 / 6 / 20, scripted and audio-conditioned models."""
+    from oracle import ref
+    if not (ref.contextimpl_available() and ref.melstreamer_available()):
+        pytest.skip("oracle/_ref is not complete (needs /root/reference)")
+    jfk = np.load(os.path.join(ROOT, "tests", "golden", "ref_test_d128.npz"))["pcm16"].astype(np.float32) / 32768.0
+    rng = np.random.default_rng(5)
+    mix = np.concatenate([jfk[:48000], np.zeros(24000, np.float32), 0.2 * rng.standard_normal(32000).astype(np.float32), jfk[60000:150000]]).astype(np.float32)
+    hp = gf.hparams_for("test-d128-ml")
+    sp = gf.special_tokens(hp)
+    beg, eot = sp["beg"], sp["eot"]
+    script = [beg, 300, 301, 302, beg + 120, beg + 120, 400, 401, 402, beg + 250, beg + 250, 500, 501, beg + 360, eot]
+    combos = [("scripted", jfk, 0.01, 0), ("scripted", mix, 0.01, 6), ("conditioned", jfk, 0.5, 20), ("conditioned", mix, 0.01, 0), ("scripted", mix, 0.5, 20)]
+    checked = 0
+    for i, (kind, pcm, thold, max_len) in enumerate(combos):
+        model = gf.scripted_model(script, 4) if kind == "scripted" else gf.conditioned_model(gf.conditioned_layout(hp), 4, kind="test-d128-ml", seed=10 + i)
+        c = dict(name="tt%d" % i, lang="en", flags=dict(no_context=True, token_timestamps=True, max_len=max_len), prompt=[1000], n_max_text_ctx=0)
+        path = str(tmp_path / (c["name"] + ".bin"))
+        gf.write_model(path, model)
+
+        w = ref.RefWhisper(path, n_threads=4, log_level=0)
+        want0 = w.full_token_timestamps(pcm, lang="en", no_context=True, prompt=[1000], n_max_text_ctx=0, thold_pt=thold, thold_ptsum=thold, max_len=max_len)
+        w.close()
+        got0 = run_case_tt(driver, tmp_path, c, pcm, 0, model, thold, None)
+        k0 = [(s["t0"], s["t1"], s["text"], [(t["id"], t["t0"], t["t1"]) for t in s["tokens"]]) for s in got0["segments"]]
+        assert k0 == [(s["t0"], s["t1"], s["text"], [(t["id"], t["t0"], t["t1"]) for t in s["tokens"]]) for s in want0], (c["name"], "rules 0")
+        assert all(abs(a["vlen"] - b["vlen"]) < 1e-4 for sa, sb in zip(got0["segments"], want0) for a, b in zip(sa["tokens"], sb["tokens"]))
+        ci = ref.RefContextImpl(path, model.filters, encoder_threads=4)
+        hr, want1 = ci.run_full(pcm, cpu_threads=4, lang="en", flags=ref.FLAG_NO_CONTEXT | ref.FLAG_TOKEN_TIMESTAMPS, prompt=[1000], n_max_text_ctx=0,
+                                thold_pt=thold, thold_ptsum=thold, max_len=max_len)
+        ci.close()
+        assert hr == 0
+        got1 = run_case_tt(driver, tmp_path, c, pcm, 1, model, thold, ref.spectrogram_pcm_to_mel(pcm, model.filters, threads=2))
+        k1 = [(s["t0"] * 100000, s["t1"] * 100000, s["text"], [(t["id"], t["t0"] * 100000, t["t1"] * 100000) for t in s["tokens"]]) for s in got1["segments"]]
+        assert k1 == [(s["t0"], s["t1"], s["text"], [(t["id"], t["t0"], t["t1"]) for t in s["tokens"]]) for s in want1], (c["name"], "rules 1")
+        checked += sum(len(s["tokens"]) for s in want0) + sum(len(s["tokens"]) for s in want1)
+    assert checked > 150
+
+
+def run_case_tt(L, tmp_path, c, pcm, rules, model, thold, mel):
+    """run_case with the two probability thresholds of the token-level timestamps set"""
+    path = str(tmp_path / (c["name"] + ".bin"))
+    fl = c["flags"]
+    p = HlParams()
+    p.flags = FLAG_NO_CONTEXT | FLAG_TOKEN_TIMESTAMPS
+    p.language = language_key("en")
+    p.n_max_text_ctx, p.max_tokens, p.max_len = c["n_max_text_ctx"], 0, fl.get("max_len", 0)
+    p.thold_pt = p.thold_ptsum = thold
+    arr = (C.c_int32 * 1)(*c["prompt"])
+    p.prompt_tokens, p.prompt_n_tokens = C.cast(arr, C.POINTER(C.c_int32)), 1
+    p.resultFlags = 3
+    if mel is not None:
+        mel = np.ascontiguousarray(mel, np.float32)
+        p.mel, p.melLen = mel.ctypes.data_as(C.POINTER(C.c_float)), mel.shape[1]
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    hr = L.hl_run(path.encode(), rules, C.byref(p), pcm, len(pcm), 4)
+    assert hr == 0, hr
+    return json.loads(L.hl_result().decode())
