@@ -93,8 +93,14 @@ def test_every_stream_equals_the_stream_alone(batch_lib, tmp_path, rules):
         want.append((hr, [(t0 * 100000 + shift, t1 * 100000 + shift, text, ids) for (t0, t1, text, ids) in segs]))
     assert sum(len(w[1]) for w in want) >= 8 and want[3][0] == 1          # the 0.5 s recording: S_FALSE, nothing transcribed
     for slots, groups, chunk, lookahead in ((2, 2, 4, 0), (3, 1, 7, 1), (64, 2, 4, 0), (1, 1, 3, 0)):
+        before = np.zeros(6, np.int64)
+        batch_lib.fake_device_counters(before)
         hr, got = run_batch(batch_lib, path, rules, bufs, streams, slots, groups, chunk, lookahead)
         assert hr == 0, hr
+        # the runner released every device context it created
+        after = np.zeros(6, np.int64)
+        batch_lib.fake_device_counters(after)
+        assert after[0] == before[0]
         for i, (st, w) in enumerate(zip(got["streams"], want)):
             assert st["hr"] == w[0], (slots, groups, i, st["hr"])
             assert [(s["t0"], s["t1"], s["text"], s["tokens"]) for s in st["segments"]] == w[1], (slots, groups, chunk, lookahead, i)
