@@ -37,6 +37,7 @@ def lib():
         L.ref_pcm_to_mel.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
         L.ref_set_mel.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
         L.ref_mel_len.argtypes = [C.c_void_p]
+        L.ref_set_mel_any.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
         L.ref_get_mel.argtypes = [C.c_void_p, _f32p]
         L.ref_encode.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ref_decode.argtypes = [C.c_void_p, _i32p, C.c_int, C.c_int, C.c_int]
@@ -122,6 +123,12 @@ class RefWhisper:
         assert mel.shape[0] == self.n_mels
         rc = self.L.ref_set_mel(self.ctx, mel, mel.shape[1], mel.shape[0])
         assert rc == 0
+
+    def set_mel_any(self, mel: np.ndarray):
+        """The context's spectrogram written directly: any number of mel bins (whisper_set_mel insists on 80); the encoder takes the count
+        from the model file, so a model of the large-v3 shape (128 bins) runs."""
+        mel = np.ascontiguousarray(mel, np.float32)
+        self.L.ref_set_mel_any(self.ctx, mel, mel.shape[1], mel.shape[0])
 
     def get_mel(self) -> np.ndarray:
         n = self.L.ref_mel_len(self.ctx)

@@ -107,6 +107,16 @@ void ref_hparams( whisper_context* ctx, int32_t* out11 )
 
 int ref_pcm_to_mel( whisper_context* ctx, const float* pcm, int n, int nThreads ) { return whisper_pcm_to_mel( ctx, pcm, n, nThreads ); }
 int ref_set_mel( whisper_context* ctx, const float* mel, int nLen, int nMel ) { return whisper_set_mel( ctx, mel, nLen, nMel ); }
+// whisper_set_mel refuses anything but WHISPER_N_MEL = 80 bins (whisper.cpp:2318-2321) although the encoder itself takes the count from the
+// model file (whisper.cpp:1097-1106): writing the context's spectrogram directly lets the reference's encoder / decoder run a model of the
+// large-v3 SHAPE (128 mel bins), which no entry point of the reference can feed
+int ref_set_mel_any( whisper_context* ctx, const float* mel, int nLen, int nMel )
+{
+	ctx->mel.n_len = nLen;
+	ctx->mel.n_mel = nMel;
+	ctx->mel.data.assign( mel, mel + (size_t)nLen * nMel );
+	return 0;
+}
 int ref_mel_len( whisper_context* ctx ) { return ctx->mel.n_len; }
 void ref_get_mel( whisper_context* ctx, float* dst ) { memcpy( dst, ctx->mel.data.data(), ctx->mel.data.size() * sizeof( float ) ); }
 

@@ -405,9 +405,11 @@ def test_single_stream_path_at_other_widths(d, heads, batch):
 
 
 def test_large_v3_shape(tmp_path):
-    """128 mel bins, vocabulary 51866 (BASELINE config 5). The reference cannot load this shape (N_MEL is a constexpr 80,
-    audioConstants.h:13; special ids keyed on 51865): an extension whose only oracle is the numpy restatement, which is
-    pinned on the 80-mel shapes. Checks conv1 with K = 384, the special ids the sampler uses, and parity with the restatement."""
+    """128 mel bins, vocabulary 51866 (BASELINE config 5). The reference's GPU model cannot load this shape (N_MEL is a constexpr 80,
+    audioConstants.h:13; special ids keyed on 51865) and no entry point of its CPU model accepts a 128-bin spectrogram -- but its CPU
+    encoder / decoder take the counts from the model file: tests/test_oracle.py::test_large_v3_shape_restatement_against_the_reference
+    runs them on this very model (spectrogram written into the context directly) and pins the numpy restatement on them AT THIS SHAPE.
+    Here: conv1 with K = 384, the special ids the sampler uses, and parity with that restatement."""
     model = gf.synth_model("test-d128-v3", seed=77, attn_sharpness=2.0)
     hp = model.hparams
     assert hp.n_mels == 128 and hp.n_vocab == 51866

@@ -201,6 +201,46 @@ def test_live_melstreamer_if_present(tiny_model):
         st.close()
 
 
+def test_large_v3_shape_restatement_against_the_reference(ref_lib_available, tmp_path):
+    """BASELINE config 5's shape (128 mel bins, vocabulary 51866). No entry point of the reference accepts it -- whisper_set_mel and the
+    spectrogram are tied to WHISPER_N_MEL = 80 (whisper.h:23, whisper.cpp:2289, :2318) -- but its ENCODER AND DECODER take the counts from
+    the model file (whisper.cpp:1097-1106, :486): with the context's spectrogram written directly (oracle/ref_harness.cpp ref_set_mel_any)
+    the reference's own arithmetic runs a model of that shape. The restatement (the oracle of tests/test_gpu_model.py::test_large_v3_shape)
+    is held against it: cross-K/V and logits at the noise level of the 80-mel shapes (max 2e-3 / mean 4e-4 there; same bounds)."""
+    if not ref_lib_available:
+        pytest.skip("oracle/_ref/libwhisper_ref.so not built (needs /root/reference)")
+    from oracle import ref
+    model = gf.synth_model("test-d128-v3", seed=77, attn_sharpness=2.0)
+    hp = model.hparams
+    assert hp.n_mels == 128 and hp.n_vocab == 51866
+    sp = gf.special_tokens(hp)
+    pcm = (0.1 * np.random.default_rng(8).standard_normal(16000 * 4)).astype(np.float32)
+    mel = wn.log_mel_spectrogram(pcm, model.filters)
+    assert mel.shape == (128, 400)
+    path = str(tmp_path / "v3.bin")
+    gf.write_model(path, model)
+    w = ref.RefWhisper(path, n_threads=1, log_level=0)
+    assert w.n_mels == 128
+    w.set_mel_any(mel)
+    w.encode(0)
+    n = wn.WhisperNP(model)
+    n.encode(mel, 0)
+    for layer in (0, hp.n_text_layer - 1):
+        k, v = w.cross_kv(layer)
+        assert np.abs(k - n.kv.cross_k[layer]).max() < E2E_MAX and np.abs(v - n.kv.cross_v[layer]).max() < 2 * E2E_MAX
+    toks = [sp["sot"], sp["sot"] + 1, sp["transcribe"]]
+    n_past = 0
+    for step in range(4):
+        logits, _ = w.decode(toks, n_past)
+        nl, _ = n.decode(toks, n_past, n_threads=1)
+        d = np.abs(logits - nl)
+        assert logits.shape[1] == 51866 and d.max() < E2E_MAX and d.mean() < E2E_MEAN, (step, d.max(), d.mean())
+        assert int(np.argmax(logits[-1])) == int(np.argmax(nl[-1]))
+        n_past += len(toks)
+        toks = [int(np.argmax(logits[-1]))]
+    w.close()
+
+
 def test_truth_model_orders_the_references(golden, golden_e2e):
     """The yardstick of SURVEY.md 8(c)(ii), from committed fixtures: exact arithmetic (WhisperTruth) vs the reference at 1 and
     8 threads. The 1-thread reference is 20x further from the truth than the 8-thread one (sequential FP16 accumulation over
