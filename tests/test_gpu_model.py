@@ -438,6 +438,18 @@ def test_large_v3_shape(tmp_path):
     sb = ctx.sample_best(1, True, True)[0]
     hb = wn.sample_best(probs[0], sp["beg"], sp["sot"], sp["solm"], sp["not_"], True, True)
     assert (sb["id"], sb["tid"]) == (hb["id"], hb["tid"]) and sp["beg"] <= sb["id"] <= sp["beg"] + 100
+    # ... and against the reference's own encoder / decoder on this model, live (oracle/_ref travels to the GPU box)
+    from oracle import ref
+    if ref.available():
+        path = str(tmp_path / "v3.bin")
+        gf.write_model(path, model)
+        w = ref.RefWhisper(path, n_threads=1, log_level=0)
+        w.set_mel_any(want)
+        w.encode(0)
+        rl, _ = w.decode(toks, 0)
+        d = report("v3-shape logits vs the reference's decoder (1 thread)", logits[0], rl[-1])
+        assert d.max() < E2E_MAX and d.mean() < E2E_MEAN and int(np.argmax(logits[0])) == int(np.argmax(rl[-1]))
+        w.close()
     ctx.close()
     m.close()
 
