@@ -7,6 +7,7 @@
     libcontextimpl_ref.so   its GPU-model iContext (Whisper/Whisper/ContextImpl.cpp, ContextImpl.misc.cpp, Languages.cpp + the spectrogram sources):
                             host loop, sampler, results, token-level timestamps -- the D3D compute context replaced by libwhisper_ref.so
                             (contextimpl_harness.cpp)
+    libcliparams_ref.so     the command line of its CLI (Examples/main/params.cpp; cliparams_harness.cpp, shim/cli/)
   ref.py                    ctypes wrappers: RefWhisper, RefMelStreamer / spectrogram_pcm_to_mel, RefContextImpl
   whisper_np.py             numpy restatement of the same arithmetic, pinned against _ref and the fixtures in tests/golden/
 

@@ -191,3 +191,68 @@ def test_mgpu_harness_one_rank_matches_the_cli(exe, tmp_path):
         assert g.endswith("] " + s["text"]), (g, s)
         t0, t1 = float(g[1:10]), float(g[15:24])
         assert abs(t0 - s["t0"] / 100.0) < 0.006 and abs(t1 - s["t1"] / 100.0) < 0.006
+
+
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "libcliparams_ref.so")
+
+
+def _ref_parse(args, argv0="main", threads=4, capture=False):
+    """The reference's own whisper_params::parse (Examples/main/params.cpp compiled unmodified, oracle/_ref/libcliparams_ref.so)."""
+    import ctypes as C
+    import tempfile
+    L = C.CDLL(REF_CLI)
+    argv = (C.c_char_p * (len(args) + 1))(argv0.encode(), *[a.encode() for a in args])
+    out = C.create_string_buffer(16384)
+    text = None
+    if capture:          # what it prints goes to the C library's stderr
+        with tempfile.TemporaryFile() as tf:
+            saved = os.dup(2)
+            os.dup2(tf.fileno(), 2)
+            try:
+                go = L.cp_parse(len(args) + 1, argv, threads, out, 16384)
+                C.CDLL(None).fflush(None)
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+            tf.seek(0)
+            text = tf.read()
+    else:
+        go = L.cp_parse(len(args) + 1, argv, threads, out, 16384)
+    return go, json.loads(out.value.decode()), text
+
+
+def test_command_line_against_the_reference_parser(exe):
+    """Row f2, the command line: whisper-main's parser (--dump-options) against the reference's whisper_params::parse, and its usage text
+    against whisper_print_usage byte for byte (Examples/main/params.cpp compiled unmodified into oracle/_ref/libcliparams_ref.so)."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/libcliparams_ref.so not built (needs /root/reference)")
+    hw = min(4, max(1, os.cpu_count() or 1))
+    cases = [
+        [],
+        ["a.wav"],
+        ["-t", "8", "-p", "2", "-ot", "1500", "-on", "3", "-d", "20000", "-mc", "64", "-ml", "40", "-wt", "0.25", "a.wav", "b.wav"],
+        ["--threads", "2", "--processors", "1", "--offset-t", "0", "--offset-n", "0", "--duration", "0", "--max-context", "0", "--max-len", "1", "--word-thold", "1", "-f", "x.wav"],
+        ["-su", "-tr", "-di", "-otxt", "-ovtt", "-osrt", "-owts", "-ps", "-nc", "-nt", "z.wav"],
+        ["--speed-up", "--translate", "--diarize", "--output-txt", "--output-vtt", "--output-srt", "--output-words", "--print-special", "--no-colors", "--no-timestamps", "--file", "z.wav"],
+        ["-l", "de", "-m", "models/ggml-medium.bin", "-gpu", "AMD Instinct MI355X", "--prompt", "Hello, \"world\" \u00e9t\u00e9", "clip one.wav"],
+        ["--language", "ja", "--model", "m.bin", "--use-gpu", "x", "one.wav", "-f", "two.wav", "three.wav"],
+        ["-mc", "4294967295", "-t", "1", "a.wav"],
+        ["a.wav", "-otxt", "b.wav", "-osrt"],
+    ]
+    for args in cases:
+        go, want, _ = _ref_parse(args, threads=hw)
+        r = run(exe, "--dump-options", *args)
+        assert go == 1 and r.returncode == 0, (args, r.stderr)
+        got = json.loads(r.stdout.decode())
+        assert set(got) == set(want)
+        for k in want:
+            if k == "word_thold":
+                assert abs(got[k] - want[k]) < 1e-6, (args, k)
+            else:
+                assert got[k] == want[k], (args, k, got[k], want[k])
+    # what stops the reference stops whisper-main: help, an unknown argument (both print the usage text)
+    for args in (["-h"], ["--help"], ["--bogus", "a.wav"], ["a.wav", "-xyz"]):
+        go, _, text = _ref_parse(args, argv0=exe, threads=hw, capture=True)
+        r = run(exe, *args)
+        assert go == 0 and r.returncode == 1, args
+        assert r.stderr == text, (args, r.stderr.decode()[-400:], text.decode()[-400:])

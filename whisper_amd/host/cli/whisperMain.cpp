@@ -41,59 +41,97 @@ namespace
 		const char* full;
 		eKind kind;
 		void* target;
+		const char* left;	   // the option's two name columns as the reference's usage text prints them (Examples/main/params.cpp:26-55)
 		const char* help;
 	};
 
 	std::vector<OptionSpec> optionTable( Options& o )
 	{
 		return {
-			{ "-gpu", "--use-gpu", eKind::Str, &o.gpu, "The graphic adapter to use for inference" },
-			{ "-t", "--threads", eKind::U32, &o.threads, "number of threads to use during computation" },
-			{ "-p", "--processors", eKind::U32, &o.processors, "number of processors to use during computation" },
-			{ "-ot", "--offset-t", eKind::U32, &o.offsetMs, "time offset in milliseconds" },
-			{ "-on", "--offset-n", eKind::U32, &o.offsetN, "segment index offset" },
-			{ "-d", "--duration", eKind::U32, &o.durationMs, "duration of audio to process in milliseconds" },
-			{ "-mc", "--max-context", eKind::U32, &o.maxContext, "maximum number of text context tokens to store" },
-			{ "-ml", "--max-len", eKind::U32, &o.maxLen, "maximum segment length in characters" },
-			{ "-wt", "--word-thold", eKind::F32, &o.wordThreshold, "word timestamp probability threshold" },
-			{ "-su", "--speed-up", eKind::Flag, &o.speedUp, "speed up audio by x2 (reduced accuracy)" },
-			{ "-tr", "--translate", eKind::Flag, &o.translate, "translate from source language to english" },
-			{ "-di", "--diarize", eKind::Flag, &o.diarize, "stereo audio diarization" },
-			{ "-otxt", "--output-txt", eKind::Flag, &o.outputTxt, "output result in a text file" },
-			{ "-ovtt", "--output-vtt", eKind::Flag, &o.outputVtt, "output result in a vtt file" },
-			{ "-osrt", "--output-srt", eKind::Flag, &o.outputSrt, "output result in a srt file" },
-			{ "-owts", "--output-words", eKind::Flag, &o.outputWords, "output script for generating karaoke video" },
-			{ "-ps", "--print-special", eKind::Flag, &o.printSpecial, "print special tokens" },
-			{ "-nc", "--no-colors", eKind::NegFlag, &o.colors, "do not print colors" },
-			{ "-nt", "--no-timestamps", eKind::Flag, &o.noTimestamps, "do not print timestamps" },
-			{ "-l", "--language", eKind::Str, &o.language, "spoken language" },
-			{ "-m", "--model", eKind::Str, &o.model, "model path" },
-			{ "-f", "--file", eKind::Input, &o.inputs, "path of the input audio file" },
-			{ nullptr, "--prompt", eKind::Str, &o.prompt, "initial prompt for the model" },
+			{ "-gpu", "--use-gpu", eKind::Str, &o.gpu, "-gpu,     --use-gpu       ", "The graphic adapter to use for inference" },
+			{ "-t", "--threads", eKind::U32, &o.threads, "-t N,     --threads N     ", "number of threads to use during computation" },
+			{ "-p", "--processors", eKind::U32, &o.processors, "-p N,     --processors N  ", "number of processors to use during computation" },
+			{ "-ot", "--offset-t", eKind::U32, &o.offsetMs, "-ot N,    --offset-t N    ", "time offset in milliseconds" },
+			{ "-on", "--offset-n", eKind::U32, &o.offsetN, "-on N,    --offset-n N    ", "segment index offset" },
+			{ "-d", "--duration", eKind::U32, &o.durationMs, "-d  N,    --duration N    ", "duration of audio to process in milliseconds" },
+			{ "-mc", "--max-context", eKind::U32, &o.maxContext, "-mc N,    --max-context N ", "maximum number of text context tokens to store" },
+			{ "-ml", "--max-len", eKind::U32, &o.maxLen, "-ml N,    --max-len N     ", "maximum segment length in characters" },
+			{ "-wt", "--word-thold", eKind::F32, &o.wordThreshold, "-wt N,    --word-thold N  ", "word timestamp probability threshold" },
+			{ "-su", "--speed-up", eKind::Flag, &o.speedUp, "-su,      --speed-up      ", "speed up audio by x2 (reduced accuracy)" },
+			{ "-tr", "--translate", eKind::Flag, &o.translate, "-tr,      --translate     ", "translate from source language to english" },
+			{ "-di", "--diarize", eKind::Flag, &o.diarize, "-di,      --diarize       ", "stereo audio diarization" },
+			{ "-otxt", "--output-txt", eKind::Flag, &o.outputTxt, "-otxt,    --output-txt    ", "output result in a text file" },
+			{ "-ovtt", "--output-vtt", eKind::Flag, &o.outputVtt, "-ovtt,    --output-vtt    ", "output result in a vtt file" },
+			{ "-osrt", "--output-srt", eKind::Flag, &o.outputSrt, "-osrt,    --output-srt    ", "output result in a srt file" },
+			{ "-owts", "--output-words", eKind::Flag, &o.outputWords, "-owts,    --output-words  ", "output script for generating karaoke video" },
+			{ "-ps", "--print-special", eKind::Flag, &o.printSpecial, "-ps,      --print-special ", "print special tokens" },
+			{ "-nc", "--no-colors", eKind::NegFlag, &o.colors, "-nc,      --no-colors     ", "do not print colors" },
+			{ "-nt", "--no-timestamps", eKind::Flag, &o.noTimestamps, "-nt,      --no-timestamps ", "do not print timestamps" },
+			{ "-l", "--language", eKind::Str, &o.language, "-l LANG,  --language LANG ", "spoken language" },
+			{ "-m", "--model", eKind::Str, &o.model, "-m FNAME, --model FNAME   ", "model path" },
+			{ "-f", "--file", eKind::Input, &o.inputs, "-f FNAME, --file FNAME    ", "path of the input audio file" },
+			{ nullptr, "--prompt", eKind::Str, &o.prompt, nullptr, "initial prompt for the model" },
 		};
 	}
 
+	// whisper_print_usage (Examples/main/params.cpp:22-56), line for line: the defaults in a 7-column bracket, numbers through %d (so the
+	// unlimited text context prints as -1), the adapter without a default, --prompt on a line of its own shape
 	void printUsage( const char* exe, Options& o )
 	{
-		fprintf( stderr, "\nusage: %s [options] file0.wav file1.wav ...\n\noptions:\n", exe );
-		fprintf( stderr, "  %-9s %-16s %-9s %s\n", "-h,", "--help", "[default]", "show this help message and exit" );
-		fprintf( stderr, "  %-9s %-16s %-9s %s\n", "-la,", "--list-adapters", "", "List graphic adapters and exit" );
+		fprintf( stderr, "\n" );
+		fprintf( stderr, "usage: %s [options] file0.wav file1.wav ...\n", exe );
+		fprintf( stderr, "\n" );
+		fprintf( stderr, "options:\n" );
+		fprintf( stderr, "  -h,       --help          [default] show this help message and exit\n" );
+		fprintf( stderr, "  -la,      --list-adapters List graphic adapters and exit\n" );
 		for( const OptionSpec& s : optionTable( o ) )
 		{
-			char def[ 64 ] = "";
+			if( !s.left )
+			{
+				fprintf( stderr, "  %-36s%s\n", s.full, s.help );
+				continue;
+			}
+			char def[ 128 ] = "";
 			switch( s.kind )
 			{
-			case eKind::Flag: snprintf( def, sizeof( def ), "[%s]", *(bool*)s.target ? "true" : "false" ); break;
-			case eKind::NegFlag: snprintf( def, sizeof( def ), "[%s]", *(bool*)s.target ? "false" : "true" ); break;
-			case eKind::U32: snprintf( def, sizeof( def ), "[%u]", *(uint32_t*)s.target ); break;
-			case eKind::F32: snprintf( def, sizeof( def ), "[%.2f]", *(float*)s.target ); break;
-			case eKind::Str: snprintf( def, sizeof( def ), "[%.40s]", ( (std::string*)s.target )->c_str() ); break;
-			case eKind::Input: break;
+			case eKind::Flag: snprintf( def, sizeof( def ), "[%-7s] ", *(bool*)s.target ? "true" : "false" ); break;
+			case eKind::NegFlag: snprintf( def, sizeof( def ), "[%-7s] ", *(bool*)s.target ? "false" : "true" ); break;
+			case eKind::U32: snprintf( def, sizeof( def ), "[%-7d] ", (int)*(uint32_t*)s.target ); break;
+			case eKind::F32: snprintf( def, sizeof( def ), "[%-7.2f] ", *(float*)s.target ); break;
+			case eKind::Str: if( s.target != &o.gpu ) snprintf( def, sizeof( def ), "[%-7s] ", ( (std::string*)s.target )->c_str() ); break;
+			case eKind::Input: snprintf( def, sizeof( def ), "[%-7s] ", "" ); break;
 			}
-			std::string brief = s.brief ? std::string( s.brief ) + "," : "";
-			fprintf( stderr, "  %-9s %-16s %-9s %s\n", brief.c_str(), s.full, def, s.help );
+			fprintf( stderr, "  %s%s%s\n", s.left, def, s.help );
 		}
 		fprintf( stderr, "\n" );
+	}
+
+	void jsonEscaped( const std::string& s )
+	{
+		putchar( '"' );
+		for( unsigned char c : s )
+		{
+			if( c == '"' || c == '\\' ) { putchar( '\\' ); putchar( c ); }
+			else if( c < 0x20 ) printf( "\\u%04x", c );
+			else putchar( c );
+		}
+		putchar( '"' );
+	}
+	// --dump-options (first argument; a test hook): the parsed command line as JSON under the reference's own parameter names
+	// (Examples/main/params.h), for the comparison with the reference's parser (tests/test_cli.py)
+	void dumpOptions( const Options& o )
+	{
+		printf( "{\"threads\":%u,\"processors\":%u,\"offset_t_ms\":%u,\"offset_n\":%u,\"duration_ms\":%u,\"max_context\":%u,\"max_len\":%u,\"word_thold\":%g,",
+			o.threads, o.processors, o.offsetMs, o.offsetN, o.durationMs, o.maxContext, o.maxLen, o.wordThreshold );
+		printf( "\"speed_up\":%d,\"translate\":%d,\"diarize\":%d,\"output_txt\":%d,\"output_vtt\":%d,\"output_srt\":%d,\"output_wts\":%d,\"print_special\":%d,\"print_colors\":%d,\"no_timestamps\":%d,",
+			o.speedUp, o.translate, o.diarize, o.outputTxt, o.outputVtt, o.outputSrt, o.outputWords, o.printSpecial, o.colors, o.noTimestamps );
+		printf( "\"language\":" ); jsonEscaped( o.language );
+		printf( ",\"model\":" ); jsonEscaped( o.model );
+		printf( ",\"gpu\":" ); jsonEscaped( o.gpu );
+		printf( ",\"prompt\":" ); jsonEscaped( o.prompt );
+		printf( ",\"inputs\":[" );
+		for( size_t i = 0; i < o.inputs.size(); i++ ) { if( i ) putchar( ',' ); jsonEscaped( o.inputs[ i ] ); }
+		printf( "]}\n" );
 	}
 
 	void printFailure( const char* what, HRESULT hr ) { fprintf( stderr, "%s: HRESULT 0x%08X\n", what, (unsigned)hr ); }
@@ -296,7 +334,10 @@ int main( int argc, char** argv )
 
 	Options o;
 	o.threads = std::min( 4u, std::max( 1u, std::thread::hardware_concurrency() ) );
+	const bool dump = argc > 1 && !strcmp( argv[ 1 ], "--dump-options" );
+	if( dump ) { argv[ 1 ] = argv[ 0 ]; argv++; argc--; }
 	if( const int stop = parse( argc, argv, o ) ) return stop - 1;
+	if( dump ) { dumpOptions( o ); return 0; }
 	if( o.colors && !isatty( STDOUT_FILENO ) ) o.colors = false;
 
 	if( o.inputs.empty() )
