@@ -78,13 +78,18 @@ struct ShimThread
 	std::thread thread;
 	std::mutex mx;
 	std::condition_variable cv;
-	bool done = false;
+	bool done = false, started = false;
 	DWORD code = 0;
 };
 inline HANDLE CreateThread( void*, size_t, DWORD ( *proc )( void* ), void* arg, DWORD, DWORD* )
 {
 	ShimThread* t = new ShimThread();
 	t->thread = std::thread( [ t, proc, arg ]() {
+		{
+			std::lock_guard<std::mutex> lk( t->mx );
+			t->started = true;
+			t->cv.notify_all();
+		}
 		const DWORD c = proc( arg );
 		std::lock_guard<std::mutex> lk( t->mx );
 		t->code = c;
@@ -96,7 +101,11 @@ inline HANDLE CreateThread( void*, size_t, DWORD ( *proc )( void* ), void* arg, 
 	// for every frame not produced yet. On Windows the caller spends its first hundred microseconds in D3D calls and the thread wins;
 	// here nothing stands between the constructor and the first makeBuffer(), so thread creation is made "slow": the oracle must
 	// never lose that race.
-	std::this_thread::sleep_for( std::chrono::milliseconds( 30 ) );
+	{
+		std::unique_lock<std::mutex> lk( t->mx );
+		t->cv.wait( lk, [ t ] { return t->started; } );		// the thread runs (however loaded the machine is) ...
+	}
+	std::this_thread::sleep_for( std::chrono::milliseconds( 30 ) );	// ... and has had time for the few instructions up to `Working`
 	return t;
 }
 inline DWORD WaitForSingleObject( HANDLE h, DWORD ms )
