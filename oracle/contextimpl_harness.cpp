@@ -72,90 +72,8 @@ void DirectCompute::WhisperContext::decode( const int* tokens, int length, const
 HRESULT COMLIGHTCALL ContextImpl::runCapture( const sFullParams&, const sCaptureCallbacks&, const iAudioCapture* ) { return E_NOTIMPL; }
 HRESULT COMLIGHTCALL ContextImpl::detectSpeaker( const sTimeInterval&, eSpeakerChannel& result ) const noexcept { result = (eSpeakerChannel)0; return S_FALSE; }
 
-// ---- PcmReader over memory for runStreamed: the same restatement of MF/PcmReader.cpp:307-428 as oracle/melstreamer_harness.cpp ----
-PcmReader::PcmReader( const iAudioReader* iar )
-{
-	if( nullptr == iar ) throw E_POINTER;
-	check( iar->getReader( &reader ) );
-	sampleHandler = nullptr;
-	m_length = reader->count / FFT_STEP;
-}
-HRESULT PcmReader::readNextSample()
-{
-	const size_t off = bufferReadOffset;
-	const size_t available = pcm.mono.size() - off;
-	if( available > 0 )
-	{
-		if( 0 != off )
-		{
-			memmove( pcm.mono.data(), pcm.mono.data() + off, available * 4 );
-			pcm.mono.resize( available );
-		}
-	}
-	else
-		pcm.clear();
-	bufferReadOffset = 0;
-	IMFSourceReader& r = *reader;
-	if( r.cursor >= r.count ) return E_EOF;
-	const size_t n = std::min( r.block, r.count - r.cursor );
-	pcm.appendMono( r.pcm + r.cursor, n );
-	r.cursor += n;
-	return S_OK;
-}
-HRESULT PcmReader::readChunk( PcmMonoChunk& mono, PcmStereoChunk* )
-{
-	while( true )
-	{
-		const size_t off = bufferReadOffset;
-		const size_t available = pcm.mono.size() - off;
-		if( available >= FFT_STEP )
-		{
-			memcpy( mono.mono.data(), &pcm.mono[ off ], FFT_STEP * 4 );
-			bufferReadOffset = off + FFT_STEP;
-			return S_OK;
-		}
-		if( !m_readerEndOfFile )
-		{
-			const HRESULT hr = readNextSample();
-			if( SUCCEEDED( hr ) ) continue;
-			if( hr != E_EOF ) return hr;
-			m_readerEndOfFile = true;
-		}
-		if( available > 0 )
-		{
-			memcpy( mono.mono.data(), &pcm.mono[ off ], available * 4 );
-			memset( mono.mono.data() + available, 0, ( FFT_STEP - available ) * 4 );
-			bufferReadOffset = off + available;
-			return S_OK;
-		}
-		return E_EOF;
-	}
-}
-ThreadPoolWork::~ThreadPoolWork() {}
-HRESULT ThreadPoolWork::create() { return S_OK; }
-HRESULT ThreadPoolWork::parallelFor( int threadsCount ) noexcept
-{
-	std::vector<std::thread> ts;
-	std::vector<HRESULT> hrs( (size_t)threadsCount, S_OK );
-	for( int i = 1; i < threadsCount; i++ ) ts.emplace_back( [ this, i, &hrs ]() { hrs[ i ] = threadPoolCallback( i ); } );
-	hrs[ 0 ] = threadPoolCallback( 0 );
-	for( auto& t : ts ) t.join();
-	for( HRESULT hr : hrs )
-		if( FAILED( hr ) ) return hr;
-	return S_OK;
-}
-HRESULT Whisper::parallelFor( pfnParallelForCallback pfn, int threadsCount, void* ctx )
-{
-	std::vector<std::thread> ts;
-	std::vector<HRESULT> hrs( (size_t)threadsCount, S_OK );
-	for( int i = 1; i < threadsCount; i++ ) ts.emplace_back( [ pfn, ctx, i, &hrs ]() { hrs[ i ] = pfn( i, ctx ); } );
-	hrs[ 0 ] = pfn( 0, ctx );
-	for( auto& t : ts ) t.join();
-	for( HRESULT hr : hrs )
-		if( FAILED( hr ) ) return hr;
-	return S_OK;
-}
-void setCurrentThreadName( const char* ) {}
+// ---- PcmReader over memory for runStreamed, the thread pool, setCurrentThreadName: shared with the streamer's harness ----
+#include "memory_reader.inl"
 
 static int g_logLevel = 0;		// 0: errors are kept for ci_last_error only; 1: errors and warnings to stderr
 static std::string g_lastError;

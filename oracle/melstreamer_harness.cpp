@@ -4,7 +4,8 @@
 // the oracle of SURVEY.md section 8 row f1 (iContext::runStreamed's per-window spectrogram, MelStreamer.cpp:125-187) and, for row a1,
 // the whole-buffer spectrogram of the GPU model's runFull (Spectrogram::pcmToMel, Spectrogram.cpp:64-122).
 //
-// What this file supplies is what those sources link against and Windows / Media Foundation would provide:
+// What this file and memory_reader.inl (shared with contextimpl_harness.cpp) supply is what those sources link against and Windows / Media
+// Foundation would provide:
 //   * PcmReader's three methods (declared in the reference's MF/PcmReader.h, defined in MF/PcmReader.cpp over IMFSourceReader):
 //     here over PCM in memory (shim/melstreamer/mfidl.h). The rules are PcmReader.cpp's: length = samples / 160 chunks
 //     (:277, :300), whole chunks while 160 samples are buffered (:399-405), ONE final partial chunk padded with zeros (:418-425,
@@ -15,7 +16,7 @@
 //     (off > 0), the next readChunk() computes size - offset below zero as an unsigned number, finds "enough data" and hands out
 //     chunk after chunk of whatever lies behind the vector instead of E_EOF. The streamer asks for two chunks more than frames
 //     (MelStreamer.cpp:32), so on Windows the LAST TWO FRAMES of a stream whose length is not a multiple of 160 samples contain
-//     stale heap memory where zeros belong. The methods below keep the reference's statements in their order, so the behaviour is
+//     stale heap memory where zeros belong. The methods of memory_reader.inl keep the reference's statements in their order, so the behaviour is
 //     reproduced (block = 1000: frame length-1 moves by 1e-2); with one chunk per delivery (block = 160, the default) the last
 //     delivery is the remainder itself, off is 0 and the end of the stream is clean -- that is the configuration the fixture is made
 //     with, and what the product defines (zeros past the last sample).
@@ -30,96 +31,7 @@
 
 using namespace Whisper;
 
-// ---- PcmReader over memory ----
-PcmReader::PcmReader( const iAudioReader* iar )
-{
-	if( nullptr == iar ) throw E_POINTER;
-	check( iar->getReader( &reader ) );
-	sampleHandler = nullptr;	// mono source, mono output (PcmReader.cpp:286-288: HandlerMono)
-	m_length = reader->count / FFT_STEP;
-}
-HRESULT PcmReader::readNextSample()
-{
-	// PcmReader.cpp:307-322 with HandlerMono::moveBufferData (:56-67): the unconsumed tail moves to the front
-	const size_t off = bufferReadOffset;
-	const size_t available = pcm.mono.size() - off;
-	if( available > 0 )
-	{
-		if( 0 != off )
-		{
-			memmove( pcm.mono.data(), pcm.mono.data() + off, available * 4 );
-			pcm.mono.resize( available );
-		}
-	}
-	else
-		pcm.clear();
-	bufferReadOffset = 0;
-	IMFSourceReader& r = *reader;
-	if( r.cursor >= r.count ) return E_EOF;
-	const size_t n = std::min( r.block, r.count - r.cursor );
-	pcm.appendMono( r.pcm + r.cursor, n );
-	r.cursor += n;
-	return S_OK;
-}
-HRESULT PcmReader::readChunk( PcmMonoChunk& mono, PcmStereoChunk* )
-{
-	while( true )
-	{
-		const size_t off = bufferReadOffset;
-		const size_t available = pcm.mono.size() - off;
-		if( available >= FFT_STEP )
-		{
-			memcpy( mono.mono.data(), &pcm.mono[ off ], FFT_STEP * 4 );
-			bufferReadOffset = off + FFT_STEP;
-			return S_OK;
-		}
-		if( !m_readerEndOfFile )
-		{
-			const HRESULT hr = readNextSample();
-			if( SUCCEEDED( hr ) ) continue;
-			if( hr != E_EOF ) return hr;
-			m_readerEndOfFile = true;
-		}
-		if( available > 0 )
-		{
-			memcpy( mono.mono.data(), &pcm.mono[ off ], available * 4 );
-			memset( mono.mono.data() + available, 0, ( FFT_STEP - available ) * 4 );
-			bufferReadOffset = off + available;
-			return S_OK;
-		}
-		return E_EOF;
-	}
-}
-
-// ---- ThreadPoolWork: threadPoolCallback( 0 .. n-1 ) on n threads, the first failure is the result ----
-ThreadPoolWork::~ThreadPoolWork() {}
-HRESULT ThreadPoolWork::create() { return S_OK; }
-HRESULT ThreadPoolWork::parallelFor( int threadsCount ) noexcept
-{
-	std::vector<std::thread> ts;
-	std::vector<HRESULT> hrs( (size_t)threadsCount, S_OK );
-	for( int i = 1; i < threadsCount; i++ ) ts.emplace_back( [ this, i, &hrs ]() { hrs[ i ] = threadPoolCallback( i ); } );
-	hrs[ 0 ] = threadPoolCallback( 0 );
-	for( auto& t : ts ) t.join();
-	for( HRESULT hr : hrs )
-		if( FAILED( hr ) ) return hr;
-	return S_OK;
-}
-
-// the free function of Utils/parallelFor.h (Spectrogram::pcmToMel with threads >= 2, Spectrogram.cpp:86-93)
-HRESULT Whisper::parallelFor( pfnParallelForCallback pfn, int threadsCount, void* ctx )
-{
-	std::vector<std::thread> ts;
-	std::vector<HRESULT> hrs( (size_t)threadsCount, S_OK );
-	for( int i = 1; i < threadsCount; i++ ) ts.emplace_back( [ pfn, ctx, i, &hrs ]() { hrs[ i ] = pfn( i, ctx ); } );
-	hrs[ 0 ] = pfn( 0, ctx );
-	for( auto& t : ts ) t.join();
-	for( HRESULT hr : hrs )
-		if( FAILED( hr ) ) return hr;
-	return S_OK;
-}
-
-void setCurrentThreadName( const char* ) {}
+#include "memory_reader.inl"
 
 static void vlog( const char* level, const char8_t* fmt, va_list ap )
 {
