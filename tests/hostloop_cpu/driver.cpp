@@ -200,3 +200,6 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_run( const char* 
 	return hr;
 }
 extern "C" __attribute__( ( visibility( "default" ) ) ) const char* hl_result() { return g_out.c_str(); }
+
+// support.cpp's language table (Whisper/Whisper/Languages.cpp, languageCodez.inl): the id behind a makeLanguageKey() key, -1 when unknown
+extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_language_id( uint32_t key ) { return lookupLanguageId( key ); }

@@ -345,3 +345,24 @@ def run_case_tt(L, tmp_path, c, pcm, rules, model, thold, mel):
     hr = L.hl_run(path.encode(), rules, C.byref(p), pcm, len(pcm), 4)
     assert hr == 0, hr
     return json.loads(L.hl_result().decode())
+
+
+def test_language_table_against_the_reference(driver):
+    """support.cpp's language table against the reference's Languages.cpp + languageCodez.inl (compiled unmodified into
+    oracle/_ref/libcontextimpl_ref.so): every code of one to three lower-case letters gives the same id (the language token is sot + 1 + id,
+    ContextImpl.cpp:508) or is unknown on both sides."""
+    from oracle import ref
+    if not ref.contextimpl_available():
+        pytest.skip("oracle/_ref/libcontextimpl_ref.so not built (needs /root/reference)")
+    R = ref._contextimpl_lib()
+    driver.hl_language_id.argtypes = [C.c_uint32]
+    import itertools
+    import string
+    known = 0
+    for n in (1, 2, 3):
+        for t in itertools.product(string.ascii_lowercase, repeat=n):
+            code = "".join(t)
+            want = R.ci_language_id(code.encode())
+            assert driver.hl_language_id(language_key(code)) == want, code
+            known += want >= 0
+    assert known >= 99
