@@ -15,6 +15,8 @@
 #include <sstream>
 
 extern "C" {
+int ref_token_special( void* ctx, int which );
+const char* ref_token_to_str( void* ctx, int token );
 void* ref_init( const char* path );
 void ref_free( void* ctx );
 void ref_set_log_level( int lvl );
@@ -203,3 +205,34 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) const char* hl_result() 
 
 // support.cpp's language table (Whisper/Whisper/Languages.cpp, languageCodez.inl): the id behind a makeLanguageKey() key, -1 when unknown
 extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_language_id( uint32_t key ) { return lookupLanguageId( key ); }
+
+// support.cpp's vocabulary loader (loadVocabulary + Vocabulary::finalize: special ids, the tokens the file does not store) against the
+// reference CPU model's own vocabulary of the same file: returns the number of differences (token strings of all ids, the six special ids)
+extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_vocabulary_differences( const char* modelPath, int* nVocabOut )
+{
+	Vocabulary vocab;
+	if( FAILED( loadVocabulary( modelPath, vocab ) ) ) return -1;
+	ref_set_log_level( 0 );
+	void* cpu = ref_init( modelPath );
+	if( !cpu ) return -1;
+	int32_t h[ 11 ];
+	ref_hparams( cpu, h );
+	int diffs = 0;
+	const int special[ 6 ] = { vocab.token_eot, vocab.token_sot, vocab.token_prev, vocab.token_solm, vocab.token_not, vocab.token_beg };
+	for( int i = 0; i < 6; i++ ) diffs += special[ i ] != ref_token_special( cpu, i );
+	diffs += vocab.token_translate != ref_token_special( cpu, 6 ) || vocab.token_transcribe != ref_token_special( cpu, 7 );
+	diffs += vocab.n_vocab != h[ 0 ];
+	for( int id = 0; id < h[ 0 ]; id++ )
+	{
+		const char* a = vocab.string( id );
+		const char* b = ref_token_to_str( cpu, id );
+		if( !a || !b || 0 != strcmp( a, b ) )
+		{
+			if( diffs < 8 ) fprintf( stderr, "vocabulary: token %d '%s' vs the reference's '%s'\n", id, a ? a : "(null)", b ? b : "(null)" );
+			diffs++;
+		}
+	}
+	if( nVocabOut ) *nVocabOut = h[ 0 ];
+	ref_free( cpu );
+	return diffs;
+}

@@ -366,3 +366,15 @@ def test_language_table_against_the_reference(driver):
             assert driver.hl_language_id(language_key(code)) == want, code
             known += want >= 0
     assert known >= 99
+
+
+@pytest.mark.parametrize("kind", ["test-d128", "test-d128-ml"])
+def test_vocabulary_against_the_reference(driver, tmp_path, kind):
+    """support.cpp's vocabulary of a ggml file -- the stored tokens, the ones the loader synthesises ([_EOT_], [_SOT_], [_TT_n], [_extra_token_n] ...)
+    and the special ids of an English-only and a multilingual model -- against the reference CPU model's vocabulary of the same file, id by id."""
+    path = str(tmp_path / "m.bin")
+    gf.write_model(path, gf.synth_model(kind, seed=3))
+    n = C.c_int(0)
+    driver.hl_vocabulary_differences.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    assert driver.hl_vocabulary_differences(path.encode(), C.byref(n)) == 0
+    assert n.value == gf.hparams_for(kind).n_vocab
