@@ -16,6 +16,7 @@
 
 extern "C" {
 int ref_token_special( void* ctx, int which );
+int ref_tokenize( void* ctx, const char* text, int32_t* tokens, int cap );
 const char* ref_token_to_str( void* ctx, int token );
 void* ref_init( const char* path );
 void ref_free( void* ctx );
@@ -233,6 +234,39 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_vocabulary_differ
 		}
 	}
 	if( nVocabOut ) *nVocabOut = h[ 0 ];
+	ref_free( cpu );
+	return diffs;
+}
+
+// Vocabulary::tokenize (iModel::tokenize, the --prompt of the CLI) against the reference's whisper_tokenize on the same file: texts are
+// '\n'-separated; returns the number of texts whose token lists differ
+extern "C" __attribute__( ( visibility( "default" ) ) ) int hl_tokenize_differences( const char* modelPath, const char* texts, int* nTextsOut, int* nTokensOut )
+{
+	Vocabulary vocab;
+	if( FAILED( loadVocabulary( modelPath, vocab ) ) ) return -1;
+	ref_set_log_level( 0 );
+	void* cpu = ref_init( modelPath );
+	if( !cpu ) return -1;
+	int diffs = 0, nTexts = 0, nTokens = 0;
+	std::istringstream in( texts );
+	std::string line;
+	while( std::getline( in, line ) )
+	{
+		std::vector<int> ours;
+		if( FAILED( vocab.tokenize( line.c_str(), ours ) ) ) { diffs++; continue; }
+		std::vector<int32_t> theirs( 4096 );
+		const int n = ref_tokenize( cpu, line.c_str(), theirs.data(), (int)theirs.size() );
+		theirs.resize( (size_t)std::max( n, 0 ) );
+		if( n < 0 || std::vector<int32_t>( ours.begin(), ours.end() ) != theirs )
+		{
+			if( diffs < 5 ) fprintf( stderr, "tokenize: '%s' -> %zu tokens vs the reference's %d\n", line.c_str(), ours.size(), n );
+			diffs++;
+		}
+		nTexts++;
+		nTokens += (int)ours.size();
+	}
+	if( nTextsOut ) *nTextsOut = nTexts;
+	if( nTokensOut ) *nTokensOut = nTokens;
 	ref_free( cpu );
 	return diffs;
 }

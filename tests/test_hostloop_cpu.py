@@ -378,3 +378,23 @@ def test_vocabulary_against_the_reference(driver, tmp_path, kind):
     driver.hl_vocabulary_differences.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     assert driver.hl_vocabulary_differences(path.encode(), C.byref(n)) == 0
     assert n.value == gf.hparams_for(kind).n_vocab
+
+
+def test_tokenizer_against_the_reference(driver, tmp_path):
+    """Vocabulary::tokenize (iModel::tokenize; the CLI's --prompt) against the reference's whisper_tokenize (whisper.cpp:2186-2248) on the same
+    vocabulary: 400 seeded texts of words the vocabulary holds, fragments of them, digits, punctuation, contractions, runs of blanks and tabs, and
+    characters it does not hold (skipped by both)."""
+    path = str(tmp_path / "m.bin")
+    model = gf.synth_model("test-d128-ml", seed=3)
+    gf.write_model(path, model)
+    rng = np.random.default_rng(12)
+    pieces = [" w%d" % i for i in range(300, 340)] + ["w301w302", " w", "w", "3", "42", " 1234", "'s", "'t", "'re", "'ve", "'m", "'ll", "'d", ",", ".", "!", "?", " -", "--",
+              " ", "  ", "\t", " \t ", "it", "It's", " don't", "\u00e9", "\u00fc", "\u4e2d", "#", "@", "(", ")", "a", "b", " the", "W300", " W300"]
+    texts = []
+    for _ in range(400):
+        k = int(rng.integers(1, 12))
+        texts.append("".join(pieces[int(i)] for i in rng.integers(0, len(pieces), k)))
+    n_texts, n_tokens = C.c_int(0), C.c_int(0)
+    driver.hl_tokenize_differences.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    assert driver.hl_tokenize_differences(path.encode(), "\n".join(texts).encode(), C.byref(n_texts), C.byref(n_tokens)) == 0
+    assert n_texts.value == 400 and n_tokens.value > 800
