@@ -54,12 +54,11 @@ N_PROMPT = 3
 N_GREEDY = 51
 # the reference's own published audio-s/s for this clip (its D3D11 backend on a GTX 1080Ti, SampleClips/summary.tsv:10, :14)
 PUBLISHED_AUDIO_S_PER_S = {"medium": 13.30, "large-v2": 7.22, "large": 7.22}
+MAX_LOCKSTEP_WINDOWS = 512   # rows of the decode kernels (csrc/kernels.h GEMV_MAX_ROWS): one context decodes up to this many windows in lock step
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
 MFMA_CLASSES = ("gemmTiled", "attentionEnc")
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc.json")
-if not os.path.exists(PMC_JSON):
-    PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_JSON = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc.json" % r) for r in (5, 4, 3)) if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc.json"))
 BCAST_NOTE = {}        # model kind -> what the weight broadcast of this run was (ranks, bytes, seconds, GB/s)
 EMPTY_KERNEL_US = 1.9
 METRIC = "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU"
@@ -335,6 +334,54 @@ def cpu_baseline(model, model_kind, pcm_one_window, prompt, hip_model=None, want
             return dict(null, cores=n_threads, sample="reference CPU run failed: %s" % str(e)[:200]), None
 
 
+def timed_ids_check(hip_model, hp, pcm_dev_clip, toks_clip, prompt, margin_band=2.5e-2):
+    """What the timed region produced against the same windows decoded ONE AT A TIME (a context of one window: decode1.hip's kernels, nothing in common
+    with the lock-step batch's decode kernels but the arithmetic they implement). toks_clip: ids [windows][1 + N_GREEDY] of one clip of the timed pass.
+    (a) every window alone through the captured greedy graph: its own ids, their checksum next to the timed pass's; (b) every window alone TEACHER-FORCED
+    with the timed pass's ids: where the lone context's argmax is another token, its own margin between the two candidates -- a disagreement is a
+    near-tie decided by FP32 summation order (random weights have many) when that margin is inside the band, and a defect when it is not."""
+    import torch
+    from whisper_amd import binding
+    n_win = int(toks_clip.shape[0])
+    ctx = binding.HipContext(hip_model, 1)
+    own, equal_windows, first_div = [], 0, []
+    disagreements, worst_margin, compared = 0, 0.0, 0
+    for w in range(n_win):
+        mel = ctx.mel_spectrogram(pcm_dev_clip[w])
+        ctx.encode(mel)
+        ctx.decode_window_start(np.asarray([prompt], np.int32), N_GREEDY, force_first_timestamp=True, first_is_initial=True)
+        ids, _ = ctx.decode_window_finish()
+        own.append(ids[:, 0])
+        same = ids[:, 0] == toks_clip[w]
+        equal_windows += int(same.all())
+        first_div.append(None if same.all() else int(np.argmin(same)))
+        # teacher-forced with the timed ids
+        ctx.encode(mel)
+        toks = np.asarray([prompt], np.int32)
+        n_past = 0
+        for s_ in range(N_GREEDY + 1):
+            gl, _ = ctx.decode(toks, n_past, want_probs=False)
+            tok = ctx.sample_best(1, s_ == 0, s_ == 0)[0]["id"]
+            timed = int(toks_clip[w][s_])
+            compared += 1
+            if tok != timed:
+                disagreements += 1
+                worst_margin = max(worst_margin, abs(float(gl[0][tok]) - float(gl[0][timed])))
+            n_past += toks.shape[1]
+            toks = np.asarray([[timed]], np.int32)
+    ctx.close()
+    own = np.stack(own)
+    return {"windows": n_win, "samples_compared": compared,
+            "tokens_checksum_timed": int(np.asarray(toks_clip, np.int64).sum() % 1000003),
+            "tokens_checksum_one_window_at_a_time": int(own.astype(np.int64).sum() % 1000003),
+            "windows_with_identical_ids": "%d/%d" % (equal_windows, n_win), "first_divergence_step": first_div,
+            "teacher_forced_disagreements": disagreements, "largest_margin_at_a_disagreement": round(worst_margin, 5), "margin_band": margin_band,
+            "consistent": bool(disagreements == 0 or worst_margin < margin_band),
+            "what": "clip 0 of the timed pass: each of its windows decoded alone (context of one window, decode1.hip kernels) -- greedily, and teacher-forced with the "
+                    "timed ids; a teacher-forced disagreement is admissible when the lone context's own logit margin between the two tokens is inside the band "
+                    "(a near-tie of random weights decided by FP32 summation order), a greedy divergence follows from the first such tie"}
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the batched pipeline (default workload; also the large_v2 sub-object)
 # ----------------------------------------------------------------------------------------------------------------------
@@ -354,7 +401,7 @@ def plan_batches(steps, C, inflight):
     return [base + 1] * extra + [base] * (nb - extra)
 
 
-def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True, plan=None):
+def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True, plan=None, single_clip=True):
     import torch
     from whisper_amd import binding
     n_frames = WINDOW_SAMPLES // 160
@@ -368,7 +415,7 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
 
     inflight = max(1, inflight)
     sizes = list(plan) if plan else plan_batches(steps, C, inflight)
-    assert sum(sizes) == steps and all(0 < n <= 128 // B for n in sizes), sizes
+    assert sum(sizes) == steps and all(0 < n <= MAX_LOCKSTEP_WINDOWS // B for n in sizes), sizes
     # contexts: for every batch size of the plan as many as are ever in flight at once (at most `inflight`); a context is
     # re-used, in order, by the later batches of its size
     pool, sequence = {}, []
@@ -381,8 +428,8 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
         sequence.append(pool[n][counters[n] % len(pool[n])])
         counters[n] += 1
     distinct = [sl for n in sorted(pool, reverse=True) for sl in pool[n]]
-    # the full-size contexts the per-kernel tables and the lone-batch latency are taken from
-    slots = (pool.get(C, []) + [make_slot(C) for _ in range(inflight)])[:inflight] if want_kernels else distinct[:inflight]
+    # the per-kernel tables and the lone-batch latency are taken from the contexts of the plan's LARGEST batch: what ran in the timed region
+    slots = distinct[:inflight]
     torch.cuda.synchronize()
 
     def barrier():
@@ -398,11 +445,13 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
     toks = run_passes(sequence, prompt, N_GREEDY, inflight)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    out = {"elapsed": elapsed, "toks": toks, "slots": slots, "single_clip_ms": None, "kernels": {}, "lone_batch_ms": None, "plan": sizes}
+    out = {"elapsed": elapsed, "elapsed_local": elapsed_local, "toks": toks, "slots": slots, "last_slot": sequence[-1], "single_clip_ms": None, "kernels": {}, "lone_batch_ms": None, "plan": sizes,
+           "kernel_clips": int(slots[0][2].shape[0]) // B}
     if want_kernels and rank == 0:
         grp = slots[0]
         # (a) one lone batch pass from the captured graph: latency of a batch with nothing else on the GPU
@@ -413,6 +462,9 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
             run_passes([grp], prompt, N_GREEDY, 1)
             lone = min(lone, 1e3 * (time.perf_counter() - t0))
         out["lone_batch_ms"] = lone
+        if not single_clip:
+            slots_k = [slots[0]] if len({int(sl[2].shape[0]) for sl in slots}) > 1 else slots
+            return finish_kernels(out, slots_k, prompt)
         # (b) a lone SINGLE clip (7 windows): the latency a caller with one recording sees from this path
         one = make_slot(1)
         run_passes([one], prompt, N_GREEDY, 1)
@@ -430,26 +482,37 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
         # the kernel (round 3, r3G: cross-attention 134.6 us in brackets with both slots eager, 116.4 us in rocprofv3's trace of
         # the timed region). Alone, the bracket is the launch; rocprofv3 of the timed region (both batches in flight, captured
         # graphs) is committed next to it and tests/test_profiles.py holds the two together.
-        for sl in slots:
-            sl[0].profile(True)
-        for sl in slots:
-            run_passes([sl], prompt, N_GREEDY, 1)
-        acc = {}
-        for sl in slots:
-            for k, v in sl[0].profile_read().items():
-                a = acc.setdefault(k, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-                for f in a:
-                    a[f] += v[f]
-            sl[0].profile(False)
-        out["kernels"] = acc
-        out["kernel_batches"] = len(slots)
+        slots_k = [sl for sl in slots if sl[2].shape[0] == slots[0][2].shape[0]]      # equal batch sizes only: per-launch averages of ONE shape
+        return finish_kernels(out, slots_k, prompt)
     return out
 
 
-def roofline_from(kernels, batch_ms_timed, lone_ms, n_batches=1):
-    """Per-launch figures of the dominant kernel class + the whole-path floor. The event bracket's own cost (class
-    "eventPair": an empty kernel between the same two records) is subtracted from every launch -- a per-launch constant,
-    not a proportional rescale."""
+def finish_kernels(out, slots, prompt):
+    """One eager pass per slot with hipEvent pairs around every launch, one slot at a time -> out["kernels"] (summed over the slots)."""
+    for sl in slots:
+        sl[0].profile(True)
+    for sl in slots:
+        run_passes([sl], prompt, N_GREEDY, 1)
+    acc = {}
+    for sl in slots:
+        for k, v in sl[0].profile_read().items():
+            a = acc.setdefault(k, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            for f in a:
+                a[f] += v[f]
+        sl[0].profile(False)
+    out["kernels"] = acc
+    out["kernel_batches"] = len(slots)
+    return out
+
+
+DECODE_CHAIN_CLASSES = ("selfBlockDec", "gemvFused", "layerNormDec", "attentionDec", "gemmDecode", "gemmSkinny", "embed", "softMaxSample", "vocabSoftMax")
+
+
+def roofline_from(kernels, batch_ms_timed, lone_ms, n_batches=1, batch_windows=None, n_layers=None):
+    """Per-launch figures of the two headline kernel classes (the encoder's matrix-core product, the decode step's HBM-bound cross-attention), the
+    decode chain outside the cross-attention as ONE class, and the whole-path floor -- all from the eager pass over the batch size the timed region
+    ran. The event bracket's own cost (class "eventPair": an empty kernel between the same two records) is subtracted from every launch -- a
+    per-launch constant, not a proportional rescale. The TOP LEVEL repeats whichever of the two headline classes sits LOWER against its roofline."""
     pair = kernels.get("eventPair")
     # the bracket around an EMPTY kernel measures the bracket plus the empty kernel's own run time, 1.9 us in
     # rocprofv3's kernel trace (profiles/r02_kernel_stats_ab.csv, probeEmpty): only the rest is bracket
@@ -480,9 +543,16 @@ def roofline_from(kernels, batch_ms_timed, lone_ms, n_batches=1):
         try:
             if name in pmc.get("kernels", {}):
                 k = pmc["kernels"][name]
-                e["traffic"] = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
-                e["traffic_source"] = "committed counters, NOT measured in this run -- %s: %s" % (os.path.relpath(PMC_JSON, ROOT), pmc.get("note", ""))
-                e["traffic_over_algorithmic"] = round(e["traffic"] / max(k.get("algorithmic_bytes_per_launch", c["bytes"] / c["calls"]), 1.0), 3)
+                counted = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
+                algo_pmc = max(k.get("algorithmic_bytes_per_launch", c["bytes"] / c["calls"]), 1.0)
+                algo_now = c["bytes"] / c["calls"]
+                e["traffic_over_algorithmic"] = round(counted / algo_pmc, 3)
+                # the counter pass ran a batch of its own size: per launch of THIS run's size = the counted ratio x this run's algorithmic bytes
+                same = abs(algo_now - algo_pmc) / algo_pmc < 0.02
+                e["traffic"] = counted if same else int(round(counted / algo_pmc * algo_now))
+                e["traffic_source"] = "committed counters, NOT measured in this run%s -- %s: %s" % (
+                    "" if same else " (counted bytes / algorithmic bytes of the counter pass x the algorithmic bytes of this run's launches)",
+                    os.path.relpath(PMC_JSON, ROOT), pmc.get("note", ""))
         except (ValueError, KeyError):
             pass
         e.update({"avg_launch_us": round(1e3 * c["ms_net"] / c["calls"], 2), "launches_per_batch_pass": c["calls"] // n_batches,
@@ -490,23 +560,43 @@ def roofline_from(kernels, batch_ms_timed, lone_ms, n_batches=1):
                   "algorithmic_per_launch": round((c["flops"] if e["bound"] == "mfma" else c["bytes"]) / c["calls"], 1)})
         return e
 
-    name, dom = max(classes.items(), key=lambda kv: kv[1]["ms_net"])
-    r = entry(name)
-    # the two classes that take turns at the top (the encoder's matrix-core product, the decode step's HBM-bound cross-attention:
-    # 27-32 % of the kernel time each) are both in every line, whichever of them is the dominant one of this run
+    heads = [entry(n) for n in ("gemmTiled", "attentionDecCross") if n in classes]
+    if not heads:
+        heads = [entry(max(classes.items(), key=lambda kv: kv[1]["ms_net"])[0])]
+    r = dict(min(heads, key=lambda e: e["frac"]))
+    r["which"] = ("the LOWER roofline fraction of the two kernel classes with the most time: mfma_kernel (the encoder's matrix-core product) and "
+                  "hbm_kernel (the decode step's cross-attention); both follow, and decode_chain is everything of a decode step outside the cross-attention")
     if "gemmTiled" in classes:
         r["mfma_kernel"] = entry("gemmTiled")
     if "attentionDecCross" in classes:
         r["hbm_kernel"] = entry("attentionDecCross")
+    if "attentionEnc" in classes:
+        r["encoder_attention"] = entry("attentionEnc")
+    chain = [classes[k] for k in DECODE_CHAIN_CLASSES if k in classes]
+    if chain:
+        ms = sum(c["ms_net"] for c in chain)
+        by = sum(c["bytes"] for c in chain)
+        calls = sum(c["calls"] for c in chain)
+        ach = by / (ms * 1e-3) / 1e9
+        r["decode_chain"] = {"kernel": "+".join(k for k in DECODE_CHAIN_CLASSES if k in classes), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_batch": round(ms / n_batches, 2),
+                             "launches_per_batch_pass": calls // n_batches, "avg_launch_us": round(1e3 * ms / calls, 2), "share_of_kernel_time": round(ms / total, 3),
+                             "us_per_window_step_layer": round(1e3 * ms / n_batches / ((N_GREEDY + 1) * n_layers * batch_windows), 4) if (n_layers and batch_windows) else None,
+                             "what": "every launch of a decode step except the cross-attention: LayerNorm + per-head QKV + cache append + self-attention (selfBlockDec), the four "
+                                     "products per layer (class gemvFused: gemvFused up to 128 sequences, gemmDecRows beyond), LayerNorm, the vocabulary product, sampler, "
+                                     "embedding, and the prompt step's tiles; algorithmic bytes = weights once per launch + activations"}
     floor_ms = sum(1e3 * (c["flops"] / (MFMA_PEAK_TFLOPS * 1e12) if k in MFMA_CLASSES else c["bytes"] / (HBM_PEAK_GBS * 1e9)) for k, c in classes.items()) / n_batches
     r.update({
         "event_pair_us": round(calib_us, 2),
+        "batch_windows": batch_windows,
         "timing": "hipEvent pairs around every launch (eager) on the launch stream, one batch pass per slot, one slot at a time, "
                   "minus %.2f us per launch = the same bracket around an empty kernel less that kernel's own 1.9 us" % calib_us,
         "end_to_end": {"floor_ms_per_batch": round(floor_ms, 2), "measured_ms_per_batch": round(batch_ms_timed, 2),
                        "frac": round(floor_ms / batch_ms_timed, 4), "lone_batch_ms": round(lone_ms, 2) if lone_ms else None,
+                       "batch_windows": batch_windows,
                        "definition": "sum over kernel classes of algorithmic flops / 2.5 PFLOP/s (gemmTiled, attentionEnc) or "
-                                     "algorithmic bytes / 8 TB/s (all others), per lock-step batch, over the measured time per batch in the timed region"}})
+                                     "algorithmic bytes / 8 TB/s (all others) of ONE lock-step batch of the size the timed region ran, over the time the timed region "
+                                     "took per such batch (elapsed / batches x batches in flight... = elapsed x batch clips / clip passes)"}})
     table = {k: {"calls": c["calls"], "ms": round(c["ms_net"], 3), "avg_us": round(1e3 * c["ms_net"] / c["calls"], 2),
                  "tflops": round(c["flops"] / c["ms_net"] / 1e9, 2), "gbs": round(c["bytes"] / c["ms_net"] / 1e6, 1)} for k, c in classes.items()}
     return r, table
@@ -599,7 +689,8 @@ def through_boundary(model_kind, steps, C, inflight, B=7):
             if first < n_clip:
                 streams.append((pcm, first, min(WINDOW_SAMPLES, n_clip - first)))
     sizes = plan_batches(steps, C, inflight)
-    slots = min(128, max(sizes) * B)
+    inflight = min(inflight, len(sizes))
+    slots = min(MAX_LOCKSTEP_WINDOWS, max(sizes) * B)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "scripted.bin")
         gf.write_model(path, model)
@@ -758,11 +849,13 @@ def main():
                          "(large-v2, strong scaling); beam5 = configs[2]: 8 x 30 s chunks x 5 hypotheses per chunk (large-v2, 50 steps); "
                          "v3stream = configs[4]: the clip workload on the large-v3 shape (128 mels, vocabulary 51866), translate task")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--clips-per-batch", type=int, default=16, help="clip passes decoded as ONE lock-step batch (7 windows each); a step stays one clip "
-                    "pass, K steps run as K // C batches plus one batch with the remainder. 16 clips = 112 windows = 1792 (window, head) pairs = exactly 7 per "
-                    "CU in the cross-attention, the kernel that streams the most bytes (28 windows leave a quarter of the CUs with half the work); measured "
-                    "on MI355X, ms per clip pass: 4 clips x 3 in flight 38.2, 8 x 3 35.8, 12 x 2 37.4, 16 x 1 40.2, 16 x 2 35.0")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight, each on its own context and HIP stream")
+    ap.add_argument("--clips-per-batch", type=int, default=64, help="the most clip passes decoded as ONE lock-step batch (7 windows each); a step stays one clip "
+                    "pass, K steps are dealt into balanced batches of at most this many clips (plan_batches). Round 5: 64 clips = 448 windows in one context (the "
+                    "decode kernels take up to 512 rows, the encoder runs in chunks of <= 128 windows); rounds 2-4 ran 16 clips = 112 windows x 2 contexts in "
+                    "flight (--clips-per-batch 16 --inflight 2 reproduces that)")
+    ap.add_argument("--inflight", type=int, default=2, help="batches in flight, each on its own context and HIP stream, when the plan has more than one batch "
+                    "(K <= clips-per-batch runs as ONE batch on one context)")
+    ap.add_argument("--no-ids-check", action="store_true", help="skip parity.timed_ids (the timed pass's ids against the same windows one at a time)")
     ap.add_argument("--plan", default=None, help="explicit batch sizes of the timed region, e.g. 16,4 (default: plan_batches(steps, clips-per-batch, inflight))")
     ap.add_argument("--batch", type=int, default=16, help="shard256 / beam5: windows per lock-step batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -850,21 +943,33 @@ def main():
 
     B = args.windows
     C = max(1, args.clips_per_batch)
-    if B * C > 128:
-        raise SystemExit("windows x clips-per-batch must not exceed 128 (rows of the decode kernel)")
+    if B * C > MAX_LOCKSTEP_WINDOWS:
+        raise SystemExit("windows x clips-per-batch must not exceed %d (rows of the decode kernels)" % MAX_LOCKSTEP_WINDOWS)
+    # everything fits ONE lock-step batch: one context, nothing in flight beside it (a second context would only halve the rows of every decode launch)
+    inflight = 1 if (args.steps <= C and not args.plan) else max(1, args.inflight)
     audio_seconds = CLIP_SECONDS * B / 7.0
     if rank == 0:
         log("warmup + timed region: %d steps ..." % args.steps)
     plan = [int(x) for x in args.plan.split(",")] if args.plan else None
-    m = measure_batched(hip_model, hp, prompt, args.steps, args.warmup, B, C, args.inflight, rank, world, dist,
+    m = measure_batched(hip_model, hp, prompt, args.steps, args.warmup, B, C, inflight, rank, world, dist,
                         want_kernels=not args.no_roofline, plan=plan)
     elapsed, toks, batch_plan = m["elapsed"], m["toks"], m.get("plan")
+    inflight = min(inflight, len(batch_plan))
     if rank == 0:
-        log("timed region done: %.3f s (batches of %s clips)" % (elapsed, batch_plan))
+        log("timed region done: %.3f s (batches of %s clips, %d in flight)" % (elapsed, batch_plan, inflight))
+    per_rank = None
+    if world > 1:
+        # every rank's own figure next to the job's (value = all ranks' audio / the slowest rank's time)
+        mine = torch.tensor([m.get("elapsed_local", elapsed)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [round(audio_seconds * args.steps / float(t.item()), 2) for t in allr]
 
     roofline, kernels = None, {}
     if rank == 0 and m["kernels"]:
-        roofline, kernels = roofline_from(m["kernels"], 1e3 * elapsed / args.steps * C, m["lone_batch_ms"], m.get("kernel_batches", 1))
+        kc = m["kernel_clips"]
+        roofline, kernels = roofline_from(m["kernels"], 1e3 * elapsed * kc / args.steps, m["lone_batch_ms"], m.get("kernel_batches", 1),
+                                          batch_windows=kc * B, n_layers=hp.n_text_layer)
         roofline["single_clip"] = {"ms": round(m["single_clip_ms"], 2), "audio_seconds_per_sec": round(audio_seconds / (m["single_clip_ms"] * 1e-3), 1),
                                    "what": "ONE %.0f s clip (7 windows as one lock-step batch) alone on the GPU, H2D to token ids" % audio_seconds}
 
@@ -873,6 +978,15 @@ def main():
         log("cpu baseline + parity (reference CPU path, bounded) ...")
         cpu, parity = cpu_baseline(model, args.model, m["slots"][0][2][0].cpu().numpy(), prompt, hip_model)
         log("cpu baseline done: %s" % cpu.get("value"))
+    if rank == 0 and world == 1 and not args.no_ids_check:
+        # the ids the TIMED region produced (last batch, clip 0) against the same windows one at a time
+        try:
+            last_slot = m["last_slot"]
+            chk = timed_ids_check(hip_model, hp, last_slot[2][:B], np.asarray(toks)[:B], prompt)
+            parity = dict(parity or {}, timed_ids=chk)
+            log("timed ids vs one window at a time: %s identical, consistent = %s" % (chk["windows_with_identical_ids"], chk["consistent"]))
+        except Exception as e:       # the sub-object must not take the line down
+            parity = dict(parity or {}, timed_ids={"error": str(e)[:300]})
     for s in m["slots"]:
         s[0].close()
     del m
@@ -881,7 +995,7 @@ def main():
     if rank == 0 and world == 1 and args.workload == "clip" and not args.no_boundary and args.model in ("medium", "large-v2"):
         log("the same workload through libWhisper.so (createBatchRunner) ...")
         try:
-            boundary = through_boundary(args.model, args.steps, C, args.inflight, B)
+            boundary = through_boundary(args.model, args.steps, C, inflight, B)
             log("through the boundary: %s audio-s/s" % boundary["value"])
         except Exception as e:
             boundary = {"error": str(e)[:300]}
@@ -900,11 +1014,21 @@ def main():
                 hp2, model2, hm2, _, _ = load("large-v2")
                 sp2 = gf.special_tokens(hp2)
                 p2 = [sp2["sot"], sp2["sot"] + 1, sp2["transcribe"]]
-                n2 = 2 * C
-                m2 = measure_batched(hm2, hp2, p2, n2, 1, B, C, args.inflight, 0, 1, dist, want_kernels=False)
+                n2 = args.steps
+                m2 = measure_batched(hm2, hp2, p2, n2, 1, B, C, inflight, 0, 1, dist, want_kernels=not args.no_roofline, single_clip=False)
                 large = {"model": "ggml-large-v2", "value": round(audio_seconds * n2 / m2["elapsed"], 2), "unit": "audio-seconds/sec", "steps": n2,
-                         "ms_per_step": round(1e3 * m2["elapsed"] / n2, 3), "same_pipeline": True,
+                         "ms_per_step": round(1e3 * m2["elapsed"] / n2, 3), "same_pipeline": True, "batch_plan": m2["plan"],
                          "vs_published_single_clip": "the reference publishes 7.22 audio-s/s for ONE sequential clip on a GTX 1080Ti (BASELINE.md section 1)"}
+                if m2["kernels"]:
+                    kc2 = m2["kernel_clips"]
+                    large["roofline"], large["kernels"] = roofline_from(m2["kernels"], 1e3 * m2["elapsed"] * kc2 / n2, m2["lone_batch_ms"], m2.get("kernel_batches", 1),
+                                                                        batch_windows=kc2 * B, n_layers=hp2.n_text_layer)
+                    # the counter file holds the medium shape: no traffic figure for this one
+                    for e in (large["roofline"], large["roofline"].get("mfma_kernel", {}), large["roofline"].get("hbm_kernel", {}), large["roofline"].get("encoder_attention", {})):
+                        for k_ in ("traffic_source", "traffic_over_algorithmic"):
+                            e.pop(k_, None)
+                        if "traffic" in e:
+                            e["traffic"] = None
                 pcm2 = m2["slots"][0][2][0].cpu().numpy()
                 for s in m2["slots"]:
                     s[0].close()
@@ -933,10 +1057,11 @@ def main():
             "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, the %d clip passes of the timed region dealt "
                                    "into lock-step batches of %s clips (at most %d), %d batches in flight on separate HIP streams; pinned host PCM -> H2D -> GPU mel + encoder + "
                                    "%d-token prompt + %d greedy steps per window, device-side sampling (captured hipGraph per token); span = first H2D byte to "
-                                   "last token id on the host" % (args.model, audio_seconds, B, args.steps, batch_plan, C, args.inflight, N_PROMPT, N_GREEDY),
+                                   "last token id on the host" % (args.model, audio_seconds, B, args.steps, batch_plan, C, inflight, N_PROMPT, N_GREEDY),
                        "model": "ggml-" + args.model, "task": "translate" if args.workload == "v3stream" else "transcribe",
                        "baseline": "BASELINE.md section 1 publishes one sequential clip on a GTX 1080Ti (13.30 audio-s/s medium): compared in single_stream, not here",
-                       "windows_per_clip": B, "clips_per_batch": C, "batch_plan": batch_plan, "batches_in_flight": args.inflight, "decode_steps_per_window": N_GREEDY + 1,
+                       "windows_per_clip": B, "clips_per_batch": C, "batch_plan": batch_plan, "batches_in_flight": inflight, "lockstep_windows": max(batch_plan) * B, "decode_steps_per_window": N_GREEDY + 1,
+                       "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_audio_seconds_per_sec": per_rank,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast outside the timed region: %s)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
             "rtf": round(elapsed / (args.steps * audio_seconds), 6),
             "roofline": roofline,

@@ -325,7 +325,7 @@ namespace Whisper
 	};
 	struct sBatchSetup
 	{
-		uint32_t maxSlots;		// streams per lock-step batch (the device contexts are sized for it); 0 = 64, at most 128
+		uint32_t maxSlots;		// streams per lock-step batch (the device contexts are sized for it); 0 = 64, at most 512
 		uint32_t groups;		// lock-step batches in flight; 0 = 2
 		uint32_t greedyChunk;	// greedy steps enqueued at a time; 0 = 4. The host applies its stop rules chunk by chunk, so up to one chunk is decoded past the end of a round
 		uint32_t flags;			// 1 = keep one more chunk queued behind the one in flight (the device never waits for the host; up to two chunks are decoded in vain)

@@ -45,7 +45,7 @@ EXPORTS = [
     "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning",
+    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -84,6 +84,7 @@ def lib():
         vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.POINTER(C.c_float)
         L.wh_last_error.restype = C.c_char_p
         L.wh_debug_set_tuning.argtypes = [C.c_uint32]
+        L.wh_debug_set_option.argtypes = [C.c_char_p, C.c_int]
         if os.environ.get("WH_TUNING"):          # kernel-variant mask for A/B runs and for testing a candidate variant
             L.wh_debug_set_tuning(int(os.environ["WH_TUNING"], 0))
         L.wh_device_info.argtypes = [i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -139,6 +140,11 @@ def lib():
 def check(rc: int):
     if rc != 0:
         raise WhisperHipError("libwhisper_hip rc=%d: %s" % (rc, lib().wh_last_error().decode(errors="replace")))
+
+
+def set_option(name: str, value: int):
+    """Integer knobs beyond the 32 tuning bits (csrc/kernels.h struct Options): dec_tile, vocab_decrows, enc_chunk, self_fuse_max_rows, self_nq."""
+    check(lib().wh_debug_set_option(name.encode(), int(value)))
 
 
 def device_count() -> int:
@@ -432,7 +438,12 @@ class HipContext:
             out = np.empty(0x5000, np.float32)
             check(lib().wh_debug_read(self.handle, what.encode(), 0, 0, out.ctypes.data_as(C.c_void_p), out.size))
             return out
-        if what == "enc.temp1":
+        if what in ("logits", "probs"):
+            shape = (rows, self.hp.n_vocab)         # rows = sequences of the last decode step
+            rows = 0
+        elif what in ("cross-k1", "cross-v1"):
+            shape = (self.hp.n_audio_ctx, d)        # rows = window index
+        elif what == "enc.temp1":
             shape = (b, 2 * self.hp.n_audio_ctx, d)
         elif what.startswith("dec-KQV"):
             shape = (rows, d)

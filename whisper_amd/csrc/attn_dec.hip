@@ -1107,7 +1107,13 @@ namespace wh
 		const int wgs1 = a.H * a.batch;
 		const bool mf = ( g_tuning & TUNE_SELF_MFMA ) != 0;
 		// (8 sequences per workgroup at 1792 pairs: 34.3 vs 32.7 us per launch -- the kernel is a latency chain, not L2-bound; not kept)
-		if( wgs1 > 768 ) return mf ? launchSelfBlockK<4, true>( a, stream ) : launchSelfBlockK<4, false>( a, stream );
+		// more than 128 sequences (one lock-step batch of 224 .. 448 windows): 8 per workgroup keep the grid at what 4 per workgroup are for 112 .. 224
+		// (option self_nq pins 1 / 2 / 4 / 8 for A/B runs)
+		const int nq = g_opt.selfNq;
+		if( mf && ( nq == 8 || ( nq == 0 && wgs1 > 3584 ) ) ) return launchSelfBlockK<8, true>( a, stream );
+		if( nq == 1 ) return mf ? launchSelfBlockK<1, true>( a, stream ) : launchSelfBlockK<1, false>( a, stream );
+		if( nq == 2 ) return mf ? launchSelfBlockK<2, true>( a, stream ) : launchSelfBlockK<2, false>( a, stream );
+		if( wgs1 > 768 || nq == 4 ) return mf ? launchSelfBlockK<4, true>( a, stream ) : launchSelfBlockK<4, false>( a, stream );
 		if( wgs1 > 320 ) return mf ? launchSelfBlockK<2, true>( a, stream ) : launchSelfBlockK<2, false>( a, stream );
 		return mf ? launchSelfBlockK<1, true>( a, stream ) : launchSelfBlockK<1, false>( a, stream );
 	}

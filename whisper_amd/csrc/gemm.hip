@@ -2716,6 +2716,155 @@ namespace wh
 					if( nn + r < a.N ) epilogueOne<EPI>( a, mm, nn + r, part[ i ][ r ] );
 			}
 		}
+
+		// -----------------------------------------------------------------------------------------------------------
+		// gemmDecRows: the products of a decode step whose lock-step batch is LARGER than 128 sequences (129 .. 512 rows: one
+		// context of 224 .. 448 windows instead of two of 112). At that many rows a product is a small GEMM (448 x 4096 x 1024:
+		// 3.8 GFLOP against 8 MB of weights), and gemvFused's 16-column workgroups would re-read the activation rows once per
+		// 16 columns: 64 KB of L2 -> CU traffic per 16 x 64 outputs. Here a workgroup owns 16 CT weight rows x 16 MT activation
+		// rows (64 x 64 by default: 8 fragment loads feed 16 MFMAs per k-step and wave, 2.5 x fewer bytes per output), the 4
+		// waves split K exactly as gemvFused's do and their partial tiles meet in LDS in wave order 0, 1, 2, 3 -- the same
+		// summation order, so a row's result does not depend on which of the two kernels (or which row tile) computed it.
+		// Grid (column tiles, row tiles). Operands come straight from L2 (every wave reads its own K quarter: nothing to share
+		// through LDS); two k-steps of loads are in flight per wave.
+		template<int EPI, int MT, int CT>
+		__global__ void __launch_bounds__( 256 ) gemmDecRows( const GemmArgs a )
+		{
+			constexpr int NW = 4, G = MT * CT;
+			constexpr int GPW = ( G + NW - 1 ) / NW;
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) float redD[];	 // [NW][G * 4][64]
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int n0 = blockIdx.x * 16 * CT;
+			const int m0 = blockIdx.y * 16 * MT;
+			const int kPer = a.K / NW;
+			const int kBeg = wave * kPer + ( lane >> 4 ) * 8;
+			const int steps = kPer / 32;
+
+			const f16* pw[ CT ];
+	#pragma unroll
+			for( int c = 0; c < CT; c++ )
+			{
+				int n = n0 + c * 16 + ( lane & 15 );
+				n = n < a.N ? n : a.N - 1;
+				pw[ c ] = a.W + (long long)n * a.K + kBeg;
+			}
+			const f16* px[ MT ];
+	#pragma unroll
+			for( int t = 0; t < MT; t++ )
+			{
+				int m = m0 + t * 16 + ( lane & 15 );
+				m = m < a.M ? m : a.M - 1;
+				px[ t ] = a.A + rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + kBeg;
+			}
+
+			f32x4 acc[ MT ][ CT ];
+	#pragma unroll
+			for( int t = 0; t < MT; t++ )
+	#pragma unroll
+				for( int c = 0; c < CT; c++ ) acc[ t ][ c ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+			// software pipeline: the fragments of k-step s + 1 are requested before the MFMAs of step s
+			f16x8 fw[ 2 ][ CT ], fx[ 2 ][ MT ];
+	#pragma unroll
+			for( int c = 0; c < CT; c++ ) fw[ 0 ][ c ] = *(const f16x8*)( pw[ c ] );
+	#pragma unroll
+			for( int t = 0; t < MT; t++ ) fx[ 0 ][ t ] = *(const f16x8*)( px[ t ] );
+			for( int s0 = 0; s0 < steps; s0 += 2 )
+			{
+	#pragma unroll
+				for( int u = 0; u < 2; u++ )
+				{
+					const int s = s0 + u;
+					if( s >= steps ) break;
+					if( s + 1 < steps )
+					{
+	#pragma unroll
+						for( int c = 0; c < CT; c++ ) fw[ u ^ 1 ][ c ] = *(const f16x8*)( pw[ c ] + ( s + 1 ) * 32 );
+	#pragma unroll
+						for( int t = 0; t < MT; t++ ) fx[ u ^ 1 ][ t ] = *(const f16x8*)( px[ t ] + ( s + 1 ) * 32 );
+					}
+	#pragma unroll
+					for( int t = 0; t < MT; t++ )
+	#pragma unroll
+						for( int c = 0; c < CT; c++ )
+							acc[ t ][ c ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ u ][ c ], fx[ u ][ t ], acc[ t ][ c ], 0, 0, 0 );
+				}
+			}
+
+			// ---- the 4 K-quarters of the workgroup meet in LDS ----
+	#pragma unroll
+			for( int t = 0; t < MT; t++ )
+	#pragma unroll
+				for( int c = 0; c < CT; c++ )
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) redD[ ( wave * G * 4 + ( t * CT + c ) * 4 + r ) * 64 + lane ] = acc[ t ][ c ][ r ];
+			__syncthreads();
+			f32x4 part[ GPW ];
+	#pragma unroll
+			for( int i = 0; i < GPW; i++ )
+			{
+				const int g = wave + NW * i;
+				if( g >= G ) continue;
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+				{
+					float v = redD[ ( 0 * G * 4 + g * 4 + r ) * 64 + lane ];
+	#pragma unroll
+					for( int w = 1; w < NW; w++ ) v += redD[ ( w * G * 4 + g * 4 + r ) * 64 + lane ];
+					part[ i ][ r ] = v;
+				}
+			}
+
+			// ---- epilogue: D[row][col]: col = lane & 15 = activation row of the tile, row = (lane >> 4) * 4 + r = weight row slot
+			const bool fast32 = EPI == EPI_F32 && ( a.N & 3 ) == 0 && a.Mb >= a.M;
+			const bool fastGelu = EPI == EPI_F16_GELU && ( a.N & 3 ) == 0 && a.Mb >= a.M;
+	#pragma unroll
+			for( int i = 0; i < GPW; i++ )
+			{
+				const int g = wave + NW * i;
+				if( g >= G ) continue;
+				const int t = g / CT, c = g - t * CT;
+				const int mm = m0 + t * 16 + ( lane & 15 );
+				const int nn = n0 + c * 16 + ( lane >> 4 ) * 4;
+				if( mm >= a.M || nn >= a.N ) continue;
+				if( fast32 )
+				{
+					// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
+					f32x4 o = part[ i ];
+					if( a.bias )
+					{
+						const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) o[ r ] += bv[ r ];
+					}
+					const long long off = (long long)mm * a.ldc + nn;
+					if( a.res )
+					{
+						const f32x4 rv = *(const f32x4*)( a.res + off );
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) o[ r ] += rv[ r ];
+					}
+					*(f32x4*)( a.out32 + off ) = o;
+					continue;
+				}
+				if( fastGelu )
+				{
+					// gelu16( acc + bias ), the arithmetic of epilogueOne<EPI_F16_GELU>, four columns as one 8-byte store
+					const f32x4 bv = *(const f32x4*)( a.bias + nn );
+					f16x4 hv;
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) hv[ r ] = gelu16( part[ i ][ r ] + bv[ r ] );
+					*(f16x4*)( a.out16 + (long long)mm * a.ldc + nn ) = hv;
+					continue;
+				}
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+					if( nn + r < a.N ) epilogueOne<EPI>( a, mm, nn + r, part[ i ][ r ] );
+			}
+		}
 	}	// namespace
 
 	template<int EPI, int MT>
@@ -2750,6 +2899,62 @@ namespace wh
 		case 7: return launchAllRowsT<EPI_F32, 7>( a, tiles, stream );
 		default: return launchAllRowsT<EPI_F32, 8>( a, tiles, stream );
 		}
+	}
+
+	template<int EPI, int MT, int CT>
+	static int launchDecRowsK( const GemmArgs& a, hipStream_t stream )
+	{
+		constexpr int lds = 4 * MT * CT * 4 * 64 * 4;
+		if( lds > 48 * 1024 )
+		{
+			static PerDeviceOnce once;
+			if( const int onceDev = once.needed(); onceDev >= 0 )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecRows<EPI, MT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				once.mark( onceDev );
+			}
+		}
+		hipLaunchKernelGGL( ( gemmDecRows<EPI, MT, CT> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 16 * MT - 1 ) / ( 16 * MT ) ), dim3( 256 ), lds, stream, a );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	// Tile of a big-batch decode product: 64 x 64 (rows x columns) while that leaves enough workgroups for the chip, else 64 x 32, else 32 x 32.
+	// Option dec_tile = <MT><CT> (44, 42, 24, 22) pins one for A/B runs and tests.
+	template<int EPI>
+	static int launchDecRowsT( const GemmArgs& a, hipStream_t stream )
+	{
+		const int pinned = g_opt.decTile;
+		auto wgs = [ & ]( int mt, int ct ) { return ( ( a.N + 16 * ct - 1 ) / ( 16 * ct ) ) * ( ( a.M + 16 * mt - 1 ) / ( 16 * mt ) ); };
+		int tile = pinned;
+		if( tile != 44 && tile != 42 && tile != 24 && tile != 22 )
+			tile = wgs( 4, 4 ) >= 192 ? 44 : ( wgs( 4, 2 ) >= 192 ? 42 : 22 );
+		switch( tile )
+		{
+		case 44: return launchDecRowsK<EPI, 4, 4>( a, stream );
+		case 42: return launchDecRowsK<EPI, 4, 2>( a, stream );
+		case 24: return launchDecRowsK<EPI, 2, 4>( a, stream );
+		default: return launchDecRowsK<EPI, 2, 2>( a, stream );
+		}
+	}
+
+	// 129 .. GEMV_MAX_ROWS rows, A in global memory (a LayerNorm in front is its own launch at this many rows)
+	static int launchDecRows( const GemmArgs& a, hipStream_t stream )
+	{
+		if( a.lnX || ( a.K % 128 ) != 0 )
+		{
+			setError( "gemv: more than 128 rows need FP16 activation rows and K a multiple of 128" );
+			return -1;
+		}
+		switch( a.epi )
+		{
+		case EPI_F32: return launchDecRowsT<EPI_F32>( a, stream );
+		case EPI_F16_GELU: return launchDecRowsT<EPI_F16_GELU>( a, stream );
+		case EPI_QKV_DEC: return launchDecRowsT<EPI_QKV_DEC>( a, stream );
+		case EPI_Q_DEC: return launchDecRowsT<EPI_Q_DEC>( a, stream );
+		}
+		setError( "gemv: epilogue not available" );
+		return -1;
 	}
 
 	template<int EPI, int PRO, int ROWS, int NW, int UNROLL, int MT>
@@ -2805,9 +3010,12 @@ namespace wh
 	{
 		if( a.M <= 0 || a.M > GEMV_MAX_ROWS || a.N <= 0 || a.K <= 0 || ( a.K % 128 ) != 0 )
 		{
-			setError( "gemv: need 0 < M <= 128 and K a multiple of 128" );
+			setError( "gemv: need 0 < M <= 512 and K a multiple of 128" );
 			return -1;
 		}
+		// more than 128 rows (a lock-step batch of 129 .. 512 sequences): 64 x 64 output tiles per workgroup (gemmDecRows).
+		// Option dec_tile = 1 keeps gemvFused (16 columns x 64 rows per workgroup, row groups in blockIdx.y) for A/B runs.
+		if( a.M > GEMV_FUSED_MAX_ROWS && ( g_opt.decTile != 1 || a.lnX ) ) return launchDecRows( a, stream );
 		const bool ln = a.lnX != nullptr;
 		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_ALLROWS ) )
 		{

@@ -52,6 +52,17 @@ namespace wh
 	};
 	extern unsigned g_tuning;
 
+	// Integer knobs beyond the 32 tuning bits: wh_debug_set_option( name, value ) in a process, WH_OPT_<NAME> in the environment at load.
+	struct Options
+	{
+		int decTile = 0;			 // "dec_tile": decode products of 129 .. 512 rows: 0 = tile by shape, 44 / 42 / 24 / 22 = 16 MT rows x 16 CT columns pinned, 1 = gemvFused row groups
+		int vocabDecRows = 0;		 // "vocab_decrows": more than 128 sequences: the vocabulary product through gemmDecRows instead of the M-tiled kernel
+		int encChunk = 128;			 // "enc_chunk": the most windows ONE encoder pass takes; contexts created afterwards encode larger batches in equal chunks
+		int selfFuseMaxRows = 512;	 // "self_fuse_max_rows": selfBlockDec up to this many sequences, LayerNorm + QKV product + attention launches beyond
+		int selfNq = 0;				 // "self_nq": sequences per selfBlockDec workgroup (0 = by grid size; 1, 2, 4, 8)
+	};
+	extern Options g_opt;
+
 	// ---------------------------------------------------------------------------------------------------------------
 	// NT GEMM: acc[m][n] = sum_k A[m][k] * W[n][k], FP16 operands, FP32 accumulate on MFMA (32x32x16).
 	// Replaces mulMatTiled.hlsl / mulMatByRowTiled.hlsl and, through the row mapping below, the five convolution*.hlsl
@@ -105,10 +116,11 @@ namespace wh
 
 	int launchGemm( const GemmArgs& a, hipStream_t stream );		// M-tiled kernel, any M
 	int launchGemmSkinny( const GemmArgs& a, hipStream_t stream );	// M <= 32 rows, any K % 64 == 0: weights streamed once
-	// M <= 32 rows, K % 128 == 0: 16 (or 4) weight rows per workgroup, every load of a wave in flight at once, optional
-	// fused LayerNorm prologue; the decode-step kernel
+	// the decode-step kernels, K % 128 == 0. M <= 128 rows: 16 (or 4) weight rows per workgroup, every load of a wave in flight at once,
+	// optional fused LayerNorm prologue (up to 32 rows); 129 .. 512 rows: 64 x 64 output tiles, FP16 activation rows only
 	int launchGemv( const GemmArgs& a, hipStream_t stream );
-	constexpr int GEMV_MAX_ROWS = 128;
+	constexpr int GEMV_FUSED_MAX_ROWS = 128;	 // gemvFused / gemmAllRows: 16 (32) columns x up to 128 rows per workgroup
+	constexpr int GEMV_MAX_ROWS = 512;		 // beyond that, up to here: gemmDecRows (64 x 64 output tiles, the lock-step batches of 129 .. 512 sequences)
 	int launchGemmVariant( const GemmArgs& a, int variant, hipStream_t stream );	// tile-shape experiments, EPI_F32 only
 	int gemmInit();													// one-time function attributes
 

@@ -35,6 +35,24 @@ struct ncclUniqueIdBlob { char internal[ 128 ]; };
 namespace wh
 {
 	unsigned g_tuning = TUNE_DEFAULT;
+	Options g_opt;
+	namespace
+	{
+		struct OptionName { const char* name; int Options::* field; };
+		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq } };
+		// WH_OPT_DEC_TILE=44 ... at load
+		const bool g_optionsFromEnv = []()
+		{
+			for( const OptionName& o : g_optionNames )
+			{
+				std::string env = "WH_OPT_";
+				for( const char* p = o.name; *p; p++ ) env.push_back( (char)toupper( (unsigned char)*p ) );
+				if( const char* e = getenv( env.c_str() ) ) g_opt.*( o.field ) = atoi( e );
+			}
+			return true;
+		}();
+	}
 	static thread_local std::string g_lastError;
 	void setError( const std::string& s ) { g_lastError = s; }
 	int hipFail( hipError_t e, const char* what, const char* file, int line )
@@ -183,13 +201,15 @@ static int bindDevice( const wh_model* m )
 enum eKernelClass : int
 {
 	KC_GEMM_TILED = 0, KC_GEMM_SKINNY, KC_GEMV, KC_ATTN_ENC, KC_ATTN_DEC, KC_ATTN_DEC_CROSS, KC_SELF_BLOCK, KC_LAYER_NORM, KC_MEL, KC_MEL_TO_CONV, KC_EMBED, KC_SOFTMAX,
-	KC_SAMPLE, KC_EVENT_PAIR, KC_COUNT
+	KC_SAMPLE, KC_EVENT_PAIR, KC_LAYER_NORM_DEC, KC_GEMM_DEC, KC_COUNT
 };
 // "attentionDecCross" = cross-attention launches (attentionDecG<NQ, true> / <NQ, false> with group or nKeys = n_audio_ctx),
 // "attentionDec" = causal self-attention; "eventPair" = the calibration launches of wh_profile_enable (an empty kernel
 // between the same two event records: what the bracket itself costs, to be subtracted from every per-launch average).
 static const char* const kernelClassNames[ KC_COUNT ] = { "gemmTiled", "gemmSkinny", "gemvFused", "attentionEnc", "attentionDec", "attentionDecCross",
-	"selfBlockDec", "layerNorm", "mel", "melToConvInput", "embed", "vocabSoftMax", "softMaxSample", "eventPair" };
+	"selfBlockDec", "layerNorm", "mel", "melToConvInput", "embed", "vocabSoftMax", "softMaxSample", "eventPair", "layerNormDec", "gemmDecode" };
+// "layerNormDec" / "gemmDecode" = the LayerNorm launches and the M-tiled products of the DECODER graph (prompt steps; the vocabulary product of more than
+// 128 sequences): kept apart from the encoder's, whose classes are the MFMA roofline of the bench line
 
 struct Profiler
 {
@@ -244,9 +264,11 @@ struct wh_context
 	bool encoded = false;
 	int lastBatch = 0;	   // decoder sequences of the last decode call
 	int lastEncBatch = 0;  // windows of the last wh_encode
+	int encChunk = 0;	   // windows the ENCODER runs at a time: its activations are sized for this many, a larger lock-step batch is encoded in
+						   // equal chunks (the products are MFMA-bound and saturated at ~100 windows; only the cross-attention caches hold all windows)
 	// encoder activations
 	f16 *convIn = nullptr, *conv1Out = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *vT = nullptr, *attn = nullptr, *h = nullptr;
-	float *x = nullptr, *encOut = nullptr;
+	float* x = nullptr;
 	int64_t convInStride = 0, conv1Stride = 0;
 	// caches
 	f16 *crossK = nullptr, *crossV = nullptr, *selfK = nullptr, *selfV = nullptr;
@@ -295,11 +317,11 @@ struct wh_context
 	int capDecRows = 0;
 	int profKeysHint = 1;	   // profiler only: keys a device-positioned self-attention launch sees (host mirror of the largest position + 1)
 	bool ownsStream = false;
-	// pinned host staging for fully asynchronous enqueues: ints [0, 1024) window offsets, [1024, 1032) the sampler state,
-	// [1032, 1032 + maxSeq) positions, then the prompt tokens of a window (up to n_text_ctx per sequence)
+	// pinned host staging for fully asynchronous enqueues: ints [0, 4096) window offsets or descriptors (6 ints each: up to 682 windows),
+	// [4096, 4104) the sampler state, [4104, 4104 + maxSeq) positions, then the prompt tokens of a window (up to n_text_ctx per sequence)
 	int32_t* pinned = nullptr;
 	int64_t pinnedInts = 0;
-	static constexpr int PIN_STATE = 1024, PIN_POS = 1032;
+	static constexpr int PIN_WINDOWS = 4096, PIN_STATE = PIN_WINDOWS, PIN_POS = PIN_STATE + 8;
 	int32_t* pinTokens() const { return pinned + PIN_POS + maxSeq; }
 	int64_t pinTokenCap() const { return pinnedInts - PIN_POS - maxSeq; }
 	struct Allocation { void* base; void* body; int64_t bytes; const char* name; };
@@ -422,7 +444,7 @@ namespace
 	EncGate g_encGate[ 64 ];
 	constexpr int ENC_SERIAL_MIN_WINDOWS = 8;	  // a one-window context (a single stream, a loader) neither waits nor makes others wait
 }
-static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
+static int gemmP( wh_context* c, const GemmArgs& g, bool skinny, bool decoder = false )
 {
 	const bool sk = skinny && g.M <= 32;
 	const double flops = 2.0 * g.M * g.N * g.K;
@@ -440,11 +462,11 @@ static int gemmP( wh_context* c, const GemmArgs& g, bool skinny )
 		static const int spare = []() { const char* e = getenv( "WH_GEMM_SPARE_CUS" ); const int v = e ? atoi( e ) : 32; return v >= 0 && v <= 128 ? v & ~7 : 32; }();
 		gl.cuLimit = c->totalCus - spare;
 	}
-	return profiled( c, sk ? KC_GEMM_SKINNY : KC_GEMM_TILED, flops, bytes, [ & ]() { return sk ? launchGemmSkinny( gl, c->stream ) : launchGemm( gl, c->stream ); } );
+	return profiled( c, sk ? KC_GEMM_SKINNY : ( decoder ? KC_GEMM_DEC : KC_GEMM_TILED ), flops, bytes, [ & ]() { return sk ? launchGemmSkinny( gl, c->stream ) : launchGemm( gl, c->stream ); } );
 }
-static int lnP( wh_context* c, const float* x, const float* w, const float* b, f16* out, int rows, int d )
+static int lnP( wh_context* c, const float* x, const float* w, const float* b, f16* out, int rows, int d, bool decoder = false )
 {
-	return profiled( c, KC_LAYER_NORM, 8.0 * rows * d, 6.0 * rows * d, [ & ]() { return launchLayerNorm( x, w, b, out, rows, d, c->stream ); } );
+	return profiled( c, decoder ? KC_LAYER_NORM_DEC : KC_LAYER_NORM, 8.0 * rows * d, 6.0 * rows * d, [ & ]() { return launchLayerNorm( x, w, b, out, rows, d, c->stream ); } );
 }
 static int attnDecP( wh_context* c, const DecAttnArgs& a, int keysHint = -1 )
 {
@@ -1119,7 +1141,14 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	c->T = T;
 	c->Tpad = roundUp( T, 256 );
 	c->maxRows = c->maxSeq * hp.n_text_ctx;
-	const int64_t rowsE = B * T;
+	{
+		// option enc_chunk = the most windows one encoder pass takes (default 128); a larger batch is cut into equal chunks
+		const int chunkMax = g_opt.encChunk >= 1 && g_opt.encChunk <= 1024 ? g_opt.encChunk : 128;
+		const int nChunks = ( maxBatch + chunkMax - 1 ) / chunkMax;
+		c->encChunk = ( maxBatch + nChunks - 1 ) / nChunks;
+	}
+	const int64_t Be = c->encChunk;
+	const int64_t rowsE = Be * T;
 	c->convInStride = ( 2ll * T + 2 ) * hp.n_mels;
 	c->conv1Stride = ( 2ll * T + 2 ) * d;
 	int rc = 0;
@@ -1129,18 +1158,17 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	// of the allocation and, like the padding rows, stays zero for the life of the context. conv2 (K = 3 d over rows of
 	// stride 2 d, last row ending at (2 T + 1) d) never leaves its (2 T + 2) d rows.
 	const int64_t conv1Tail = conv1Kpad( hp ) - 3 * hp.n_mels;
-	rc = rc ? rc : c->alloc( c->convIn, B * c->convInStride + conv1Tail, wh_context::MUST_BE_ZERO, "convIn" );
-	rc = rc ? rc : c->alloc( c->conv1Out, B * c->conv1Stride, wh_context::MUST_BE_ZERO, "conv1Out" );
+	rc = rc ? rc : c->alloc( c->convIn, Be * c->convInStride + conv1Tail, wh_context::MUST_BE_ZERO, "convIn" );
+	rc = rc ? rc : c->alloc( c->conv1Out, Be * c->conv1Stride, wh_context::MUST_BE_ZERO, "conv1Out" );
 	rc = rc ? rc : c->alloc( c->x, rowsE * d, wh_context::DONT_CARE, "x" );
-	rc = rc ? rc : c->alloc( c->encOut, rowsE * d, wh_context::DONT_CARE, "encOut" );
 	rc = rc ? rc : c->alloc( c->xn, rowsE * d, wh_context::DONT_CARE, "xn" );
 	rc = rc ? rc : c->alloc( c->q, rowsE * d, wh_context::DONT_CARE, "q" );
 	rc = rc ? rc : c->alloc( c->k, rowsE * d, wh_context::DONT_CARE, "k" );
-	rc = rc ? rc : c->alloc( c->vT, B * H * HEAD_DIM * c->Tpad, wh_context::MUST_BE_ZERO, "vT" );
+	rc = rc ? rc : c->alloc( c->vT, Be * H * HEAD_DIM * c->Tpad, wh_context::MUST_BE_ZERO, "vT" );
 	rc = rc ? rc : c->alloc( c->attn, rowsE * d, wh_context::DONT_CARE, "attn" );
 	rc = rc ? rc : c->alloc( c->h, rowsE * 4 * d, wh_context::DONT_CARE, "h" );
-	rc = rc ? rc : c->alloc( c->crossK, (int64_t)hp.n_text_layer * rowsE * d, wh_context::MUST_BE_ZERO, "crossK" );
-	rc = rc ? rc : c->alloc( c->crossV, (int64_t)hp.n_text_layer * rowsE * d, wh_context::MUST_BE_ZERO, "crossV" );
+	rc = rc ? rc : c->alloc( c->crossK, (int64_t)hp.n_text_layer * B * T * d, wh_context::MUST_BE_ZERO, "crossK" );
+	rc = rc ? rc : c->alloc( c->crossV, (int64_t)hp.n_text_layer * B * T * d, wh_context::MUST_BE_ZERO, "crossV" );
 	rc = rc ? rc : c->alloc( c->selfK, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, wh_context::MUST_BE_ZERO, "selfK" );
 	rc = rc ? rc : c->alloc( c->selfV, (int64_t)hp.n_text_layer * S * hp.n_text_ctx * d, wh_context::MUST_BE_ZERO, "selfV" );
 	const int64_t rowsD = c->maxRows;
@@ -1433,9 +1461,10 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 	const Layout& L = m->L;
 	hipStream_t st = c->stream;
 	const int d = hp.n_audio_state, H = hp.n_audio_head, T = c->T;
-	const int M = batch * T;
+	const int batchAll = batch;
 
-	if( batch > 1024 ) { setError( "encode: batch too large" ); return WH_E_INVALIDARG; }
+	if( batch > wh_context::PIN_WINDOWS ) { setError( "encode: batch too large" ); return WH_E_INVALIDARG; }
+	if( batch > c->encChunk && ( c->flags & WH_FLAG_DEBUG_CAPTURE ) ) { setError( "encode: the probe-point capture needs a batch of one encoder chunk" ); return WH_E_INVALIDARG; }
 	const bool gated = ( g_tuning & TUNE_ENC_SERIAL ) && batch >= ENC_SERIAL_MIN_WINDOWS && liveContexts( m ).load( std::memory_order_relaxed ) > 1;
 	if( gated )
 	{
@@ -1443,7 +1472,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 		EncGate& gate = g_encGate[ m->device & 63 ];
 		if( gate.last && gate.owner != c ) WH_HIP( hipStreamWaitEvent( st, gate.last, 0 ) );
 	}
-	// offsets go through pinned staging (ints [0, 1024)): the copy is truly asynchronous and the call never blocks.
+	// offsets go through pinned staging (ints [0, 4096)): the copy is truly asynchronous and the call never blocks.
 	// The staging is rewritten by the next wh_encode only, which the stream orders after this copy has been consumed
 	// as long as the caller synchronises once per window (wh_decode / wh_decode_window_finish do).
 	const MelWindow* winsDev = nullptr;
@@ -1451,7 +1480,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 	{
 		// per-window sources (wh_encode_windows): descriptors through the same staging, 6 ints each
 		static_assert( sizeof( MelWindow ) == 24 && sizeof( wh_mel_window ) == 24, "window descriptor layout" );
-		if( (size_t)batch * sizeof( MelWindow ) > 1024 * sizeof( int32_t ) ) { setError( "encode_windows: batch too large" ); return WH_E_INVALIDARG; }
+		if( (size_t)batch * sizeof( MelWindow ) > wh_context::PIN_WINDOWS * sizeof( int32_t ) ) { setError( "encode_windows: batch too large" ); return WH_E_INVALIDARG; }
 		MelWindow* const stage = (MelWindow*)c->pinned;
 		for( int i = 0; i < batch; i++ )
 		{
@@ -1466,8 +1495,18 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 		for( int i = 0; i < batch; i++ ) c->pinned[ i ] = melOffsets ? melOffsets[ i ] : 0;
 		WH_HIP( hipMemcpyAsync( c->melOffsetsDev, c->pinned, sizeof( int32_t ) * batch, hipMemcpyHostToDevice, st ) );
 	}
+	// A batch larger than the encoder's chunk is encoded chunk by chunk through the same activations: windows are independent, the
+	// products are MFMA-bound and saturated at a chunk's row count, and only the cross-attention caches (written in place at the
+	// chunk's window offset) are sized for the whole batch.
+	const int nChunks = ( batchAll + c->encChunk - 1 ) / c->encChunk;
+	const int perChunk = ( batchAll + nChunks - 1 ) / nChunks;
+	for( int b0 = 0; b0 < batchAll; b0 += perChunk )
+	{
+	batch = std::min( perChunk, batchAll - b0 );
+	const int M = batch * T;
 	WH_CHECK( profiled( c, KC_MEL_TO_CONV, 0.0, 6.0 * batch * 2.0 * T * hp.n_mels,
-		[ & ]() { return launchMelToConvInput( melDev, melStride, melLen, c->melOffsetsDev, winsDev, c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ); } ) );
+		[ & ]() { return launchMelToConvInput( melDev ? melDev + (int64_t)b0 * melStride : nullptr, melStride, melLen, c->melOffsetsDev + b0, winsDev ? winsDev + b0 : nullptr,
+			c->convIn, c->convInStride, hp.n_mels, 2 * T, batch, st ); } ) );
 
 	// conv1 (k=3, stride 1, pad 1) + bias + GELU as an implicit GEMM over the padded time-major input:
 	// row t of the im2col matrix is the contiguous slice starting at padded row t (whisper.cpp:1127-1136; ggml.c:5199-5318)
@@ -1537,10 +1576,13 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 		g.epi = EPI_CROSS_KV;
 		g.bias = m->at<float>( L.bcross );
 		g.scale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
-		g.k = c->crossK; g.v = c->crossV;
+		// [layer][window][head][T][64]: the chunk's first window; the layer stride stays maxBatch windows
+		g.k = c->crossK + (int64_t)b0 * T * d; g.v = c->crossV + (int64_t)b0 * T * d;
 		g.T = T; g.H = H; g.B = c->maxBatch;
 		WH_CHECK( gemmP( c, g, false ) );
 	}
+	}	// chunks
+	batch = batchAll;
 	if( gated )
 	{
 		std::lock_guard<std::mutex> lk( g_encGateMx );
@@ -1581,14 +1623,14 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	// (from 9 sequences up: with fewer, one workgroup per (head, sequence) leaves the 6 d^2 bytes of QKV weights to H CUs at
 	// ~25 GB/s each -- 15.7 us per layer at one sequence -- and the separate gemv + attention launches are faster: 74.3 vs 86.6 ms
 	// per window at batch 1, 100.4 vs 101.9 at 7)
-	const bool fuseSelf = nTokens == 1 && d <= 1280 && hp.n_text_ctx <= 512 && parity == 0 && batch > 8 && ( g_tuning & TUNE_FUSE_SELF_BLOCK );
+	const bool fuseSelf = nTokens == 1 && d <= 1280 && hp.n_text_ctx <= 512 && parity == 0 && batch > 8 && batch <= g_opt.selfFuseMaxRows && ( g_tuning & TUNE_FUSE_SELF_BLOCK );
 	// decode steps: the cross-attention kernel normalises the residual row and projects its own head's query
 	const bool fuseCrossQ = nTokens == 1 && d <= 1280 && parity <= 8 && ( g_tuning & TUNE_FUSE_CROSS_Q );
 
 	auto product = [ & ]( GemmArgs& g, const float* lnW, const float* lnB ) -> int
 	{
 		g.nPastDev = nPastDev;
-		if( !gemv ) return gemmP( c, g, true );
+		if( !gemv ) return gemmP( c, g, true, true );
 		if( lnW && fuseLn )
 		{
 			g.lnX = c->dx; g.lnW = lnW; g.lnB = lnB;
@@ -1755,7 +1797,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 		}
 		else
 		{
-		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d ) );
+		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln1w ), m->at<float>( e.ln1b ), c->dxn, M, d, true ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wqkv ), M, 3 * d, d );
 			g.epi = EPI_QKV_DEC;
@@ -1787,7 +1829,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 		// cross-attention
 		if( !fuseCrossQ )
 		{
-			if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d ) );
+			if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.lncw ), m->at<float>( e.lncb ), c->dxn, M, d, true ) );
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.wcq ), M, d, d );
 			g.epi = EPI_Q_DEC; g.bias = m->at<float>( e.bcq ); g.scale = kqScale; g.q = c->dq;
 			WH_CHECK( product( g, m->at<float>( e.lncw ), m->at<float>( e.lncb ) ) );
@@ -1823,7 +1865,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 			WH_CHECK( product( g, nullptr, nullptr ) );
 		}
 		// MLP
-		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d ) );
+		if( !fuseLn ) WH_CHECK( lnP( c, c->dx, m->at<float>( e.ln2w ), m->at<float>( e.ln2b ), c->dxn, M, d, true ) );
 		{
 			GemmArgs g = plainGemm( c->dxn, m->at<f16>( e.w1 ), M, 4 * d, d );
 			g.epi = EPI_F16_GELU; g.bias = m->at<float>( e.b1 ); g.out16 = c->dh;
@@ -1838,7 +1880,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	// final norm + logits for the LAST token of every sequence only (the reference computes all rows, whisper.cpp:1840,
 	// and then consumes just the last one, ContextImpl.cpp:159-169). The norm stays a separate launch here: fusing it
 	// into the 3242 workgroups of the vocabulary product would re-read the rows 3242 times.
-	WH_CHECK( lnP( c, c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d ) );
+	WH_CHECK( lnP( c, c->dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), c->dxn, M, d, true ) );
 	// prompts of different lengths (rows right-padded to nTokens): the row of every sequence's own last token moves to where the
 	// product below reads, row nTokens - 1 of the sequence
 	if( c->raggedLastPos && nTokens > 1 ) WH_CHECK( launchGatherLastRows( c->dxn, c->raggedLastPos, batch, nTokens, d, st ) );
@@ -1846,7 +1888,16 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 		GemmArgs g = plainGemm( c->dxn + (int64_t)( nTokens - 1 ) * d, m->at<f16>( L.te ), batch, hp.n_vocab, d );
 		g.lda = nTokens * d;
 		g.epi = EPI_F32; g.out32 = c->logits; g.ldc = hp.n_vocab;
-		WH_CHECK( product( g, nullptr, nullptr ) );
+		// more than 128 sequences: the vocabulary matrix (106 / 133 MB) against that many rows is a GEMM of ~50 GFLOP whose weight tiles should be
+		// fetched once: the M-tiled kernel (128 x 128 tiles, 400 column tiles x ceil(batch / 128) row tiles)
+		// (option vocab_decrows: gemmDecRows instead, for A/B runs)
+		if( gemv && batch > GEMV_FUSED_MAX_ROWS && !g_opt.vocabDecRows )
+		{
+			g.nPastDev = nPastDev;
+			WH_CHECK( gemmP( c, g, true, true ) );
+		}
+		else
+			WH_CHECK( product( g, nullptr, nullptr ) );
 	}
 	return 0;
 }
@@ -2394,9 +2445,26 @@ int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* 
 		for( int i = 0; i < EXP_TABLE_ENTRIES; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
 		return 0;
 	}
+	if( w == "logits" || w == "probs" )
+	{
+		// what the LAST decode step left: logits (or, after wh_decode with probsHost / the sampler, probabilities) of every sequence, [seqs][n_vocab]
+		const int64_t n = (int64_t)seqs * hp.n_vocab;
+		if( n <= 0 || dstCapFloats < n ) return WH_E_BOUNDS;
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		WH_HIP( hipMemcpy( dstHost, w == "logits" ? c->logits : c->probs, (size_t)n * 4, hipMemcpyDeviceToHost ) );
+		return 0;
+	}
+	if( w == "cross-k1" || w == "cross-v1" )
+	{
+		// ONE window (index `rows`) of a layer's cross-attention cache: [n_ctx][d] -- contexts of hundreds of windows
+		if( layer < 0 || layer >= hp.n_text_layer || rows < 0 || rows >= batch || dstCapFloats < (int64_t)c->T * d ) return WH_E_BOUNDS;
+		const f16* base = ( w == "cross-k1" ? c->crossK : c->crossV ) + ( (int64_t)layer * c->maxBatch + rows ) * c->T * d;
+		return readHeadMajor( c, base, 1, c->T, c->T, dstHost );
+	}
 	if( w == "encode-out" )
 	{
-		// the FP16 LayerNorm output that feeds the cross-attention projection
+		// the FP16 LayerNorm output that feeds the cross-attention projection (of a batch the encoder took in one chunk)
+		if( batch > c->encChunk ) { setError( "debug_read: encode-out holds the last encoder chunk only" ); return WH_E_BOUNDS; }
 		const int64_t n = (int64_t)batch * c->T * d;
 		if( dstCapFloats < n ) return WH_E_BOUNDS;
 		std::vector<uint16_t> tmp( (size_t)n );
@@ -2622,6 +2690,19 @@ int wh_debug_set_tuning( uint32_t mask )
 {
 	g_tuning = mask;
 	return 0;
+}
+
+int wh_debug_set_option( const char* name, int value )
+{
+	if( !name ) { setError( "debug_set_option: null name" ); return WH_E_INVALIDARG; }
+	for( const OptionName& o : g_optionNames )
+		if( 0 == strcmp( o.name, name ) )
+		{
+			g_opt.*( o.field ) = value;
+			return 0;
+		}
+	setError( "debug_set_option: unknown option" );
+	return WH_E_INVALIDARG;
 }
 
 int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter )

@@ -462,7 +462,7 @@ namespace Whisper
 				if( const char* e = getenv( "WHISPER_BATCH_CHUNK" ) ) chunk = atoi( e );
 				if( const char* e = getenv( "WHISPER_BATCH_LOOKAHEAD" ) ) lookahead = atoi( e ) ? 1 : 0;
 				chunk = std::max( 1, std::min( chunk, 64 ) );
-				maxSlots = std::max<uint32_t>( 1, std::min<uint32_t>( maxSlots, 128 ) );
+				maxSlots = std::max<uint32_t>( 1, std::min<uint32_t>( maxSlots, 512 ) );
 				nGroups = std::max<uint32_t>( 1, std::min<uint32_t>( nGroups, 8 ) );
 			}
 			~BatchRunner() override
