@@ -841,7 +841,7 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64, help="clip passes in the timed region (default 64 = two lock-step batches of 32 clips = 224 windows in flight)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default=None, help="medium (default), large-v2, large-v3")
     ap.add_argument("--workload", default="clip", choices=["clip", "shard256", "beam5", "v3stream"],
@@ -945,8 +945,10 @@ def main():
     C = max(1, args.clips_per_batch)
     if B * C > MAX_LOCKSTEP_WINDOWS:
         raise SystemExit("windows x clips-per-batch must not exceed %d (rows of the decode kernels)" % MAX_LOCKSTEP_WINDOWS)
-    # everything fits ONE lock-step batch: one context, nothing in flight beside it (a second context would only halve the rows of every decode launch)
-    inflight = 1 if (args.steps <= C and not args.plan) else max(1, args.inflight)
+    # Measured (profiles/r05_ab_variants.txt section 1): two contexts in flight beat one of twice the size at every K (8821 vs 8400 audio-s/s at 64 passes,
+    # 7614 vs 7297 at 20), so the K passes are always dealt into an even number of batches of at most C clips: 20 -> 10 + 10, 32 -> 16 + 16 (rounds 2-4's
+    # plan), 64 -> 32 + 32 and 128 -> 64 + 64 (the 224- / 448-window contexts of round 5: decode products on gemmDecRows, encoder in chunks)
+    inflight = max(1, args.inflight)
     audio_seconds = CLIP_SECONDS * B / 7.0
     if rank == 0:
         log("warmup + timed region: %d steps ..." % args.steps)
