@@ -774,15 +774,45 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
         best = np.argmax(score, axis=1)
         return hist[np.arange(k), best]
 
+    def beam_start(c, mel_batch):
+        """The same search with the ranking ON THE DEVICE (wh_beam_window_*, round 5): encoder, prompt step, first ranking and n_steps ranked steps are
+        enqueued without a host sync -- every step one replay of a captured graph (cache reorder -> decode -> softmax -> candidates -> ranking)."""
+        k = mel_batch.shape[0]
+        c.encode(mel_batch, sync=False)
+        c.beam_window_start(np.tile(base, (k, 1)), hyp, n_steps)          # rules = None: forced steps, like the host-ranked loop above
+
+    def beam_finish(c, k):
+        st = c.beam_window_status()
+        rec = c.beam_window_records(0, n_steps + 1)
+        out = np.zeros((k, n_steps + 1), np.int32)
+        for w in range(k):
+            best = max(range(st[w]["nLive"]), key=lambda j: (st[w]["live"][j]["sum"], -j))
+            out[w] = c.beam_chain(rec, w, st[w]["live"][best]["rec"])
+        return out
+
     def transcribe(lb, le):
         outs, pending = [], []
         idx = list(range(lb - b, le - b, per))
-        if hyp > 1:
+        if hyp > 1 and getattr(args, "beam_host", False):
             # host-ranked steps: one batch at a time per context; the contexts still alternate
             for n, i0 in enumerate(idx):
                 k = min(per, le - b - i0)
                 best = beam_batch(ctxs[n % len(ctxs)], mels[i0:i0 + k])
                 outs.append(np.concatenate([best] * hyp, axis=1))      # one row of hyp * (n_steps + 1) ints per window, like the greedy layout
+            ids = np.concatenate(outs, axis=0) if outs else np.zeros((0, hyp * (n_steps + 1)), np.int32)
+            return ids.reshape(le - lb, hyp * (n_steps + 1))
+        if hyp > 1:
+            # device-ranked: nothing comes back between the steps, so the contexts overlap like the greedy ones do
+            for n, i0 in enumerate(idx):
+                c = ctxs[n % len(ctxs)]
+                while len(pending) >= len(ctxs):
+                    pc, pk = pending.pop(0)
+                    outs.append(np.concatenate([beam_finish(pc, pk)] * hyp, axis=1))
+                k = min(per, le - b - i0)
+                beam_start(c, mels[i0:i0 + k])
+                pending.append((c, k))
+            for pc, pk in pending:
+                outs.append(np.concatenate([beam_finish(pc, pk)] * hyp, axis=1))
             ids = np.concatenate(outs, axis=0) if outs else np.zeros((0, hyp * (n_steps + 1)), np.int32)
             return ids.reshape(le - lb, hyp * (n_steps + 1))
         for n, i0 in enumerate(idx):
@@ -828,7 +858,9 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
                                "shards over %d rank(s), lock-step batches of %d windows x %d hypotheses sharing one pass over the cross-attention K/V%s, "
                                "%d contexts in flight, %d-token prompt + %d greedy steps per sequence; token ids gathered on rank 0"
                                % (args.model, n_chunks, world, per, hyp, " (beam search: every step the pool of hyp x hyp continuations of a window is ranked by cumulative "
-                                  "log-probability on the host, the best hyp survive, parents' self-attention cache rows move with them)" if hyp > 1 else "",
+                                  "log-probability %s, the best hyp survive, parents' self-attention cache rows move with them)" %
+                                  ("on the host after every step (--beam-host)" if getattr(args, "beam_host", False) else
+                                   "ON THE DEVICE by a kernel inside the captured step graph: no host round trip between the steps of a window") if hyp > 1 else "",
                                   len(ctxs), N_PROMPT, n_steps),
                    "model": "ggml-" + args.model, "chunks": n_chunks, "hypotheses": hyp, "windows_per_batch": per,
                    "parallelism": "dp%d (independent windows; RCCL weight broadcast outside the timed region: %s; no collective in the step)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
@@ -858,6 +890,8 @@ def main():
     ap.add_argument("--no-ids-check", action="store_true", help="skip parity.timed_ids (the timed pass's ids against the same windows one at a time)")
     ap.add_argument("--plan", default=None, help="explicit batch sizes of the timed region, e.g. 16,4 (default: plan_batches(steps, clips-per-batch, inflight))")
     ap.add_argument("--batch", type=int, default=16, help="shard256 / beam5: windows per lock-step batch")
+    ap.add_argument("--beam-host", action="store_true", help="beam5: rank every step's candidates on the host (round 4's data path) instead of on the device")
+    ap.add_argument("--no-beam", action="store_true", help="skip the beam5 sub-object of the default line (BASELINE configs[2] on the large-v2 model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
@@ -1035,6 +1069,16 @@ def main():
                 for s in m2["slots"]:
                     s[0].close()
                 log("large-v2: %s audio-s/s" % large["value"])
+                if not args.no_beam:
+                    # BASELINE configs[2]: large-v2, 8 x 30 s synthetic mel chunks, beam_size = 5 -- ranking on the device
+                    try:
+                        ba = argparse.Namespace(batch=8, inflight=2, warmup=2, steps=8, model="large-v2", beam_host=False)
+                        bl = run_chunks(ba, hm2, hp2, p2, 0, 1, dist, 8, 5, 50, 0.0)
+                        large["beam5"] = {"value": bl["value"], "unit": "audio-seconds/sec", "sequences_per_second": bl["sequences_per_second"], "ms_per_step": bl["ms_per_step"],
+                                          "steps": bl["steps"], "tokens_checksum": bl["tokens_checksum"], "workload": bl["config"]["workload"]}
+                        log("large-v2 beam5: %s audio-s/s" % bl["value"])
+                    except Exception as e:
+                        large["beam5"] = {"error": str(e)[:300]}
                 if not args.no_cpu_baseline:
                     # BASELINE names both models: the reference's CPU path beside the large-v2 figure too (one window: its encoder alone
                     # is ~15-20 s on 16 threads), and the same parity object as the headline's, at d = 1280 / 20 heads / 32 layers

@@ -80,6 +80,10 @@ int32_t whisperc_debug_token_string( const char* modelPath, int32_t token, char*
  * (Whisper/source/whisper.cpp:2765-3120: drops the past prompt when < 5 s remain, retries a failed window once without it),
  * 1 = its GPU model's ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:452-793: neither rule). */
 int32_t whisperc_set_host_loop_rules( int mode );
+/* Where eSamplingStrategy::BeamSearch ranks a step's candidates: 0 (default) = on the device, the whole step a captured graph and the host polling
+ * `done` every 16 steps (wh_beam_window_*); 1 = on the host after every step (wh_beam_candidates / wh_reorder_self_cache: the round-4 decoder, kept as
+ * the checker of the device's restatement -- the two must give the same transcript). Process-wide. */
+int32_t whisperc_set_beam_ranking( int onHost );
 #ifdef __cplusplus
 }
 #endif

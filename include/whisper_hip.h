@@ -222,6 +222,51 @@ WH_API int wh_sample_best( wh_context* c, int batch, int forceTimestamp, int isI
 WH_API int wh_beam_candidates( wh_context* c, int batch, int width, int forceTimestamp, int isInitial, wh_token_data* out );
 WH_API int wh_reorder_self_cache( wh_context* c, int batch, const int32_t* parents, int rows );
 
+/* Beam search WITHOUT the host in the loop (round 5; configs[2] of BASELINE.json). The per-step ranking above -- pool of live hypotheses x candidates
+ * by parent score + log p, the best `width` accepted, the window's stop rules applied to each (WindowScan of libWhisper.so's host loop =
+ * Whisper/Whisper/ContextImpl.cpp:597-673), finished / live lists, "can a live hypothesis still win" -- runs as a kernel behind every decode step,
+ * writes the parents the next step's cache reorder reads and the tokens its embedding reads, and the whole step (reorder -> decode -> softmax ->
+ * candidates -> ranking) is ONE captured graph replayed per token. The host enqueues chunks of steps and polls `done`.
+ *   wh_beam_window_start    windows x (hypotheses of the context) sequences; promptTokens HOST [windows][nPrompt] (every slot of a window starts from
+ *                           it); rules HOST [windows]; the prompt step, the first ranking (sampleTimestamp( true ) rules) and nSteps ranked steps are
+ *                           enqueued, nothing blocks. forced != 0 in a window's rules: no stop rules, every hypothesis lives (random-weight workloads).
+ *   wh_beam_window_continue nSteps more (bounded by n_text_ctx like wh_decode_window_continue). Steps enqueued after a window is done change nothing.
+ *   wh_beam_window_status   blocks until everything enqueued has run; the search state of every window: HOST [windows].
+ *   wh_beam_window_records  the accepted proposals of ranking steps [firstStep, firstStep + count): HOST [count][windows][width]; a hypothesis' token
+ *                           chain is followed from its `rec` (= step * width + index) through `parent` down to -1 (parent == -2: unused entry).
+ * Width 1 is the greedy decoder token for token. */
+typedef struct wh_beam_rules
+{
+	int32_t seek, seekEnd;		/* the window's first frame and the stream's end, 10 ms units */
+	int32_t nMax;				/* n_text_ctx / 2 - 4 */
+	int32_t maxTokens;			/* sFullParams::max_tokens (0 = no limit) */
+	int32_t singleSegment;
+	int32_t tokenBeg, tokenEot;
+	int32_t forced;
+} wh_beam_rules;
+typedef struct wh_beam_hyp
+{
+	double sum;					/* cumulative log-probability */
+	int32_t i, hasTs, seekDelta, resultLen, failed, over;	/* WindowScan's state */
+	int32_t nTok, rec;
+} wh_beam_hyp;
+typedef struct wh_beam_window
+{
+	int32_t step, nLive, nFinished, done;
+	int32_t nPrompt, nTextCtx, reserved0, reserved1;
+	wh_beam_hyp live[ 8 ];
+	wh_beam_hyp finished[ 24 ];
+} wh_beam_window;
+typedef struct wh_beam_record
+{
+	wh_token_data t;
+	int32_t parent, finished, reserved;
+} wh_beam_record;
+WH_API int wh_beam_window_start( wh_context* c, int windows, const int32_t* promptTokens, int nPrompt, int width, const wh_beam_rules* rules, int nSteps );
+WH_API int wh_beam_window_continue( wh_context* c, int nSteps );
+WH_API int wh_beam_window_status( wh_context* c, wh_beam_window* out );
+WH_API int wh_beam_window_records( wh_context* c, int firstStep, int count, wh_beam_record* out );
+
 /* The greedy loop of ContextImpl::runFullImpl (Whisper/Whisper/ContextImpl.cpp:597-673: decode -> sampleBest ->
  * feed the token back) kept on the device for nSteps tokens: firstTokens (HOST, [batch]) are fed at position nPast, each
  * step runs the decoder for one token per sequence, samples with the sampleBest rules and feeds the choice back, with

@@ -36,6 +36,13 @@ static HRESULT onSegment( iContext* ctx, uint32_t nNew, void* user ) noexcept
 	sTranscribeLength len;
 	r->getSize( len );
 	r->Release();
+	// and the reference's own idiom (Examples/main/main.cpp:57-58): no NewObject, released on scope exit -- the context's embedded object
+	iTranscribeResult* emb = nullptr;
+	if( FAILED( ctx->getResults( eResultFlags::Timestamps | eResultFlags::Tokens, &emb ) ) || !emb ) return E_FAIL;
+	sTranscribeLength len2;
+	emb->getSize( len2 );
+	emb->Release();
+	if( len2.countSegments != len.countSegments ) return E_FAIL;
 	s.visible.push_back( len.countSegments );
 	iModel* m = nullptr;
 	if( FAILED( ctx->getModel( &m ) ) || !m ) return E_FAIL;

@@ -64,7 +64,28 @@ namespace
 		HRESULT getTime( int64_t& rdi ) const override { rdi = time; return S_OK; }
 	};
 	int g_newSegments = 0;
-	HRESULT newSegment( iContext*, uint32_t nNew, void* ) noexcept { g_newSegments += (int)nNew; return S_OK; }
+	int g_callbackFaults = 0;
+	// The reference's own callback idiom (Examples/main/main.cpp:55-58: `CComPtr<iTranscribeResult> r; ctx->getResults( flags, &r );`): results WITHOUT
+	// eResultFlags::NewObject, released on scope exit. The object belongs to the context -- Release must not delete it, and the next getResults (and the
+	// context's destructor) must find it alive. Called twice per callback, the second through the first's storage.
+	HRESULT newSegment( iContext* ctx, uint32_t nNew, void* ) noexcept
+	{
+		g_newSegments += (int)nNew;
+		uint32_t seen[ 2 ] = { 0, 0 };
+		const iTranscribeResult* firstObject = nullptr;
+		for( int k = 0; k < 2; k++ )
+		{
+			iTranscribeResult* r = nullptr;
+			if( FAILED( ctx->getResults( eResultFlags::Timestamps | eResultFlags::Tokens, &r ) ) || !r ) { g_callbackFaults++; return S_OK; }
+			sTranscribeLength len;
+			r->getSize( len );
+			seen[ k ] = len.countSegments;
+			if( k == 0 ) firstObject = r; else if( r != firstObject ) g_callbackFaults++;
+			r->Release();
+		}
+		if( seen[ 0 ] != seen[ 1 ] || seen[ 0 ] < nNew ) g_callbackFaults++;
+		return S_OK;
+	}
 	std::string g_out;
 	void jsonString( std::ostringstream& o, const char* s )
 	{
@@ -93,6 +114,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int bt_run( const char* 
 {
 	g_out.clear();
 	g_newSegments = 0;
+	g_callbackFaults = 0;
 	g_hostLoopRules = (eHostLoopRules)rules;
 	std::shared_ptr<LoadedModel> lm = std::make_shared<LoadedModel>();
 	HRESULT hr = loadVocabulary( modelPath, lm->vocab );
@@ -155,7 +177,7 @@ extern "C" __attribute__( ( visibility( "default" ) ) ) int bt_run( const char* 
 		}
 		o << "]}";
 	}
-	o << "],\"new_segments\":" << g_newSegments << "}";
+	o << "],\"new_segments\":" << g_newSegments << ",\"callback_faults\":" << g_callbackFaults << "}";
 	g_out = o.str();
 	runner->Release();
 	return hr;

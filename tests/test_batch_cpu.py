@@ -107,6 +107,9 @@ def test_every_stream_equals_the_stream_alone(batch_lib, tmp_path, rules):
             assert st["hr"] == w[0], (slots, groups, i, st["hr"])
             assert [(s["t0"], s["t1"], s["text"], s["tokens"]) for s in st["segments"]] == w[1], (slots, groups, chunk, lookahead, i)
         assert got["new_segments"] == sum(len(w[1]) for w in want)
+        # every new_segment callback asked for the results the reference's way (no NewObject, Release on scope exit), twice: the object is the
+        # context's own and survives the Release (a heap object handed out without AddRef was freed by the first such callback)
+        assert got["callback_faults"] == 0
 
 
 def _driver():

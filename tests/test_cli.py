@@ -8,6 +8,7 @@ produced for that model (tests/golden/ref_hostloop.json)."""
 import json
 import os
 import subprocess
+import time as time_mod
 import wave
 
 import numpy as np
@@ -147,9 +148,9 @@ def test_mgpu_harness_ends_the_job_when_a_rank_dies_or_hangs(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1 and time.time() - t0 < 20, r.stderr.decode()[-500:]
     assert b"ending the other ranks" in r.stderr
-    # every rank stuck: the job's deadline (4 x -timeout) ends them
+    # every rank stuck: the JOB's deadline (-job-timeout; -timeout is the deadline of a collective, not of the job) ends them
     t0 = time.time()
-    r = subprocess.run(args + ["-n", "2", "-timeout", "0.5"], env=dict(os.environ, WHISPER_MGPU_TEST_FAULT="all:hang"),
+    r = subprocess.run(args + ["-n", "2", "-timeout", "0.5", "-job-timeout", "2"], env=dict(os.environ, WHISPER_MGPU_TEST_FAULT="all:hang"),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1 and 1.5 < time.time() - t0 < 20, r.stderr.decode()[-500:]
     assert b"did not finish within" in r.stderr
@@ -160,6 +161,29 @@ def test_mgpu_harness_ends_the_job_when_a_rank_dies_or_hangs(tmp_path):
     syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_LIB], stdout=subprocess.PIPE, text=True).stdout
     for name in ("wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32"):
         assert (" T " + name) in syms, name
+
+
+def test_mgpu_id_file_carries_the_job_not_a_start_time(tmp_path):
+    """The rendezvous file of whisper-mgpu under an external launcher: a rank that starts long after rank 0 published the id must still take
+    it -- freshness against the rank's OWN start time rejected the valid file on every poll -- while the file of another job (same path, other token)
+    and a file older than the rendezvous deadline allows are refused."""
+    if not os.path.exists(build.MGPU_BIN):
+        build.build_all()
+    path = str(tmp_path / "job.id")
+
+    def run(*a):
+        return subprocess.run([build.MGPU_BIN] + [str(x) for x in a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=30).returncode
+
+    assert run("--id-write", path, "run-17/29500/") == 0
+    assert os.path.getsize(path) == 64 + 128
+    assert run("--id-read", path, "run-17/29500/", 0, 300) == 0
+    assert run("--id-read", path, "run-17/29500/", 120, 300) == 0            # this rank starts two minutes after the file was published
+    assert run("--id-read", path, "run-18/29500/", 0, 300) == 1              # an earlier job's file under the same name
+    assert run("--id-read", path, "run-17/29500/", 400, 300) == 1            # older than the rendezvous deadline: rank 0 has given up by then
+    old = time_mod.time() - 1000
+    os.utime(path, (old, old))
+    assert run("--id-read", path, "run-17/29500/", 0, 300) == 1
+    assert run("--id-read", str(tmp_path / "missing.id"), "x", 0, 300) == 1
 
 
 @pytest.mark.gpu

@@ -1035,6 +1035,61 @@ def test_beam_candidates_and_cache_reorder(hip_tiny, golden, tiny_model):
     ctx.close()
 
 
+def test_beam_search_steps_on_the_device(hip_tiny, golden, tiny_model):
+    """wh_beam_window_*: 3 windows x 5 hypotheses, FORCED steps (no stop rules: what bench.py --workload beam5 runs on random weights), the ranking
+    as a kernel inside the captured step graph -- against the same search ranked on the host after every step through wh_beam_candidates /
+    wh_reorder_self_cache (numpy: parent score + log p, stable order; round 4's data path): the best hypothesis' ids of every window, its score,
+    and the chain of every surviving hypothesis are the same. Chunked enqueueing (start + continue) equals one enqueue."""
+    hp = tiny_model.hparams
+    sp = gf.special_tokens(hp)
+    k, hyp, n_steps = 3, 5, 20
+    rng = np.random.default_rng(21)
+    mel = np.stack([np.roll(golden["mel"], 53 * b, axis=1) + 0.02 * rng.standard_normal(golden["mel"].shape).astype(np.float32) for b in range(k)]).astype(np.float32)
+    mel_dev = torch.from_numpy(mel).cuda()
+    base = np.asarray([sp["sot"], sp["transcribe"], sp["not_"]], np.int32)
+    S = k * hyp
+    c = binding.HipContext(hip_tiny, k, hypotheses=hyp)
+    # ---- host-ranked ----
+    c.encode(mel_dev)
+    c.decode(np.tile(base, (S, 1)), 0, want_logits=False, want_probs=False)
+    cand = c.beam_candidates(S, hyp, True, True)
+    p0 = cand["p"][::hyp].astype(np.float64)
+    order = np.argsort(-np.log(np.maximum(p0, 1e-30)), axis=1, kind="stable")
+    score = np.take_along_axis(np.log(np.maximum(p0, 1e-30)), order, axis=1)
+    tok = np.take_along_axis(cand["id"][::hyp], order, axis=1).astype(np.int32)
+    parents = (np.arange(k)[:, None] * hyp + np.zeros((1, hyp), np.int64)).astype(np.int32)
+    hist = tok[:, :, None]
+    for s_ in range(n_steps):
+        c.reorder_self_cache(parents.reshape(-1), len(base) + s_)
+        c.decode(tok.reshape(-1, 1), len(base) + s_, want_logits=False, want_probs=False)
+        cand = c.beam_candidates(S, hyp)
+        pool = score[:, :, None] + np.log(np.maximum(cand["p"].reshape(k, hyp, hyp).astype(np.float64), 1e-30))
+        flat = pool.reshape(k, hyp * hyp)
+        order = np.argsort(-flat, axis=1, kind="stable")[:, :hyp]
+        par_local = order // hyp
+        score = np.take_along_axis(flat, order, axis=1)
+        tok = np.take_along_axis(cand["id"].reshape(k, hyp * hyp), order, axis=1).astype(np.int32)
+        parents = (np.arange(k)[:, None] * hyp + par_local).astype(np.int32)
+        hist = np.concatenate([np.take_along_axis(hist, par_local[:, :, None], axis=1), tok[:, :, None]], axis=2)
+    # ---- device-ranked, in one enqueue and in chunks ----
+    for chunks in ([n_steps], [7, 1, 12]):
+        c.encode(mel_dev)
+        c.beam_window_start(np.tile(base, (k, 1)), hyp, chunks[0])
+        for more in chunks[1:]:
+            c.beam_window_continue(more)
+        st = c.beam_window_status()
+        rec = c.beam_window_records(0, n_steps + 1)
+        for w in range(k):
+            assert st[w]["step"] == n_steps + 1 and st[w]["nLive"] == hyp and st[w]["nFinished"] == 0 and not st[w]["done"]
+            for j in range(hyp):
+                h = st[w]["live"][j]
+                ids = c.beam_chain(rec, w, h["rec"])
+                assert ids == [int(x) for x in hist[w, j]], (chunks, w, j)
+                assert abs(h["sum"] - score[w, j]) < 1e-9 * max(1.0, abs(score[w, j])) and h["nTok"] == n_steps + 1
+    print("device-ranked beam search == host-ranked on %d windows x %d hypotheses x %d steps; best scores %s" % (k, hyp, n_steps, np.round(score[:, 0], 4)))
+    c.close()
+
+
 @pytest.mark.parametrize("M", [65, 100, 112, 128])
 def test_gemv_all_rows_variant(M):
     """TUNE_GEMV_MT8: the 65 .. 128-row decode product with ALL rows in one workgroup (weights streamed once), against the default

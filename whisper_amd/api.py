@@ -74,6 +74,11 @@ def set_host_loop_rules(mode: int):
     _check(lib().whisperc_set_host_loop_rules(mode), "set_host_loop_rules")
 
 
+def set_beam_ranking(on_host: bool):
+    """eSamplingStrategy::BeamSearch: rank every step's candidates on the host (round 4's decoder, the checker) instead of on the device (default)."""
+    _check(lib().whisperc_set_beam_ranking(1 if on_host else 0), "set_beam_ranking")
+
+
 def _check(hr: int, what: str) -> int:
     if hr < 0:
         raise WhisperError(hr, what)

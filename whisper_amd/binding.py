@@ -45,7 +45,7 @@ EXPORTS = [
     "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
+    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -56,6 +56,22 @@ class HParamsC(C.Structure):
 
 class TokenDataC(C.Structure):
     _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float)]
+
+
+class BeamRulesC(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("seek", "seekEnd", "nMax", "maxTokens", "singleSegment", "tokenBeg", "tokenEot", "forced")]
+
+
+class BeamHypC(C.Structure):
+    _fields_ = [("sum", C.c_double)] + [(k, C.c_int32) for k in ("i", "hasTs", "seekDelta", "resultLen", "failed", "over", "nTok", "rec")]
+
+
+class BeamWindowC(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("step", "nLive", "nFinished", "done", "nPrompt", "nTextCtx", "reserved0", "reserved1")] + [("live", BeamHypC * 8), ("finished", BeamHypC * 24)]
+
+
+class BeamRecordC(C.Structure):
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float), ("parent", C.c_int32), ("finished", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MelWindowC(C.Structure):
@@ -85,6 +101,10 @@ def lib():
         L.wh_last_error.restype = C.c_char_p
         L.wh_debug_set_tuning.argtypes = [C.c_uint32]
         L.wh_debug_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.wh_beam_window_start.argtypes = [vp, i32, vp, i32, i32, C.POINTER(BeamRulesC), i32]
+        L.wh_beam_window_continue.argtypes = [vp, i32]
+        L.wh_beam_window_status.argtypes = [vp, C.POINTER(BeamWindowC)]
+        L.wh_beam_window_records.argtypes = [vp, i32, i32, C.POINTER(BeamRecordC)]
         if os.environ.get("WH_TUNING"):          # kernel-variant mask for A/B runs and for testing a candidate variant
             L.wh_debug_set_tuning(int(os.environ["WH_TUNING"], 0))
         L.wh_device_info.argtypes = [i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -332,6 +352,52 @@ class HipContext:
         """Sequence j continues sequence parents[j]: its self-attention cache rows [0, rows) are replaced by the parent's."""
         p = np.ascontiguousarray(parents, np.int32)
         check(lib().wh_reorder_self_cache(self.handle, len(p), p.ctypes.data_as(C.c_void_p), rows))
+
+    # ---- beam search with the ranking on the device ----
+    def beam_window_start(self, prompts, width: int, n_steps: int, rules=None):
+        """prompts: int array [windows][n_prompt]; rules: list of dicts (seek, seekEnd, nMax, maxTokens, singleSegment, tokenBeg, tokenEot, forced) per window,
+        or None = forced steps (no stop rules). Non-blocking."""
+        t = np.ascontiguousarray(prompts, np.int32)
+        if t.ndim == 1:
+            t = t[None, :]
+        w = t.shape[0]
+        arr = (BeamRulesC * w)()
+        for i in range(w):
+            r = rules[i] if rules is not None else dict(forced=1)
+            arr[i] = BeamRulesC(*[int(r.get(k, 0)) for k in ("seek", "seekEnd", "nMax", "maxTokens", "singleSegment", "tokenBeg", "tokenEot", "forced")])
+        self._beam = (w, width)
+        check(lib().wh_beam_window_start(self.handle, w, t.ctypes.data_as(C.c_void_p), t.shape[1], width, arr, n_steps))
+
+    def beam_window_continue(self, n_steps: int):
+        check(lib().wh_beam_window_continue(self.handle, n_steps))
+
+    def beam_window_status(self):
+        """Blocks; the search state per window: list of dicts (step, nLive, nFinished, done, live [..], finished [..])."""
+        w, _ = self._beam
+        arr = (BeamWindowC * w)()
+        check(lib().wh_beam_window_status(self.handle, arr))
+        hyp = lambda h: {k: getattr(h, k) for k in ("sum", "i", "hasTs", "seekDelta", "resultLen", "failed", "over", "nTok", "rec")}
+        return [dict(step=a.step, nLive=a.nLive, nFinished=a.nFinished, done=a.done, live=[hyp(a.live[j]) for j in range(a.nLive)],
+                     finished=[hyp(a.finished[j]) for j in range(a.nFinished)]) for a in arr]
+
+    def beam_window_records(self, first: int, count: int):
+        """Structured array [count][windows][width] with fields id, tid, p, pt, ptsum, parent, finished."""
+        w, width = self._beam
+        out = (BeamRecordC * (count * w * width))()
+        check(lib().wh_beam_window_records(self.handle, first, count, out))
+        dt = np.dtype([("id", "<i4"), ("tid", "<i4"), ("p", "<f4"), ("pt", "<f4"), ("ptsum", "<f4"), ("parent", "<i4"), ("finished", "<i4"), ("reserved", "<i4")])
+        return np.frombuffer(out, dtype=dt).reshape(count, w, width).copy()
+
+    @staticmethod
+    def beam_chain(records, window: int, rec: int):
+        """The token ids of the hypothesis whose last record is `rec` (= step * width + index), oldest first."""
+        width = records.shape[2]
+        ids = []
+        while rec >= 0:
+            r = records[rec // width, window, rec % width]
+            ids.append(int(r["id"]))
+            rec = int(r["parent"])
+        return ids[::-1]
 
     def decode_greedy(self, first_tokens, n_past: int, n_steps: int, force_first_timestamp: bool = False,
                       first_is_initial: bool = False):

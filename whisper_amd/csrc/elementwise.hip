@@ -301,17 +301,189 @@ namespace wh
 		// phase 0: scratch[ j ] = cache[ parents[ j ] ], phase 1: cache[ j ] = scratch[ j ]; sequences with parents[ j ] == j are skipped.
 		// grid (heads, sequences, layers x 2 (K, V)); rows x 128 bytes per block.
 		__global__ void __launch_bounds__( 256 ) reorderCacheKernel( f16* __restrict__ cacheK, f16* __restrict__ cacheV, f16* __restrict__ scratchK,
-			f16* __restrict__ scratchV, const int* __restrict__ parents, int heads, int seqStrideSeqs, int keyStride, int rows, int phase )
+			f16* __restrict__ scratchV, const int* __restrict__ parents, int heads, int seqStrideSeqs, int keyStride, int rows, int phase,
+			const int* __restrict__ rowsDev )
 		{
 			const int h = blockIdx.x, j = blockIdx.y, l = blockIdx.z >> 1, kv = blockIdx.z & 1;
 			const int p = parents[ j ];
 			if( p == j ) return;
+			// beam search inside a captured graph: the rows that exist are the sequence's decoder position, in device memory
+			if( rowsDev ) rows = min( max( rowsDev[ j ], 0 ), keyStride );
 			f16* const cache = kv ? cacheV : cacheK;
 			f16* const scratch = kv ? scratchV : scratchK;
 			const long long layer = (long long)l * seqStrideSeqs * heads * keyStride * HEAD_DIM;
 			const f16* src = ( phase == 0 ? cache + layer + ( (long long)p * heads + h ) * keyStride * HEAD_DIM : scratch + layer + ( (long long)j * heads + h ) * keyStride * HEAD_DIM );
 			f16* dst = ( phase == 0 ? scratch : cache ) + layer + ( (long long)j * heads + h ) * keyStride * HEAD_DIM;
 			for( int i = threadIdx.x; i < rows * 8; i += 256 ) *(f16x8*)( dst + i * 8 ) = *(const f16x8*)( src + i * 8 );
+		}
+
+		// ---- beam search: the ranking of a step on the device (see kernels.h; the host version it restates: ContextImpl::decodeWindowBeam) ----
+		constexpr int BEAM_CHUNK_FRAMES = 3000;	   // CHUNK_FRAMES of host/hostLoop.h
+		// WindowScan::feed (host/hostLoop.h = ContextImpl.cpp:597-673) on the state of one hypothesis; true = its window is over
+		__device__ __forceinline__ bool beamFeed( BeamHyp& h, const BeamRules& r, int id )
+		{
+			if( r.forced ) { h.nTok++; h.i++; return false; }
+			if( h.over ) return true;
+			if( id > r.tokenBeg )
+			{
+				// a timestamp token moves the sliding window; going back in time ends the window (the token is not kept)
+				const int seekDeltaNew = 2 * ( id - r.tokenBeg );
+				if( h.hasTs && h.seekDelta > seekDeltaNew && h.resultLen < h.i ) { h.over = 1; return true; }
+				h.seekDelta = seekDeltaNew;
+				h.resultLen = h.i + 1;
+				h.hasTs = 1;
+			}
+			h.nTok++;
+			const bool endOfAudio = h.hasTs && r.seek + h.seekDelta + 100 >= r.seekEnd;
+			if( id == r.tokenEot || ( r.maxTokens > 0 && h.i >= r.maxTokens ) || endOfAudio )
+			{
+				if( h.resultLen == 0 )
+				{
+					if( r.seek + h.seekDelta + 100 >= r.seekEnd )
+						h.resultLen = h.i + 1;
+					else
+					{
+						h.failed = 1; h.over = 1;
+						return true;
+					}
+				}
+				if( r.singleSegment )
+				{
+					h.resultLen = h.i + 1;
+					h.seekDelta = BEAM_CHUNK_FRAMES;
+				}
+				h.over = 1;
+				return true;
+			}
+			// stuck in a repetition loop: give up on this window
+			if( h.i == r.nMax - 1 && ( h.resultLen == 0 || h.seekDelta < BEAM_CHUNK_FRAMES / 2 ) )
+			{
+				h.failed = 1; h.over = 1;
+				return true;
+			}
+			h.i++;
+			if( h.i >= r.nMax ) h.over = 1;
+			return h.over != 0;
+		}
+		__device__ __forceinline__ double beamPerToken( const BeamHyp& h ) { return h.sum / (double)max( 1, h.nTok ); }
+
+		// One workgroup (one working lane: 64 proposals, a handful of state machines) per window.
+		__global__ void __launch_bounds__( 64 ) beamRankKernel( const TokenData* __restrict__ cand, int slots, int width, const BeamRules* __restrict__ rules,
+			BeamWindow* __restrict__ state, BeamRecord* __restrict__ records, int maxSteps, int windows, int* __restrict__ parents, int* __restrict__ nextTokens )
+		{
+			if( threadIdx.x != 0 ) return;
+			const int w = blockIdx.x;
+			BeamWindow& S = state[ w ];
+			const int base = w * slots;
+			if( S.done || S.step >= maxSteps )
+			{
+				// nothing moves any more: every slot continues itself (the reorder skips it) and feeds its last token again
+				for( int b = 0; b < slots; b++ ) parents[ base + b ] = base + b;
+				S.done = 1;
+				return;
+			}
+			const BeamRules R = rules[ w ];
+			const int step = S.step;
+			const bool first = step == 0;
+			// ---- the pool: (parent, candidate) with parent score + log p, ranked; ties keep the parent's order, then the candidate's ----
+			struct Prop { int parent, k; double score; };
+			Prop pool[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
+			int nPool = 0;
+			const int nParents = first ? 1 : S.nLive;	   // the first sample: every slot holds the same prompt, slot 0 speaks for all
+			for( int i = 0; i < nParents; i++ )
+				for( int k = 0; k < width; k++ )
+				{
+					const double lp = log( fmax( (double)cand[ (long long)( base + i ) * width + k ].p, 1e-30 ) );
+					pool[ nPool++ ] = Prop{ i, k, ( first ? 0.0 : S.live[ i ].sum ) + lp };
+				}
+			for( int a = 1; a < nPool; a++ )	   // stable insertion sort, descending score
+			{
+				const Prop x = pool[ a ];
+				int b = a - 1;
+				while( b >= 0 && pool[ b ].score < x.score ) { pool[ b + 1 ] = pool[ b ]; b--; }
+				pool[ b + 1 ] = x;
+			}
+			// ---- the best `width` proposals continue their parents: live or, when the stop rules end the window, finished ----
+			BeamHyp newLive[ BEAM_MAX_WIDTH ];
+			int parentSlot[ BEAM_MAX_WIDTH ], lastTok[ BEAM_MAX_WIDTH ];
+			int nNew = 0, accepted = 0;
+			BeamRecord* const rec = records + ( (long long)step * windows + w ) * width;
+			for( int q = 0; q < nPool && accepted < width; q++ )
+			{
+				const Prop pr = pool[ q ];
+				const TokenData t = cand[ (long long)( base + pr.parent ) * width + pr.k ];
+				BeamHyp h;
+				if( first )
+				{
+					h.sum = 0.0; h.i = 0; h.hasTs = 0; h.seekDelta = BEAM_CHUNK_FRAMES; h.resultLen = 0; h.failed = 0; h.over = 0; h.nTok = 0; h.rec = -1;
+				}
+				else
+					h = S.live[ pr.parent ];
+				const int parentRec = h.rec;
+				h.sum = pr.score;
+				const bool over = beamFeed( h, R, t.id );
+				h.rec = step * width + accepted;
+				rec[ accepted ] = BeamRecord{ t, parentRec, over ? 1 : 0, 0 };
+				accepted++;
+				if( over )
+				{
+					if( S.nFinished < BEAM_MAX_FINISHED ) S.finished[ S.nFinished++ ] = h;
+				}
+				else
+				{
+					parentSlot[ nNew ] = pr.parent;
+					lastTok[ nNew ] = t.id;
+					newLive[ nNew++ ] = h;
+				}
+			}
+			for( int a = accepted; a < width; a++ ) rec[ a ] = BeamRecord{ TokenData{ 0, 0, 0.0f, 0.0f, 0.0f }, -2, 0, 0 };	   // unused entries of the step
+			for( int i = 0; i < nNew; i++ ) S.live[ i ] = newLive[ i ];
+			S.nLive = nNew;
+			S.step = step + 1;
+			// ---- does a live hypothesis still have a chance? (a cumulative log-probability only ever decreases) ----
+			bool keep = nNew > 0;
+			if( keep && S.nFinished >= width )
+			{
+				double bestFinished = -1e300, bestLive = -1e300;
+				for( int i = 0; i < S.nFinished; i++ )
+					if( !S.finished[ i ].failed ) bestFinished = fmax( bestFinished, S.finished[ i ].sum );
+				for( int i = 0; i < nNew; i++ ) bestLive = fmax( bestLive, S.live[ i ].sum );
+				keep = bestLive >= bestFinished;
+			}
+			if( keep && S.nFinished > 2 * width )
+			{
+				// the finished list keeps its best `width` entries: successful windows first, then log-probability per token (stable)
+				for( int a = 1; a < S.nFinished; a++ )
+				{
+					const BeamHyp x = S.finished[ a ];
+					int b = a - 1;
+					while( b >= 0 )
+					{
+						const BeamHyp& y = S.finished[ b ];
+						const bool xFirst = x.failed != y.failed ? !x.failed : beamPerToken( x ) > beamPerToken( y );
+						if( !xFirst ) break;
+						S.finished[ b + 1 ] = y;
+						b--;
+					}
+					S.finished[ b + 1 ] = x;
+				}
+				S.nFinished = width;
+			}
+			// the context's end (WindowScan's own bound fires first for every prompt the host loop builds)
+			if( keep && S.nPrompt + ( S.step - 1 ) >= S.nTextCtx ) keep = false;
+			if( !keep )
+			{
+				S.done = 1;
+				for( int b = 0; b < slots; b++ ) parents[ base + b ] = base + b;
+				return;
+			}
+			// live hypothesis j decodes in slot j next: its cache rows come from its parent's slot; idle slots repeat hypothesis 0 and are ignored
+			for( int b = 0; b < slots; b++ )
+			{
+				const int j = b < nNew ? b : 0;
+				parents[ base + b ] = base + parentSlot[ j ];
+				nextTokens[ base + b ] = lastTok[ j ];
+			}
 		}
 
 		// ---- logits row -> table softmax -> sampleBest in ONE kernel, the row held in registers -----------------------
@@ -712,9 +884,30 @@ namespace wh
 		for( int phase = 0; phase < 2; phase++ )
 		{
 			hipLaunchKernelGGL( reorderCacheKernel, dim3( heads, sequences, layers * 2 ), dim3( 256 ), 0, stream, cacheK, cacheV, scratchK, scratchV, parents,
-				heads, maxSeq, keyStride, rows, phase );
+				heads, maxSeq, keyStride, rows, phase, (const int*)nullptr );
 			WH_HIP( hipGetLastError() );
 		}
+		return 0;
+	}
+
+	int launchReorderCacheDev( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, const int* rowsDev, int layers, int sequences, int maxSeq,
+		int heads, int keyStride, hipStream_t stream )
+	{
+		for( int phase = 0; phase < 2; phase++ )
+		{
+			hipLaunchKernelGGL( reorderCacheKernel, dim3( heads, sequences, layers * 2 ), dim3( 256 ), 0, stream, cacheK, cacheV, scratchK, scratchV, parents,
+				heads, maxSeq, keyStride, 0, phase, rowsDev );
+			WH_HIP( hipGetLastError() );
+		}
+		return 0;
+	}
+
+	int launchBeamRank( const TokenData* cand, int windows, int slots, int width, const BeamRules* rules, BeamWindow* state, BeamRecord* records, int maxSteps,
+		int* parents, int* nextTokens, hipStream_t stream )
+	{
+		if( width < 1 || width > BEAM_MAX_WIDTH || slots < width || slots > BEAM_MAX_WIDTH || windows <= 0 ) { setError( "beamRank: 1 <= width <= slots <= 8" ); return -1; }
+		hipLaunchKernelGGL( beamRankKernel, dim3( windows ), dim3( 64 ), 0, stream, cand, slots, width, rules, state, records, maxSteps, windows, parents, nextTokens );
+		WH_HIP( hipGetLastError() );
 		return 0;
 	}
 

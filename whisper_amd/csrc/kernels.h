@@ -275,6 +275,53 @@ namespace wh
 	int launchReorderCache( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, int layers, int sequences, int maxSeq,
 		int heads, int keyStride, int rows, hipStream_t stream );
 
+	// ---- beam search WITHOUT the host in the loop (round 5) ------------------------------------------------------------------
+	// One window = `slots` decoder sequences sharing its cross-attention K/V. After every decode step beamRankKernel does, per window, what
+	// ContextImpl::decodeWindowBeam (host/whisperImpl.cpp) does on the host: pool = live hypotheses x their `width` candidates ranked by
+	// parent score + log p (stable: ties keep parent order, then candidate order), the best `width` accepted, each fed through the
+	// window's stop rules (WindowScan of host/hostLoop.h = ContextImpl.cpp:597-673, restated below as beamFeed) -> live or finished;
+	// the search ends when no live hypothesis can still beat the best finished one. It writes where the NEXT step reads: parents[] (what
+	// reorderCacheKernel moves), nextTokens[] (what the embedding reads), and one BeamRecord per accepted proposal (token + the record of its
+	// parent) from which the host re-derives the winner's token chain. Everything of a step is in one captured graph; the host polls `done`.
+	struct BeamRules
+	{
+		int seek, seekEnd;		 // WindowScan: the window's first frame and the stream's end, 10 ms units
+		int nMax;				 // n_text_ctx / 2 - 4
+		int maxTokens;			 // sFullParams::max_tokens (0 = no limit)
+		int singleSegment;		 // eFullParamsFlags::SingleSegment
+		int tokenBeg, tokenEot;
+		int forced;				 // != 0: no stop rules at all -- every hypothesis lives for as many steps as are enqueued (random-weight workloads)
+	};
+	struct BeamHyp
+	{
+		double sum;				 // cumulative log-probability
+		int i, hasTs, seekDelta, resultLen, failed, over;	 // WindowScan's state
+		int nTok;				 // tokens WindowScan kept
+		int rec;				 // record of its last token: step * width + index among that step's accepted proposals
+	};
+	constexpr int BEAM_MAX_WIDTH = 8, BEAM_MAX_FINISHED = 3 * BEAM_MAX_WIDTH;
+	struct BeamWindow
+	{
+		int step;				 // ranking steps done (the first one ranks the prompt step's candidates)
+		int nLive, nFinished, done;
+		int nPrompt, nTextCtx, reserved0, reserved1;
+		BeamHyp live[ BEAM_MAX_WIDTH ];	 // live[ j ] decodes in slot j of the window
+		BeamHyp finished[ BEAM_MAX_FINISHED ];
+	};
+	struct BeamRecord
+	{
+		TokenData t;
+		int parent;				 // record index of the hypothesis it continues (-1: the prompt)
+		int finished;			 // 1: this proposal ended its hypothesis' window
+		int reserved;
+	};
+	// cand [windows * slots][width] from beamCandidatesKernel; records [maxSteps][windows][width]; parents / nextTokens [windows * slots] (absolute sequence indices)
+	int launchBeamRank( const TokenData* cand, int windows, int slots, int width, const BeamRules* rules, BeamWindow* state, BeamRecord* records, int maxSteps,
+		int* parents, int* nextTokens, hipStream_t stream );
+	// launchReorderCache with the number of rows taken from device memory: rowsDev[ j ] rows of sequence j (its decoder position)
+	int launchReorderCacheDev( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, const int* rowsDev, int layers, int sequences, int maxSeq,
+		int heads, int keyStride, hipStream_t stream );
+
 	// Device-resident state of the greedy loop: lets one captured hipGraph be replayed for every token. The POSITIONS live next to
 	// it as one int per sequence (wh_context::seqPos): the sequences of a lock-step batch may stand at different positions (streams
 	// of a batch scheduler carry prompts of different lengths), every kernel that needs a position reads its own sequence's.

@@ -284,6 +284,14 @@ struct wh_context
 	uint8_t* sampleScratch = nullptr;		   // TUNE_SAMPLE_SPREAD: slice records of the spread sampler (allocated on first use, before any capture)
 	TokenData* beamCand = nullptr;			   // beam search: [maxSeq][8] candidates (allocated on first use)
 	f16 *selfKScratch = nullptr, *selfVScratch = nullptr;	   // beam search: the copy a cache reorder goes through (allocated on first use)
+	// beam search on the device (wh_beam_window_*): per-window rules and state, the records of every step, the parents a step's reorder reads
+	BeamRules* beamRules = nullptr;
+	BeamWindow* beamState = nullptr;
+	BeamRecord* beamRecords = nullptr;
+	int* beamParents = nullptr;
+	hipGraphExec_t beamGraphExec = nullptr;
+	int beamGraphBatch = 0, beamGraphWidth = 0;
+	int beamWindows = 0, beamWidth = 0, beamSteps = 0;	   // the window in progress: windows, width, ranking steps enqueued so far
 	float* melScratch = nullptr;
 	// device-side greedy loop: the sampler's state and one position per sequence (the sequences of a lock-step batch may differ)
 	DecodeState* state = nullptr;
@@ -1241,6 +1249,7 @@ void wh_context_destroy( wh_context* c )
 	(void)bindDevice( c->m );
 	if( c->stream ) (void)hipStreamSynchronize( c->stream );
 	if( c->graphExec ) (void)hipGraphExecDestroy( c->graphExec );
+	if( c->beamGraphExec ) (void)hipGraphExecDestroy( c->beamGraphExec );
 	for( auto& mk : c->marks ) (void)hipEventDestroy( mk.ev );
 	for( hipEvent_t e : c->markPool ) (void)hipEventDestroy( e );
 	if( c->copyStream ) (void)hipStreamDestroy( c->copyStream );
@@ -2363,6 +2372,174 @@ int wh_reorder_self_cache( wh_context* c, int batch, const int32_t* parents, int
 	return profiled( c, KC_EMBED, 0.0, 4.0 * 2.0 * 2.0 * rows * hp.n_text_state * hp.n_text_layer * batch,
 		[ & ]() { return launchReorderCache( c->selfK, c->selfV, c->selfKScratch, c->selfVScratch, (const int*)c->tokDataDev, hp.n_text_layer, batch, c->maxSeq,
 			hp.n_text_head, hp.n_text_ctx, rows, c->stream ); } );
+}
+
+// ---- beam search with the ranking on the device: no host round trip between the steps of a window ----
+static int beamBuffers( wh_context* c )
+{
+	const wh_hparams& hp = c->m->hp;
+	if( !c->beamCand ) WH_CHECK( c->alloc( c->beamCand, (int64_t)c->maxSeq * 8, wh_context::DONT_CARE, "beamCand" ) );
+	const int64_t n = (int64_t)hp.n_text_layer * c->maxSeq * hp.n_text_ctx * hp.n_text_state;
+	if( !c->selfKScratch ) WH_CHECK( c->alloc( c->selfKScratch, n, wh_context::DONT_CARE, "selfKScratch" ) );
+	if( !c->selfVScratch ) WH_CHECK( c->alloc( c->selfVScratch, n, wh_context::DONT_CARE, "selfVScratch" ) );
+	if( !c->beamRules ) WH_CHECK( c->alloc( c->beamRules, c->maxBatch, wh_context::MUST_BE_ZERO, "beamRules" ) );
+	if( !c->beamState ) WH_CHECK( c->alloc( c->beamState, c->maxBatch, wh_context::MUST_BE_ZERO, "beamState" ) );
+	if( !c->beamRecords ) WH_CHECK( c->alloc( c->beamRecords, (int64_t)hp.n_text_ctx * c->maxBatch * BEAM_MAX_WIDTH, wh_context::DONT_CARE, "beamRecords" ) );
+	if( !c->beamParents ) WH_CHECK( c->alloc( c->beamParents, c->maxSeq, wh_context::MUST_BE_ZERO, "beamParents" ) );
+	return 0;
+}
+
+// one step: parents' cache rows move -> every slot decodes its token -> probabilities -> candidates -> ranking (writes the next step's parents and tokens)
+static int beamStep( wh_context* c, int batch, int width )
+{
+	const wh_hparams& hp = c->m->hp;
+	const SpecialIds sp = specialIds( hp );
+	hipStream_t st = c->stream;
+	WH_CHECK( profiled( c, KC_EMBED, 0.0, 4.0 * 2.0 * 2.0 * c->profKeysHint * hp.n_text_state * hp.n_text_layer * batch,
+		[ & ]() { return launchReorderCacheDev( c->selfK, c->selfV, c->selfKScratch, c->selfVScratch, c->beamParents, c->seqPos, hp.n_text_layer, batch, c->maxSeq,
+			hp.n_text_head, hp.n_text_ctx, st ); } ) );
+	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
+	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab, [ & ]() { return launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ); } ) );
+	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, ( 4.0 + width ) * 4.0 * batch * hp.n_vocab,
+		[ & ]() { return launchBeamCandidates( c->probs, batch, hp.n_vocab, sp.beg, sp.sot, sp.solm, sp.tnot, 0, 0, width, c->beamCand, st ); } ) );
+	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, 0.0, [ & ]() { return launchBeamRank( c->beamCand, batch / c->hyp, c->hyp, width, c->beamRules, c->beamState, c->beamRecords,
+		hp.n_text_ctx, c->beamParents, c->tokensDev, st ); } ) );
+	return launchAdvanceState( c->state, c->seqPos, batch, st );
+}
+
+static int beamEnqueue( wh_context* c, int nSteps )
+{
+	const int batch = c->beamWindows * c->hyp, width = c->beamWidth;
+	// the graph wh_beam_window_start captured for this shape; eager launches when there is none (profiler on, WH_FLAG_NO_GRAPH, WH_DEBUG_SYNC)
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && !debugSync() && c->beamGraphExec && c->beamGraphBatch == batch && c->beamGraphWidth == width;
+	for( int s = 0; s < nSteps; s++ )
+	{
+		if( useGraph ) WH_HIP( hipGraphLaunch( c->beamGraphExec, c->stream ) );
+		else
+		{
+			c->profKeysHint = c->windowPos + s + 1;
+			WH_CHECK( beamStep( c, batch, width ) );
+		}
+	}
+	c->beamSteps += nSteps;
+	c->windowPos += nSteps;
+	return 0;
+}
+
+int wh_beam_window_start( wh_context* c, int windows, const int32_t* promptTokens, int nPrompt, int width, const wh_beam_rules* rules, int nSteps )
+{
+	if( !c || !promptTokens || !rules || windows <= 0 || windows > c->maxBatch || nPrompt <= 0 || nSteps < 0 || width < 1 || width > c->hyp || width > BEAM_MAX_WIDTH )
+	{
+		setError( "beam_window_start: bad argument (1 <= width <= hypotheses per window of the context <= 8)" );
+		return WH_E_INVALIDARG;
+	}
+	if( !c->encoded ) { setError( "beam_window_start: wh_encode has not run" ); return WH_E_NOT_READY; }
+	WH_BIND( c->m );
+	const wh_hparams& hp = c->m->hp;
+	const int batch = windows * c->hyp;
+	if( nPrompt + nSteps > hp.n_text_ctx || (int64_t)batch * nPrompt > c->pinTokenCap() ) { setError( "beam_window_start: too many tokens" ); return WH_E_BOUNDS; }
+	static_assert( sizeof( wh_beam_rules ) == sizeof( BeamRules ) && sizeof( wh_beam_window ) == sizeof( BeamWindow ) && sizeof( wh_beam_record ) == sizeof( BeamRecord ) &&
+		sizeof( wh_beam_hyp ) == sizeof( BeamHyp ), "beam structure layouts" );
+	WH_CHECK( beamBuffers( c ) );
+	hipStream_t st = c->stream;
+	WH_HIP( hipStreamSynchronize( st ) );	   // the staging and the search state may still be read by an earlier window
+	const SpecialIds sp = specialIds( hp );
+	c->beamWindows = windows;
+	c->beamWidth = width;
+	c->beamSteps = 0;
+	const bool useGraph = !c->prof.on && !( c->flags & WH_FLAG_NO_GRAPH ) && !debugSync();
+	if( useGraph && ( !c->beamGraphExec || c->beamGraphBatch != batch || c->beamGraphWidth != width ) )
+	{
+		// first use for this shape: one eager step with a finished search (the ranking returns at once, parents = identity) sets the per-kernel function
+		// attributes, then the capture. Blocking, once per context and shape; what it leaves behind is overwritten below.
+		std::vector<BeamWindow> idle( (size_t)windows );
+		memset( idle.data(), 0, idle.size() * sizeof( BeamWindow ) );
+		for( BeamWindow& w : idle ) w.done = 1;
+		std::vector<int32_t> zeros( (size_t)batch, 0 ), ident( (size_t)batch );
+		for( int b = 0; b < batch; b++ ) ident[ (size_t)b ] = b;
+		const DecodeState warm = { 0, 0, 0, 0 };
+		WH_HIP( hipMemcpy( c->beamState, idle.data(), idle.size() * sizeof( BeamWindow ), hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->beamRules, rules, sizeof( BeamRules ) * windows, hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->beamParents, ident.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->state, &warm, sizeof( warm ), hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->seqPos, zeros.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->tokensDev, zeros.data(), sizeof( int32_t ) * batch, hipMemcpyHostToDevice ) );
+		WH_CHECK( beamStep( c, batch, width ) );
+		WH_HIP( hipStreamSynchronize( st ) );
+		if( c->beamGraphExec ) { (void)hipGraphExecDestroy( c->beamGraphExec ); c->beamGraphExec = nullptr; }
+		// the launch sequence of a step is the same for every token: positions, parents, tokens and the search state live in device memory
+		{
+			hipGraph_t graph = nullptr;
+			WH_HIP( hipStreamBeginCapture( st, hipStreamCaptureModeThreadLocal ) );
+			const int rc = beamStep( c, batch, width );
+			const hipError_t e = hipStreamEndCapture( st, &graph );
+			if( rc != 0 ) { if( graph ) (void)hipGraphDestroy( graph ); return rc; }
+			if( e != hipSuccess ) return hipFail( e, "hipStreamEndCapture", __FILE__, __LINE__ );
+			const hipError_t e2 = hipGraphInstantiate( &c->beamGraphExec, graph, nullptr, nullptr, 0 );
+			(void)hipGraphDestroy( graph );
+			if( e2 != hipSuccess ) { c->beamGraphExec = nullptr; return hipFail( e2, "hipGraphInstantiate", __FILE__, __LINE__ ); }
+			c->beamGraphBatch = batch;
+			c->beamGraphWidth = width;
+		}
+	}
+	// the window's own state: rules, an empty search, the prompt of every slot, positions
+	{
+		std::vector<BeamWindow> init( (size_t)windows );
+		memset( init.data(), 0, init.size() * sizeof( BeamWindow ) );
+		for( BeamWindow& w : init ) { w.nPrompt = nPrompt; w.nTextCtx = hp.n_text_ctx; }
+		WH_HIP( hipMemcpy( c->beamState, init.data(), init.size() * sizeof( BeamWindow ), hipMemcpyHostToDevice ) );
+		WH_HIP( hipMemcpy( c->beamRules, rules, sizeof( BeamRules ) * windows, hipMemcpyHostToDevice ) );
+	}
+	int32_t* const stTok = c->pinTokens();
+	const int M = batch * nPrompt;
+	for( int w = 0; w < windows; w++ )
+	{
+		WH_CHECK( checkTokens( hp, promptTokens + (size_t)w * nPrompt, nPrompt, "beam_window_start" ) );
+		for( int j = 0; j < c->hyp; j++ )
+			for( int i = 0; i < nPrompt; i++ ) stTok[ ( (size_t)w * c->hyp + j ) * nPrompt + i ] = promptTokens[ (size_t)w * nPrompt + i ];
+	}
+	const DecodeState s0 = { 0, 0, 0, 0 };
+	WH_CHECK( uploadDecodeState( c, batch, s0, nullptr, nPrompt ) );	   // after the prompt step every slot stands at position nPrompt
+	WH_HIP( hipMemcpyAsync( c->tokensDev, stTok, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
+	WH_CHECK( decodeGraph( c, batch, nPrompt, 0, false ) );
+	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab, [ & ]() { return launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ); } ) );
+	// the first sample of a window: the reference's sampleTimestamp( true ) rules (forced timestamp, the 1.00 s cap)
+	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, ( 4.0 + width ) * 4.0 * batch * hp.n_vocab,
+		[ & ]() { return launchBeamCandidates( c->probs, batch, hp.n_vocab, sp.beg, sp.sot, sp.solm, sp.tnot, 1, 1, width, c->beamCand, st ); } ) );
+	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, 0.0, [ & ]() { return launchBeamRank( c->beamCand, windows, c->hyp, width, c->beamRules, c->beamState, c->beamRecords, hp.n_text_ctx,
+		c->beamParents, c->tokensDev, st ); } ) );
+	c->beamSteps = 1;
+	c->windowPos = nPrompt;
+	c->lastBatch = batch;
+	return beamEnqueue( c, nSteps );
+}
+
+int wh_beam_window_continue( wh_context* c, int nSteps )
+{
+	if( !c || nSteps <= 0 || c->beamSteps <= 0 ) { setError( "beam_window_continue: no window in progress" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	if( c->windowPos + nSteps > c->m->hp.n_text_ctx ) { setError( "beam_window_continue: n_text_ctx exceeded" ); return WH_E_BOUNDS; }
+	return beamEnqueue( c, nSteps );
+}
+
+int wh_beam_window_status( wh_context* c, wh_beam_window* out )
+{
+	if( !c || !out || c->beamSteps <= 0 ) { setError( "beam_window_status: no window in progress" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	WH_HIP( hipMemcpyAsync( out, c->beamState, sizeof( BeamWindow ) * (size_t)c->beamWindows, hipMemcpyDeviceToHost, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
+}
+
+int wh_beam_window_records( wh_context* c, int firstStep, int count, wh_beam_record* out )
+{
+	if( !c || !out || firstStep < 0 || count <= 0 || firstStep + count > c->beamSteps ) { setError( "beam_window_records: steps outside what was enqueued" ); return WH_E_BOUNDS; }
+	WH_BIND( c->m );
+	// device layout [step][windows of the call][width]
+	const size_t perStep = (size_t)c->beamWindows * c->beamWidth;
+	WH_HIP( hipMemcpyAsync( out, c->beamRecords + (size_t)firstStep * perStep, sizeof( BeamRecord ) * perStep * count, hipMemcpyDeviceToHost, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	return 0;
 }
 
 int wh_profile_enable( wh_context* c, int on )

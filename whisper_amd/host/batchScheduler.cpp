@@ -36,26 +36,30 @@ namespace Whisper
 		{
 			iModel* const owner;
 			const Vocabulary& vocab;
-			mutable TranscribeResult* live = nullptr;
+			// what getResults hands out without NewObject: embedded, Release never deletes -- the ownership ContextImpl has
+			// (a heap object held in a raw pointer here was freed by the first callback that released it the reference's way)
+			mutable TranscribeResultStatic live;
 		public:
 			std::vector<Segment> resultAll;
 			int64_t mediaTimeOffset = 0;
 			StreamContext( iModel* m, const Vocabulary& v ) : owner( m ), vocab( v ) {}
-			~StreamContext() override { if( live ) live->Release(); }
 			HRESULT runFull( const sFullParams&, const iAudioBuffer* ) override { return E_NOTIMPL; }
 			HRESULT runStreamed( const sFullParams&, const sProgressSink&, const iAudioReader* ) override { return E_NOTIMPL; }
 			HRESULT runCapture( const sFullParams&, const sCaptureCallbacks&, const iAudioCapture* ) override { return E_NOTIMPL; }
 			HRESULT getResults( eResultFlags flags, iTranscribeResult** pp ) const override
 			{
 				if( !pp ) return E_POINTER;
-				TranscribeResult* r = new TranscribeResult();
-				const HRESULT hr = fillResultData( resultAll, vocab, mediaTimeOffset, flags, *r );
-				if( FAILED( hr ) ) { r->Release(); return hr; }
-				if( flags & eResultFlags::NewObject ) { *pp = r; return S_OK; }
+				if( flags & eResultFlags::NewObject )
+				{
+					TranscribeResult* r = new TranscribeResult();
+					const HRESULT hr = fillResultData( resultAll, vocab, mediaTimeOffset, flags, *r );
+					if( FAILED( hr ) ) { r->Release(); return hr; }
+					*pp = r;
+					return S_OK;
+				}
 				// without NewObject the reference hands out an object that lives as long as the context (TranscribeResult.h:34-43)
-				if( live ) live->Release();
-				live = r;
-				*pp = r;
+				CHECK( fillResultData( resultAll, vocab, mediaTimeOffset, flags, live ) );
+				*pp = &live;
 				return S_OK;
 			}
 			HRESULT detectSpeaker( const sTimeInterval&, eSpeakerChannel& result ) const override { result = eSpeakerChannel::NoStereoData; return S_FALSE; }

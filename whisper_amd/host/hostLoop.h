@@ -36,6 +36,11 @@ namespace Whisper
 		std::vector<TokenData> tokens;
 		WindowScan( const sFullParams& p, const Vocabulary& v, int seek_, int seekEnd_, int nMax_ ) : params( p ), vocab( v ), seek( seek_ ), seekEnd( seekEnd_ ), nMax( nMax_ ) {}
 		int consumed() const { return i; }
+		// the constants feed() tests, for the device-side restatement of these rules (beam search without the host in the loop: wh_beam_rules)
+		void constants( int& seekOut, int& seekEndOut, int& nMaxOut, int& maxTokensOut, bool& singleSegmentOut ) const
+		{
+			seekOut = seek; seekEndOut = seekEnd; nMaxOut = nMax; maxTokensOut = params.max_tokens; singleSegmentOut = params.flag( eFullParamsFlags::SingleSegment );
+		}
 		// beam search: the window's result becomes that of the hypothesis that won (same window: same seek, bounds and parameters)
 		void adopt( const WindowScan& o )
 		{

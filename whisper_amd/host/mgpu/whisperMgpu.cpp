@@ -1,6 +1,6 @@
 // One process per GPU over the C ABI, no Python and no torch: the multi-GPU harness of the drop-in library.
 //
-//   whisper-mgpu -n 8 -m ggml-medium.bin -f recording.wav [-l en] [-o out.txt] [-timeout 300] [-slots 64] [-id file]
+//   whisper-mgpu -n 8 -m ggml-medium.bin -f recording.wav [-l en] [-o out.txt] [-timeout 300] [-job-timeout 0] [-slots 64] [-id file] [-job token]
 //
 // The parent forks N ranks (or, when RANK / WORLD_SIZE / LOCAL_RANK are set by an external launcher, runs as that rank).
 // Rank r binds GPU LOCAL_RANK % devices (sModelSetup.adapter); rank 0 creates the RCCL id and publishes it through a file;
@@ -38,8 +38,10 @@ namespace
 	struct Args
 	{
 		int ranks = 1, slots = 64;
-		double timeout = 300.0;
+		double timeout = 300.0;		// deadline of the rendezvous and of every collective
+		double jobTimeout = 0.0;	// deadline of the whole job (forked mode: the parent ends the ranks); 0 = none
 		std::string model, wav, lang = "en", out = "transcript.txt", idFile;
+		std::string job;			// token of THIS job: stamped into the id file by rank 0, required by the ranks that read it
 	};
 	std::wstring widen( const std::string& s )
 	{
@@ -54,16 +56,45 @@ namespace
 		b = rank * q + ( rank < r ? rank : r );
 		e = b + q + ( rank < r ? 1 : 0 );
 	}
-	// the id file of THIS job: present, complete, and not older than this process (a file a previous job left behind is not taken)
-	bool readFreshFile( const std::string& path, void* dst, size_t n, time_t notBefore )
+	// The id file: a header naming the job, then the 128-byte id. A rank takes the file only when it carries ITS job's token -- not when it merely
+	// looks recent: under an external launcher (torchrun / srun / mpirun) a rank may start many seconds after rank 0 published the id, so
+	// freshness is judged against the rendezvous deadline (a file older than `-timeout` before this rank started cannot be this job's: rank 0
+	// would have given up by now), never against this rank's own start time (that rejected the valid file on every poll).
+	struct IdFileHeader
+	{
+		char magic[ 8 ];	 // "WHMGPU1"
+		char job[ 56 ];		 // NUL-padded token
+	};
+	IdFileHeader makeHeader( const std::string& job )
+	{
+		IdFileHeader h;
+		memset( &h, 0, sizeof( h ) );
+		memcpy( h.magic, "WHMGPU1", 7 );
+		strncpy( h.job, job.c_str(), sizeof( h.job ) - 1 );
+		return h;
+	}
+	bool writeIdFile( const std::string& path, const std::string& job, const void* id, size_t n )
+	{
+		const std::string tmp = path + ".tmp";
+		FILE* f = fopen( tmp.c_str(), "wb" );
+		if( !f ) return false;
+		const IdFileHeader h = makeHeader( job );
+		const bool ok = fwrite( &h, 1, sizeof( h ), f ) == sizeof( h ) && fwrite( id, 1, n, f ) == n;
+		fclose( f );
+		if( !ok ) { unlink( tmp.c_str() ); return false; }
+		return 0 == rename( tmp.c_str(), path.c_str() );	// atomic publish
+	}
+	bool readIdFile( const std::string& path, const std::string& job, void* dst, size_t n, time_t notBefore )
 	{
 		struct stat st;
 		if( 0 != stat( path.c_str(), &st ) || st.st_mtime < notBefore ) return false;
 		FILE* f = fopen( path.c_str(), "rb" );
 		if( !f ) return false;
-		const size_t got = fread( dst, 1, n, f );
+		IdFileHeader h;
+		const bool ok = fread( &h, 1, sizeof( h ), f ) == sizeof( h ) && fread( dst, 1, n, f ) == n;
 		fclose( f );
-		return got == n;
+		const IdFileHeader want = makeHeader( job );
+		return ok && 0 == memcmp( &h, &want, sizeof( h ) );
 	}
 	// WHISPER_MGPU_TEST_FAULT="<rank|all>:<exit|hang>" -- test hook (tests/test_cli.py, no GPU needed): the named rank exits with code 7 or
 	// sleeps for ever before it touches a device, so that the parent's handling of a dead / stuck rank can be exercised anywhere
@@ -93,21 +124,18 @@ namespace
 
 		// ---- communicator: the 128-byte id travels through a file ----
 		unsigned char id[ WH_COMM_ID_BYTES ];
-		const std::string tmp = a.idFile + ".tmp";
 		if( rank == 0 )
 		{
 			unlink( a.idFile.c_str() );	   // whatever an earlier job left under this name
 			if( 0 != wh_comm_unique_id( id ) ) { fprintf( stderr, "[rank 0] %s\n", wh_last_error() ); return 3; }
-			FILE* f = fopen( tmp.c_str(), "wb" );
-			if( !f || fwrite( id, 1, sizeof( id ), f ) != sizeof( id ) ) { fprintf( stderr, "[rank 0] cannot write %s\n", tmp.c_str() ); return 3; }
-			fclose( f );
-			rename( tmp.c_str(), a.idFile.c_str() );	// atomic publish
+			if( !writeIdFile( a.idFile, a.job, id, sizeof( id ) ) ) { fprintf( stderr, "[rank 0] cannot write %s\n", a.idFile.c_str() ); return 3; }
 		}
 		else
 		{
-			while( !readFreshFile( a.idFile, id, sizeof( id ), started - 2 ) )
+			// this job's token, and not older than the rendezvous deadline allows (see readIdFile)
+			while( !readIdFile( a.idFile, a.job, id, sizeof( id ), started - (time_t)a.timeout - 2 ) )
 			{
-				if( since() > a.timeout ) { fprintf( stderr, "[rank %d] no communicator id in %s after %.0f s\n", rank, a.idFile.c_str(), a.timeout ); return 3; }
+				if( since() > a.timeout ) { fprintf( stderr, "[rank %d] no communicator id of job '%s' in %s after %.0f s\n", rank, a.job.c_str(), a.idFile.c_str(), a.timeout ); return 3; }
 				std::this_thread::sleep_for( std::chrono::milliseconds( 10 ) );
 			}
 		}
@@ -152,7 +180,7 @@ namespace
 		for( int w = wb; w < we; w++ )
 			streams.push_back( sBatchStream{ audio, (int64_t)w * chunk, std::min( chunk, nSamples - (int64_t)w * chunk ), nullptr } );
 		iBatchRunner* runner = nullptr;
-		const sBatchSetup bs{ (uint32_t)std::max( 1, std::min( a.slots, 128 ) ), 0, 0, 0 };
+		const sBatchSetup bs{ (uint32_t)std::max( 1, std::min( a.slots, 512 ) ), 0, 0, 0 };
 		if( !streams.empty() && FAILED( createBatchRunner( model, &bs, &runner ) ) ) return 6;
 
 		if( 0 != wh_comm_barrier( comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 8; }
@@ -257,6 +285,8 @@ int main( int argc, char** argv )
 		else if( !strcmp( argv[ i ], "-o" ) ) a.out = val();
 		else if( !strcmp( argv[ i ], "-id" ) ) a.idFile = val();
 		else if( !strcmp( argv[ i ], "-timeout" ) ) a.timeout = atof( val() );
+		else if( !strcmp( argv[ i ], "-job-timeout" ) ) a.jobTimeout = atof( val() );
+		else if( !strcmp( argv[ i ], "-job" ) ) a.job = val();
 		else if( !strcmp( argv[ i ], "-slots" ) ) a.slots = atoi( val() );
 		else if( !strcmp( argv[ i ], "--shard-range" ) )
 		{
@@ -268,7 +298,26 @@ int main( int argc, char** argv )
 			printf( "%d %d\n", b, e );
 			return 0;
 		}
-		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-timeout seconds] [-slots n] [-id id-file]\n" ); return 1; }
+		else if( !strcmp( argv[ i ], "--id-write" ) )
+		{
+			// test hooks (no GPU): the id file of job <token> as rank 0 publishes it / as a rank that started <late> seconds after it takes it
+			const std::string path = val(), job = val();
+			unsigned char id[ WH_COMM_ID_BYTES ];
+			for( size_t k = 0; k < sizeof( id ); k++ ) id[ k ] = (unsigned char)( k * 7 + 1 );
+			return writeIdFile( path, job, id, sizeof( id ) ) ? 0 : 1;
+		}
+		else if( !strcmp( argv[ i ], "--id-read" ) )
+		{
+			const std::string path = val(), job = val();
+			const double late = atof( val() ), timeout = atof( val() );
+			unsigned char id[ WH_COMM_ID_BYTES ];
+			// a rank whose own start lies `late` seconds in the future of now
+			const bool ok = readIdFile( path, job, id, sizeof( id ), time( nullptr ) + (time_t)late - (time_t)timeout - 2 );
+			for( size_t k = 0; ok && k < sizeof( id ); k++ )
+				if( id[ k ] != (unsigned char)( k * 7 + 1 ) ) return 2;
+			return ok ? 0 : 1;
+		}
+		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-timeout seconds (rendezvous and collectives)] [-job-timeout seconds (whole job; default none)] [-slots n] [-id id-file] [-job token]\n" ); return 1; }
 	}
 	if( a.model.empty() || a.wav.empty() || a.ranks < 1 ) { fprintf( stderr, "whisper-mgpu: -m and -f are required\n" ); return 1; }
 	if( a.timeout <= 0 ) a.timeout = 300.0;
@@ -289,9 +338,17 @@ int main( int argc, char** argv )
 			}
 			a.idFile = std::string( "/tmp/whisper-mgpu." ) + std::to_string( (long)getuid() ) + "." + ( port ? port : "0" ) + ".id";
 		}
+		if( a.job.empty() )
+		{
+			// what every rank of ONE launch shares and two launches do not: the launcher's run / job id where it exports one, plus the rendezvous port
+			for( const char* name : { "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE", "MASTER_ADDR", "MASTER_PORT" } )
+				if( const char* v = getenv( name ) ) { a.job += v; a.job += '/'; }
+			if( a.job.empty() ) a.job = "external";
+		}
 		return runRank( a, atoi( wr ), world, local );
 	}
 	if( a.idFile.empty() ) a.idFile = "/tmp/whisper-mgpu." + std::to_string( (long)getuid() ) + "." + std::to_string( (long)getpid() ) + ".id";
+	if( a.job.empty() ) a.job = "fork/" + std::to_string( (long)getpid() ) + "/" + std::to_string( (long)time( nullptr ) );
 	unlink( a.idFile.c_str() );
 	std::vector<pid_t> kids;
 	for( int r = 0; r < a.ranks; r++ )
@@ -301,8 +358,9 @@ int main( int argc, char** argv )
 		if( pid < 0 ) { perror( "fork" ); for( pid_t k : kids ) kill( k, SIGKILL ); return 1; }
 		kids.push_back( pid );
 	}
-	// the ranks' own collectives give up after -timeout; the job as a whole gets that plus what model loading and decoding may take
-	const int rc = superviseRanks( kids, 4.0 * a.timeout );
+	// the ranks' own rendezvous and collectives give up after -timeout; the JOB has a deadline only when -job-timeout names one (a long recording or
+	// a slow model read is not a hang: ADVICE r4 -- 4 x -timeout killed legitimate long jobs and deleted their partial output)
+	const int rc = superviseRanks( kids, a.jobTimeout );
 	unlink( a.idFile.c_str() );
 	if( rc == 0 )
 	{

@@ -25,6 +25,30 @@ namespace Whisper
 		const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
 	};
 
+	// The object EMBEDDED in a context: handed out by getResults without eResultFlags::NewObject, it lives as long as the context and its
+	// Release never deletes (Whisper/Whisper/TranscribeResult.h:34-43, ContextImpl.misc.cpp:203-209): the idiomatic
+	// `CComPtr<iTranscribeResult> r; ctx->getResults( flags, &r );` of a callback (Examples/main/main.cpp:57-58) releases it on scope exit.
+	class TranscribeResultStatic : public iTranscribeResult, public ResultData
+	{
+	public:
+		HRESULT QueryInterface( const ComLight::GUID& riid, void** ppv ) override
+		{
+			if( !ppv ) return E_POINTER;
+			if( riid == iTranscribeResult::iid() || riid == ComLight::IID_IUnknown ) { *ppv = this; return S_OK; }
+			return E_NOINTERFACE;
+		}
+		uint32_t AddRef() override { return 1; }
+		uint32_t Release() override { return 1; }
+		HRESULT getSize( sTranscribeLength& rdi ) const override
+		{
+			rdi.countSegments = (uint32_t)segments.size();
+			rdi.countTokens = (uint32_t)tokens.size();
+			return S_OK;
+		}
+		const sSegment* getSegments() const override { return segments.empty() ? nullptr : segments.data(); }
+		const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
+	};
+
 	// Segment times: 10 ms units -> 100 ns ticks, plus the media time of the first sample (ContextImpl.misc.cpp getResults)
 	inline HRESULT fillResultData( const std::vector<Segment>& resultAll, const Vocabulary& vocab, int64_t mediaTimeOffset, eResultFlags flags, ResultData& res )
 	{

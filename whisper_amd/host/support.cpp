@@ -331,29 +331,34 @@ namespace Whisper
 
 	HRESULT loadGgmlFile( const std::string& path, int device, const sLoadModelCallbacks* callbacks, std::shared_ptr<LoadedModel>& out, wh_comm* comm, int root )
 	{
-		std::ifstream f( path, std::ios::binary );
-		if( !f )
-		{
-			logError( "failed to open model file '%s'", path.c_str() );
-			return (HRESULT)0x80070002;	   // HRESULT_FROM_WIN32( ERROR_FILE_NOT_FOUND )
-		}
-		f.seekg( 0, std::ios::end );
-		const int64_t fileSize = (int64_t)f.tellg();
-		f.seekg( 0 );
-		auto lm = std::make_shared<LoadedModel>();
-		int32_t nMel = 0, nFft = 0;
-		std::vector<float> filters;
-		CHECK( readGgmlHeader( f, path, lm->hp, nMel, nFft, filters, lm->vocab ) );
-
-		CHECK_WH( wh_device_set( device ) );
-		CHECK_WH( wh_model_create( &lm->hp, nullptr, 0, &lm->gpu ) );
-		CHECK_WH( wh_model_set_filters( lm->gpu, nMel, nFft, filters.data() ) );
-
 		int rank = 0, world = 1;
 		if( comm ) CHECK_WH( wh_comm_info( comm, &rank, &world ) );
 		const bool readsTensors = !comm || rank == root;
-		// Failure has to be collective: a root that cannot read the file must not leave the other ranks inside ncclBroadcast. So the
-		// root reads (and keeps its HRESULT), every rank takes part in a 4-byte status broadcast, and only then the arena travels.
+		std::ifstream f;
+		int64_t fileSize = 0;
+		auto lm = std::make_shared<LoadedModel>();
+		// Failure has to be collective: a rank that cannot open the file, parse its header or create its device model -- the root or any other --
+		// must not leave the others inside ncclBroadcast. So EVERYTHING up to the arena's broadcast runs under one HRESULT per rank, the ranks
+		// exchange those (4 bytes each, every rank in turn the root of a status broadcast), and only when all are S_OK does the arena travel.
+		auto prepare = [ & ]() -> HRESULT
+		{
+			f.open( path, std::ios::binary );
+			if( !f )
+			{
+				logError( "failed to open model file '%s'", path.c_str() );
+				return (HRESULT)0x80070002;	   // HRESULT_FROM_WIN32( ERROR_FILE_NOT_FOUND )
+			}
+			f.seekg( 0, std::ios::end );
+			fileSize = (int64_t)f.tellg();
+			f.seekg( 0 );
+			int32_t nMel = 0, nFft = 0;
+			std::vector<float> filters;
+			CHECK( readGgmlHeader( f, path, lm->hp, nMel, nFft, filters, lm->vocab ) );
+			CHECK_WH( wh_device_set( device ) );
+			CHECK_WH( wh_model_create( &lm->hp, nullptr, 0, &lm->gpu ) );
+			CHECK_WH( wh_model_set_filters( lm->gpu, nMel, nFft, filters.data() ) );
+			return S_OK;
+		};
 		auto readTensors = [ & ]() -> HRESULT
 		{
 			std::vector<char> payload;
@@ -390,16 +395,23 @@ namespace Whisper
 			CHECK_WH( wh_model_finalize( lm->gpu ) );
 			return S_OK;
 		};
-		HRESULT hrRead = readsTensors ? readTensors() : S_OK;
+		HRESULT hrRead = prepare();
+		if( SUCCEEDED( hrRead ) && readsTensors ) hrRead = readTensors();
 		if( comm )
 		{
-			int32_t status = (int32_t)hrRead;
-			CHECK_WH( wh_comm_broadcast_i32( comm, root, &status ) );
-			if( rank == root && FAILED( hrRead ) ) return hrRead;
-			if( FAILED( (HRESULT)status ) )
+			HRESULT firstPeer = S_OK;
+			int failedRank = -1;
+			for( int r = 0; r < world; r++ )
 			{
-				logError( "loadModelShared: rank %d could not read the model (0x%08x); rank %d gives up with it", root, (unsigned)status, rank );
-				return (HRESULT)status;
+				int32_t status = r == rank ? (int32_t)hrRead : 0;
+				CHECK_WH( wh_comm_broadcast_i32( comm, r, &status ) );
+				if( FAILED( (HRESULT)status ) && failedRank < 0 ) { failedRank = r; firstPeer = (HRESULT)status; }
+			}
+			if( FAILED( hrRead ) ) return hrRead;
+			if( failedRank >= 0 )
+			{
+				logError( "loadModelShared: rank %d could not load the model (0x%08x); rank %d gives up with it", failedRank, (unsigned)firstPeer, rank );
+				return firstPeer;
 			}
 			double seconds = 0;
 			CHECK_WH( wh_model_broadcast( lm->gpu, comm, root, &seconds ) );

@@ -26,35 +26,14 @@ namespace Whisper
 		// vain when a window ends: one sequential 199 s clip through runFull, medium shape, ran at 265 / 308 / 330 / 351 audio-s/s
 		// with chunks of 8 / 4 / 2 / 1 in round 3 (1.13 ms per step; a fetch polls the sampler's pinned mailbox, it enqueues
 		// nothing). WHISPER_GREEDY_CHUNK overrides (1 .. 64).
+		// eSamplingStrategy::BeamSearch: candidates ranked on the host after every step (round 4's decoder, the checker) instead of on the device
+		bool g_beamRankingOnHost = []() { const char* e = getenv( "WHISPER_BEAM_HOST" ); return e && atoi( e ) != 0; }();
 		static const int GREEDY_CHUNK = []() {
 			const char* e = getenv( "WHISPER_GREEDY_CHUNK" );
 			const int v = e ? atoi( e ) : 0;
 			return v >= 1 && v <= 64 ? v : 1;
 		}();
 
-
-		// The object embedded in a context: handed out without NewObject, it lives as long as the context and its
-		// Release never deletes (Whisper/Whisper/TranscribeResult.h:34-43)
-		class TranscribeResultStatic : public iTranscribeResult, public ResultData
-		{
-		public:
-			HRESULT QueryInterface( const ComLight::GUID& riid, void** ppv ) override
-			{
-				if( !ppv ) return E_POINTER;
-				if( riid == iTranscribeResult::iid() || riid == ComLight::IID_IUnknown ) { *ppv = this; return S_OK; }
-				return E_NOINTERFACE;
-			}
-			uint32_t AddRef() override { return 1; }
-			uint32_t Release() override { return 1; }
-			HRESULT getSize( sTranscribeLength& rdi ) const override
-			{
-				rdi.countSegments = (uint32_t)segments.size();
-				rdi.countTokens = (uint32_t)tokens.size();
-				return S_OK;
-			}
-			const sSegment* getSegments() const override { return segments.empty() ? nullptr : segments.data(); }
-			const sToken* getTokens() const override { return tokens.empty() ? nullptr : tokens.data(); }
-		};
 
 		// ---- iAudioBuffer -----------------------------------------------------------------------------------------
 		class AudioBuffer : public ComObject<iAudioBuffer>
@@ -157,6 +136,7 @@ namespace Whisper
 			HRESULT encodeWindow( wh_context* ctx, int seek );
 			HRESULT beamContext( int width );
 			HRESULT decodeWindowBeam( const std::vector<int>& prompt, int width, WindowScan& scan, int& steps );
+			HRESULT decodeWindowBeamDevice( const std::vector<int>& prompt, int width, WindowScan& scan, int& steps );
 
 		public:
 			ContextImpl( const std::shared_ptr<LoadedModel>& m, iModel* o ) : model( m ), owner( o )
@@ -567,6 +547,86 @@ namespace Whisper
 			return S_OK;
 		}
 
+		// The same search with the ranking ON THE DEVICE (round 5): wh_beam_window_* keeps pool, ranking, stop rules, finished / live lists and the
+		// "can a live hypothesis still win" test in a kernel behind every decode step, the whole step is one captured graph, and this loop only polls
+		// `done` every 16 steps -- a window of ~50 tokens costs 4 host round trips instead of 100. What comes back: the search state (who finished with
+		// which score) and one record per accepted proposal; the winner is chosen by decodeWindowBeam's own rule and its tokens are REPLAYED through the
+		// window's WindowScan, which both builds the result and checks the device's restatement of the stop rules against the host's.
+		HRESULT ContextImpl::decodeWindowBeamDevice( const std::vector<int>& prompt, int width, WindowScan& result, int& steps )
+		{
+			const int n = (int)prompt.size(), nCtx = model->hp.n_text_ctx;
+			wh_beam_rules rules{};
+			bool single = false;
+			{
+				int seek = 0, seekEnd = 0, nMax = 0, maxTokens = 0;
+				result.constants( seek, seekEnd, nMax, maxTokens, single );
+				rules.seek = seek; rules.seekEnd = seekEnd; rules.nMax = nMax; rules.maxTokens = maxTokens;
+			}
+			rules.singleSegment = single ? 1 : 0;
+			rules.tokenBeg = model->vocab.token_beg;
+			rules.tokenEot = model->vocab.token_eot;
+			rules.forced = 0;
+			constexpr int CHUNK = 16;
+			int enqueued = std::max( 0, std::min( CHUNK - 1, nCtx - n ) );
+			std::vector<int32_t> tokens( prompt.begin(), prompt.end() );
+			CHECK_WH( wh_beam_window_start( gpuBeam, 1, tokens.data(), n, width, &rules, enqueued ) );
+			wh_beam_window st{};
+			while( true )
+			{
+				CHECK_WH( wh_beam_window_status( gpuBeam, &st ) );
+				if( st.done ) break;
+				const int more = std::min( CHUNK, nCtx - n - enqueued );
+				if( more <= 0 ) break;
+				CHECK_WH( wh_beam_window_continue( gpuBeam, more ) );
+				enqueued += more;
+			}
+			steps = st.step;
+			if( st.step <= 0 ) return E_UNEXPECTED;
+			std::vector<wh_beam_record> rec( (size_t)st.step * width );
+			CHECK_WH( wh_beam_window_records( gpuBeam, 0, st.step, rec.data() ) );
+			// the candidates in decodeWindowBeam's order: the finished list, then whoever was still live (those end where they stand, as failed windows)
+			struct Cand { wh_beam_hyp h; bool wasLive; };
+			std::vector<Cand> cands;
+			for( int i = 0; i < st.nFinished; i++ ) cands.push_back( Cand{ st.finished[ i ], false } );
+			for( int i = 0; i < st.nLive; i++ )
+			{
+				Cand c{ st.live[ i ], true };
+				if( !c.h.over ) c.h.failed = c.h.over = 1;
+				cands.push_back( c );
+			}
+			auto perToken = []( const wh_beam_hyp& h ) { return h.sum / (double)std::max( 1, h.nTok ); };
+			const Cand* best = nullptr;
+			for( const Cand& c : cands )
+				if( !best || ( best->h.failed && !c.h.failed ) || ( ( best->h.failed != 0 ) == ( c.h.failed != 0 ) && perToken( c.h ) > perToken( best->h ) ) ) best = &c;
+			if( !best ) return E_UNEXPECTED;
+			// its tokens, oldest first
+			std::vector<const wh_beam_record*> chain;
+			for( int r = best->h.rec; r >= 0; )
+			{
+				if( r >= st.step * width ) return E_UNEXPECTED;
+				const wh_beam_record& x = rec[ (size_t)r ];
+				chain.push_back( &x );
+				r = x.parent;
+			}
+			WindowScan replay( result );
+			for( size_t k = chain.size(); k-- > 0; )
+			{
+				const wh_beam_record& x = *chain[ k ];
+				TokenData td;
+				td.id = x.t.id; td.tid = x.t.tid; td.p = x.t.p; td.pt = x.t.pt; td.ptsum = x.t.ptsum;
+				replay.feed( td );
+			}
+			if( best->wasLive && !replay.over ) replay.failed = replay.over = true;
+			if( replay.failed != ( best->h.failed != 0 ) || (int)replay.tokens.size() != best->h.nTok || replay.resultLen != best->h.resultLen )
+			{
+				logError( "beam search: the device's stop rules and the host's disagree on the winning hypothesis (failed %d / %d, tokens %d / %d, resultLen %d / %d)",
+					(int)replay.failed, best->h.failed, (int)replay.tokens.size(), best->h.nTok, replay.resultLen, best->h.resultLen );
+				return E_UNEXPECTED;
+			}
+			result.adopt( replay );
+			return S_OK;
+		}
+
 		HRESULT ContextImpl::runFullImpl( const sFullParams& params, const sProgressSink& progress )
 		{
 			// the stream's rules (seek range, prompt carry-over, stop rules, segments, callbacks) live in hostLoop.h, shared with the
@@ -590,6 +650,8 @@ namespace Whisper
 				}
 				CHECK( beamContext( beamWidth ) );
 			}
+			// the ONE device context this run works on: the window x hypotheses context of a beam search, else the stream's own
+			wh_context* const active = beamWidth >= 1 ? gpuBeam : gpu;
 			std::vector<int> prompt;
 			while( true )
 			{
@@ -600,16 +662,16 @@ namespace Whisper
 					// enqueued without a host sync: the decoder's launches line up behind the encoder's on the context's stream.
 					// With WHISPER_PROFILE=1 the two are separated so that the "Encode" block means what it means in the reference.
 					const auto t = Clock::now();
-					CHECK( encodeWindow( beamWidth >= 1 ? gpuBeam : gpu, run.seek ) );
-					if( gpuProfile ) CHECK_WH( wh_context_synchronize( gpu ) );
+					CHECK( encodeWindow( active, run.seek ) );
+					if( gpuProfile ) CHECK_WH( wh_context_synchronize( active ) );	   // the context the encoder was queued on ("Encode" measures the encoder, not its enqueue)
 					msEncode += msSince( t );
 					nEncode++;
 				}
 				const auto tDec = Clock::now();
-				WindowDecoder dec( gpu, hp.n_text_ctx );
+				WindowDecoder dec( active, hp.n_text_ctx );
 				WindowScan scan( run.fullParams(), vocab, run.seek, run.seekEnd(), run.maxTokens() );
 				if( beamWidth >= 1 )
-					CHECK( decodeWindowBeam( prompt, beamWidth, scan, dec.steps ) );
+					CHECK( g_beamRankingOnHost ? decodeWindowBeam( prompt, beamWidth, scan, dec.steps ) : decodeWindowBeamDevice( prompt, beamWidth, scan, dec.steps ) );
 				else
 				for( bool first = true; !scan.over; first = false )
 				{
@@ -1257,6 +1319,12 @@ WHISPER_EXPORT int32_t whisperc_format_measure( const char* name, double ticks, 
 	memcpy( out, s.data(), n );
 	out[ n ] = 0;
 	return (int32_t)n;
+}
+WHISPER_EXPORT int32_t whisperc_set_beam_ranking( int onHost )
+{
+	if( onHost != 0 && onHost != 1 ) return E_INVALIDARG;
+	g_beamRankingOnHost = onHost != 0;
+	return S_OK;
 }
 WHISPER_EXPORT int32_t whisperc_set_host_loop_rules( int mode )
 {
