@@ -123,6 +123,38 @@ def test_mul_mat_gelu_big_batch_decode_rows(M, N, K, golden):
         assert torch.equal(out, first)
 
 
+@pytest.mark.parametrize("seqs,heads,n_past,stride", [(150, 16, 54, 448), (70, 20, 0, 448), (129, 3, 63, 448), (130, 2, 64, 448), (66, 4, 200, 448), (65, 2, 447, 448)])
+def test_self_attention_a_wave_per_sequence_and_head(seqs, heads, n_past, stride):
+    """selfAttnDecWave: the causal self-attention of a single-token step for more than 64 sequences (what a lock-step batch beyond 128 runs behind its QKV
+    product) against the restatement of mulMat(K,Q) -> diagMaskInf -> softMax -> mulMat(V,.) (whisper.cpp:1618-1660), and against attentionDecG -- the
+    kernel the same call takes with the wave kernel switched off -- to the last FP16 ulp of the output. Key counts on both sides of the 64-key and
+    8-slot boundaries, the first token (one key) and the last position of the context."""
+    from test_gpu_ops import _np_decoder_attention
+    from oracle import whisper_np as wn
+    rng = np.random.default_rng(seqs * 100 + n_past)
+    d = heads * 64
+    n_keys = n_past + 1
+    q = (rng.standard_normal((seqs, d)) * 0.8).astype(np.float16)
+    K = (rng.standard_normal((seqs, heads, stride, 64)) * 0.8).astype(np.float16)
+    V = rng.standard_normal((seqs, heads, stride, 64)).astype(np.float16)
+    want = _np_decoder_attention(q, K, V, 1, n_keys, 1, n_past, 1, 0)
+    qd, kd, vd = dev(q), dev(K), dev(V)
+    L = binding.lib()
+    got = {}
+    for name, min_rows in (("wave", 64), ("attentionDecG", 1 << 20)):
+        with option("self_wave_min_rows", min_rows, 64):
+            out = torch.full((seqs, d), float("nan"), dtype=torch.float16, device="cuda")
+            binding.check(L.wh_op_decoder_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), seqs, heads, 1, n_keys, stride, 1, n_past, 1, 0))
+            torch.cuda.synchronize()
+        got[name] = out.cpu().numpy().astype(np.float32)
+        assert np.isfinite(got[name]).all()
+        dd = report("self-attention %s %d seqs x %d heads, %d keys" % (name, seqs, heads, n_keys), got[name], wn.r16(want))
+        assert dd.max() < 2e-3 and dd.mean() < 2e-4
+    dk = np.abs(got["wave"] - got["attentionDecG"])
+    print("    wave kernel vs attentionDecG: max %.3e, %.4f %% of the outputs differ" % (dk.max(), 100.0 * (dk > 0).mean()))
+    assert dk.max() <= 2e-3 and (dk > 0).mean() < 0.02
+
+
 def test_encoder_in_chunks(tiny_model, golden):
     """An 11-window batch encoded in chunks of 4 + 4 + 3 windows (option enc_chunk) against the same batch in one pass: the cross-attention caches
     of every window (first, middle and last decoder layer) agree bit for bit -- a window's rows never meet another window's -- and so do the logits
@@ -190,9 +222,9 @@ def test_big_lock_step_batch_on_the_toy_model(tiny_model, golden):
     ids_s, ps_s = cs.decode_window_finish()
     cs.close()
     results = {}
-    for name, opts in (("default", {}), ("self_nq 8", {"self_nq": 8}), ("self_nq 4", {"self_nq": 4}), ("self block as separate launches", {"self_fuse_max_rows": 128}),
+    for name, opts in (("default", {}), ("self_nq 8", {"self_nq": 8}), ("self_nq 4", {"self_nq": 4}), ("self block as separate launches", {"self_fuse_max_rows": 128}), ("... through attentionDecG", {"self_fuse_max_rows": 128, "self_wave_min_rows": 1 << 20}),
                        ("vocabulary on gemmDecRows", {"vocab_decrows": 1}), ("gemvFused row groups", {"dec_tile": 1})):
-        defaults = {"self_nq": 0, "self_fuse_max_rows": 512, "vocab_decrows": 0, "dec_tile": 0}
+        defaults = {"self_nq": 0, "self_fuse_max_rows": 512, "vocab_decrows": 0, "dec_tile": 0, "self_wave_min_rows": 64}
         try:
             for k, v in opts.items():
                 binding.set_option(k, v)

@@ -1012,6 +1012,119 @@ namespace wh
 			}
 		}
 
+		// ---------------------------------------------------------------------------------------------------------------
+		// selfAttnDecWave: causal self-attention of a single-token decode step for MANY sequences (a lock-step batch of more than 128: there the
+		// fused selfBlockDec no longer fits one round of workgroups and the self-attention half runs as its own launch behind the QKV product).
+		// A WAVE per (sequence, head) -- a sequence sees at most n_text_ctx <= 512 keys, 7 KB of K and V each at 55 keys -- four of them per
+		// workgroup, no workgroup barrier. Scores: a lane owns whole K rows (keys lane, lane + 64, ...; the FMAs in attentionDec's order, so the
+		// scores are the same bits); the reference's table softmax with a double sum; P.V in FP32: 8 key slots x 8 lanes of 8 dims, slots added by
+		// shuffles. The new token's K / V rows were appended to the cache by the QKV product's epilogue (EPI_QKV_DEC) before this launch.
+		constexpr int SAW_WAVES = 4, SAW_MAX_KEYS = 512;
+		__global__ void __launch_bounds__( SAW_WAVES * 64 ) selfAttnDecWave( const DecAttnArgs a )
+		{
+			__shared__ float scW[ SAW_WAVES ][ SAW_MAX_KEYS ];
+			__shared__ float qsW[ SAW_WAVES ][ HEAD_DIM ];
+			const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+			const int pair = blockIdx.x * SAW_WAVES + wave;
+			if( pair >= a.batch * a.H ) return;
+			const int b = pair / a.H, h = pair - b * a.H;
+			const int d = a.H * HEAD_DIM;
+			const int nPast = a.nPastDev ? a.nPastDev[ b ] : a.nPast;
+			const int nk = min( nPast + 1, a.keyStride );
+			const f16* const K = a.kc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
+			const f16* const V = a.vc + ( (long long)b * a.H + h ) * a.keyStride * HEAD_DIM;
+			float* const sc = scW[ wave ];
+			float* const qs = qsW[ wave ];
+			// the first 64 K rows and the first 8 V rows go out before anything else (a decode step rarely sees more keys)
+			f16x8 k0[ 8 ];
+			{
+				const f16* kr = K + (long long)min( lane, nk - 1 ) * HEAD_DIM;
+#pragma unroll
+				for( int c8 = 0; c8 < 8; c8++ ) k0[ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+			}
+			const int g = lane >> 3, j8 = ( lane & 7 ) * 8;
+			f16x8 v0 = *(const f16x8*)( V + (long long)min( g, nk - 1 ) * HEAD_DIM + j8 );
+			qs[ lane ] = (float)a.q[ (long long)b * d + h * HEAD_DIM + lane ];
+			__builtin_amdgcn_wave_barrier();	   // LDS operations of a wave execute in order; this only keeps the compiler from moving reads above the write
+			// ---- scores ----
+			float mx = -INFINITY;
+			for( int k00 = 0; k00 < nk; k00 += 64 )
+			{
+				const int key = k00 + lane;
+				if( k00 > 0 )
+				{
+					const f16* kr = K + (long long)min( key, nk - 1 ) * HEAD_DIM;
+#pragma unroll
+					for( int c8 = 0; c8 < 8; c8++ ) k0[ c8 ] = *(const f16x8*)( kr + c8 * 8 );
+				}
+				float sAcc = 0.0f;
+#pragma unroll
+				for( int c8 = 0; c8 < 8; c8++ )
+#pragma unroll
+					for( int e = 0; e < 8; e++ ) sAcc = fmaf( (float)k0[ c8 ][ e ], qs[ c8 * 8 + e ], sAcc );
+				if( key < nk )
+				{
+					sc[ key ] = sAcc;
+					mx = fmaxf( mx, sAcc );
+				}
+			}
+			mx = waveReduceMax( mx );
+			__builtin_amdgcn_wave_barrier();
+			// ---- table softmax (ggml.c:5030-5090): e = exp16( s - max ), double sum, p = e * float( 1 / sum ) ----
+			double sum = 0.0;
+			for( int key = lane; key < nk; key += 64 )
+			{
+				const float e = exp16( sc[ key ] - mx );
+				sc[ key ] = e;
+				sum += (double)e;
+			}
+			sum = waveReduceSumD( sum );
+			__builtin_amdgcn_wave_barrier();
+			const float inv = (float)( 1.0 / sum );
+			// ---- P.V ----
+			float acc[ 8 ];
+#pragma unroll
+			for( int j = 0; j < 8; j++ ) acc[ j ] = 0.0f;
+			{
+				const float p = g < nk ? sc[ g ] * inv : 0.0f;
+#pragma unroll
+				for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)v0[ j ], p, acc[ j ] );
+			}
+			for( int k00 = 8; k00 < nk; k00 += 64 )
+			{
+				f16x8 vv[ 8 ];
+				float pp[ 8 ];
+#pragma unroll
+				for( int u = 0; u < 8; u++ )
+				{
+					const int key = k00 + u * 8 + g;
+					const int kcl = min( key, nk - 1 );
+					vv[ u ] = *(const f16x8*)( V + (long long)kcl * HEAD_DIM + j8 );
+					pp[ u ] = key < nk ? sc[ kcl ] * inv : 0.0f;
+				}
+#pragma unroll
+				for( int u = 0; u < 8; u++ )
+#pragma unroll
+					for( int j = 0; j < 8; j++ ) acc[ j ] = fmaf( (float)vv[ u ][ j ], pp[ u ], acc[ j ] );
+			}
+#pragma unroll
+			for( int j = 0; j < 8; j++ )
+			{
+				float t = acc[ j ];
+				t += __shfl_xor( t, 8, 64 );
+				t += __shfl_xor( t, 16, 64 );
+				t += __shfl_xor( t, 32, 64 );
+				acc[ j ] = t;
+			}
+			if( lane < 8 )
+			{
+				f16x8 o;
+#pragma unroll
+				for( int j = 0; j < 8; j++ ) o[ j ] = (f16)acc[ j ];
+				*(f16x8*)( a.out + (long long)b * d + h * HEAD_DIM + lane * 8 ) = o;
+			}
+		}
+
 		template<int NQ, bool MF>
 		int launchSelfBlockK( const DecSelfArgs& a, hipStream_t stream )
 		{
@@ -1063,6 +1176,13 @@ namespace wh
 		{
 			setError( "attentionDec: unsupported group / fused-query configuration" );
 			return -1;
+		}
+		// single-token causal self-attention of a big lock-step batch: a wave per (sequence, head)
+		if( a.causal && a.nTok == 1 && group == 1 && !fuse && a.parityThreads <= 0 && a.keyStride <= SAW_MAX_KEYS && a.batch > g_opt.selfWaveMinRows )
+		{
+			hipLaunchKernelGGL( selfAttnDecWave, dim3( ( a.batch * a.H + SAW_WAVES - 1 ) / SAW_WAVES ), dim3( SAW_WAVES * 64 ), 0, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
 		}
 		if( !( g_tuning & TUNE_ATTN_DEC_G ) && group == 1 && !fuse )
 		{

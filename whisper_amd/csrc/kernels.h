@@ -60,6 +60,7 @@ namespace wh
 		int encChunk = 128;			 // "enc_chunk": the most windows ONE encoder pass takes; contexts created afterwards encode larger batches in equal chunks
 		int selfFuseMaxRows = 512;	 // "self_fuse_max_rows": selfBlockDec up to this many sequences, LayerNorm + QKV product + attention launches beyond
 		int selfNq = 0;				 // "self_nq": sequences per selfBlockDec workgroup (0 = by grid size; 1, 2, 4, 8)
+		int selfWaveMinRows = 64;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
 	};
 	extern Options g_opt;
 
