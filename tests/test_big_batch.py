@@ -222,9 +222,10 @@ def test_big_lock_step_batch_on_the_toy_model(tiny_model, golden):
     ids_s, ps_s = cs.decode_window_finish()
     cs.close()
     results = {}
-    for name, opts in (("default", {}), ("self_nq 8", {"self_nq": 8}), ("self_nq 4", {"self_nq": 4}), ("self block as separate launches", {"self_fuse_max_rows": 128}), ("... through attentionDecG", {"self_fuse_max_rows": 128, "self_wave_min_rows": 1 << 20}),
+    for name, opts in (("default", {}), ("selfBlockDec, 8 sequences per workgroup", {"self_fuse_max_rows": 512, "self_nq": 8}), ("selfBlockDec, 4 per workgroup", {"self_fuse_max_rows": 512, "self_nq": 4}),
+                       ("self-attention through attentionDecG", {"self_wave_min_rows": 1 << 20}),
                        ("vocabulary on gemmDecRows", {"vocab_decrows": 1}), ("gemvFused row groups", {"dec_tile": 1})):
-        defaults = {"self_nq": 0, "self_fuse_max_rows": 512, "vocab_decrows": 0, "dec_tile": 0, "self_wave_min_rows": 64}
+        defaults = {"self_nq": 0, "self_fuse_max_rows": 128, "vocab_decrows": 0, "dec_tile": 0, "self_wave_min_rows": 64}
         try:
             for k, v in opts.items():
                 binding.set_option(k, v)
