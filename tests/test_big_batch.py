@@ -141,8 +141,8 @@ def test_self_attention_a_wave_per_sequence_and_head(seqs, heads, n_past, stride
     qd, kd, vd = dev(q), dev(K), dev(V)
     L = binding.lib()
     got = {}
-    for name, min_rows in (("wave", 64), ("attentionDecG", 1 << 20)):
-        with option("self_wave_min_rows", min_rows, 64):
+    for name, min_rows in (("wave", 32), ("attentionDecG", 1 << 20)):
+        with option("self_wave_min_rows", min_rows, 32):
             out = torch.full((seqs, d), float("nan"), dtype=torch.float16, device="cuda")
             binding.check(L.wh_op_decoder_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), seqs, heads, 1, n_keys, stride, 1, n_past, 1, 0))
             torch.cuda.synchronize()
@@ -225,7 +225,7 @@ def test_big_lock_step_batch_on_the_toy_model(tiny_model, golden):
     for name, opts in (("default", {}), ("selfBlockDec, 8 sequences per workgroup", {"self_fuse_max_rows": 512, "self_nq": 8}), ("selfBlockDec, 4 per workgroup", {"self_fuse_max_rows": 512, "self_nq": 4}),
                        ("self-attention through attentionDecG", {"self_wave_min_rows": 1 << 20}),
                        ("vocabulary on gemmDecRows", {"vocab_decrows": 1}), ("gemvFused row groups", {"dec_tile": 1})):
-        defaults = {"self_nq": 0, "self_fuse_max_rows": 128, "vocab_decrows": 0, "dec_tile": 0, "self_wave_min_rows": 64}
+        defaults = {"self_nq": 0, "self_fuse_max_rows": 32, "vocab_decrows": 0, "dec_tile": 0, "self_wave_min_rows": 32}
         try:
             for k, v in opts.items():
                 binding.set_option(k, v)

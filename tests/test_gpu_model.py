@@ -348,8 +348,13 @@ def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
     mel = torch.from_numpy(pad).cuda()
     L = binding.lib()
     res = {}
+    # the fused self-attention block serves 9 .. 32 sequences by default (round 5: beyond that the self-attention is its own launch, selfAttnDecWave);
+    # its 2- and 4-sequence workgroups only exist at larger batches, so the bound is lifted for these cases
+    lift = bit in ("TUNE_FUSE_SELF_BLOCK", "TUNE_SELF_MFMA")
     for name, mask in (("fused", binding.TUNE_DEFAULT | getattr(binding, bit)), ("separate", binding.TUNE_DEFAULT & ~getattr(binding, bit))):
         L.wh_debug_set_tuning(mask)
+        if lift:
+            binding.set_option("self_fuse_max_rows", 512)
         try:
             ctx = binding.HipContext(hip_tiny, batch)
             ctx.encode(torch.stack([mel] * batch))
@@ -360,6 +365,7 @@ def test_fused_launches_match_separate_launches(hip_tiny, golden, bit, batch):
             ctx.close()
         finally:
             L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+            binding.set_option("self_fuse_max_rows", 32)
     for i in range(2):
         d = report("%s on vs off, step %d" % (bit, i), res["fused"][i][0], res["separate"][i][0])
         assert d.max() < 3e-3 and d.mean() < 4e-4

@@ -58,10 +58,12 @@ namespace wh
 		int decTile = 0;			 // "dec_tile": decode products of 129 .. 512 rows: 0 = tile by shape, 44 / 42 / 24 / 22 = 16 MT rows x 16 CT columns pinned, 1 = gemvFused row groups
 		int vocabDecRows = 0;		 // "vocab_decrows": more than 128 sequences: the vocabulary product through gemmDecRows instead of the M-tiled kernel
 		int encChunk = 128;			 // "enc_chunk": the most windows ONE encoder pass takes; contexts created afterwards encode larger batches in equal chunks
-		int selfFuseMaxRows = 128;	 // "self_fuse_max_rows": selfBlockDec up to this many sequences, LayerNorm + QKV product + attention launches beyond
-									 // (measured, profiles/r05_ab_variants.txt: 224 windows 68.7 us fused vs 17.5 + 10.1 + 2.3 us, 448 windows 127 vs 45 us)
+		int selfFuseMaxRows = 32;	 // "self_fuse_max_rows": selfBlockDec up to this many sequences, LayerNorm + QKV product + attention launches beyond
+									 // (measured, profiles/r05_ab_variants.txt: 224 windows 68.7 us fused vs 17.5 + 10.1 + 2.3 us, 448 windows 127 vs 45 us; two contexts of
+									 // 70 / 112 windows: +1.6 % / +3.6 % on the job with the self-attention as selfAttnDecWave -- round 2 measured the fused launch ahead
+									 // when the separate attention was attentionDecG at 43 us)
 		int selfNq = 0;				 // "self_nq": sequences per selfBlockDec workgroup (0 = by grid size; 1, 2, 4, 8)
-		int selfWaveMinRows = 64;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
+		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
 	};
 	extern Options g_opt;
 
