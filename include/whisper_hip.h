@@ -82,6 +82,9 @@ WH_API int wh_model_hparams( const wh_model* m, wh_hparams* out );
  * caller's own buffer) and marks those models finalized; it returns the measured seconds in *secondsOut when non-NULL. */
 #define WH_COMM_ID_BYTES 128
 typedef struct wh_comm wh_comm;
+/* Packaging check without a GPU: the collective library opens under one of the names the entry points below try (librccl.so.1, librccl.so, the same two
+ * under /opt/rocm/lib) and exports every function they call; detail (optional) receives what was opened or what is missing. 0 or WH_E_NOT_READY. */
+WH_API int wh_comm_runtime_check( char* detail, size_t detailCap );
 WH_API int wh_comm_unique_id( void* id128 );
 WH_API int wh_comm_create( const void* id128, int rank, int worldSize, wh_comm** out );
 WH_API int wh_comm_destroy( wh_comm* comm );

@@ -217,6 +217,47 @@ def test_mgpu_harness_one_rank_matches_the_cli(exe, tmp_path):
         assert abs(t0 - s["t0"] / 100.0) < 0.006 and abs(t1 - s["t1"] / 100.0) < 0.006
 
 
+@pytest.mark.gpu
+def test_mgpu_two_ranks_over_rccl_or_a_loud_failure(exe, tmp_path):
+    """whisper-mgpu -n 2 through the C++ path (wh_comm_* over RCCL, loadModelShared, one batch runner per rank). With two devices visible: two ranks on two
+    GPUs, the arena broadcast over the fabric, and the concatenated transcript is the one rank's (chunks are independent recordings). With ONE device
+    (the test box): both ranks bind device 0, which RCCL cannot serve -- the job must END with an error inside the rendezvous deadline (RCCL's own
+    refusal or wh_comm_create_timeout's), never hang, and leave no partial output."""
+    import time
+    from whisper_amd import binding
+    case = [c for c in json.load(open(GOLDEN))["cases"] if c["name"] == "first_window_no_prompt"][0]
+    model = str(tmp_path / "m.bin")
+    gf.write_model(model, gf.scripted_model(case["script"], case["prompt_len"]))
+    rng = np.random.default_rng(case["pcm_seed"])
+    pcm = np.tile((0.05 * rng.standard_normal(case["n_samples"])).astype(np.float32), 3)[:16000 * 75]      # three chunks: ranks get 2 + 1
+    wav = str(tmp_path / "clip.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2").tobytes())
+    outs = {}
+    n_dev = binding.device_count()
+    for ranks in (1, 2):
+        out = str(tmp_path / ("t%d.txt" % ranks))
+        t0 = time.time()
+        r = subprocess.run([build.MGPU_BIN, "-n", str(ranks), "-m", model, "-f", wav, "-l", case["lang"], "-o", out, "-timeout", "25", "-job-timeout", "120"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
+        dt = time.time() - t0
+        err = r.stderr.decode()
+        print("ranks %d on %d device(s): rc %d in %.1f s\n%s" % (ranks, n_dev, r.returncode, dt, err[-1500:]))
+        if ranks == 1 or n_dev >= 2:
+            assert r.returncode == 0, err[-800:]
+            outs[ranks] = open(out).read()
+            assert json.loads(r.stdout.decode().strip().splitlines()[-1])["ranks"] == ranks
+        else:
+            assert r.returncode != 0 and dt < 90, "two ranks on one device must fail loudly and soon"
+            assert ("ending the other ranks" in err) and ("gave up" in err or "RCCL" in err or "nccl" in err.lower() or "communicator" in err), err[-800:]
+            assert not os.path.exists(out) and not any(f.startswith("t2.txt") for f in os.listdir(tmp_path))
+    if 2 in outs:
+        assert outs[1] == outs[2] and len(outs[1].splitlines()) >= 3
+
+
 REF_CLI = os.path.join(ROOT, "oracle", "_ref", "libcliparams_ref.so")
 
 

@@ -149,3 +149,21 @@ def test_gloo_world_size_2_shard_transcribe_gather(tmp_path, n_windows):
         assert p.exitcode == 0
     assert results[1] is None
     assert np.array_equal(np.array(results[0], np.int32), want)
+
+
+def test_the_collective_library_is_packaged_as_the_loader_expects():
+    """No GPU needed: wh_comm_* open librccl.so by name on first use (nothing is linked). The names they try must be what the image ships under
+    /opt/rocm/lib, and every entry point they call must resolve -- so that the first multi-GPU lease cannot fail before its first timed step for a
+    packaging reason."""
+    import ctypes as C
+    from whisper_amd import binding
+    L = binding.lib()
+    L.wh_comm_runtime_check.argtypes = [C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(512)
+    rc = L.wh_comm_runtime_check(buf, 512)
+    print(buf.value.decode())
+    shipped = set(os.listdir("/opt/rocm/lib")) if os.path.isdir("/opt/rocm/lib") else set()
+    assert {"librccl.so", "librccl.so.1"} & shipped, "the image does not ship librccl under /opt/rocm/lib"
+    assert rc == 0, buf.value.decode()
+    assert b"ncclBroadcast" in buf.value and b"librccl.so" in buf.value
+

@@ -95,3 +95,78 @@ def test_pmc_traffic_covers_the_cited_kernel_classes():
     # nothing on the path re-reads more than ~2x its algorithmic bytes; the streaming kernels sit at 1.0x
     assert kernels["attentionDecCross"]["traffic_over_algorithmic"] < 1.1 and kernels["layerNorm"]["traffic_over_algorithmic"] < 1.1
     assert g["traffic_over_algorithmic"] < 2.5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 5: the line says what it is -- top level = the LOWER fraction of the two headline classes, the decode chain as a class,
+# the large model's own roofline, end_to_end at the batch size the plan ran; every figure recomputed from the rocprofv3 statistics of the same command
+# ----------------------------------------------------------------------------------------------------------------------
+import pytest  # noqa: E402
+
+
+def _load5():
+    try:
+        line = json.load(open(os.path.join(PROF, "r05_bench.json")))
+        stats = list(csv.DictReader(open(os.path.join(PROF, "r05_kernel_stats.csv"))))
+    except OSError:
+        pytest.skip("profiles/r05_bench.json / r05_kernel_stats.csv not committed yet")
+    return line, stats
+
+
+def test_r05_line_structure():
+    line, _ = _load5()
+    r = line["roofline"]
+    m, h = r["mfma_kernel"], r["hbm_kernel"]
+    low = m if m["frac"] <= h["frac"] else h
+    assert r["kernel"] == low["kernel"] and all(r[f] == low[f] for f in ("bound", "achieved", "peak", "frac", "traffic"))
+    for e in (m, h, r["encoder_attention"], r["decode_chain"]):
+        assert abs(e["frac"] - e["achieved"] / e["peak"]) < 2e-3 and 0 < e["frac"] < 1
+    plan = line["config"]["batch_plan"]
+    assert sum(plan) == line["steps"] and r["batch_windows"] == max(plan) * line["config"]["windows_per_clip"] == r["end_to_end"]["batch_windows"]
+    # measured_ms_per_batch = the timed region's time per batch of that size
+    want = line["ms_per_step"] * max(plan)
+    assert abs(r["end_to_end"]["measured_ms_per_batch"] - want) / want < 1e-3
+    assert abs(r["end_to_end"]["frac"] - r["end_to_end"]["floor_ms_per_batch"] / r["end_to_end"]["measured_ms_per_batch"]) < 1e-3
+    ch = r["decode_chain"]
+    assert ch["bound"] == "hbm" and ch["frac"] < 0.2 and ch["share_of_kernel_time"] < 0.35 and ch["us_per_window_step_layer"] > 0
+    # the ids of the timed region against the same windows one at a time
+    t = line["parity"]["timed_ids"]
+    assert t["consistent"] is True and t["samples_compared"] == 7 * 52
+    # the large model: its own rooflines and the device-ranked beam search (BASELINE configs[2]) in the same line
+    lv = line["large_v2"]
+    lr = lv["roofline"]
+    for k in ("mfma_kernel", "hbm_kernel", "decode_chain", "end_to_end"):
+        assert k in lr, k
+    assert 0.2 < lr["mfma_kernel"]["frac"] < 0.6 and 0.6 < lr["hbm_kernel"]["frac"] < 1.0 and 0.2 < lr["end_to_end"]["frac"] < 0.8
+    assert lv["beam5"]["value"] > 0 and lv["parity"] is not None and lv["cpu_baseline"]["value"] > 0
+
+
+def test_r05_rooflines_recomputed_from_the_rocprof_statistics():
+    line, stats = _load5()
+    r, k = line["roofline"], line["kernels"]
+    x = r["hbm_kernel"]
+    avg, _ = _avg_us(stats, lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n)
+    frac = x["algorithmic_per_launch"] / (avg * 1e-6) / 1e9 / x["peak"]
+    print("attentionDecCross: bench %.4f, rocprof %.4f" % (x["frac"], frac))
+    assert -0.02 < (x["frac"] - frac) / x["frac"] < 0.10
+    # the encoder's product: time per batch pass of the persistent launches in the trace (warm-up + timed passes; their number follows from the encoder
+    # attention's launch count) against the class of the line (which also holds conv1's and the prompt step's small tiles: a few percent)
+    g = r["mfma_kernel"]
+    enc_calls_per_pass = r["encoder_attention"]["launches_per_batch_pass"]
+    passes = sum(int(x_["Calls"]) for x_ in stats if "attentionEnc" in x_["Name"]) / enc_calls_per_pass
+    trace_ms = sum(float(x_["TotalDurationNs"]) for x_ in stats if "gemmTiled8" in x_["Name"] or "gemmTiled4" in x_["Name"]) / 1e6 / passes
+    frac = g["algorithmic_per_launch"] * g["launches_per_batch_pass"] / (trace_ms * 1e-3) / 1e12 / g["peak"]
+    print("gemmTiled: bench %.4f, rocprof %.4f (%.1f ms per batch pass over %.1f passes)" % (g["frac"], frac, trace_ms, passes))
+    assert passes >= 2 and abs(frac - g["frac"]) / g["frac"] < 0.10
+    for cls, match in (("attentionDecCross", lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n), ("attentionEnc", lambda n: "attentionEnc" in n)):
+        avg, _ = _avg_us(stats, match)
+        print("%s: bench %.2f us, rocprof %.2f us" % (cls, k[cls]["avg_us"], avg))
+        assert -0.03 < (avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.10
+    # the decode chain's own kernels (round 5): the products of > 128 rows and the wave-per-pair self-attention
+    avg, calls = _avg_us(stats, lambda n: "gemmDecRows" in n)
+    print("gemmDecRows: rocprof %.2f us over %d launches; bench class gemvFused %.2f us" % (avg, calls, k["gemvFused"]["avg_us"]))
+    assert calls > 0 and 0.7 * avg < k["gemvFused"]["avg_us"] < 1.6 * avg
+    avg, calls = _avg_us(stats, lambda n: "selfAttnDecWave" in n)
+    print("selfAttnDecWave: rocprof %.2f us over %d launches; bench class attentionDec %.2f us" % (avg, calls, k["attentionDec"]["avg_us"]))
+    assert calls > 0 and avg < 25.0
+

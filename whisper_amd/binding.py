@@ -42,7 +42,7 @@ EXPORTS = [
     "wh_last_error", "wh_device_count", "wh_device_info", "wh_device_set",
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
-    "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
+    "wh_comm_runtime_check", "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
     "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",

@@ -854,7 +854,8 @@ namespace
 		int ( *broadcast )( const void*, void*, size_t, int, int, void*, hipStream_t ) = nullptr;
 		int ( *allReduce )( const void*, void*, size_t, int, int, void*, hipStream_t ) = nullptr;
 		const char* ( *errorString )( int ) = nullptr;
-		std::string why;
+		int ( *getVersion )( int* ) = nullptr;	   // optional
+		std::string why, loadedAs;
 	};
 	RcclApi* rccl()
 	{
@@ -865,7 +866,7 @@ namespace
 			for( const char* n : names )
 			{
 				api.lib = dlopen( n, RTLD_NOW | RTLD_LOCAL );
-				if( api.lib ) break;
+				if( api.lib ) { api.loadedAs = n; break; }
 			}
 			if( !api.lib )
 			{
@@ -884,6 +885,7 @@ namespace
 			api.broadcast = (decltype( api.broadcast ))sym( "ncclBroadcast" );
 			api.allReduce = (decltype( api.allReduce ))sym( "ncclAllReduce" );
 			api.errorString = (decltype( api.errorString ))sym( "ncclGetErrorString" );
+			api.getVersion = (decltype( api.getVersion ))dlsym( api.lib, "ncclGetVersion" );
 		} );
 		return &api;
 	}
@@ -932,6 +934,24 @@ namespace
 			if( spins > 64 ) std::this_thread::sleep_for( std::chrono::microseconds( 200 ) );
 		}
 	}
+}
+
+// Packaging check, callable without a GPU: is the collective library there under one of the names wh_comm_* opens, with every entry point they use?
+// (The first multi-GPU lease must not fail before its first timed step for a reason a single-GPU box could have shown.)
+int wh_comm_runtime_check( char* detail, size_t detailCap )
+{
+	RcclApi* r = rccl();
+	const bool ok = r->lib && r->why.empty() && r->getUniqueId && r->commInitRank && r->commDestroy && r->broadcast && r->allReduce && r->errorString;
+	int version = 0;
+	if( ok && r->getVersion ) (void)r->getVersion( &version );
+	if( detail && detailCap )
+	{
+		if( ok ) snprintf( detail, detailCap, "opened as %s, version %d, ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclAllReduce / ncclGetErrorString resolved",
+			r->loadedAs.c_str(), version );
+		else snprintf( detail, detailCap, "%s", r->why.empty() ? "librccl.so: an entry point is missing" : r->why.c_str() );
+	}
+	if( !ok ) { setError( r->why.empty() ? "librccl.so: an entry point is missing" : r->why ); return WH_E_NOT_READY; }
+	return 0;
 }
 
 int wh_comm_unique_id( void* id128 )
