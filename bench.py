@@ -996,10 +996,11 @@ def main():
     per_rank = None
     if world > 1:
         # every rank's own figure next to the job's (value = all ranks' audio / the slowest rank's time)
-        mine = torch.tensor([m.get("elapsed_local", elapsed)], dtype=torch.float64, device="cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [round(audio_seconds * args.steps / float(t.item()), 2) for t in allr]
+        # (a sum over one-hot vectors: all_reduce is the one collective both RCCL and the dry run's gloo take on device tensors)
+        slots_t = torch.zeros(world, dtype=torch.float64, device="cuda")
+        slots_t[rank] = m.get("elapsed_local", elapsed)
+        dist.all_reduce(slots_t, op=dist.ReduceOp.SUM)
+        per_rank = [round(audio_seconds * args.steps / float(t), 2) for t in slots_t.cpu().tolist()]
 
     roofline, kernels = None, {}
     if rank == 0 and m["kernels"]:

@@ -2727,7 +2727,7 @@ namespace wh
 		// summation order, so a row's result does not depend on which of the two kernels (or which row tile) computed it.
 		// Grid (column tiles, row tiles). Operands come straight from L2 (every wave reads its own K quarter: nothing to share
 		// through LDS); two k-steps of loads are in flight per wave.
-		template<int EPI, int MT, int CT>
+		template<int EPI, int MT, int CT, int DEPTH>
 		__global__ void __launch_bounds__( 256 ) gemmDecRows( const GemmArgs a )
 		{
 			constexpr int NW = 4, G = MT * CT;
@@ -2766,25 +2766,34 @@ namespace wh
 	#pragma unroll
 				for( int c = 0; c < CT; c++ ) acc[ t ][ c ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
-			// software pipeline: the fragments of k-step s + 1 are requested before the MFMAs of step s
-			f16x8 fw[ 2 ][ CT ], fx[ 2 ][ MT ];
+			// software pipeline: the fragments of k-steps s + 1 .. s + DEPTH - 1 are in flight behind the MFMAs of step s (a ring of DEPTH register sets; the
+			// smaller tiles have the registers for a deeper ring, and need it: fewer MFMAs per step to hide an L2 round trip behind)
+			// (DEPTH: 2 at 64 x 64 -- 152 VGPRs already --, 3 at 64 x 32 / 32 x 64, 4 at 32 x 32; option dec_depth = 2 pins the round-5a pipeline for A/B runs)
+			f16x8 fw[ DEPTH ][ CT ], fx[ DEPTH ][ MT ];
 	#pragma unroll
-			for( int c = 0; c < CT; c++ ) fw[ 0 ][ c ] = *(const f16x8*)( pw[ c ] );
+			for( int d = 0; d < DEPTH - 1; d++ )
+				if( d < steps )
+				{
 	#pragma unroll
-			for( int t = 0; t < MT; t++ ) fx[ 0 ][ t ] = *(const f16x8*)( px[ t ] );
-			for( int s0 = 0; s0 < steps; s0 += 2 )
+					for( int c = 0; c < CT; c++ ) fw[ d ][ c ] = *(const f16x8*)( pw[ c ] + d * 32 );
+	#pragma unroll
+					for( int t = 0; t < MT; t++ ) fx[ d ][ t ] = *(const f16x8*)( px[ t ] + d * 32 );
+				}
+			for( int s0 = 0; s0 < steps; s0 += DEPTH )
 			{
 	#pragma unroll
-				for( int u = 0; u < 2; u++ )
+				for( int u = 0; u < DEPTH; u++ )
 				{
 					const int s = s0 + u;
 					if( s >= steps ) break;
-					if( s + 1 < steps )
+					constexpr int ahead = DEPTH - 1;
+					const int nxt = ( u + ahead ) % DEPTH;	  // the set step s - 1 has just released
+					if( s + ahead < steps )
 					{
 	#pragma unroll
-						for( int c = 0; c < CT; c++ ) fw[ u ^ 1 ][ c ] = *(const f16x8*)( pw[ c ] + ( s + 1 ) * 32 );
+						for( int c = 0; c < CT; c++ ) fw[ nxt ][ c ] = *(const f16x8*)( pw[ c ] + ( s + ahead ) * 32 );
 	#pragma unroll
-						for( int t = 0; t < MT; t++ ) fx[ u ^ 1 ][ t ] = *(const f16x8*)( px[ t ] + ( s + 1 ) * 32 );
+						for( int t = 0; t < MT; t++ ) fx[ nxt ][ t ] = *(const f16x8*)( px[ t ] + ( s + ahead ) * 32 );
 					}
 	#pragma unroll
 					for( int t = 0; t < MT; t++ )
@@ -2901,8 +2910,8 @@ namespace wh
 		}
 	}
 
-	template<int EPI, int MT, int CT>
-	static int launchDecRowsK( const GemmArgs& a, hipStream_t stream )
+	template<int EPI, int MT, int CT, int DEPTH>
+	static int launchDecRowsD( const GemmArgs& a, hipStream_t stream )
 	{
 		constexpr int lds = 4 * MT * CT * 4 * 64 * 4;
 		if( lds > 48 * 1024 )
@@ -2910,13 +2919,21 @@ namespace wh
 			static PerDeviceOnce once;
 			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecRows<EPI, MT, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecRows<EPI, MT, CT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
 				once.mark( onceDev );
 			}
 		}
-		hipLaunchKernelGGL( ( gemmDecRows<EPI, MT, CT> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 16 * MT - 1 ) / ( 16 * MT ) ), dim3( 256 ), lds, stream, a );
+		hipLaunchKernelGGL( ( gemmDecRows<EPI, MT, CT, DEPTH> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 16 * MT - 1 ) / ( 16 * MT ) ), dim3( 256 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
+	}
+	template<int EPI, int MT, int CT>
+	static int launchDecRowsK( const GemmArgs& a, hipStream_t stream )
+	{
+		constexpr int deep = MT * CT >= 16 ? 2 : ( MT * CT >= 8 ? 3 : 4 );
+		if constexpr( deep != 2 )
+			if( g_opt.decDepth != 2 ) return launchDecRowsD<EPI, MT, CT, deep>( a, stream );
+		return launchDecRowsD<EPI, MT, CT, 2>( a, stream );
 	}
 
 	// Tile of a big-batch decode product: 64 x 64 (rows x columns) while that leaves enough workgroups for the chip, else 64 x 32, else 32 x 32.
