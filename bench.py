@@ -12,25 +12,29 @@ Tools/PerfSummary/Summary.cs:50) = 7 windows of 30 s, processed as one lock-step
 weights never emit EOT sensibly, so the step count is forced while the sampled token IS fed back). One "step" of the
 bench = one pass over the whole clip; the span is first H2D byte to last token id on the host. value = audio seconds /
 wall seconds; weak scaling for N > 1 (every rank transcribes its own clip; the weight arena is broadcast once over RCCL
-before the timed region). The K clip passes are dealt into balanced lock-step batches of at most --clips-per-batch clips for
-the --inflight contexts (plan_batches: 32 passes = 16 + 16, 20 passes = 10 + 10; `config.batch_plan`).
+before the timed region). The K clip passes are dealt into an even number of balanced lock-step batches of at most --clips-per-batch (64) clips for
+the --inflight (2) contexts (plan_batches: 20 passes = 10 + 10 -- the driver's invocation --, 32 = 16 + 16, 64 = 32 + 32 = 224 windows each, the default;
+`config.batch_plan`). Round 5: a context decodes up to 512 windows in lock step (encoder in chunks of <= 128, decode products of > 128 rows on gemmDecRows).
 
 Objects next to the contract fields:
-  roofline      dominant kernel class: algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on
-                the launch stream (one batch at a time) minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per
-                launch from the committed PMC pass (profiles/r04_pmc.json; counters cannot be collected inside a timed run). Two classes take turns at the top, so both are in
-                every line: `mfma_kernel` (the encoder's matrix-core product) and `hbm_kernel` (the decode step's
-                cross-attention); the top level repeats the larger. `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured
+  roofline      algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on the launch stream (one batch of the size the timed
+                region ran, one context at a time) minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per launch from the committed PMC
+                pass (profiles/r05_pmc.json; counters cannot be collected inside a timed run). The two classes with the most kernel time are both in
+                every line -- `mfma_kernel` (the encoder's matrix-core product) and `hbm_kernel` (the decode step's cross-attention) -- and the TOP LEVEL
+                repeats whichever of them sits LOWER against its roofline; `encoder_attention`; `decode_chain` = every launch of a decode step outside the
+                cross-attention as one class; `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured, per batch of the size that ran
   cpu_baseline  the reference's own CPU path (oracle/_ref, kind "reference") on a bounded sample, same run
   parity        ggml-medium shape, window 0: the measured (FP32 P.V) GPU path against the reference CPU path -- cross-KV,
-                logits of the prompt and of teacher-forced greedy steps, top-1 agreement
+                logits of the prompt and of teacher-forced greedy steps, top-1 agreement; `timed_ids` = the ids the TIMED region produced for clip 0
+                against the same windows decoded one at a time (contexts of one window), greedily and teacher-forced
   through_boundary  the SAME workload driven by the plain C++ host code: libWhisper.so createBatchRunner / iBatchRunner::run (lock-step
                 scheduler, the reference's host loop per stream) on a scripted model -- what a caller of the drop-in library gets
   single_stream the SAME clip through the drop-in boundary, sequentially: libWhisper.so iContext::runFull with prompt
                 carry-over on a scripted medium-shape model (7 windows x 52 steps) -- the like-for-like figure against the
                 reference's published single-clip number (`vs_baseline` lives here; `roofline_frac` = its byte / FLOP floor over
                 the measured time), plus T host threads x their own iContext
-  large_v2      the batched pipeline once more on the ggml-large-v2 shape (BASELINE names both models)
+  large_v2      the batched pipeline once more on the ggml-large-v2 shape (BASELINE names both models), with its own roofline / parity / cpu_baseline and
+                `beam5` = BASELINE configs[2] (8 x 30 s chunks, beam_size 5, the ranking on the device)
 
 Other workloads (BASELINE configs 3-5): --workload shard256 | beam5 | v3stream, see --help.
 """

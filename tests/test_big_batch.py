@@ -366,6 +366,55 @@ def test_timed_batch_parity_chain_large_v2():
     _chain("large-v2", 224, n_cmp_steps=6)
 
 
+@pytest.mark.parametrize("M,N,K", [(40, 4096, 1024), (70, 4096, 1024), (100, 5120, 1280), (112, 3072, 1024), (128, 2048, 512), (33, 4096, 1024)])
+def test_wide_decode_products_in_one_row_tile(M, N, K, golden):
+    """Option dec_wide_rows: 33 .. 128 rows against N >= 2048 (the MLP up-projection of a decode step) as gemmDecRows with ALL rows in one row tile per 32
+    columns, against gemvFused's 16-column workgroups: the same K split and summation order, so the FP16 GELU outputs are the same bits."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = torch.randn((M, K), generator=g, device="cuda").half()
+    w = (0.1 * torch.randn((N, K), generator=g, device="cuda")).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    L = binding.lib()
+    outs = {}
+    for on in (0, 1):
+        with option("dec_wide_rows", on, binding.get_option_default("dec_wide_rows")):
+            out = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+            binding.check(L.wh_op_mul_mat_gelu(None, ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K))
+            torch.cuda.synchronize()
+        outs[on] = out
+    pre = (a.double() @ w.double().T + bias.double()).float()
+    table = torch.from_numpy(golden["table_gelu"].astype(np.int32)).cuda()
+    want = table[(pre.half().view(torch.int16).to(torch.int32) & 0xFFFF).long()].to(torch.int16).view(torch.float16).float()
+    d = (outs[1].float() - want).abs()
+    assert float((d > 0).float().mean()) < 0.02 and bool((d <= torch.maximum(torch.tensor(4e-3, device="cuda"), want.abs() * 2.0 ** -10)).all())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_wide_decode_products_in_the_model(hip_medium):
+    """The same switch inside the decoder at the batch sizes of bench.py's 20- and 32-pass plans (70 and 112 windows per context): QKV (cache append in the
+    epilogue) and the MLP up-projection through the one-row-tile instances -- the greedy ids of every window and the last step's logits are bit-identical."""
+    import bench
+    hp = hip_medium.hp
+    sp = gf.special_tokens(hp)
+    prompt = [sp["sot"], sp["sot"] + 1, sp["transcribe"]]
+    for n_win in (70, 112):
+        res = {}
+        for on in (0, 1):
+            binding.set_option("dec_wide_rows", on)
+            try:
+                ctx = binding.HipContext(hip_medium, n_win)
+                pcm_dev = torch.from_numpy(bench.synth_pcm(7, seed=100)).cuda()
+                mels = _mels(ctx, pcm_dev, range(7))
+                ctx.encode(mels[torch.arange(n_win, device="cuda") % 7].contiguous())
+                ctx.decode_window_start(np.tile(np.asarray(prompt, np.int32), (n_win, 1)), 20)
+                ids, _ = ctx.decode_window_finish()
+                res[on] = (ids, ctx.debug_read("logits", rows=n_win))
+                ctx.close()
+            finally:
+                binding.set_option("dec_wide_rows", binding.get_option_default("dec_wide_rows"))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), n_win
+
+
 def test_parity_mode_at_medium_shape_vs_one_thread(ref_lib_available, tmp_path):
     """north_star's 1e-3 at the measured shape where the reference IS a point: its decoder at ONE thread (FP16 P.V accumulated key by key in one
     partition, ggml.c:4689-4735) against WH_FLAG_PARITY_PV with one emulated thread (and the reference's fp16(e / sum) operand in the encoder).

@@ -2955,6 +2955,34 @@ namespace wh
 		}
 	}
 
+	// 33 .. 128 rows against a WIDE weight matrix (N >= 2048: the MLP up-projection, the fused QKV product): ALL rows in one row tile of 16 MT rows and 32
+	// columns per workgroup. gemvFused's 16-column workgroups re-read the rows once per 16 columns: at 70 rows and N = 4096 that is 82 MB of L2 -> CU
+	// traffic for 8 MB of weights (15 us per launch); here 29 MB over N / 32 workgroups. Same K split and summation order: the same bits.
+	template<int EPI>
+	static int launchDecRowsOneTile( const GemmArgs& a, hipStream_t stream )
+	{
+		switch( ( a.M + 15 ) / 16 )
+		{
+		case 3: return launchDecRowsK<EPI, 3, 2>( a, stream );
+		case 4: return launchDecRowsK<EPI, 4, 2>( a, stream );
+		case 5: return launchDecRowsK<EPI, 5, 2>( a, stream );
+		case 6: return launchDecRowsK<EPI, 6, 2>( a, stream );
+		case 7: return launchDecRowsK<EPI, 7, 2>( a, stream );
+		default: return launchDecRowsK<EPI, 8, 2>( a, stream );
+		}
+	}
+	// returns 1 when the shape is not one of these
+	static int launchDecRowsWide( const GemmArgs& a, hipStream_t stream )
+	{
+		if( a.lnX || a.M <= 32 || a.M > GEMV_FUSED_MAX_ROWS || a.N < 2048 || ( a.K % 128 ) != 0 || a.K > 2048 ) return 1;
+		switch( a.epi )
+		{
+		case EPI_F16_GELU: return launchDecRowsOneTile<EPI_F16_GELU>( a, stream );
+		case EPI_QKV_DEC: return launchDecRowsOneTile<EPI_QKV_DEC>( a, stream );
+		}
+		return 1;
+	}
+
 	// 129 .. GEMV_MAX_ROWS rows, A in global memory (a LayerNorm in front is its own launch at this many rows)
 	static int launchDecRows( const GemmArgs& a, hipStream_t stream )
 	{
@@ -3034,6 +3062,12 @@ namespace wh
 		// Option dec_tile = 1 keeps gemvFused (16 columns x 64 rows per workgroup, row groups in blockIdx.y) for A/B runs.
 		if( a.M > GEMV_FUSED_MAX_ROWS && ( g_opt.decTile != 1 || a.lnX ) ) return launchDecRows( a, stream );
 		const bool ln = a.lnX != nullptr;
+		// option dec_wide_rows: 33 .. 128 rows against N >= 2048 in one row tile per 32 columns (gemmDecRows) instead of gemvFused's 16-column workgroups
+		if( a.M > 32 && !ln && g_opt.decWideRows )
+		{
+			const int rc = launchDecRowsWide( a, stream );
+			if( rc <= 0 ) return rc;
+		}
 		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_ALLROWS ) )
 		{
 			const int rc = launchAllRows( a, stream );
