@@ -2979,6 +2979,7 @@ namespace wh
 		{
 		case EPI_F16_GELU: return launchDecRowsOneTile<EPI_F16_GELU>( a, stream );
 		case EPI_QKV_DEC: return launchDecRowsOneTile<EPI_QKV_DEC>( a, stream );
+		case EPI_F32: if( g_opt.decWideRows == 2 ) return launchDecRowsOneTile<EPI_F32>( a, stream ); break;	 // (diagnostic: the accumulators of the one-tile instances in FP32)
 		}
 		return 1;
 	}
