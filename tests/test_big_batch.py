@@ -404,6 +404,35 @@ def test_wide_decode_products_in_one_row_tile(M, N, K, golden):
     assert bool((dd <= outs[0].float().abs() * 2.0 ** -9 + 1e-7).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(40, 1024, 4096), (70, 1024, 4096), (100, 1280, 5120), (112, 1024, 4096), (128, 1024, 2048), (33, 2048, 4096), (70, 1000, 4096)])
+def test_deep_decode_products_all_rows_per_workgroup(M, N, K):
+    """Option dec_deep_rows: 33 .. 128 rows against N <= 2048, K >= 2048 (the MLP down-projection of a decode step) as gemmDecRows with all rows per 16-column
+    workgroup and EIGHT waves over K -- gemvFused's own split for this product (TUNE_GEMV_K8) -- against gemvFused: FP32 + bias + residual, the same bits
+    (N = 1000 is not a multiple of 16: stays on gemvFused in both settings)."""
+    rng = np.random.default_rng(M * 3 + N)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    w = (0.05 * rng.standard_normal((N, K))).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    want = (a.astype(np.float64) @ w.astype(np.float64).T + bias + res).astype(np.float32)
+    ad, wd, bd, rd = dev(a), dev(w), dev(bias), dev(res)
+    L = binding.lib()
+    outs = {}
+    default = binding.get_option_default("dec_deep_rows")
+    try:
+        for on in (0, 1):
+            binding.set_option("dec_deep_rows", on)
+            out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+            binding.check(L.wh_op_mul_mat(None, ptr(ad), ptr(wd), ptr(bd), ptr(rd), ptr(out), M, N, K))
+            torch.cuda.synchronize()
+            outs[on] = out
+    finally:
+        binding.set_option("dec_deep_rows", default)
+    d = report("deep decode product %dx%dx%d" % (M, N, K), outs[1].cpu().numpy(), want)
+    assert d.max() < 2e-5 * max(1.0, np.sqrt(K / 128))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_wide_qkv_product_appends_the_same_cache_rows(hip_medium):
     """The QKV product of a single-token step through the one-tile instances (EPI_QKV_DEC: scaled query out, K and V rows appended to the self-attention
     cache): at 70 and 112 windows per context the rows decoder layer 0 appends on the first single-token step are bit-identical to gemvFused's (no GELU

@@ -13,7 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-DEFAULTS = {"dec_tile": 0, "dec_depth": 0, "dec_wide_rows": 1, "vocab_decrows": 0, "enc_chunk": 128, "self_fuse_max_rows": 32, "self_nq": 0, "self_wave_min_rows": 32}
+DEFAULTS = {"dec_tile": 0, "dec_depth": 0, "dec_wide_rows": 1, "dec_deep_rows": 0, "vocab_decrows": 0, "enc_chunk": 128, "self_fuse_max_rows": 32, "self_nq": 0, "self_wave_min_rows": 32}
 
 
 def kernel_table(prof, batches=1):

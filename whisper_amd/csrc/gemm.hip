@@ -2727,10 +2727,11 @@ namespace wh
 		// summation order, so a row's result does not depend on which of the two kernels (or which row tile) computed it.
 		// Grid (column tiles, row tiles). Operands come straight from L2 (every wave reads its own K quarter: nothing to share
 		// through LDS); two k-steps of loads are in flight per wave.
-		template<int EPI, int MT, int CT, int DEPTH>
-		__global__ void __launch_bounds__( 256 ) gemmDecRows( const GemmArgs a )
+		template<int EPI, int MT, int CT, int DEPTH, int NW = 4>
+		__global__ void __launch_bounds__( NW * 64 ) gemmDecRows( const GemmArgs a )
 		{
-			constexpr int NW = 4, G = MT * CT;
+			// NW = waves that split K: 4, or 8 for the MLP down-projection (K = 4 d) of 33 .. 128 rows -- gemvFused's own split there (TUNE_GEMV_K8), same order
+			constexpr int G = MT * CT;
 			constexpr int GPW = ( G + NW - 1 ) / NW;
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) float redD[];	 // [NW][G * 4][64]
 
@@ -2910,20 +2911,20 @@ namespace wh
 		}
 	}
 
-	template<int EPI, int MT, int CT, int DEPTH>
+	template<int EPI, int MT, int CT, int DEPTH, int NW = 4>
 	static int launchDecRowsD( const GemmArgs& a, hipStream_t stream )
 	{
-		constexpr int lds = 4 * MT * CT * 4 * 64 * 4;
+		constexpr int lds = NW * MT * CT * 4 * 64 * 4;
 		if( lds > 48 * 1024 )
 		{
 			static PerDeviceOnce once;
 			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecRows<EPI, MT, CT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecRows<EPI, MT, CT, DEPTH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
 				once.mark( onceDev );
 			}
 		}
-		hipLaunchKernelGGL( ( gemmDecRows<EPI, MT, CT, DEPTH> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 16 * MT - 1 ) / ( 16 * MT ) ), dim3( 256 ), lds, stream, a );
+		hipLaunchKernelGGL( ( gemmDecRows<EPI, MT, CT, DEPTH, NW> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 16 * MT - 1 ) / ( 16 * MT ) ), dim3( NW * 64 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -2969,6 +2970,21 @@ namespace wh
 		case 6: return launchDecRowsK<EPI, 6, 2>( a, stream );
 		case 7: return launchDecRowsK<EPI, 7, 2>( a, stream );
 		default: return launchDecRowsK<EPI, 8, 2>( a, stream );
+		}
+	}
+	// 33 .. 128 rows against a NARROW, DEEP weight matrix (N <= 2048, K >= 2048: the MLP down-projection): 16 columns x all rows per workgroup, EIGHT waves
+	// splitting K -- gemvFused's own split for this product (TUNE_GEMV_K8), so the same bits -- instead of its 16 columns x 32 rows with the rows re-read per group
+	static int launchDecRowsDeep( const GemmArgs& a, hipStream_t stream )
+	{
+		if( a.lnX || a.epi != EPI_F32 || a.M <= 32 || a.M > GEMV_FUSED_MAX_ROWS || a.N > 2048 || ( a.N % 16 ) != 0 || a.K < 2048 || ( a.K % 256 ) != 0 || !( g_tuning & TUNE_GEMV_K8 ) ) return 1;
+		switch( ( a.M + 15 ) / 16 )
+		{
+		case 3: return launchDecRowsD<EPI_F32, 3, 1, 4, 8>( a, stream );
+		case 4: return launchDecRowsD<EPI_F32, 4, 1, 4, 8>( a, stream );
+		case 5: return launchDecRowsD<EPI_F32, 5, 1, 4, 8>( a, stream );
+		case 6: return launchDecRowsD<EPI_F32, 6, 1, 4, 8>( a, stream );
+		case 7: return launchDecRowsD<EPI_F32, 7, 1, 4, 8>( a, stream );
+		default: return launchDecRowsD<EPI_F32, 8, 1, 3, 8>( a, stream );
 		}
 	}
 	// returns 1 when the shape is not one of these
@@ -3067,6 +3083,12 @@ namespace wh
 		if( a.M > 32 && !ln && g_opt.decWideRows )
 		{
 			const int rc = launchDecRowsWide( a, stream );
+			if( rc <= 0 ) return rc;
+		}
+		// option dec_deep_rows: 33 .. 128 rows against N <= 2048, K >= 2048 (MLP down-projection) with all rows per 16-column workgroup and 8 waves over K
+		if( a.M > 32 && !ln && g_opt.decDeepRows )
+		{
+			const int rc = launchDecRowsDeep( a, stream );
 			if( rc <= 0 ) return rc;
 		}
 		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_ALLROWS ) )

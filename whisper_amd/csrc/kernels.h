@@ -59,6 +59,7 @@ namespace wh
 		int decDepth = 0;			 // "dec_depth": gemmDecRows: 0 = k-steps in flight by tile shape (2 / 3 / 4), 2 = two everywhere
 		int decWideRows = 1;		 // "dec_wide_rows": 33 .. 128 rows x N >= 2048 (MLP up-projection, QKV): all rows in one row tile per 32 columns (gemmDecRows) instead of gemvFused
 									 // (0 = gemvFused; 2 = also the FP32 epilogue, for tests). Measured: two contexts of 70 / 112 windows +1.4 % / +1.7 % on the job
+		int decDeepRows = 0;		 // "dec_deep_rows": 33 .. 128 rows x N <= 2048, K >= 2048 (MLP down-projection): all rows per 16-column workgroup, 8 waves over K (gemmDecRows<.., NW = 8>)
 		int vocabDecRows = 0;		 // "vocab_decrows": more than 128 sequences: the vocabulary product through gemmDecRows instead of the M-tiled kernel
 		int encChunk = 128;			 // "enc_chunk": the most windows ONE encoder pass takes; contexts created afterwards encode larger batches in equal chunks
 		int selfFuseMaxRows = 32;	 // "self_fuse_max_rows": selfBlockDec up to this many sequences, LayerNorm + QKV product + attention launches beyond

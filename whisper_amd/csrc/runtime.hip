@@ -39,7 +39,7 @@ namespace wh
 	namespace
 	{
 		struct OptionName { const char* name; int Options::* field; };
-		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
+		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
 			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
