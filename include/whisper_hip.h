@@ -338,8 +338,8 @@ WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, 
 /* Bit mask of kernel-variant switches (whisper_amd/csrc/kernels.h eTuning) for in-process A/B runs; contexts created
  * afterwards (and their captured graphs) use the new setting. */
 WH_API int wh_debug_set_tuning( uint32_t mask );
-/* Integer knobs beyond the 32 switches (whisper_amd/csrc/kernels.h struct Options: "dec_tile", "vocab_decrows", "enc_chunk", "self_fuse_max_rows",
- * "self_nq"); also settable as WH_OPT_<NAME> in the environment at load. Unknown names: WH_E_INVALIDARG. */
+/* Integer knobs beyond the 32 switches (whisper_amd/csrc/kernels.h struct Options: "dec_tile", "dec_depth", "dec_wide_rows", "dec_deep_rows", "vocab_decrows",
+ * "enc_chunk", "self_fuse_max_rows", "self_nq", "self_wave_min_rows"); also settable as WH_OPT_<NAME> in the environment at load. Unknown names: WH_E_INVALIDARG. */
 WH_API int wh_debug_set_option( const char* name, int value );
 WH_API int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter );
 
