@@ -42,12 +42,17 @@ def main():
     if mode == "plans":
         for item in sys.argv[2].split(","):
             ci, steps = item.split(":")
-            C, I = (int(x) for x in ci.split("x"))
-            steps = int(steps)
+            explicit = None
+            if ci.startswith("p"):          # "p9+11:2" = the explicit batch plan [9, 11] with 2 contexts in flight
+                explicit = [int(x) for x in ci[1:].split("+")]
+                C, I, steps = max(explicit), int(steps), sum(explicit)
+            else:
+                C, I = (int(x) for x in ci.split("x"))
+                steps = int(steps)
             t0 = time.time()
             best = 1e9
             for rep in range(int(os.environ.get("SWEEP_REPS", "2"))):
-                m = bench.measure_batched(hm, hp, prompt, steps, 1 if rep == 0 else 0, 7, C, I, 0, 1, dist, want_kernels=False)
+                m = bench.measure_batched(hm, hp, prompt, steps, 1 if rep == 0 else 0, 7, C, I, 0, 1, dist, want_kernels=False, plan=explicit)
                 best = min(best, m["elapsed"])
                 plan = m["plan"]
                 for s in m["slots"]:
