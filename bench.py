@@ -10,11 +10,12 @@ Tools/PerfSummary/Summary.cs:50) = 7 windows of 30 s, processed as one lock-step
 (NoContext semantics, ContextImpl.cpp:476-477): pinned host PCM -> H2D -> GPU mel -> encoder -> 3-token prompt step +
 51 greedy steps per window (the reference's observed 511 steps / 10 windows, columbia-medium-1080ti.txt:8-10; random
 weights never emit EOT sensibly, so the step count is forced while the sampled token IS fed back). One "step" of the
-bench = one pass over the whole clip; the span is first H2D byte to last token id on the host. value = audio seconds /
-wall seconds; weak scaling for N > 1 (every rank transcribes its own clip; the weight arena is broadcast once over RCCL
-before the timed region). The K clip passes are dealt into an even number of balanced lock-step batches of at most --clips-per-batch (64) clips for
-the --inflight (2) contexts (plan_batches: 20 passes = 10 + 10 -- the driver's invocation --, 32 = 16 + 16, 64 = 32 + 32 = 224 windows each, the default;
-`config.batch_plan`). Round 5: a context decodes up to 512 windows in lock step (encoder in chunks of <= 128, decode products of > 128 rows on gemmDecRows).
+bench = one pass of the hot path over ONE LOCK-STEP BATCH: --clips-per-step (32) passes over the clip = 224 windows encoded and decoded in lock step on one
+context (round 5: a context takes up to 512 windows -- encoder in chunks of <= 128, decode products of > 128 rows on gemmDecRows); the K steps alternate over
+--inflight (2) contexts, so two batches are in flight. The span is first H2D byte to last token id on the host. value = audio seconds / wall seconds; weak
+scaling for N > 1 (every rank its own clips; the weight arena is broadcast once over RCCL before the timed region). Rounds 1-4 called one CLIP pass a step
+and dealt the K passes into batches -- at the driver's K = 20 two batches of 70 windows, a job so small that the latency-bound decode chain is a third of it;
+that measurement is still in every line: `small_job`.
 
 Objects next to the contract fields:
   roofline      algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on the launch stream (one batch of the size the timed
@@ -27,7 +28,8 @@ Objects next to the contract fields:
   parity        ggml-medium shape, window 0: the measured (FP32 P.V) GPU path against the reference CPU path -- cross-KV,
                 logits of the prompt and of teacher-forced greedy steps, top-1 agreement; `timed_ids` = the ids the TIMED region produced for clip 0
                 against the same windows decoded one at a time (contexts of one window), greedily and teacher-forced
-  through_boundary  the SAME workload driven by the plain C++ host code: libWhisper.so createBatchRunner / iBatchRunner::run (lock-step
+  small_job     20 CLIP passes as two lock-step batches of 70 windows in flight: the timed region of rounds 1-4's driver invocation
+  through_boundary  the SAME workload (two batches) driven by the plain C++ host code: libWhisper.so createBatchRunner / iBatchRunner::run (lock-step
                 scheduler, the reference's host loop per stream) on a scripted model -- what a caller of the drop-in library gets
   single_stream the SAME clip through the drop-in boundary, sequentially: libWhisper.so iContext::runFull with prompt
                 carry-over on a scripted medium-shape model (7 windows x 52 steps) -- the like-for-like figure against the
@@ -405,7 +407,9 @@ def plan_batches(steps, C, inflight):
     return [base + 1] * extra + [base] * (nb - extra)
 
 
-def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True, plan=None, single_clip=True):
+def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, world, dist, want_kernels, h2d=True, plan=None, single_clip=True, warmup_batches=None):
+    """`steps` CLIP passes dealt into lock-step batches (plan, or plan_batches(steps, C, inflight)). warmup = passes over every distinct context, or -- with
+    warmup_batches -- that many untimed batch passes alternating over the contexts (at least one per context: the graphs are captured there)."""
     import torch
     from whisper_amd import binding
     n_frames = WINDOW_SAMPLES // 160
@@ -442,8 +446,12 @@ def measure_batched(hip_model, hp, prompt, steps, warmup, B, C, inflight, rank, 
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        run_passes(distinct, prompt, N_GREEDY, inflight)
+    if warmup_batches is not None:
+        n_warm = max(int(warmup_batches), len(distinct))
+        run_passes([distinct[i % len(distinct)] for i in range(n_warm)], prompt, N_GREEDY, inflight)
+    else:
+        for _ in range(warmup):
+            run_passes(distinct, prompt, N_GREEDY, inflight)
     barrier()
     t0 = time.perf_counter()
     toks = run_passes(sequence, prompt, N_GREEDY, inflight)
@@ -877,7 +885,7 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="clip passes in the timed region (default 64 = two lock-step batches of 32 clips = 224 windows in flight)")
+    ap.add_argument("--steps", type=int, default=4, help="steps in the timed region; a step = one lock-step batch of --clips-per-step clips (default 4 = 128 clip passes, two batches in flight)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default=None, help="medium (default), large-v2, large-v3")
     ap.add_argument("--workload", default="clip", choices=["clip", "shard256", "beam5", "v3stream"],
@@ -885,14 +893,13 @@ def main():
                          "(large-v2, strong scaling); beam5 = configs[2]: 8 x 30 s chunks x 5 hypotheses per chunk (large-v2, 50 steps); "
                          "v3stream = configs[4]: the clip workload on the large-v3 shape (128 mels, vocabulary 51866), translate task")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--clips-per-batch", type=int, default=64, help="the most clip passes decoded as ONE lock-step batch (7 windows each); a step stays one clip "
-                    "pass, K steps are dealt into balanced batches of at most this many clips (plan_batches). Round 5: 64 clips = 448 windows in one context (the "
-                    "decode kernels take up to 512 rows, the encoder runs in chunks of <= 128 windows); rounds 2-4 ran 16 clips = 112 windows x 2 contexts in "
-                    "flight (--clips-per-batch 16 --inflight 2 reproduces that)")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight, each on its own context and HIP stream, when the plan has more than one batch "
-                    "(K <= clips-per-batch runs as ONE batch on one context)")
+    ap.add_argument("--clips-per-step", "--clips-per-batch", dest="clips_per_step", type=int, default=32, help="clips (7 windows each) in the lock-step batch that "
+                    "ONE STEP encodes and decodes on one context: 32 = 224 windows (the decode kernels take up to 512 rows; the encoder runs in chunks of <= 128 "
+                    "windows). Rounds 1-4 called one CLIP pass a step: that figure is the line's `small_job`")
+    ap.add_argument("--inflight", type=int, default=2, help="contexts the steps alternate over = batches in flight, each on its own HIP stream")
+    ap.add_argument("--no-small-job", action="store_true", help="skip the small_job sub-object (20 clip passes as two batches of 70 windows: rounds 1-4's driver line)")
     ap.add_argument("--no-ids-check", action="store_true", help="skip parity.timed_ids (the timed pass's ids against the same windows one at a time)")
-    ap.add_argument("--plan", default=None, help="explicit batch sizes of the timed region, e.g. 16,4 (default: plan_batches(steps, clips-per-batch, inflight))")
+    ap.add_argument("--plan", default=None, help="explicit batch sizes (clips) of the timed region for experiments, e.g. 16,4 (default: --steps batches of --clips-per-step clips)")
     ap.add_argument("--batch", type=int, default=16, help="shard256 / beam5: windows per lock-step batch")
     ap.add_argument("--beam-host", action="store_true", help="beam5: rank every step's candidates on the host (round 4's data path) instead of on the device")
     ap.add_argument("--no-beam", action="store_true", help="skip the beam5 sub-object of the default line (BASELINE configs[2] on the large-v2 model)")
@@ -980,19 +987,22 @@ def main():
         return
 
     B = args.windows
-    C = max(1, args.clips_per_batch)
+    C = max(1, args.clips_per_step)
     if B * C > MAX_LOCKSTEP_WINDOWS:
-        raise SystemExit("windows x clips-per-batch must not exceed %d (rows of the decode kernels)" % MAX_LOCKSTEP_WINDOWS)
-    # Measured (profiles/r05_ab_variants.txt section 1): two contexts in flight beat one of twice the size at every K (8821 vs 8400 audio-s/s at 64 passes,
-    # 7614 vs 7297 at 20), so the K passes are always dealt into an even number of batches of at most C clips: 20 -> 10 + 10, 32 -> 16 + 16 (rounds 2-4's
-    # plan), 64 -> 32 + 32 and 128 -> 64 + 64 (the 224- / 448-window contexts of round 5: decode products on gemmDecRows, encoder in chunks)
+        raise SystemExit("windows x clips-per-step must not exceed %d (rows of the decode kernels)" % MAX_LOCKSTEP_WINDOWS)
+    # A STEP = one pass of the hot path over ONE LOCK-STEP BATCH: C clips (default 32 = 224 windows of 30 s) encoded and decoded in lock step on one
+    # context; the K steps of the timed region alternate over `inflight` (2) contexts, so two batches are in flight at any time. (Rounds 1-4 called one
+    # CLIP pass a step and dealt the K passes into batches; at the driver's K = 20 that made two batches of 70 windows -- a job so small that the
+    # latency-bound decode chain is a third of it. That figure is still in the line: `small_job`.) Measured (profiles/r05_ab_variants.txt section 1):
+    # two contexts in flight beat one of twice the size (8821 vs 8400 audio-s/s), and 224 windows per context is within 2 % of 448.
     inflight = max(1, args.inflight)
     audio_seconds = CLIP_SECONDS * B / 7.0
+    plan = [int(x) for x in args.plan.split(",")] if args.plan else [C] * args.steps
+    passes = sum(plan)                      # clip passes in the timed region
     if rank == 0:
-        log("warmup + timed region: %d steps ..." % args.steps)
-    plan = [int(x) for x in args.plan.split(",")] if args.plan else None
-    m = measure_batched(hip_model, hp, prompt, args.steps, args.warmup, B, C, inflight, rank, world, dist,
-                        want_kernels=not args.no_roofline, plan=plan)
+        log("warmup + timed region: %d steps of %d clips ..." % (args.steps, C))
+    m = measure_batched(hip_model, hp, prompt, passes, args.warmup, B, C, inflight, rank, world, dist,
+                        want_kernels=not args.no_roofline, plan=plan, warmup_batches=args.warmup)
     elapsed, toks, batch_plan = m["elapsed"], m["toks"], m.get("plan")
     inflight = min(inflight, len(batch_plan))
     if rank == 0:
@@ -1004,12 +1014,12 @@ def main():
         slots_t = torch.zeros(world, dtype=torch.float64, device="cuda")
         slots_t[rank] = m.get("elapsed_local", elapsed)
         dist.all_reduce(slots_t, op=dist.ReduceOp.SUM)
-        per_rank = [round(audio_seconds * args.steps / float(t), 2) for t in slots_t.cpu().tolist()]
+        per_rank = [round(audio_seconds * passes / float(t), 2) for t in slots_t.cpu().tolist()]
 
     roofline, kernels = None, {}
     if rank == 0 and m["kernels"]:
         kc = m["kernel_clips"]
-        roofline, kernels = roofline_from(m["kernels"], 1e3 * elapsed * kc / args.steps, m["lone_batch_ms"], m.get("kernel_batches", 1),
+        roofline, kernels = roofline_from(m["kernels"], 1e3 * elapsed * kc / passes, m["lone_batch_ms"], m.get("kernel_batches", 1),
                                           batch_windows=kc * B, n_layers=hp.n_text_layer)
         roofline["single_clip"] = {"ms": round(m["single_clip_ms"], 2), "audio_seconds_per_sec": round(audio_seconds / (m["single_clip_ms"] * 1e-3), 1),
                                    "what": "ONE %.0f s clip (7 windows as one lock-step batch) alone on the GPU, H2D to token ids" % audio_seconds}
@@ -1032,11 +1042,28 @@ def main():
         s[0].close()
     del m
 
+    small = None
+    if rank == 0 and world == 1 and args.workload == "clip" and not args.no_small_job:
+        # what rounds 1-4's driver line measured: 20 CLIP passes = two lock-step batches of 70 windows in flight (a step was one clip pass)
+        try:
+            ms_ = measure_batched(hip_model, hp, prompt, 20, 1, B, 16, 2, 0, 1, dist, want_kernels=False)
+            small = {"value": round(audio_seconds * 20 / ms_["elapsed"], 2), "unit": "audio-seconds/sec", "clip_passes": 20, "batch_plan": ms_["plan"],
+                     "ms_per_clip_pass": round(1e3 * ms_["elapsed"] / 20, 3),
+                     "what": "the timed region of rounds 1-4's driver invocation (--steps 20 when a step was ONE clip pass): two lock-step batches of 70 windows -- "
+                             "a job of 140 windows, where the latency-bound decode chain (the same ~60 us per layer and step whatever the batch) is a third of the time; "
+                             "BENCH_r04.json: 7582"}
+            for s_ in ms_["slots"]:
+                s_[0].close()
+            del ms_
+            log("small job (20 clip passes): %s audio-s/s" % small["value"])
+        except Exception as e:
+            small = {"error": str(e)[:300]}
+
     single = large = boundary = None
     if rank == 0 and world == 1 and args.workload == "clip" and not args.no_boundary and args.model in ("medium", "large-v2"):
         log("the same workload through libWhisper.so (createBatchRunner) ...")
         try:
-            boundary = through_boundary(args.model, args.steps, C, inflight, B)
+            boundary = through_boundary(args.model, min(passes, 2 * C), C, inflight, B)
             log("through the boundary: %s audio-s/s" % boundary["value"])
         except Exception as e:
             boundary = {"error": str(e)[:300]}
@@ -1055,10 +1082,10 @@ def main():
                 hp2, model2, hm2, _, _ = load("large-v2")
                 sp2 = gf.special_tokens(hp2)
                 p2 = [sp2["sot"], sp2["sot"] + 1, sp2["transcribe"]]
-                n2 = args.steps
+                n2 = min(passes, 2 * C)
                 m2 = measure_batched(hm2, hp2, p2, n2, 1, B, C, inflight, 0, 1, dist, want_kernels=not args.no_roofline, single_clip=False)
-                large = {"model": "ggml-large-v2", "value": round(audio_seconds * n2 / m2["elapsed"], 2), "unit": "audio-seconds/sec", "steps": n2,
-                         "ms_per_step": round(1e3 * m2["elapsed"] / n2, 3), "same_pipeline": True, "batch_plan": m2["plan"],
+                large = {"model": "ggml-large-v2", "value": round(audio_seconds * n2 / m2["elapsed"], 2), "unit": "audio-seconds/sec", "steps": len(m2["plan"]),
+                         "clip_passes": n2, "ms_per_step": round(1e3 * m2["elapsed"] / len(m2["plan"]), 3), "same_pipeline": True, "batch_plan": m2["plan"],
                          "vs_published_single_clip": "the reference publishes 7.22 audio-s/s for ONE sequential clip on a GTX 1080Ti (BASELINE.md section 1)"}
                 if m2["kernels"]:
                     kc2 = m2["kernel_clips"]
@@ -1096,7 +1123,7 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        value = world * audio_seconds * args.steps / elapsed
+        value = world * audio_seconds * passes / elapsed
         line = {
             "metric": METRIC,
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1105,20 +1132,24 @@ def main():
             # the like-for-like ratio is single_stream.vs_baseline
             "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows per GPU, the %d clip passes of the timed region dealt "
-                                   "into lock-step batches of %s clips (at most %d), %d batches in flight on separate HIP streams; pinned host PCM -> H2D -> GPU mel + encoder + "
-                                   "%d-token prompt + %d greedy steps per window, device-side sampling (captured hipGraph per token); span = first H2D byte to "
-                                   "last token id on the host" % (args.model, audio_seconds, B, args.steps, batch_plan, C, inflight, N_PROMPT, N_GREEDY),
+            "config": {"workload": "ggml-%s shape (random weights), %.3f s clip = %d x 30 s independent windows; ONE STEP = one lock-step batch of %d clips = %d windows "
+                                   "(%.1f s of audio) on one context: pinned host PCM -> H2D -> GPU mel + encoder + %d-token prompt + %d greedy steps per window, device-side "
+                                   "sampling (captured hipGraph per token); the %d steps of the timed region (%d clip passes, plan %s) alternate over %d contexts on separate HIP "
+                                   "streams, so %d batches are in flight; span = first H2D byte to last token id on the host"
+                                   % (args.model, audio_seconds, B, C, C * B, audio_seconds * C, N_PROMPT, N_GREEDY, args.steps, passes,
+                                      batch_plan if len(batch_plan) <= 8 else "%s x %d" % ([batch_plan[0]], len(batch_plan)), inflight, inflight),
                        "model": "ggml-" + args.model, "task": "translate" if args.workload == "v3stream" else "transcribe",
                        "baseline": "BASELINE.md section 1 publishes one sequential clip on a GTX 1080Ti (13.30 audio-s/s medium): compared in single_stream, not here",
-                       "windows_per_clip": B, "clips_per_batch": C, "batch_plan": batch_plan, "batches_in_flight": inflight, "lockstep_windows": max(batch_plan) * B, "decode_steps_per_window": N_GREEDY + 1,
+                       "windows_per_clip": B, "clips_per_step": C, "clip_passes": passes, "audio_seconds_per_step": round(audio_seconds * passes / args.steps, 3),
+                       "clips_per_batch": C, "batch_plan": batch_plan, "batches_in_flight": inflight, "lockstep_windows": max(batch_plan) * B, "decode_steps_per_window": N_GREEDY + 1,
                        "ranks_seen": (dist.get_world_size() if world > 1 else 1), "per_rank_audio_seconds_per_sec": per_rank,
                        "parallelism": "dp%d (independent windows, RCCL weight broadcast outside the timed region: %s)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
-            "rtf": round(elapsed / (args.steps * audio_seconds), 6),
+            "rtf": round(elapsed / (passes * audio_seconds), 6),
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity": parity,
             "through_boundary": boundary,
+            "small_job": small,
             "single_stream": single,
             "large_v2": large,
             "kernels": kernels,
