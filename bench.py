@@ -10,7 +10,7 @@ Tools/PerfSummary/Summary.cs:50) = 7 windows of 30 s, processed as one lock-step
 (NoContext semantics, ContextImpl.cpp:476-477): pinned host PCM -> H2D -> GPU mel -> encoder -> 3-token prompt step +
 51 greedy steps per window (the reference's observed 511 steps / 10 windows, columbia-medium-1080ti.txt:8-10; random
 weights never emit EOT sensibly, so the step count is forced while the sampled token IS fed back). One "step" of the
-bench = one pass of the hot path over ONE LOCK-STEP BATCH: --clips-per-step (32) passes over the clip = 224 windows encoded and decoded in lock step on one
+bench = one pass of the hot path over ONE LOCK-STEP BATCH: --clips-per-step (64) passes over the clip = 448 windows encoded and decoded in lock step on one
 context (round 5: a context takes up to 512 windows -- encoder in chunks of <= 128, decode products of > 128 rows on gemmDecRows); the K steps alternate over
 --inflight (2) contexts, so two batches are in flight. The span is first H2D byte to last token id on the host. value = audio seconds / wall seconds; weak
 scaling for N > 1 (every rank its own clips; the weight arena is broadcast once over RCCL before the timed region). Rounds 1-4 called one CLIP pass a step
@@ -885,7 +885,7 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4, help="steps in the timed region; a step = one lock-step batch of --clips-per-step clips (default 4 = 128 clip passes, two batches in flight)")
+    ap.add_argument("--steps", type=int, default=4, help="steps in the timed region; a step = one lock-step batch of --clips-per-step clips (default 4 = 256 clip passes, two batches in flight)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default=None, help="medium (default), large-v2, large-v3")
     ap.add_argument("--workload", default="clip", choices=["clip", "shard256", "beam5", "v3stream"],
@@ -893,9 +893,10 @@ def main():
                          "(large-v2, strong scaling); beam5 = configs[2]: 8 x 30 s chunks x 5 hypotheses per chunk (large-v2, 50 steps); "
                          "v3stream = configs[4]: the clip workload on the large-v3 shape (128 mels, vocabulary 51866), translate task")
     ap.add_argument("--windows", type=int, default=7, help="30 s windows per clip (7 = the 198.762 s columbia clip)")
-    ap.add_argument("--clips-per-step", "--clips-per-batch", dest="clips_per_step", type=int, default=32, help="clips (7 windows each) in the lock-step batch that "
-                    "ONE STEP encodes and decodes on one context: 32 = 224 windows (the decode kernels take up to 512 rows; the encoder runs in chunks of <= 128 "
-                    "windows). Rounds 1-4 called one CLIP pass a step: that figure is the line's `small_job`")
+    ap.add_argument("--clips-per-step", "--clips-per-batch", dest="clips_per_step", type=int, default=64, help="clips (7 windows each) in the lock-step batch that "
+                    "ONE STEP encodes and decodes on one context: 64 = 448 windows (the decode kernels take up to 512 rows; the encoder runs in chunks of <= 128 "
+                    "windows; 90 GB of KV caches per context). Measured at 20 steps, two contexts in flight: 32 clips 9274-9281 audio-s/s, 64 clips 9478; three "
+                    "contexts of 32: 9389-9394, four: 9135. Rounds 1-4 called one CLIP pass a step: that figure is the line's `small_job`")
     ap.add_argument("--inflight", type=int, default=2, help="contexts the steps alternate over = batches in flight, each on its own HIP stream")
     ap.add_argument("--no-small-job", action="store_true", help="skip the small_job sub-object (20 clip passes as two batches of 70 windows: rounds 1-4's driver line)")
     ap.add_argument("--no-ids-check", action="store_true", help="skip parity.timed_ids (the timed pass's ids against the same windows one at a time)")
@@ -990,11 +991,11 @@ def main():
     C = max(1, args.clips_per_step)
     if B * C > MAX_LOCKSTEP_WINDOWS:
         raise SystemExit("windows x clips-per-step must not exceed %d (rows of the decode kernels)" % MAX_LOCKSTEP_WINDOWS)
-    # A STEP = one pass of the hot path over ONE LOCK-STEP BATCH: C clips (default 32 = 224 windows of 30 s) encoded and decoded in lock step on one
+    # A STEP = one pass of the hot path over ONE LOCK-STEP BATCH: C clips (default 64 = 448 windows of 30 s) encoded and decoded in lock step on one
     # context; the K steps of the timed region alternate over `inflight` (2) contexts, so two batches are in flight at any time. (Rounds 1-4 called one
     # CLIP pass a step and dealt the K passes into batches; at the driver's K = 20 that made two batches of 70 windows -- a job so small that the
     # latency-bound decode chain is a third of it. That figure is still in the line: `small_job`.) Measured (profiles/r05_ab_variants.txt section 1):
-    # two contexts in flight beat one of twice the size (8821 vs 8400 audio-s/s), and 224 windows per context is within 2 % of 448.
+    # two contexts in flight beat one of twice the size (8821 vs 8400 audio-s/s); 448 windows per context: +2.2 % over 224 (9478 vs 9274-9281, section 14).
     inflight = max(1, args.inflight)
     audio_seconds = CLIP_SECONDS * B / 7.0
     plan = [int(x) for x in args.plan.split(",")] if args.plan else [C] * args.steps
@@ -1063,7 +1064,8 @@ def main():
     if rank == 0 and world == 1 and args.workload == "clip" and not args.no_boundary and args.model in ("medium", "large-v2"):
         log("the same workload through libWhisper.so (createBatchRunner) ...")
         try:
-            boundary = through_boundary(args.model, min(passes, 2 * C), C, inflight, B)
+            Cb = min(C, 32)         # the batch runner's groups at 224 slots each (what tests/test_batch_api.py and the sessions cover)
+            boundary = through_boundary(args.model, min(passes, 2 * Cb), Cb, inflight, B)
             log("through the boundary: %s audio-s/s" % boundary["value"])
         except Exception as e:
             boundary = {"error": str(e)[:300]}
@@ -1082,8 +1084,9 @@ def main():
                 hp2, model2, hm2, _, _ = load("large-v2")
                 sp2 = gf.special_tokens(hp2)
                 p2 = [sp2["sot"], sp2["sot"] + 1, sp2["transcribe"]]
-                n2 = min(passes, 2 * C)
-                m2 = measure_batched(hm2, hp2, p2, n2, 1, B, C, inflight, 0, 1, dist, want_kernels=not args.no_roofline, single_clip=False)
+                C2 = min(C, 32)         # large-v2: 224 windows per context (71 GB of KV caches each; 448 would be 143 GB x 2)
+                n2 = min(passes, 2 * C2)
+                m2 = measure_batched(hm2, hp2, p2, n2, 1, B, C2, inflight, 0, 1, dist, want_kernels=not args.no_roofline, single_clip=False)
                 large = {"model": "ggml-large-v2", "value": round(audio_seconds * n2 / m2["elapsed"], 2), "unit": "audio-seconds/sec", "steps": len(m2["plan"]),
                          "clip_passes": n2, "ms_per_step": round(1e3 * m2["elapsed"] / len(m2["plan"]), 3), "same_pipeline": True, "batch_plan": m2["plan"],
                          "vs_published_single_clip": "the reference publishes 7.22 audio-s/s for ONE sequential clip on a GTX 1080Ti (BASELINE.md section 1)"}

@@ -127,7 +127,7 @@ def test_r05_line_structure():
     assert r["batch_windows"] == max(plan) * line["config"]["windows_per_clip"] == r["end_to_end"]["batch_windows"]
     # value = audio seconds per step / time per step
     assert abs(line["value"] - line["config"]["audio_seconds_per_step"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 2e-3
-    assert abs(line["config"]["audio_seconds_per_step"] - 198.762 * cps) < 0.01
+    assert abs(line["config"]["audio_seconds_per_step"] - 198.762 * cps) < 0.01 and cps in (32, 64)
     # measured_ms_per_batch = the timed region's time per batch of that size = a step
     want = line["ms_per_step"] * max(plan) / cps
     assert abs(r["end_to_end"]["measured_ms_per_batch"] - want) / want < 1e-3
