@@ -36,12 +36,9 @@ namespace wh
 		// a K step); 3 or 4 = one or two MORE tiles stay in flight across the step's barrier (counted vmcnt + raw s_barrier),
 		// which is what covers an HBM round trip that is longer than one K step.
 		// PIPE: see below (fragment prefetch / loads spread behind the MFMA groups).
-		// ABL (probe only, wrong results by construction): 1 = no global -> LDS loads in the K loop, 2 = MFMA fragments read from LDS
-		// once instead of every k-substep, 3 = both, 4 = loads issued but never waited for, 8 / 16 = only the A / only the W tile is loaded: what the K loop costs without one of its streams.
-		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2, int PIPE_ = 0, int ABL_ = 0>
+		template<int BM_, int BN_, int BK_, int MINW_, int PF_, bool GL_ = false, int TI_ = 2, int TJ_ = 2, int NBUF_ = 2, int PIPE_ = 0>
 		struct TileCfg
 		{
-			static constexpr int ABL = ABL_;
 			static constexpr int BM = BM_, BN = BN_, BK = BK_, MINW = MINW_, PF = PF_, TI = TI_, TJ = TJ_, NBUF = NBUF_;
 			// PIPE (GL only): 1 = FRAGPF, the MFMA fragments of k-substep s+1 are read from LDS before the MFMAs of substep s are
 			// issued (two register sets; hipcc on its own re-uses one set, so every substep starts with an exposed LDS round trip).
@@ -534,10 +531,6 @@ namespace wh
 					f16* const dstA = lds + buf * C::STAGE + wave * C::IA * C::RPI * BK;
 					f16* const dstW = lds + buf * C::STAGE + C::A_HALFS + wave * C::IW * C::RPI * BK;
 					const int ko = kt * BK;
-					if constexpr( ( C::ABL & 1 ) != 0 )
-					{
-						if( kt > 0 ) return;
-					}
 					if constexpr( C::FRAGPF )
 					{
 						// Issued as assembly: hipcc models the builtin as a FLAT access that may touch LDS and, while one is in
@@ -547,11 +540,11 @@ namespace wh
 						const unsigned baseW = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)dstW );
 	#pragma unroll
 						for( int i = 0; i < C::IA; i++ )
-							if( i >= p0 && i < p1 && ( ( C::ABL & 16 ) == 0 || kt == 0 ) )
+							if( i >= p0 && i < p1 )
 								ldsDma16( gA[ i ] + ko, baseA + i * C::RPI * BK * 2 );
 	#pragma unroll
 						for( int i = 0; i < C::IW; i++ )
-							if( C::IA + i >= p0 && C::IA + i < p1 && ( ( C::ABL & 8 ) == 0 || kt == 0 ) )
+							if( C::IA + i >= p0 && C::IA + i < p1 )
 								ldsDma16( gW[ i ] + ko, baseW + i * C::RPI * BK * 2 );
 						return;
 					}
@@ -573,7 +566,7 @@ namespace wh
 					const int buf = kt % NB;
 					if constexpr( NB == 2 )
 					{
-						if constexpr( ( C::ABL & 4 ) == 0 ) asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+						asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 						__syncthreads();
 					}
 					else
@@ -595,10 +588,6 @@ namespace wh
 						auto readFrags = [ & ]( auto set, int ks )
 						{
 							constexpr int S = decltype( set )::value;
-							if constexpr( ( C::ABL & 2 ) != 0 )
-							{
-								if( kt > 0 ) return;
-							}
 	#pragma unroll
 							for( int i = 0; i < C::TI; i++ )
 								fa[ S ][ i ] = *(const f16x8*)( ldsA + glOffset<C>( wm * 32 * C::TI + i * 32 + fragRow, ks * 2 + fragC ) );
@@ -859,7 +848,7 @@ namespace wh
 		// element, FP16 outputs in one pass ([32][64] halfs), FP32 outputs in two ([16][64] floats each), 16-byte chunk index XORed
 		// with the row so that the column-wise writes and the row-wise reads are both conflict free. m0 / n0 = first row / column.
 		// Preconditions as for tileEpilogueWide (a.wideEpi). Residual / positional rows are requested before the LDS round trip.
-		template<int EPI, bool NT = false>
+		template<int EPI>
 		__device__ __forceinline__ void epilogueBlock32x64( const GemmArgs& a, const f32x16& c0, const f32x16& c1, int m0, int n0, int lane, unsigned char* ldsWave )
 		{
 			const int hi = lane >> 5, c = lane & 31;
@@ -996,10 +985,7 @@ namespace wh
 						f32x4 o;
 	#pragma unroll
 						for( int e = 0; e < 4; e++ ) o[ e ] = EPI == EPI_F32 ? v[ e ] + ex[ hh ][ u ][ e ] : ex[ hh ][ u ][ e ] + v[ e ];
-						if constexpr( NT )
-							__builtin_nontemporal_store( o, (f32x4*)( a.out32 + off[ hh ][ u ] ) );
-						else
-							*(f32x4*)( a.out32 + off[ hh ][ u ] ) = o;
+						*(f32x4*)( a.out32 + off[ hh ][ u ] ) = o;
 					}
 					__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
 					__builtin_amdgcn_wave_barrier();
@@ -1108,12 +1094,10 @@ namespace wh
 		}
 
 		// the interior-tile epilogue of both persistent kernels (defined with gemmTiled4 below)
-		template<int EPI, bool HASRES, int ABL = 0, int FIRST = 0, int LAST = 16, int TJ = 4, bool AGPR = true>
+		template<int EPI, bool HASRES, int FIRST = 0, int LAST = 16, int TJ = 4, bool AGPR = true>
 		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ TJ ], int mW, int nW, int lane, unsigned char* stage );
 
-		// ABL (probe only, wrong results by construction): 1 = no LDS-DMA inside the K loop, 2 = fragments read from LDS for the first K tile
-		// only, 4 = no MFMAs, 16 = every tile reads the first A tile (operands stay in L2), 32 = no epilogue stores
-		template<int EPI, bool WIDE, int ABL = 0>
+		template<int EPI, bool WIDE>
 		__global__ void __launch_bounds__( 512, 2 ) gemmTiled8( const GemmArgs a )
 		{
 			using C = Cfg8;
@@ -1173,7 +1157,7 @@ namespace wh
 					{
 						const int row = h * 128 + ( wave * 2 + i ) * 8 + rIn;
 						const int c = cPhys ^ ( ( row >> 1 ) & 7 );
-						int m = ( ( ABL & 16 ) ? 0 : tm ) * BM + row;
+						int m = tm * BM + row;
 						m = m < a.M ? m : a.M - 1;
 						offA[ h ][ i ] = (unsigned)( ( rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + c * 8 ) * 2 );
 						int n = tn * BN + row;
@@ -1190,10 +1174,6 @@ namespace wh
 				constexpr int P = decltype( part )::value;
 				constexpr bool isW = P < 2;
 				constexpr int h = P & 1;
-				if constexpr( ( ABL & 1 ) != 0 )
-				{
-					if( kt > 1 || ( kt == 1 && P >= 2 ) ) return;
-				}
 				const unsigned dst = pieceBase + (unsigned)( kt & 1 ) * ( C::STAGE * 2 ) + ( isW ? C::A_HALFS * 2 : 0 ) + h * 16384;
 				const f16* const base = ( isW ? a.W : a.A ) + kt * BK;
 				if constexpr( isW )
@@ -1231,12 +1211,6 @@ namespace wh
 			int tm, tn;
 			int lin = linFirst;
 			if( lin >= linEnd ) return;
-			if constexpr( ( ABL & 64 ) != 0 )
-			{
-				// start the workgroups of an XCD a quarter tile apart so that their epilogues (the HBM write bursts) do not coincide
-				const int q = ( ABL & 256 ) ? ( blockIdx.x & 3 ) : ( ( blockIdx.x >> 3 ) & 3 );	  // 256: whole XCDs a quarter tile apart
-				for( int i = 0; i < q * ( nk >> 3 ); i++ ) __builtin_amdgcn_s_sleep( 127 );
-			}
 			tileCoords( lin, tm, tn );
 			tileOffsets( tm, tn );
 			stageFirst();
@@ -1251,13 +1225,8 @@ namespace wh
 	#pragma unroll
 						for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
 				f16x8 fa[ 2 ][ 4 ], fb0[ 4 ], fb1[ 4 ];
-				int ablTile = 0;
 				auto readA = [ & ]( const f16* bufA, int half )
 				{
-					if constexpr( ( ABL & 2 ) != 0 )
-					{
-						if( ablTile > 0 ) return;
-					}
 	#pragma unroll
 					for( int i = 0; i < 2; i++ )
 	#pragma unroll
@@ -1266,22 +1235,12 @@ namespace wh
 				};
 				auto readB = [ & ]( const f16* bufW, int j, f16x8( &fb )[ 4 ] )
 				{
-					if constexpr( ( ABL & 2 ) != 0 )
-					{
-						if( ablTile > 0 ) return;
-					}
 	#pragma unroll
 					for( int ks = 0; ks < 4; ks++ ) fb[ ks ] = *(const f16x8*)( bufW + ( wRow0 + j * 32 ) * BK + laneK[ ks ] );
 				};
 				auto quadrant = [ & ]( auto i0c, auto jc, const f16x8( &fb )[ 4 ] )
 				{
 					constexpr int i0 = decltype( i0c )::value, j = decltype( jc )::value;
-					if constexpr( ( ABL & 4 ) != 0 )
-					{
-	#pragma unroll
-						for( int ks = 0; ks < 4; ks++ ) asm volatile( "" ::"v"( fa[ 0 ][ ks ] ), "v"( fa[ 1 ][ ks ] ), "v"( fb[ ks ] ) );
-						return;
-					}
 					__builtin_amdgcn_s_setprio( 1 );
 	#pragma unroll
 					for( int ks = 0; ks < 4; ks++ )
@@ -1294,8 +1253,6 @@ namespace wh
 				using I1 = std::integral_constant<int, 1>;
 				using I2 = std::integral_constant<int, 2>;
 
-				long long tStamp0 = 0;
-				if constexpr( ( ABL & 1024 ) != 0 ) tStamp0 = __builtin_readcyclecounter();
 				// the tile's first operands were requested before the previous tile's epilogue (or above): K tile 0 must have landed
 				if( nk > 1 )
 					asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
@@ -1303,57 +1260,7 @@ namespace wh
 					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 				WH_BAR();
 				if( wr == 1 ) WH_BAR();	   // wave row 1 runs one barrier behind row 0
-				long long tStamp1 = 0;
-				if constexpr( ( ABL & 1024 ) != 0 ) tStamp1 = __builtin_readcyclecounter();
 
-				if constexpr( ( ABL & 2048 ) != 0 )
-				{
-					// TWO phases per K tile (16 MFMAs = 512 matrix-pipe cycles per barrier interval instead of 8 = 256: the hand-over
-					// between the wave rows costs ~100 cycles per interval, profiles/r03_gemm8_ablation.txt section 5):
-					//   phase    fragments read from LDS          MFMAs              staged global -> LDS
-					//   1        b0, b1 (8 reads), a0 (8)         a0 x b0, a0 x b1   A rows 0..127 of K tile t+1 (2)
-					//   2        a1 (8)                           a1 x b1, a1 x b0   A rows 128..255 of t+1 (2), W of t+2 (4)
-					// A read segment ends with lgkmcnt(0) BEFORE its barrier, so every fragment read of an interval has left the LDS
-					// when the other wave row issues the DMA that overwrites it one interval later (W of t+2 over the W tile read in
-					// phase 1; A rows 128.. of t+1 two intervals after their last read, rows 0..127 two intervals after theirs).
-					for( int kt = 0; kt < nk; kt++ )
-					{
-						const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
-						const f16* const bufW = bufA + C::A_HALFS;
-						const bool next = kt + 1 < nk, next2 = kt + 2 < nk;
-						readB( bufW, 0, fb0 );
-						readB( bufW, 1, fb1 );
-						readA( bufA, 0 );
-						if( next ) stage( kt + 1, PA0{} );
-						asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
-						WH_BAR();
-						quadrant( I0{}, I0{}, fb0 );
-						quadrant( I0{}, I1{}, fb1 );
-						WH_BAR();
-						readA( bufA, 1 );
-						if( next ) stage( kt + 1, PA1{} );
-						if( next2 )
-						{
-							stage( kt + 2, PW0{} );
-							stage( kt + 2, PW1{} );
-							asm volatile( "s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory" );
-						}
-						else if( next )
-							asm volatile( "s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory" );
-						else
-							asm volatile( "s_waitcnt lgkmcnt(0)" ::: "memory" );
-						WH_BAR();
-						quadrant( I2{}, I1{}, fb1 );
-						quadrant( I2{}, I0{}, fb0 );
-						if( next2 )
-							asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
-						else
-							asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-						WH_BAR();
-						ablTile = 1;
-					}
-				}
-				else
 				for( int kt = 0; kt < nk; kt++ )
 				{
 					const f16* const bufA = lds + ( kt & 1 ) * C::STAGE;
@@ -1394,13 +1301,10 @@ namespace wh
 					else
 						asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 					WH_BAR();
-					ablTile = 1;
 				}
 				if( wr == 0 ) WH_BAR();
 				// every wave has passed the same number of barriers and retired all its fragment reads: both operand buffers are dead
 
-				long long tStamp2 = 0;
-				if constexpr( ( ABL & 1024 ) != 0 ) tStamp2 = __builtin_readcyclecounter();
 				const int tmDone = tm, tnDone = tn;
 				lin += linStep;
 				const bool more = lin < linEnd;
@@ -1411,81 +1315,60 @@ namespace wh
 					stageFirst();	  // lands under the epilogue below
 				}
 
-				if constexpr( ( ABL & 32 ) != 0 )
+				bool direct = !WIDE;
+				bool fastDone = false;
+				if constexpr( WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
 				{
-	#pragma unroll
-					for( int i = 0; i < 4; i++ ) asm volatile( "" ::"v"( acc[ i ][ 0 ] ), "v"( acc[ i ][ 1 ] ) );
+					// interior tiles: the lean epilogue written for gemmTiled4 (no bounds checks, no divisions per row, residual rows requested a unit
+					// ahead of the stores); a.wideEpi == 2 = the launcher has checked what it relies on
+					const int mW = tmDone * BM + wr * 128, nW = tnDone * BN + wc * 64;
+					const bool isV = EPI == EPI_QKV_ENC && nW >= 2 * a.H * HEAD_DIM;
+					if( a.wideEpi == 2 && !isV && ( tmDone + 1 ) * BM <= a.M && ( tnDone + 1 ) * BN <= a.N )
+					{
+						unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
+						if constexpr( EPI == EPI_F32 )
+						{
+							if( a.res )
+								epilogueFast4<EPI, true, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
+							else
+								epilogueFast4<EPI, false, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
+						}
+						else
+							epilogueFast4<EPI, false, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
+						fastDone = true;
+					}
+				}
+				if( fastDone )
+				{
 				}
 				else
+				if constexpr( WIDE && EPI == EPI_QKV_ENC )
 				{
-					bool direct = !WIDE;
-					bool fastDone = false;
-					if constexpr( ABL == 0 && WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
+					// fragment-major V: straight from the registers (groups of 4 consecutive keys; T % 4 != 0 keeps the element-wise path)
+					if( ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM )
 					{
-						// interior tiles: the lean epilogue written for gemmTiled4 (no bounds checks, no divisions per row, residual rows requested a unit
-						// ahead of the stores); a.wideEpi == 2 = the launcher has checked what it relies on
-						const int mW = tmDone * BM + wr * 128, nW = tnDone * BN + wc * 64;
-						const bool isV = EPI == EPI_QKV_ENC && nW >= 2 * a.H * HEAD_DIM;
-						if( a.wideEpi == 2 && !isV && ( tmDone + 1 ) * BM <= a.M && ( tnDone + 1 ) * BN <= a.N )
-						{
-							unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
-							if constexpr( EPI == EPI_F32 )
-							{
-								if( a.res )
-									epilogueFast4<EPI, true, 0, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
-								else
-									epilogueFast4<EPI, false, 0, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
-							}
-							else
-								epilogueFast4<EPI, false, 0, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
-							fastDone = true;
-						}
-					}
-					if( fastDone )
-					{
-					}
-					else
-					if constexpr( WIDE && EPI == EPI_QKV_ENC )
-					{
-						// fragment-major V: straight from the registers (groups of 4 consecutive keys; T % 4 != 0 keeps the element-wise path)
-						if( ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM )
-						{
-							direct = ( a.T & 3 ) != 0;
-							if( !direct )
-							{
-		#pragma unroll
-								for( int i = 0; i < 4; i++ )
-									epilogueBlockV32x64( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane );
-							}
-						}
-					}
-					if( fastDone )
-					{
-					}
-					else if( direct )
-						tileEpilogue<EPI, Cfg8>( a, acc, tmDone, tnDone, wr, wc, lane );
-					else if( !( WIDE && EPI == EPI_QKV_ENC && ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM ) )
-					{
-						if constexpr( WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_CONV2 || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
+						direct = ( a.T & 3 ) != 0;
+						if( !direct )
 						{
 	#pragma unroll
 							for( int i = 0; i < 4; i++ )
-								epilogueBlock32x64<EPI, ( ABL & 128 ) != 0>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], ( ( ABL & 512 ) ? 0 : tmDone ) * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
-									smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
+								epilogueBlockV32x64( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane );
 						}
 					}
 				}
-				if constexpr( ( ABL & 1024 ) != 0 )
+				if( fastDone )
 				{
-					// probe: cycles of wave 0 spent waiting for the first operands, in the K loop and in the epilogue (a.pe = 4 counters)
-					const long long tStamp3 = __builtin_readcyclecounter();
-					if( tid == 0 )
+				}
+				else if( direct )
+					tileEpilogue<EPI, Cfg8>( a, acc, tmDone, tnDone, wr, wc, lane );
+				else if( !( WIDE && EPI == EPI_QKV_ENC && ( tnDone * BN + wc * 64 ) >= 2 * a.H * HEAD_DIM ) )
+				{
+					if constexpr( WIDE && ( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_CONV2 || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV ) )
 					{
-						unsigned long long* const dbg = (unsigned long long*)a.pe;
-						atomicAdd( dbg + 0, (unsigned long long)( tStamp1 - tStamp0 ) );
-						atomicAdd( dbg + 1, (unsigned long long)( tStamp2 - tStamp1 ) );
-						atomicAdd( dbg + 2, (unsigned long long)( tStamp3 - tStamp2 ) );
-						atomicAdd( dbg + 3, 1ull );
+#pragma unroll
+						for( int i = 0; i < 4; i++ )
+							epilogueBlock32x64<EPI>( a, acc[ i ][ 0 ], acc[ i ][ 1 ], tmDone * BM + wr * 128 + i * 32, tnDone * BN + wc * 64, lane,
+								smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
 					}
 				}
 				if( !more ) break;
@@ -1558,7 +1441,7 @@ namespace wh
 		//     rows cross at most one boundary (segments are at least 128 rows long).
 		// Same arithmetic per element as tileEpilogue / epilogueBlock32x64 (bit-identical outputs).
 		// TJ = MFMA tiles per wave in N: 4 (gemmTiled4: 128 x 128 per wave) or 2 (gemmTiled8: 128 x 64); AGPR = the accumulators are read as assembly (gemmTiled4)
-		template<int EPI, bool HASRES, int ABL, int FIRST, int LAST, int TJ, bool AGPR>
+		template<int EPI, bool HASRES, int FIRST, int LAST, int TJ, bool AGPR>
 		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ TJ ], int mW, int nW, int lane, unsigned char* stage )
 		{
 			static_assert( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV, "fast epilogue" );
@@ -1720,10 +1603,7 @@ namespace wh
 	#pragma unroll
 						for( int e = 0; e < 4; e++ ) o[ e ] = dv[ it ][ e ] + ex[ it ][ e ];
 					}
-					if constexpr( ( ABL & 1 ) != 0 )
-						asm volatile( "" ::"v"( o ) );	   // probe: everything but the global stores
-					else
-						*(f32x4*)( b + voff[ i ][ it ] ) = o;
+					*(f32x4*)( b + voff[ i ][ it ] ) = o;
 				}
 			};
 
@@ -1837,10 +1717,9 @@ namespace wh
 			static constexpr int LDS_BYTES = EPI_OFFSET + 4 * EPI_PER_WAVE;
 		};
 
-		// SCH (probe builds; 0 = the instance that ships): 1 = the DMA pieces of a K tile spread 3 / 3 / 2 over three substeps (else 4 / 4 over
-		// two), 2 = the compiler's own order inside a chunk, 4 = 2 fragment reads per chunk instead of 4 + 4 + 0 + 0, 16384 = no early W
-		// pieces / counted wait after the epilogue (all correct); ablations with WRONG results: 256 = no LDS-DMA in the K loop, 512 = no
-		// epilogue, 1024 = the epilogue without its global stores
+		// SCH (probe builds; 0 = the instance that ships; all give correct results): 1 = the DMA pieces of a K tile spread 3 / 3 / 2 over three
+		// substeps (else 4 / 4 over two), 2 = the compiler's own order inside a chunk, 4 = 2 fragment reads per chunk instead of 4 + 4 + 0 + 0,
+		// 16384 = no early W pieces / counted wait after the epilogue
 		template<int EPI, bool WIDE, int SCH = 0>
 		__global__ void __launch_bounds__( 256, 1 ) gemmTiled4( const GemmArgs a )
 		{
@@ -1959,7 +1838,6 @@ namespace wh
 			auto dmaAfter = [ & ]( auto sc, auto cc, auto posc )
 			{
 				constexpr int s = decltype( sc )::value, c = decltype( cc )::value, pos = decltype( posc )::value;
-				if constexpr( ( SCH & 256 ) != 0 ) return;
 				if constexpr( ( SCH & 1 ) == 0 && ( SCH & 16384 ) == 0 )
 				{
 					if constexpr( pos == 1 && s == 0 ) return;
@@ -2110,14 +1988,6 @@ namespace wh
 			auto epilogue = [ & ]( int tmD, int tnD, bool lastTile )
 			{
 				postEpi = 0;
-				if constexpr( ( SCH & 512 ) != 0 )
-				{
-	#pragma unroll
-					for( int i = 0; i < 4; i++ )
-	#pragma unroll
-						for( int j = 0; j < 4; j++ ) asm volatile( "" ::"a"( acc[ i ][ j ] ) );
-					return;
-				}
 				if constexpr( WIDE )
 				{
 					const int mW = tmD * BM + wr * 128, nW = tnD * BN + wc * 128;
@@ -2140,7 +2010,7 @@ namespace wh
 							if( a.res )
 								epilogueFast4<EPI, true>( a, acc, mW, nW, lane, stage );
 							else
-								epilogueFast4<EPI, false, ( SCH & 1024 ) ? 1 : 0>( a, acc, mW, nW, lane, stage );
+								epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
 						}
 						else
 							epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
@@ -2184,12 +2054,6 @@ namespace wh
 				}
 			};
 
-			if constexpr( ( SCH & 2048 ) != 0 )
-			{
-				// probe: the workgroups of an XCD start a quarter tile apart, so that the epilogues of the chip (its store bursts) do not coincide
-				const int phase = ( blockIdx.x >> 3 ) & 3;
-				for( int i = 0; i < phase * nk; i++ ) __builtin_amdgcn_s_sleep( 16 );
-			}
 			// ---- prologue: K tile 0 of the first output tile completely, then the first part of K tile 1
 			int lin = linFirst;
 			tileOffsets( lin, pOffA, pOffW );
@@ -3192,7 +3056,7 @@ namespace wh
 		return fast;
 	}
 
-	template<int EPI, bool WIDE, int ABL = 0>
+	template<int EPI, bool WIDE>
 	static int launchTiled8K( const GemmArgs& b, hipStream_t stream )
 	{
 		static PerDeviceOnce once;
@@ -3201,7 +3065,7 @@ namespace wh
 		if( hipGetDevice( &dev ) != hipSuccess ) dev = 0;
 		if( const int onceDev = once.needed(); onceDev >= 0 )
 		{
-			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled8<EPI, WIDE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg8::LDS_BYTES ) );
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled8<EPI, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg8::LDS_BYTES ) );
 			int cus = 0;
 			WH_HIP( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, dev ) );
 			cusOfDevice[ onceDev ] = cus;
@@ -3212,7 +3076,7 @@ namespace wh
 		int cus = cusOfDevice[ dev & 63 ] > 0 ? cusOfDevice[ dev & 63 ] : 256;
 		if( b.cuLimit > 0 && b.cuLimit < cus ) cus = b.cuLimit;
 		const int grid = tilesM * tilesN < cus ? tilesM * tilesN : cus;
-		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE, ABL> ), dim3( grid ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
+		hipLaunchKernelGGL( ( gemmTiled8<EPI, WIDE> ), dim3( grid ), dim3( Cfg8::NT ), Cfg8::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -3306,32 +3170,11 @@ namespace wh
 		case 26: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1, true, 2, 2, 2, 1>>( a, stream );
 		case 2: return launchTiledT<EPI_F32, TileCfg<128, 128, 32, 3, 1>>( a, stream );	   // register-staged 128x128x32: what wh_debug_probe checks every variant against
 #ifdef WH_PROBES
-		case 60: return launchTiled4<EPI_F32, 256>( a, stream );	   // ablations (60 .. 69, wrong results, not checked): no LDS-DMA in the K loop
-		case 61: return launchTiled4<EPI_F32, 512>( a, stream );	   // ... no epilogue
-		case 62: return launchTiled4<EPI_F32, 768>( a, stream );	   // ... neither
-		case 63: return launchTiled4<EPI_F32, 1024>( a, stream );	   // ... the epilogue without its global stores
 		case 51: return launchTiled4<EPI_F32, 16384>( a, stream );	   // correct: without the early W pieces / the counted wait after the epilogue
-		// Everything below exists for tools/*probe*: tile-shape experiments and ABLATIONS of the production kernels, several of them WRONG BY
-		// CONSTRUCTION (loads or fragment reads removed to see what the rest costs). The shipped objects do not contain them: build with
-		// WH_PROBES=1 python -m whisper_amd.build --force to get them back.
-		case 41: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1>( b, stream ); }	 // ablations: 31 .. 39 and 41 .. 49 are not checked
-		case 42: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2>( b, stream ); }
-		case 43: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 3>( b, stream ); }
-		case 44: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 4>( b, stream ); }
-		case 45: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 6>( b, stream ); }
-		case 46: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16>( b, stream ); }
-		case 47: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 16 + 6>( b, stream ); }
-		case 48: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 32>( b, stream ); }
-		case 49: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 64>( b, stream ); }	   // correct results: staggered start
-		case 39: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 128>( b, stream ); }   // correct results: non-temporal stores
-		case 37: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 64 + 256>( b, stream ); }   // correct results: XCDs staggered
-		case 36: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 512>( b, stream ); }   // every tile stores into tile row 0 (L2-resident writes)
-		case 34: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2048>( b, stream ); }   // correct results: two phases per K tile
-		case 33: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 2048 + 1024>( b, stream ); }   // ... with cycle stamps
-		case 35: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 1024>( b, stream ); }   // correct results: cycle stamps into a.pe
-		case 38: { GemmArgs b = a; b.groupM = b.groupM ? b.groupM : 4; b.wideEpi = 1; return launchTiled8K<EPI_F32, true, 192>( b, stream ); }
-		case 31: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 1>>( a, stream );
-		case 32: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1, 2>>( a, stream );
+		// Everything below exists for tools/*probe*: tile-shape experiments (all correct). The shipped objects do not contain them: build with
+		// WH_PROBES=1 python -m whisper_amd.build --force to get them back. (The ABLATIONS of rounds 2-4 -- kernels with loads, fragment reads,
+		// MFMAs or stores removed to see what the rest costs: profiles/r02_gemm_kloop_ablation.txt, r03_gemm8_ablation.txt, r04_gemm4_probe.txt --
+		// lived in the production kernels' source as compile-time branches until round 5; they are in the history up to commit 7317048.)
 		case 27: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3, 1>>( a, stream );
 		case 20: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 3>>( a, stream );
 		case 21: return launchTiledT<EPI_F32, TileCfg<256, 256, 32, 4, 1, true, 2, 2, 4>>( a, stream );
