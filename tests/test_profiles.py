@@ -155,7 +155,9 @@ def test_r05_rooflines_recomputed_from_the_rocprof_statistics():
     avg, _ = _avg_us(stats, lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n)
     frac = x["algorithmic_per_launch"] / (avg * 1e-6) / 1e9 / x["peak"]
     print("attentionDecCross: bench %.4f, rocprof %.4f" % (x["frac"], frac))
-    assert -0.02 < (x["frac"] - frac) / x["frac"] < 0.10
+    # (the committed statistics are of the default command with ONE context in flight: at 448 windows per batch two contexts' launches overlap inside a traced
+    # run as well, and a kernel's traced duration then holds the time it shared the chip -- profiles/r05_kernel_stats_two_in_flight.csv, checked below)
+    assert abs(x["frac"] - frac) / x["frac"] < 0.06
     # the encoder's product: time per batch pass of the persistent launches in the trace (warm-up + timed passes; their number follows from the encoder
     # attention's launch count) against the class of the line (which also holds conv1's and the prompt step's small tiles: a few percent)
     g = r["mfma_kernel"]
@@ -168,7 +170,7 @@ def test_r05_rooflines_recomputed_from_the_rocprof_statistics():
     for cls, match in (("attentionDecCross", lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n), ("attentionEnc", lambda n: "attentionEnc" in n)):
         avg, _ = _avg_us(stats, match)
         print("%s: bench %.2f us, rocprof %.2f us" % (cls, k[cls]["avg_us"], avg))
-        assert -0.03 < (avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.10
+        assert abs(avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.06
     # the decode chain's own kernels (round 5): the products of > 128 rows and the wave-per-pair self-attention
     avg, calls = _avg_us(stats, lambda n: "gemmDecRows" in n)
     print("gemmDecRows: rocprof %.2f us over %d launches; bench class gemvFused %.2f us" % (avg, calls, k["gemvFused"]["avg_us"]))
@@ -177,3 +179,23 @@ def test_r05_rooflines_recomputed_from_the_rocprof_statistics():
     print("selfAttnDecWave: rocprof %.2f us over %d launches; bench class attentionDec %.2f us" % (avg, calls, k["attentionDec"]["avg_us"]))
     assert calls > 0 and avg < 25.0
 
+
+
+def test_r05_two_contexts_in_flight_under_the_tracer():
+    """The same command with its default two contexts in flight (session U): the cross-attention's launches are never faster than alone, their AVERAGE is the
+    time they shared HBM with the other context's kernels -- which is why the per-kernel rooflines are taken with one context at a time."""
+    line, one = _load5()
+    try:
+        two = list(csv.DictReader(open(os.path.join(PROF, "r05_kernel_stats_two_in_flight.csv"))))
+    except OSError:
+        pytest.skip("profiles/r05_kernel_stats_two_in_flight.csv not committed")
+    match = lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n  # noqa: E731
+    avg1, _ = _avg_us(one, match)
+    avg2, _ = _avg_us(two, match)
+    min2 = min(float(x["MinNs"]) for x in two if match(x["Name"])) / 1e3
+    print("attentionDecCross: %.1f us alone, %.1f us average / %.1f us minimum with two contexts in flight" % (avg1, avg2, min2))
+    assert avg2 > avg1 and abs(min2 - avg1) / avg1 < 0.08
+    # whole-job check that holds whatever overlaps: cross-attention bytes of a step over the step's time stay below the HBM peak
+    x = line["roofline"]["hbm_kernel"]
+    per_step = x["algorithmic_per_launch"] * x["launches_per_batch_pass"]
+    assert per_step / (line["ms_per_step"] * 1e-3) / 1e9 < x["peak"]
