@@ -124,7 +124,16 @@ typedef enum wh_flags
 	WH_FLAG_NO_GRAPH = 2,
 	/* Keep copies of the intermediates at the reference's Tracing probe points (Whisper/Whisper/WhisperContext.cpp:142-638,
 	 * source/whisper.cpp:1121-1869) for wh_debug_read: "enc.temp1", "enc.layer0.in", "enc-KQV", "dec-KQV", "dec-KQV#2". */
-	WH_FLAG_DEBUG_CAPTURE = 4
+	WH_FLAG_DEBUG_CAPTURE = 4,
+	/* wh_encode and wh_decode compute the reference CPU path's arithmetic IN THE REFERENCE'S SUMMATION ORDER: ggml_vec_dot_f16's 32 chains and
+	 * reduction tree for every product (Whisper/source/ggml.c:751-790), sequential double sums in LayerNorm (:4098-4156), the 65536-entry GELU /
+	 * exp tables, flash_attn_f16's FP16 P (:5912-6097), and the decoder's FP16 key-by-key P.V over `parityThreads` thread ranges (:4689-4735).
+	 * Cross-attention caches, logits and probabilities are then the reference's BITS at that thread count (tests/test_gpu_exact.py), which is what
+	 * north_star's "within 1e-3 on logits" is checked against without the reference's own thread-count band (0.05 .. 0.5 on logits) in the way.
+	 * One thread per output on the VALU, no MFMA: ~100 x slower than the timed kernels, never measured. Host-stepped decoding only (wh_decode +
+	 * wh_sample_best; the device-side greedy loop and beam search refuse the flag). The caches it fills are the product's own, so a timed decode
+	 * step can be run on top of exact caches and vice versa. */
+	WH_FLAG_PARITY_EXACT = 8
 } wh_flags;
 
 WH_API int wh_context_create( wh_model* m, int maxBatch, void* stream, wh_context** out );

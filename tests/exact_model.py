@@ -87,7 +87,7 @@ class WhisperExact:
         return out
 
     # ---- encoder ----
-    def encode(self, mel, mel_offset=0):
+    def encode(self, mel, mel_offset=0, trace=None, n_layers=None):
         hp, t = self.hp, self.t
         n_ctx, d, H = hp.n_audio_ctx, hp.n_audio_state, hp.n_audio_head
         inp = np.zeros((hp.n_mels, 2 * n_ctx), F32)
@@ -95,12 +95,18 @@ class WhisperExact:
         inp[:, :i1 - i0] = mel[:, i0:i1]
         cur = self.conv(t["encoder.conv1.weight"], inp, 1)
         cur = self.gelu((t["encoder.conv1.bias"].reshape(-1, 1).astype(F32) + cur).astype(F32))
+        if trace is not None:
+            trace["conv1"] = cur.T.copy()
         cur = self.conv(t["encoder.conv2.weight"], cur, 2)
         cur = self.gelu((t["encoder.conv2.bias"].reshape(-1, 1).astype(F32) + cur).astype(F32))
         x = (t["encoder.positional_embedding"][:n_ctx].astype(F32) + cur.T).astype(F32)
-        for il in range(hp.n_audio_layer):
+        for il in range(hp.n_audio_layer if n_layers is None else n_layers):
             p = f"encoder.blocks.{il}"
+            if trace is not None:
+                trace["x_in"] = x.copy()
             cur = self.layer_norm(x, t[p + ".attn_ln.weight"], t[p + ".attn_ln.bias"])
+            if trace is not None:
+                trace["ln1"] = cur.copy()
             q = (self.mul_mat(t[p + ".attn.query.weight"], cur) + t[p + ".attn.query.bias"].astype(F32)).astype(F32)
             k = self.mul_mat(t[p + ".attn.key.weight"], cur)
             v = (self.mul_mat(t[p + ".attn.value.weight"], cur) + t[p + ".attn.value.bias"].astype(F32)).astype(F32)
@@ -110,12 +116,24 @@ class WhisperExact:
                 o = h * 64
                 lib().x_flash_attn(C.c_void_p(q16.ctypes.data + 2 * o), C.c_void_p(k16.ctypes.data + 2 * o), C.c_void_p(v16.ctypes.data + 2 * o),
                                    d, n_ctx, _p(self.exp_t), C.c_void_p(kqv.ctypes.data + 4 * o), d)
+            if trace is not None:
+                trace.update(q=q.copy(), k=k.copy(), v=v.copy(), kqv=kqv.copy())
             cur = (self.mul_mat(t[p + ".attn.out.weight"], kqv) + t[p + ".attn.out.bias"].astype(F32)).astype(F32)
             x = (cur + x).astype(F32)
+            if trace is not None:
+                trace["x_attn"] = x.copy()
             cur = self.layer_norm(x, t[p + ".mlp_ln.weight"], t[p + ".mlp_ln.bias"])
+            if trace is not None:
+                trace["ln2"] = cur.copy()
             cur = self.gelu((self.mul_mat(t[p + ".mlp.0.weight"], cur) + t[p + ".mlp.0.bias"].astype(F32)).astype(F32))
+            if trace is not None:
+                trace["h"] = cur.copy()
             cur = (self.mul_mat(t[p + ".mlp.2.weight"], cur) + t[p + ".mlp.2.bias"].astype(F32)).astype(F32)
             x = (cur + x).astype(F32)
+        if trace is not None:
+            trace["x"] = x.copy()
+        if n_layers is not None:
+            return x
         out = self.layer_norm(x, t["encoder.ln_post.weight"], t["encoder.ln_post.bias"])
         ks = F32(np.power(np.float64(F32(d) / F32(H)), -0.25))
         self.cross_k, self.cross_v = [], []

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libwhisper_hip.so")
 WH_FLAG_PARITY_PV = 1
 WH_FLAG_NO_GRAPH = 2
 WH_FLAG_DEBUG_CAPTURE = 4
+WH_FLAG_PARITY_EXACT = 8      # the reference CPU path's arithmetic in its own summation order (exact.hip); never timed
 # kernel-variant switches (whisper_amd/csrc/kernels.h eTuning); TUNE_DEFAULT is what the library starts with
 TUNE_GEMM_8WAVE = 16
 TUNE_GEMM_4WAVE = 4
@@ -510,6 +511,16 @@ class HipContext:
         b = self.batch
         if what == "exp-table":
             out = np.empty(0x5000, np.float32)
+            check(lib().wh_debug_read(self.handle, what.encode(), 0, 0, out.ctypes.data_as(C.c_void_p), out.size))
+            return out
+        if what in ("exact-gelu-table", "exact-exp-table"):
+            out = np.empty(65536, np.float32)
+            check(lib().wh_debug_read(self.handle, what.encode(), 0, 0, out.ctypes.data_as(C.c_void_p), out.size))
+            return out
+        if what.startswith("exact:"):
+            mult = 4 if what == "exact:h" else 1
+            shape = (b, 2 * self.hp.n_audio_ctx, d) if what == "exact:conv1" else (b, self.hp.n_audio_ctx, d * mult)
+            out = np.empty(shape, np.float32)
             check(lib().wh_debug_read(self.handle, what.encode(), 0, 0, out.ctypes.data_as(C.c_void_p), out.size))
             return out
         if what in ("logits", "probs"):

@@ -20,7 +20,9 @@ HIP_LIB = os.path.join(LIB_DIR, "libwhisper_hip.so")
 HOST_LIB = os.path.join(LIB_DIR, "libWhisper.so")
 CLI_BIN = os.path.join(LIB_DIR, "whisper-main")
 
-HIP_SOURCES = ["gemm.hip", "decode1.hip", "attn_enc.hip", "attn_dec.hip", "elementwise.hip", "mel.hip", "runtime.hip"]
+HIP_SOURCES = ["gemm.hip", "decode1.hip", "attn_enc.hip", "attn_dec.hip", "elementwise.hip", "mel.hip", "exact.hip", "runtime.hip"]
+# exact.hip restates the reference CPU path's summation order: a fused multiply-add only where the source says fma()
+EXTRA_FLAGS = {"exact.hip": ["-ffp-contract=off"]}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -44,7 +46,7 @@ def _run(cmd):
 def build_hip(force: bool = False) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "epilogue.h")] + [os.path.join(ROOT, "include", "whisper_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "epilogue.h", "exact_ops.h")] + [os.path.join(ROOT, "include", "whisper_hip.h")]
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     for s in HIP_SOURCES:
@@ -53,7 +55,7 @@ def build_hip(force: bool = False) -> str:
         if force or _newer(obj, [src] + headers):
             # WH_PROBES=1: the tile-shape experiments and ablation instances of tools/*probe* (not in the shipped objects)
             probes = ["-DWH_PROBES"] if os.environ.get("WH_PROBES", "") not in ("", "0") else []
-            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + probes +
+            _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"] + probes + EXTRA_FLAGS.get(s, []) +
                  ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
         objs.append(obj)
     if force or _newer(HIP_LIB, objs):

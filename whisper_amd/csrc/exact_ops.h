@@ -29,7 +29,17 @@ namespace whx
 	typedef _Float16 h16;
 
 	WH_HD float toF32( h16 v ) { return (float)v; }
-	WH_HD h16 toF16( float v ) { return (h16)v; }	   // round to nearest even, like _cvtss_sh( x, 0 ) (ggml.c:159)
+	// FP32 -> FP16, round to nearest even, like _cvtss_sh( x, 0 ) (ggml.c:159) -- of a value that HAS BEEN ROUNDED TO FP32. On gfx950 the compiler
+	// selects v_fma_mixlo_f16 for fptrunc( fmul / fma ), and that instruction rounds the exact product ONCE, to FP16: the reference rounds twice
+	// (F32 result, then F16C), and the two differ in ~2^-13 of the cases (measured: 443 of 192000 outputs of one encoder layer's attention). The empty
+	// asm makes the FP32 value opaque, so the conversion stays a v_cvt_f16_f32 of the rounded FP32 result.
+	WH_HD h16 toF16( float v )
+	{
+#if defined( __HIP_DEVICE_COMPILE__ )
+		asm volatile( "" : "+v"( v ) );
+#endif
+		return (h16)v;
+	}
 	WH_HD uint16_t bitsOf( h16 v )
 	{
 		union { h16 h; uint16_t u; } c;

@@ -67,6 +67,7 @@ namespace wh
 									 // 70 / 112 windows: +1.6 % / +3.6 % on the job with the self-attention as selfAttnDecWave -- round 2 measured the fused launch ahead
 									 // when the separate attention was attentionDecG at 43 us)
 		int selfNq = 0;				 // "self_nq": sequences per selfBlockDec workgroup (0 = by grid size; 1, 2, 4, 8)
+		int exactEncLayers = -1;	 // "exact_enc_layers": WH_FLAG_PARITY_EXACT, debugging: encode only this many layers and stop (buffers readable as "exact:<name>"); -1 = all
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
 	};
 	extern Options g_opt;
@@ -153,6 +154,24 @@ namespace wh
 		int nVocab, int nTextCtx, hipStream_t stream );
 	// in-place table softmax of FP32 rows (softMax*.hlsl with the CPU path's FP16 exp table semantics)
 	int launchSoftMaxRows( float* x, int rows, int cols, hipStream_t stream );
+
+	// ---------------------------------------------------------------------------------------------------------------
+	// WH_FLAG_PARITY_EXACT (exact.hip): the reference CPU path's arithmetic in the reference's summation order, built from exact_ops.h. Never timed.
+	// ---------------------------------------------------------------------------------------------------------------
+	// out[m][n] = epi( ggml_vec_dot_f16( W[n], fp16( X[m] ) ) ), epi = [bias +] [* scale] [GELU table] [+ residual], each a rounding of its own
+	int launchExactMulMat( const f16* W, int N, int K, const float* X, long long ldx, int M, float* out, long long ldo, const float* bias, float scale, bool useScale,
+		const f16* geluTab, const float* residual, long long ldr, hipStream_t stream );
+	int launchExactNorm( const float* x, const float* w, const float* b, float* out, int rows, int n, hipStream_t stream );
+	// k = 3, padding 1; X: FP16 [b][t+1][ic] with zero rows around (in16) or FP32 [b][t][ic]; out FP32 [b][t][oc] = [pe +] GELU( bias + conv )
+	int launchExactConv( const f16* W, int kpad, int ic, const void* X, bool in16, long long xBatchStride, int Tin, int stride, const float* bias, const f16* geluTab,
+		const float* pe, float* out, long long outBatchStride, int oc, int batch, hipStream_t stream );
+	int launchExactFlashAttn( const float* q, const float* k, const float* v, float* out, int batch, int H, int T, const f16* expTab, hipStream_t stream );
+	int launchExactPackHeads( const float* src, f16* dst, int batch, int rowsPer, int rowCap, int r0, int H, hipStream_t stream );
+	// scores [seqs][H][N][nKeys] scratch; sequence s reads the cache of s / hyp; nth = the reference's thread count (it partitions the keys of P.V)
+	int launchExactDecAttention( const float* Q, const f16* Kc, const f16* Vc, float* scores, float* out, int seqs, int N, int nKeys, int H, int rowCap, int hyp,
+		int nPast, bool masked, int nth, const f16* expTab, hipStream_t stream );
+	int launchExactSoftMax( const float* src, float* dst, int rows, int cols, const f16* expTab, hipStream_t stream );
+	void exactBuildTables( uint16_t* gelu, uint16_t* expt );
 
 	// ---------------------------------------------------------------------------------------------------------------
 	// attention

@@ -40,7 +40,7 @@ namespace wh
 	{
 		struct OptionName { const char* name; int Options::* field; };
 		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
-			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows } };
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
 		{
@@ -324,6 +324,18 @@ struct wh_context
 	float* capLayer0In = nullptr;
 	int capDecRows = 0;
 	int profKeysHint = 1;	   // profiler only: keys a device-positioned self-attention launch sees (host mirror of the largest position + 1)
+	// WH_FLAG_PARITY_EXACT (exact.hip): FP32 activations of the reference-order graph, allocated on first use for up to EXACT_CHUNK windows at a time
+	// (a larger batch is encoded chunk by chunk), the decoder's rows and score scratch grown on demand; ggml_init's two 65536-entry tables
+	struct Exact
+	{
+		static constexpr int CHUNK = 8;
+		f16 *gelu = nullptr, *expt = nullptr;
+		float *x = nullptr, *cur = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *kqv = nullptr, *h = nullptr, *conv1 = nullptr;
+		float *dx = nullptr, *dcur = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dkqv = nullptr, *dh = nullptr, *scores = nullptr;
+		int64_t decRows = 0, scoreFloats = 0;
+		int encWindows = 0;
+		std::vector<void*> owned;
+	} ex;
 	bool ownsStream = false;
 	// pinned host staging for fully asynchronous enqueues: ints [0, 4096) window offsets or descriptors (6 ints each: up to 682 windows),
 	// [4096, 4104) the sampler state, [4104, 4104 + maxSeq) positions, then the prompt tokens of a window (up to n_text_ctx per sequence)
@@ -1284,6 +1296,7 @@ void wh_context_destroy( wh_context* c )
 	if( c->encGateEv ) (void)hipEventDestroy( c->encGateEv );
 	if( c->verifyGuards() != 0 ) fprintf( stderr, "WH_GUARD_VIOLATION: context %p wrote outside its buffers\n", (void*)c );
 	for( const auto& a : c->allocations ) (void)hipFree( a.base );
+	for( void* p : c->ex.owned ) (void)hipFree( p );
 	if( c->pinned ) (void)hipHostFree( c->pinned );
 	if( c->mailData ) (void)hipHostFree( c->mailData );
 	if( c->mailFlag ) (void)hipHostFree( c->mailFlag );
@@ -1481,6 +1494,176 @@ int wh_encode( wh_context* c, const float* melDev, int batch, int64_t melLen, in
 	return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// WH_FLAG_PARITY_EXACT: the reference's graphs (whisper.cpp:1084-1496, :1508-1872) over the exact-order kernels of exact.hip
+// ------------------------------------------------------------------------------------------------------------------
+static int exactAlloc( wh_context* c, void** p, int64_t bytes )
+{
+	void* v = nullptr;
+	WH_HIP( hipMalloc( &v, (size_t)bytes ) );
+	WH_HIP( hipMemsetAsync( v, 0, (size_t)bytes, c->stream ) );
+	c->ex.owned.push_back( v );
+	c->vram += bytes;
+	*p = v;
+	return 0;
+}
+static int exactTables( wh_context* c )
+{
+	wh_context::Exact& e = c->ex;
+	if( e.gelu ) return 0;
+	std::vector<uint16_t> g( 65536 ), x( 65536 );
+	exactBuildTables( g.data(), x.data() );
+	WH_CHECK( exactAlloc( c, (void**)&e.gelu, 65536 * 2 ) );
+	WH_CHECK( exactAlloc( c, (void**)&e.expt, 65536 * 2 ) );
+	WH_HIP( hipMemcpyAsync( e.gelu, g.data(), 65536 * 2, hipMemcpyHostToDevice, c->stream ) );
+	WH_HIP( hipMemcpyAsync( e.expt, x.data(), 65536 * 2, hipMemcpyHostToDevice, c->stream ) );
+	WH_HIP( hipStreamSynchronize( c->stream ) );	   // the staging vectors go out of scope
+	return 0;
+}
+
+static int encodeExact( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets, const wh_mel_window* wins )
+{
+	const wh_model* m = c->m;
+	const wh_hparams& hp = m->hp;
+	const Layout& L = m->L;
+	hipStream_t st = c->stream;
+	const int d = hp.n_audio_state, H = hp.n_audio_head, T = c->T;
+	wh_context::Exact& e = c->ex;
+	WH_CHECK( exactTables( c ) );
+	const int chunk = std::min( { wh_context::Exact::CHUNK, c->maxBatch, c->encChunk } );
+	if( !e.x )
+	{
+		const int64_t rows = (int64_t)chunk * T;
+		for( float** p : { &e.x, &e.cur, &e.q, &e.k, &e.v, &e.kqv } ) WH_CHECK( exactAlloc( c, (void**)p, rows * d * 4 ) );
+		WH_CHECK( exactAlloc( c, (void**)&e.h, rows * 4 * d * 4 ) );
+		WH_CHECK( exactAlloc( c, (void**)&e.conv1, rows * 2 * d * 4 ) );
+		e.encWindows = chunk;
+	}
+	const float kScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
+	auto mm = [ & ]( int64_t wOff, int N, int K, const float* X, int M, float* out, int64_t biasOff, bool useScale, bool gelu, const float* res ) -> int
+	{
+		return launchExactMulMat( m->at<f16>( wOff ), N, K, X, K, M, out, N, biasOff >= 0 ? m->at<float>( biasOff ) : nullptr, kScale, useScale,
+			gelu ? e.gelu : nullptr, res, N, st );
+	};
+	for( int b0 = 0; b0 < batch; b0 += chunk )
+	{
+		const int nb = std::min( chunk, batch - b0 );
+		const int M = nb * T;
+		// the product's own conv input: fp16( mel ) time-major with the padding rows, exactly the operand ggml_conv_1d_1s builds (ggml.c:5270-5282)
+		if( wins )
+		{
+			MelWindow* const stage = (MelWindow*)c->pinned;
+			for( int i = 0; i < nb; i++ ) stage[ i ] = MelWindow{ wins[ b0 + i ].melDev, (long long)wins[ b0 + i ].melLen, wins[ b0 + i ].offset, 0 };
+			WH_HIP( hipMemcpyAsync( c->melWindowsDev, stage, sizeof( MelWindow ) * nb, hipMemcpyHostToDevice, st ) );
+		}
+		else
+		{
+			for( int i = 0; i < nb; i++ ) c->pinned[ i ] = melOffsets ? melOffsets[ b0 + i ] : 0;
+			WH_HIP( hipMemcpyAsync( c->melOffsetsDev, c->pinned, sizeof( int32_t ) * nb, hipMemcpyHostToDevice, st ) );
+		}
+		WH_CHECK( launchMelToConvInput( melDev ? melDev + (int64_t)b0 * melStride : nullptr, melStride, melLen, c->melOffsetsDev, wins ? c->melWindowsDev : nullptr,
+			c->convIn, c->convInStride, hp.n_mels, 2 * T, nb, st ) );
+		WH_HIP( hipStreamSynchronize( st ) );	   // the pinned staging is rewritten by the next chunk
+		WH_CHECK( launchExactConv( m->at<f16>( L.conv1w ), conv1Kpad( hp ), hp.n_mels, c->convIn, true, c->convInStride, 2 * T, 1, m->at<float>( L.conv1b ), e.gelu,
+			nullptr, e.conv1, 2ll * T * d, d, nb, st ) );
+		WH_CHECK( launchExactConv( m->at<f16>( L.conv2w ), 3 * d, d, e.conv1, false, 2ll * T * d, 2 * T, 2, m->at<float>( L.conv2b ), e.gelu,
+			m->at<float>( L.encPe ), e.x, (int64_t)T * d, d, nb, st ) );
+		const int encLayers = g_opt.exactEncLayers >= 0 ? std::min( g_opt.exactEncLayers, hp.n_audio_layer ) : hp.n_audio_layer;
+		for( int il = 0; il < encLayers; il++ )
+		{
+			const EncLayer& el = L.enc[ il ];
+			WH_CHECK( launchExactNorm( e.x, m->at<float>( el.ln1w ), m->at<float>( el.ln1b ), e.cur, M, d, st ) );
+			WH_CHECK( mm( el.wqkv, d, d, e.cur, M, e.q, el.bqkv, false, false, nullptr ) );
+			WH_CHECK( mm( el.wqkv + 2ll * d * d, d, d, e.cur, M, e.k, -1, false, false, nullptr ) );
+			WH_CHECK( mm( el.wqkv + 4ll * d * d, d, d, e.cur, M, e.v, el.bqkv + 8ll * d, false, false, nullptr ) );
+			WH_CHECK( launchExactFlashAttn( e.q, e.k, e.v, e.kqv, nb, H, T, e.expt, st ) );
+			WH_CHECK( mm( el.wo, d, d, e.kqv, M, e.x, el.bo, false, false, e.x ) );
+			WH_CHECK( launchExactNorm( e.x, m->at<float>( el.ln2w ), m->at<float>( el.ln2b ), e.cur, M, d, st ) );
+			WH_CHECK( mm( el.w1, 4 * d, d, e.cur, M, e.h, el.b1, false, true, nullptr ) );
+			WH_CHECK( mm( el.w2, d, 4 * d, e.h, M, e.x, el.b2, false, false, e.x ) );
+		}
+		if( g_opt.exactEncLayers >= 0 ) continue;	   // debugging: the buffers hold the state after `encLayers` layers
+		WH_CHECK( launchExactNorm( e.x, m->at<float>( L.lnPostW ), m->at<float>( L.lnPostB ), e.cur, M, d, st ) );
+		for( int il = 0; il < hp.n_text_layer; il++ )
+		{
+			// Kcross = scale( mul_mat ), Vcross = mul_mat + bias, both copied into the FP16 caches (whisper.cpp:1448-1487)
+			WH_CHECK( mm( L.wcross + 2ll * ( 2ll * il ) * d * d, d, d, e.cur, M, e.k, -1, true, false, nullptr ) );
+			WH_CHECK( mm( L.wcross + 2ll * ( 2ll * il + 1 ) * d * d, d, d, e.cur, M, e.v, L.bcross + 4ll * ( 2ll * il + 1 ) * d, false, false, nullptr ) );
+			const int64_t layerOff = ( (int64_t)il * c->maxBatch + b0 ) * T * d;
+			WH_CHECK( launchExactPackHeads( e.k, c->crossK + layerOff, nb, T, T, 0, H, st ) );
+			WH_CHECK( launchExactPackHeads( e.v, c->crossV + layerOff, nb, T, T, 0, H, st ) );
+		}
+	}
+	c->encoded = true;
+	c->lastEncBatch = batch;
+	c->lastBatch = batch * c->hyp;
+	return 0;
+}
+
+// whisper_decode: every sequence's nTokens tokens at nPast; logits and probabilities of the LAST token of every sequence into c->logits / c->probs
+static int decodeExact( wh_context* c, int batch, int nTokens, int nPast )
+{
+	const wh_model* m = c->m;
+	const wh_hparams& hp = m->hp;
+	const Layout& L = m->L;
+	hipStream_t st = c->stream;
+	const int d = hp.n_text_state, H = hp.n_text_head, T = c->T, N = nTokens;
+	wh_context::Exact& e = c->ex;
+	WH_CHECK( exactTables( c ) );
+	const int64_t rows = (int64_t)batch * N;
+	if( rows > e.decRows )
+	{
+		WH_HIP( hipStreamSynchronize( st ) );
+		for( float** p : { &e.dx, &e.dcur, &e.dq, &e.dk, &e.dv, &e.dkqv } ) WH_CHECK( exactAlloc( c, (void**)p, rows * d * 4 ) );
+		WH_CHECK( exactAlloc( c, (void**)&e.dh, rows * 4 * d * 4 ) );
+		e.decRows = rows;
+	}
+	const int maxKeys = std::max( T, nPast + N );
+	const int64_t needScores = (int64_t)batch * H * N * maxKeys;
+	if( needScores > e.scoreFloats )
+	{
+		WH_HIP( hipStreamSynchronize( st ) );
+		WH_CHECK( exactAlloc( c, (void**)&e.scores, needScores * 4 ) );
+		e.scoreFloats = needScores;
+	}
+	const float s = (float)pow( (double)( (float)d / (float)H ), -0.25 );
+	const int M = (int)rows;
+	auto mm = [ & ]( int64_t wOff, int Nn, int K, const float* X, float* out, int64_t biasOff, bool useScale, bool gelu, const float* res ) -> int
+	{
+		return launchExactMulMat( m->at<f16>( wOff ), Nn, K, X, K, M, out, Nn, biasOff >= 0 ? m->at<float>( biasOff ) : nullptr, s, useScale, gelu ? e.gelu : nullptr, res, Nn, st );
+	};
+	// token + positional embedding: one FP32 add per element, which launchEmbed already is (ggml_add of get_rows, whisper.cpp:1560-1571)
+	WH_CHECK( launchEmbed( c->tokensDev, m->at<f16>( L.te ), m->at<float>( L.decPe ), e.dx, M, N, nPast, nullptr, d, hp.n_vocab, hp.n_text_ctx, st ) );
+	for( int il = 0; il < hp.n_text_layer; il++ )
+	{
+		const DecLayer& dl = L.dec[ il ];
+		WH_CHECK( launchExactNorm( e.dx, m->at<float>( dl.ln1w ), m->at<float>( dl.ln1b ), e.dcur, M, d, st ) );
+		WH_CHECK( mm( dl.wqkv, d, d, e.dcur, e.dq, dl.bqkv, true, false, nullptr ) );						// Qcur = scale( mul_mat + b )
+		WH_CHECK( mm( dl.wqkv + 2ll * d * d, d, d, e.dcur, e.dk, -1, true, false, nullptr ) );				// Kcur = scale( mul_mat )
+		WH_CHECK( mm( dl.wqkv + 4ll * d * d, d, d, e.dcur, e.dv, dl.bqkv + 8ll * d, false, false, nullptr ) );	// Vcur = mul_mat + b
+		f16* const sk = c->selfK + (int64_t)il * c->maxSeq * hp.n_text_ctx * d;
+		f16* const sv = c->selfV + (int64_t)il * c->maxSeq * hp.n_text_ctx * d;
+		WH_CHECK( launchExactPackHeads( e.dk, sk, batch, N, hp.n_text_ctx, nPast, H, st ) );
+		WH_CHECK( launchExactPackHeads( e.dv, sv, batch, N, hp.n_text_ctx, nPast, H, st ) );
+		WH_CHECK( launchExactDecAttention( e.dq, sk, sv, e.scores, e.dkqv, batch, N, nPast + N, H, hp.n_text_ctx, 1, nPast, true, c->parityThreads, e.expt, st ) );
+		WH_CHECK( mm( dl.wo, d, d, e.dkqv, e.dx, dl.bo, false, false, e.dx ) );
+		WH_CHECK( launchExactNorm( e.dx, m->at<float>( dl.lncw ), m->at<float>( dl.lncb ), e.dcur, M, d, st ) );
+		WH_CHECK( mm( dl.wcq, d, d, e.dcur, e.dq, dl.bcq, true, false, nullptr ) );
+		const int64_t crossOff = (int64_t)il * c->maxBatch * T * d;
+		WH_CHECK( launchExactDecAttention( e.dq, c->crossK + crossOff, c->crossV + crossOff, e.scores, e.dkqv, batch, N, T, H, T, c->hyp, 0, false, c->parityThreads, e.expt, st ) );
+		WH_CHECK( mm( dl.wco, d, d, e.dkqv, e.dx, dl.bco, false, false, e.dx ) );
+		WH_CHECK( launchExactNorm( e.dx, m->at<float>( dl.ln2w ), m->at<float>( dl.ln2b ), e.dcur, M, d, st ) );
+		WH_CHECK( mm( dl.w1, 4 * d, d, e.dcur, e.dh, dl.b1, false, true, nullptr ) );
+		WH_CHECK( mm( dl.w2, d, 4 * d, e.dh, e.dx, dl.b2, false, false, e.dx ) );
+	}
+	WH_CHECK( launchExactNorm( e.dx, m->at<float>( L.decLnW ), m->at<float>( L.decLnB ), e.dcur, M, d, st ) );
+	// logits of the last token of every sequence: row b of the product is row b * N + N - 1 of the normalised stream
+	WH_CHECK( launchExactMulMat( m->at<f16>( L.te ), hp.n_vocab, d, e.dcur + (int64_t)( N - 1 ) * d, (int64_t)N * d, batch, c->logits, hp.n_vocab, nullptr, 0.0f, false, nullptr,
+		nullptr, 0, st ) );
+	WH_CHECK( launchExactSoftMax( c->logits, c->probs, batch, hp.n_vocab, e.expt, st ) );
+	return 0;
+}
+
 static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t melLen, int64_t melStride, const int32_t* melOffsets, const wh_mel_window* wins )
 {
 	if( !c || ( !melDev && !wins ) || batch <= 0 || batch > c->maxBatch || ( !wins && melLen <= 0 ) ) { setError( "encode: bad argument" ); return WH_E_INVALIDARG; }
@@ -1493,6 +1676,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 	const int batchAll = batch;
 
 	if( batch > wh_context::PIN_WINDOWS ) { setError( "encode: batch too large" ); return WH_E_INVALIDARG; }
+	if( c->flags & WH_FLAG_PARITY_EXACT ) return encodeExact( c, melDev, batch, melLen, melStride, melOffsets, wins );
 	if( batch > c->encChunk && ( c->flags & WH_FLAG_DEBUG_CAPTURE ) ) { setError( "encode: the probe-point capture needs a batch of one encoder chunk" ); return WH_E_INVALIDARG; }
 	const bool gated = ( g_tuning & TUNE_ENC_SERIAL ) && batch >= ENC_SERIAL_MIN_WINDOWS && liveContexts( m ).load( std::memory_order_relaxed ) > 1;
 	if( gated )
@@ -1637,6 +1821,7 @@ static int encodeImpl( wh_context* c, const float* melDev, int batch, int64_t me
 // steps) takes the M <= 32 skinny or the tiled kernel.
 static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool devState )
 {
+	if( c->flags & WH_FLAG_PARITY_EXACT ) { setError( "WH_FLAG_PARITY_EXACT: host-stepped decoding only (wh_decode + wh_sample_best)" ); return WH_E_INVALIDARG; }
 	const wh_model* m = c->m;
 	const wh_hparams& hp = m->hp;
 	const Layout& L = m->L;
@@ -1957,9 +2142,14 @@ int wh_decode( wh_context* c, const int32_t* tokens, int batch, int nTokens, int
 	const int M = batch * nTokens;
 	WH_CHECK( checkTokens( hp, tokens, M, "decode" ) );
 	WH_HIP( hipMemcpyAsync( c->tokensDev, tokens, sizeof( int32_t ) * M, hipMemcpyHostToDevice, st ) );
+	if( c->flags & WH_FLAG_PARITY_EXACT )
+		WH_CHECK( decodeExact( c, batch, nTokens, nPast ) );
+	else
+	{
 	WH_CHECK( decodeGraph( c, batch, nTokens, nPast, false ) );
 	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab,
 		[ & ]() { return launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ); } ) );
+	}
 	c->lastBatch = batch;
 	if( logitsHost ) WH_HIP( hipMemcpyAsync( logitsHost, c->logits, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
 	if( probsHost ) WH_HIP( hipMemcpyAsync( probsHost, c->probs, sizeof( float ) * batch * hp.n_vocab, hipMemcpyDeviceToHost, st ) );
@@ -2640,6 +2830,29 @@ int wh_debug_read( wh_context* c, const char* what, int layer, int rows, float* 
 		std::vector<uint16_t> tmp( EXP_TABLE_ENTRIES );
 		WH_HIP( hipMemcpy( tmp.data(), c->m->at<f16>( c->m->L.expTab ), EXP_TABLE_ENTRIES * 2, hipMemcpyDeviceToHost ) );
 		for( int i = 0; i < EXP_TABLE_ENTRIES; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
+		return 0;
+	}
+	if( w == "exact-gelu-table" || w == "exact-exp-table" )
+	{
+		// WH_FLAG_PARITY_EXACT's copies of ggml_init's tables, all 65536 entries, as FP32 values
+		if( dstCapFloats < 65536 ) return WH_E_BOUNDS;
+		WH_CHECK( exactTables( c ) );
+		std::vector<uint16_t> tmp( 65536 );
+		WH_HIP( hipMemcpy( tmp.data(), w == "exact-gelu-table" ? c->ex.gelu : c->ex.expt, 65536 * 2, hipMemcpyDeviceToHost ) );
+		for( int i = 0; i < 65536; i++ ) dstHost[ i ] = f16BitsToF32( tmp[ (size_t)i ] );
+		return 0;
+	}
+	if( w.compare( 0, 6, "exact:" ) == 0 )
+	{
+		// a buffer of the exact-order encoder as the last wh_encode left it (first chunk of windows): x, cur, q, k, v, kqv [windows][n_ctx][d], h [..][4 d], conv1 [..][2 n_ctx][d]
+		const std::string n = w.substr( 6 );
+		const wh_context::Exact& e = c->ex;
+		const float* src = n == "x" ? e.x : n == "cur" ? e.cur : n == "q" ? e.q : n == "k" ? e.k : n == "v" ? e.v : n == "kqv" ? e.kqv : n == "h" ? e.h : n == "conv1" ? e.conv1 : nullptr;
+		if( !src ) { setError( "debug_read: no such exact-mode buffer (or the mode has not run)" ); return WH_E_NOT_READY; }
+		const int64_t count = (int64_t)std::min( batch, e.encWindows ) * c->T * d * ( n == "h" ? 4 : n == "conv1" ? 2 : 1 );
+		if( dstCapFloats < count ) return WH_E_BOUNDS;
+		WH_HIP( hipStreamSynchronize( c->stream ) );
+		WH_HIP( hipMemcpy( dstHost, src, (size_t)count * 4, hipMemcpyDeviceToHost ) );
 		return 0;
 	}
 	if( w == "logits" || w == "probs" )
