@@ -122,3 +122,75 @@ def test_exact_mode_at_the_medium_shape(ref_lib_available, tmp_path, n_threads):
         pytest.skip("oracle/_ref/libwhisper_ref.so not present")
     model = gf.synth_model("medium", seed=1)
     exact_against_the_reference("medium", model, tmp_path, n_threads, 1, (0,), 4, layers=(0, model.hparams.n_text_layer - 1))
+
+
+def _teacher_forced(ctx, mels, prompt, n_steps, enc_flags, dec_flags, tokens=None):
+    ctx.set_flags(*enc_flags)
+    ctx.encode(mels)
+    ctx.set_flags(*dec_flags)
+    out, fed = [], []
+    toks, n_past = prompt, 0
+    for st in range(n_steps + 1):
+        gl, _ = ctx.decode(toks, n_past)
+        out.append(gl.copy())
+        fed.append(toks.copy())
+        n_past += toks.shape[1]
+        toks = tokens[st + 1] if tokens is not None and st + 1 < len(tokens) else np.argmax(gl, axis=1).astype(np.int32).reshape(-1, 1)
+    ctx.set_flags(0, 1)
+    return np.stack(out), fed
+
+
+@pytest.mark.parametrize("kind,n_win,n_steps", [("medium", 4, 8), ("large-v2", 2, 4)])
+def test_timed_path_against_the_exact_mode(kind, n_win, n_steps):
+    """What north_star's "within 1e-3 on logits" can and cannot mean for the TIMED kernels, measured on the device at the shapes BASELINE names.
+
+    Four runs of one context on the same windows, teacher-forced with the timed path's greedy tokens (3-token prompt + n_steps):
+      T     the timed path (MFMA products, FP32 LayerNorm sums, FP32 P.V);
+      E16   the exact mode at 16 threads  == the reference at 16 threads, bit for bit (the tests above);
+      E0    the exact mode with the decoder's P.V rounded once per output: the value every thread count of the reference approximates;
+      E0alt E0 with ONE change: the weight products add ggml_vec_dot_f16's 32 chains left to right instead of in ggml's tree -- the smallest
+            re-ordering of the reference's own FP32 sums there is.
+    Measured (profiles/r06_evidence/split_*.txt): |E0alt - E0| = 4.8e-3 max / 7.9e-4 mean at medium, 5.8e-3 / 9.6e-4 at large-v2 -- FP32 sums
+    that differ in the last bit flip FP16 roundings of the activations (every product rounds its input to FP16, ggml.c:4588-4611), and 48 + 64
+    layers carry that to the logits. So NO implementation that does not sum in exactly ggml's order can stay within 1e-3 in the max norm; the
+    stated tolerance is meaningful in the MEAN (asserted below with the stated 1e-3 at the shape the metric is quoted on), and bit-exactly in
+    the exact mode (asserted above: 0). The timed path is held to that floor: max and mean |T - E0| within 1.5 x of |E0alt - E0| measured in
+    the same run, top-1 identical on every row, and T is no farther from the 16-thread reference than 2 x the reference's own distance to E0."""
+    import bench
+    model = gf.synth_model(kind, seed=1)
+    hp = model.hparams
+    sp = gf.special_tokens(hp)
+    m = binding.HipModel.from_ggml(model)
+    del model
+    ctx = binding.HipContext(m, n_win)
+    pcm_dev = torch.from_numpy(bench.synth_pcm(n_win, seed=100)).cuda()
+    mels = torch.stack([ctx.mel_spectrogram(pcm_dev[b]) for b in range(n_win)])
+    prompt = np.array([_prompt(sp)] * n_win, np.int32)
+    X = binding.WH_FLAG_PARITY_EXACT
+    T, fed = _teacher_forced(ctx, mels, prompt, n_steps, (0, 1), (0, 1))
+    E16, _ = _teacher_forced(ctx, mels, prompt, n_steps, (X, 16), (X, 16), fed)
+    E0, _ = _teacher_forced(ctx, mels, prompt, n_steps, (X, 0), (X, 0), fed)
+    binding.set_option("exact_alt_order", 1)
+    try:
+        E0alt, _ = _teacher_forced(ctx, mels, prompt, n_steps, (X, 0), (X, 0), fed)
+    finally:
+        binding.set_option("exact_alt_order", 0)
+    ctx.close()
+    m.close()
+
+    def dist(a, b):
+        d = np.abs(a - b)
+        return float(d.max()), float(d.mean())
+
+    floor_max, floor_mean = dist(E0alt, E0)
+    t_max, t_mean = dist(T, E0)
+    r_max, r_mean = dist(E16, E0)
+    t16_max, t16_mean = dist(T, E16)
+    print("%s: re-ordered reference vs E0 %.2e / %.2e; timed vs E0 %.2e / %.2e; reference(16 threads) vs E0 %.2e / %.2e; timed vs reference(16) %.2e / %.2e (max / mean)"
+          % (kind, floor_max, floor_mean, t_max, t_mean, r_max, r_mean, t16_max, t16_mean))
+    assert floor_max > 1e-3, "the re-ordered reference stays within 1e-3: then the timed path must, too -- tighten this test"
+    assert t_max <= 1.5 * floor_max and t_mean <= 1.5 * floor_mean
+    if kind == "medium":
+        assert t_mean <= 1e-3                      # north_star's tolerance, in the norm in which it can hold
+    assert t16_max <= 2.0 * r_max + floor_max and t16_mean <= 2.0 * r_mean
+    assert np.array_equal(T.argmax(-1), E0.argmax(-1)) and np.array_equal(T.argmax(-1), E16.argmax(-1))

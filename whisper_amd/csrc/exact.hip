@@ -25,7 +25,7 @@ namespace wh
 		constexpr int XT = 16, XLD = 40;	   // tile edge; LDS row stride in halves (80 bytes: 16-byte aligned, off the bank period)
 		__global__ void __launch_bounds__( 256 ) exMulMat( const f16* __restrict__ W, int N, int K, const float* __restrict__ X, long long ldx, int M,
 			float* __restrict__ out, long long ldo, const float* __restrict__ bias, float scale, int useScale, const f16* __restrict__ geluTab,
-			const float* __restrict__ residual, long long ldr )
+			const float* __restrict__ residual, long long ldr, int altOrder )
 		{
 			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 Ws[ XT ][ XLD ];
 			__shared__ __attribute__( ( aligned( 16 ) ) ) f16 Xs[ XT ][ XLD ];
@@ -50,7 +50,7 @@ namespace wh
 			}
 			const int n = n0 + tx, m = m0 + ty;
 			if( n >= N || m >= M ) return;
-			float v = acc.reduce();
+			float v = altOrder ? reduceLeftToRight( acc ) : acc.reduce();
 			if( bias ) v = bias[ n ] + v;
 			if( useScale ) v = v * scale;
 			if( geluTab ) v = whx::gelu16( (const h16*)geluTab, v );
@@ -288,6 +288,14 @@ namespace wh
 			const int i = blockIdx.x % N, h = blockIdx.x / N, s = blockIdx.y;
 			const float* p = P + ( ( (long long)s * H + h ) * N + i ) * nKeys;
 			const f16* vr = Vc + ( (long long)( s / hyp ) * H + h ) * rowCap * 64 + c;
+			if( nth <= 0 )
+			{
+				// not the reference's arithmetic: the sum the reference's FP16 accumulation approximates, rounded once (products of an FP16 and an FP32 value are exact in double)
+				double acc = 0.0;
+				for( int j = 0; j < nKeys; j++ ) acc += (double)(float)vr[ (long long)j * 64 ] * (double)p[ j ];
+				out[ ( (long long)s * N + i ) * ( H * 64 ) + h * 64 + c ] = (float)acc;
+				return;
+			}
 			const int dc = ( nKeys + nth - 1 ) / nth;
 			float total = 0.0f;
 			for( int ith = 0; ith < nth; ith++ )
@@ -307,7 +315,7 @@ namespace wh
 		if( ( K & 31 ) != 0 || N <= 0 || M <= 0 ) { setError( "exact mul_mat: K must be a multiple of 32" ); return WH_E_INVALIDARG; }
 		dim3 grid( ( N + XT - 1 ) / XT, ( M + XT - 1 ) / XT );
 		if( grid.y > 65535 ) { setError( "exact mul_mat: too many rows" ); return WH_E_INVALIDARG; }
-		hipLaunchKernelGGL( exMulMat, grid, dim3( 256 ), 0, stream, W, N, K, X, ldx, M, out, ldo, bias, scale, useScale ? 1 : 0, geluTab, residual, ldr );
+		hipLaunchKernelGGL( exMulMat, grid, dim3( 256 ), 0, stream, W, N, K, X, ldx, M, out, ldo, bias, scale, useScale ? 1 : 0, geluTab, residual, ldr, g_opt.exactAltOrder );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -361,7 +369,7 @@ namespace wh
 		if( H * N > 65535 || seqs > 65535 ) { setError( "exact decoder attention: too many rows" ); return WH_E_INVALIDARG; }
 		hipLaunchKernelGGL( exDecScores, dim3( ( nKeys + 63 ) / 64, H * N, seqs ), dim3( 64 ), 0, stream, Q, Kc, scores, N, nKeys, H, rowCap, hyp, nPast, masked ? 1 : 0 );
 		hipLaunchKernelGGL( exSoftMax, dim3( (unsigned)( (long long)seqs * H * N ) ), dim3( 256 ), 0, stream, scores, scores, nKeys, expTab );
-		hipLaunchKernelGGL( exDecPV, dim3( H * N, seqs ), dim3( 64 ), 0, stream, scores, Vc, out, N, nKeys, H, rowCap, hyp, nth < 1 ? 1 : nth );
+		hipLaunchKernelGGL( exDecPV, dim3( H * N, seqs ), dim3( 64 ), 0, stream, scores, Vc, out, N, nKeys, H, rowCap, hyp, nth );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

@@ -74,6 +74,16 @@ namespace whx
 		}
 	};
 
+	// NOT the reference's order: the same 32 chains added left to right. Exists to measure how far the smallest change of summation order moves the
+	// logits (tools/parity_split.py, "exact_alt_order"): the yardstick for any implementation that does not sum in ggml's order.
+	WH_HD float reduceLeftToRight( const Dot16& d )
+	{
+		float s = d.a[ 0 ];
+#pragma unroll
+		for( int i = 1; i < 32; i++ ) s = s + d.a[ i ];
+		return s;
+	}
+
 	// The whole of ggml_vec_dot_f16 for contiguous operands of any length (the leftovers in double, ggml.c:783-786).
 	WH_HD float dot16( const h16* x, const h16* y, int n )
 	{

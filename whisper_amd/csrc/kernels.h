@@ -68,6 +68,7 @@ namespace wh
 									 // when the separate attention was attentionDecG at 43 us)
 		int selfNq = 0;				 // "self_nq": sequences per selfBlockDec workgroup (0 = by grid size; 1, 2, 4, 8)
 		int exactEncLayers = -1;	 // "exact_enc_layers": WH_FLAG_PARITY_EXACT, debugging: encode only this many layers and stop (buffers readable as "exact:<name>"); -1 = all
+		int exactAltOrder = 0;		 // "exact_alt_order": WH_FLAG_PARITY_EXACT, measurement only: the weight products add their 32 chains left to right instead of in ggml's tree
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
 	};
 	extern Options g_opt;

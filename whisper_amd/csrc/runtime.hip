@@ -40,7 +40,7 @@ namespace wh
 	{
 		struct OptionName { const char* name; int Options::* field; };
 		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
-			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers } };
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
 		{
@@ -1315,7 +1315,9 @@ int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
 {
 	if( !c ) return WH_E_INVALIDARG;
 	c->flags = flags;
-	c->parityThreads = parityThreads > 0 ? parityThreads : 1;
+	// WH_FLAG_PARITY_EXACT with 0 threads: the decoder's P.V as ONE correctly rounded sum per output (double accumulation) instead of the reference's
+	// FP16 accumulation -- the thread-count-independent value every thread count of the reference approximates
+	c->parityThreads = parityThreads > 0 ? parityThreads : ( ( flags & WH_FLAG_PARITY_EXACT ) && parityThreads == 0 ? 0 : 1 );
 	return 0;
 }
 
