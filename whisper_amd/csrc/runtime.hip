@@ -3256,6 +3256,100 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 		}
 		(void)hipFree( counters ); (void)hipFree( buf ); (void)hipFree( err );
 	}
+	else if( kind == 4 )
+	{
+		// MFMA-bound product NEXT TO the HBM-bound cross-attention, measured directly: the encoder product of M x N x K (the production
+		// launch: persistent gemmTiled8) `iters` times on stream A, attentionDecG<1,...> over `variant` windows x 16 heads x 1500 keys on stream B as often as fills
+		// the same time; each alone, then together -- for the persistent grid limited to 256 / 224 / 192 / 160 / 128 CUs, without CU masks (the attention's
+		// workgroups land where LDS and registers are free) and with complementary CU masks on the two streams. Results on stderr; ms = the unmasked 256-CU pair.
+		const int wins = variant > 0 ? variant : 224, H = 16, T = 1500, d = H * HEAD_DIM;
+		void *A = nullptr, *W = nullptr, *out = nullptr, *kc = nullptr, *vc = nullptr, *q = nullptr, *ao = nullptr;
+		WH_HIP( hipMalloc( &A, (size_t)M * K * 2 ) );
+		WH_HIP( hipMalloc( &W, (size_t)N * K * 2 ) );
+		WH_HIP( hipMalloc( &out, (size_t)M * N * 4 ) );
+		const size_t kvBytes = (size_t)wins * H * T * HEAD_DIM * 2;
+		WH_HIP( hipMalloc( &kc, kvBytes ) );
+		WH_HIP( hipMalloc( &vc, kvBytes ) );
+		WH_HIP( hipMalloc( &q, (size_t)wins * d * 2 ) );
+		WH_HIP( hipMalloc( &ao, (size_t)wins * d * 2 ) );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)A, (long long)M * K, 1u );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)W, (long long)N * K, 2u );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)kc, (long long)( kvBytes / 2 ), 3u );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)vc, (long long)( kvBytes / 2 ), 4u );
+		hipLaunchKernelGGL( probeFill, dim3( 1024 ), dim3( 256 ), 0, st, (_Float16*)q, (long long)wins * d, 5u );
+		WH_HIP( hipStreamSynchronize( st ) );
+		GemmArgs g = plainGemm( (const f16*)A, (const f16*)W, M, N, K );
+		g.epi = EPI_F32; g.out32 = (float*)out;
+		DecAttnArgs a = {};
+		a.q = (const f16*)q; a.kc = (const f16*)kc; a.vc = (const f16*)vc; a.out = (f16*)ao;
+		a.batch = wins; a.H = H; a.nTok = 1; a.nKeys = T; a.keyStride = T; a.causal = 0; a.group = 1;
+		int cus = 0;
+		WH_HIP( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, c->m->device ) );
+		auto wall = []() { return std::chrono::duration<double, std::milli>( std::chrono::steady_clock::now().time_since_epoch() ).count(); };
+		auto timeIt = [ & ]( hipStream_t sa, hipStream_t sb, int nA, int nB, int cuLimit, double& msOut ) -> int
+		{
+			GemmArgs gl = g;
+			gl.cuLimit = cuLimit;
+			WH_HIP( hipDeviceSynchronize() );
+			const double t0 = wall();
+			// interleave the enqueues so that neither stream starts far ahead of the other
+			const int n = std::max( nA, nB );
+			for( int i = 0; i < n; i++ )
+			{
+				if( i < nA ) WH_CHECK( launchGemm( gl, sa ) );
+				if( i < nB ) WH_CHECK( launchAttentionDec( a, sb ) );
+			}
+			WH_HIP( hipDeviceSynchronize() );
+			msOut = wall() - t0;
+			return 0;
+		};
+		hipStream_t sa = nullptr, sb = nullptr;
+		WH_HIP( hipStreamCreateWithFlags( &sa, hipStreamNonBlocking ) );
+		WH_HIP( hipStreamCreateWithFlags( &sb, hipStreamNonBlocking ) );
+		double tA1 = 0, tB1 = 0, dummy = 0;
+		rc = timeIt( sa, sb, 3, 3, 0, dummy );	   // warm-up
+		if( rc == 0 ) rc = timeIt( sa, sb, iters, 0, 0, tA1 );
+		if( rc == 0 ) rc = timeIt( sa, sb, 0, iters, 0, tB1 );
+		const int nA = iters, nB = std::max( 1, (int)( iters * tA1 / std::max( tB1, 1e-6 ) + 0.5 ) );
+		double tA = 0, tB = 0;
+		if( rc == 0 ) rc = timeIt( sa, sb, nA, 0, 0, tA );
+		if( rc == 0 ) rc = timeIt( sa, sb, 0, nB, 0, tB );
+		if( rc == 0 )
+		{
+			fprintf( stderr, "[pair] product %d x %d x %d: %d launches %.2f ms alone (%.0f TFLOP/s); cross-attention %d windows: %d launches %.2f ms alone (%.2f TB/s)\n", M, N, K, nA, tA,
+				2.0 * M * N * K * nA / tA * 1e-9, wins, nB, tB, 2.0 * kvBytes * nB / tB * 1e-9 );
+			const int limits[] = { 0, 224, 192, 160, 128 };
+			for( int li = 0; li < 5 && rc == 0; li++ )
+			{
+				const int lim = limits[ li ];
+				double tAl = 0, tp = 0;
+				rc = timeIt( sa, sb, nA, 0, lim, tAl );
+				if( rc == 0 ) rc = timeIt( sa, sb, nA, nB, lim, tp );
+				if( rc == 0 ) fprintf( stderr, "[pair] no masks, product on %3d CUs: product alone %.2f ms, pair %.2f ms = %.3f of (A + B) = %.3f of (A at this limit + B)\n", lim ? lim : cus, tAl, tp,
+					tp / ( tA + tB ), tp / ( tAl + tB ) );
+				if( li == 0 ) ms = (float)tp * (float)iters;
+			}
+			// complementary CU masks: CU i of the mask belongs to XCD i % 8 (a multiple of 8 keeps the split even over the XCDs)
+			for( int li = 1; li < 5 && rc == 0; li++ )
+			{
+				const int lim = limits[ li ];
+				uint32_t mA[ 16 ] = {}, mB[ 16 ] = {};
+				const uint32_t words = (uint32_t)( ( cus + 31 ) / 32 );
+				for( int i = 0; i < cus && i < 512; i++ ) ( i < lim ? mA : mB )[ i >> 5 ] |= 1u << ( i & 31 );
+				hipStream_t ma = nullptr, mb = nullptr;
+				if( hipExtStreamCreateWithCUMask( &ma, words, mA ) != hipSuccess || hipExtStreamCreateWithCUMask( &mb, words, mB ) != hipSuccess ) { fprintf( stderr, "[pair] CU-masked streams unavailable\n" ); break; }
+				double tAl = 0, tBl = 0, tp = 0;
+				rc = timeIt( ma, mb, nA, 0, lim, tAl );
+				if( rc == 0 ) rc = timeIt( ma, mb, 0, nB, lim, tBl );
+				if( rc == 0 ) rc = timeIt( ma, mb, nA, nB, lim, tp );
+				if( rc == 0 ) fprintf( stderr, "[pair] masks %3d | %3d CUs: product alone %.2f ms, attention alone %.2f ms (%.2f TB/s), pair %.2f ms = %.3f of (A + B at 256 CUs)\n", lim, cus - lim, tAl, tBl,
+					2.0 * kvBytes * nB / tBl * 1e-9, tp, tp / ( tA + tB ) );
+				(void)hipStreamDestroy( ma ); (void)hipStreamDestroy( mb );
+			}
+		}
+		(void)hipStreamDestroy( sa ); (void)hipStreamDestroy( sb );
+		(void)hipFree( A ); (void)hipFree( W ); (void)hipFree( out ); (void)hipFree( kc ); (void)hipFree( vc ); (void)hipFree( q ); (void)hipFree( ao );
+	}
 	else
 		rc = WH_E_INVALIDARG;
 	(void)hipEventDestroy( e0 );
