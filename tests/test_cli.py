@@ -158,6 +158,13 @@ def test_mgpu_harness_ends_the_job_when_a_rank_dies_or_hangs(tmp_path):
     # under an external launcher every rank is its own process: the id file must be common (-id) or derivable (MASTER_PORT)
     r = subprocess.run(args, env=dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1 and b"-id" in r.stderr
+    # ... and the launch must be nameable: torchrun's default run id is the literal "none", the same for every launch on a port, so a rank could take
+    # the id file a crashed earlier launch left behind; without a per-launch id from the launcher the ranks insist on -job
+    ext = dict(os.environ, RANK="1", WORLD_SIZE="2", LOCAL_RANK="1", MASTER_PORT="29999", TORCHELASTIC_RUN_ID="none")
+    for k in ("SLURM_JOB_ID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE"):
+        ext.pop(k, None)
+    r = subprocess.run(args, env=ext, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b"-job" in r.stderr and b"per-launch id" in r.stderr
     syms = subprocess.run(["nm", "-D", "--defined-only", build.HIP_LIB], stdout=subprocess.PIPE, text=True).stdout
     for name in ("wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32"):
         assert (" T " + name) in syms, name

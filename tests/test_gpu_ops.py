@@ -172,15 +172,21 @@ def test_flash_attention(batch, heads, T):
     results = {}
     for name, mask in (("two-sweep", (binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP) & ~binding.TUNE_ATTN_ENC_TABLE),
                        ("table", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
+                       ("valu-exp", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
+                       ("wide", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
+                       ("wide-online", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
                        ("three-sweep", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_2SWEEP),
                        ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
         L.wh_debug_set_tuning(mask)
+        # attentionEncT<0> (the table in LDS) / <1> (v_exp_f32) / attentionEncW<false> (64 query rows per wave) / <true> (one sweep, lazily raised running maximum)
+        binding.set_option("enc_exp", {"valu-exp": 1, "wide": 2, "wide-online": 3}.get(name, 0))
         try:
             out = torch.full((batch, T, heads * D), float("nan"), dtype=torch.float16, device="cuda")
             binding.check(L.wh_op_flash_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), batch, heads, T))
             torch.cuda.synchronize()
         finally:
             L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+            binding.set_option("enc_exp", 1)
         got = out.cpu().numpy().astype(np.float32)
         assert np.isfinite(got).all()
         d = report("flash_attention %s b%d h%d T%d" % (name, batch, heads, T), got, wn.r16(want))
@@ -195,6 +201,19 @@ def test_flash_attention(batch, heads, T):
     dt = np.abs(results["table"] - results["two-sweep"]).max()
     print("table kernel vs exp16 kernel: %.4f of the outputs identical, max difference %.2e" % (same, dt))
     assert same > 0.9 and dt < 2e-3
+    # attentionEncT<1> (the timed path since round 6): the same sweeps with e = fp16( 2^( fp16( s - max ) * log2 e ) ) from v_exp_f32 instead of the table: the
+    # FP32 product and the instruction's last bit move e by one FP16 ulp in ~0.3 % of the entries; an output sums hundreds of them
+    same_v = float((results["valu-exp"] == results["table"]).mean())
+    dv = np.abs(results["valu-exp"] - results["table"])
+    print("VALU-exponential kernel vs table kernel: %.4f of the outputs identical, max difference %.2e, mean %.2e" % (same_v, dv.max(), dv.mean()))
+    assert dv.max() < 2e-3 and dv.mean() < 2e-5
+    # attentionEncW: the same two sweeps with two query groups per wave -- the same MFMAs on the same operands per query row, so it must equal attentionEncT<1> exactly;
+    # its one-sweep form rounds the exponentials' arguments against the RUNNING maximum: each e moves by an FP16 rounding, an output sums hundreds of them
+    assert np.array_equal(results["wide"], results["valu-exp"])
+    do = np.abs(results["wide-online"] - results["wide"])
+    print("one-sweep (lazy running maximum) vs two-sweep: max difference %.2e, mean %.2e; against the reference's softmax: max %.2e mean %.2e"
+          % (do.max(), do.mean(), np.abs(results["wide-online"] - wn.r16(want)).max(), np.abs(results["wide-online"] - wn.r16(want)).mean()))
+    assert do.max() < 4e-3 and do.mean() < 1e-4
 
 
 def test_exp_table_in_the_arena(golden):

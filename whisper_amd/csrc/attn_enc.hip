@@ -575,12 +575,20 @@ namespace wh
 		constexpr int T_TABLE_HALFS = EXP_TABLE_ENTRIES;
 		constexpr int T_LDS_BYTES = T_TABLE_HALFS * 2 + 4 * F_TILE * 2;
 
+		// MODE 0: the table lookup above (bit-exact e; the LDS pipe is its bound: 16 two-byte gathers per 32 x 32 sub-tile and wave, ~4100 cycles per sub-tile
+		//         and CU against ~1000 on the matrix cores -- round 5's 0.22 of the MFMA peak).
+		// MODE 1 (round 6, the timed path): e = fp16( 2^( fp32( fp16( s - max ) ) * log2 e ) ) on the VALU -- v_exp_f32 issues at ~5/3 of a plain VALU slot on
+		//         gfx950 (MI355X_MICROARCH.md), so a score costs ~4.2 slots and no LDS access: the sub-tile's exponentials (~1070 cycles per SIMD) balance its
+		//         8 MFMAs (1024). Same argument rounding as the reference (fp16( s - max ), ggml.c:6008); the FP32 product x * log2 e and v_exp_f32's last
+		//         bit move e across an FP16 rounding boundary in ~0.3 % of the entries (one FP16 ulp each) -- measured against the table kernel in
+		//         tests/test_gpu_ops.py::test_encoder_attention_valu_exp.
+		template<int MODE>
 		__global__ void __launch_bounds__( 1024, 4 ) attentionEncT( const f16* __restrict__ q, const f16* __restrict__ k,
 			const f16* __restrict__ vT, f16* __restrict__ out, const f16* __restrict__ expTab, int heads, int T, int Tpad, int nQ, int xcdRemap )
 		{
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemT[];
-			f16* const ldsTab = (f16*)smemT;				  // [EXP_TABLE_ENTRIES] at LDS offset 0
-			f16* const ldsK = ldsTab + T_TABLE_HALFS;		  // [2][128][64], chunk-swizzled rows
+			f16* const ldsTab = (f16*)smemT;				  // [EXP_TABLE_ENTRIES] at LDS offset 0 (MODE 0 only)
+			f16* const ldsK = ldsTab + ( MODE == 0 ? T_TABLE_HALFS : 0 );		  // [2][128][64], chunk-swizzled rows
 			f16* const ldsV = ldsK + 2 * F_TILE;			  // [2][8 key blocks][2 dd halves][64 lanes][8]
 			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
 			typedef const __attribute__( ( address_space( 1 ) ) ) void* GlobalPtr;
@@ -612,6 +620,7 @@ namespace wh
 			const int nTiles = ( T + FK - 1 ) / FK;
 
 			// the table: 40 pieces of 1 KiB, lane-linear; needed from the second sweep on, so it lands under the first
+			if constexpr( MODE == 0 )
 			for( int piece = wave; piece < T_TABLE_HALFS / 512; piece += 16 )
 				__builtin_amdgcn_global_load_lds( (GlobalPtr)( expTab + piece * 512 + lane * 8 ), (LdsPtr)( ldsTab + piece * 512 ), 16, 0, 0 );
 
@@ -654,6 +663,8 @@ namespace wh
 				}
 				if( t == nTiles - 1 )
 				{
+					// (peeling the last tile into its own instantiation, so that the other tiles carry no compares / selects, was measured in round 6: the second copy of
+					// the loop body costs 17 spilled VGPRs under the 128-register cap and the kernel 8 %: profiles/r06_evidence/enc_attn_ablation.txt)
 					int limit = T - ( t * FK + st * 32 + 4 * hi );
 					asm volatile( "" : "+v"( limit ) );
 	#pragma unroll
@@ -727,11 +738,24 @@ namespace wh
 						typedef _Float16 h2 __attribute__( ( ext_vector_type( 2 ) ) );
 						typedef unsigned short u16x2 __attribute__( ( ext_vector_type( 2 ) ) );
 						const h2 hd = { (f16)( S[ r ] - mx ), (f16)( S[ r + 1 ] - mx ) };	  // the reference's fp16( s - max ) (ggml.c:6008)
-						u16x2 mag = __builtin_bit_cast( u16x2, __builtin_bit_cast( unsigned, hd ) & 0x7FFF7FFFu );
-						const u16x2 lim = { (unsigned short)EXP_TABLE_LIMIT, (unsigned short)EXP_TABLE_LIMIT };
-						mag = __builtin_elementwise_min( mag, lim );
-						P[ r >> 3 ][ r & 7 ] = ldsTab[ mag[ 0 ] ];
-						P[ r >> 3 ][ ( r & 7 ) + 1 ] = ldsTab[ mag[ 1 ] ];
+						if constexpr( MODE == 0 )
+						{
+							u16x2 mag = __builtin_bit_cast( u16x2, __builtin_bit_cast( unsigned, hd ) & 0x7FFF7FFFu );
+							const u16x2 lim = { (unsigned short)EXP_TABLE_LIMIT, (unsigned short)EXP_TABLE_LIMIT };
+							mag = __builtin_elementwise_min( mag, lim );
+							P[ r >> 3 ][ r & 7 ] = ldsTab[ mag[ 0 ] ];
+							P[ r >> 3 ][ ( r & 7 ) + 1 ] = ldsTab[ mag[ 1 ] ];
+						}
+						else
+						{
+							typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
+							constexpr float L2E = 1.44269504088896340736f;
+							const h2 hp = __builtin_convertvector( f2{ S[ r ] - mx, S[ r + 1 ] - mx }, h2 );	   // one v_cvt_pk_f16_f32
+							const f2 e = { __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hp[ 0 ], L2E, 0.0f ) ), __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hp[ 1 ], L2E, 0.0f ) ) };	   // v_fma_mix_f32 + v_exp_f32
+							const h2 eh = __builtin_convertvector( e, h2 );
+							P[ r >> 3 ][ r & 7 ] = eh[ 0 ];
+							P[ r >> 3 ][ ( r & 7 ) + 1 ] = eh[ 1 ];
+						}
 					}
 					sum += (double)sumP( P );
 	#pragma unroll
@@ -770,17 +794,356 @@ namespace wh
 			}
 		}
 
+		// ---------------------------------------------------------------------------------------------------------------
+		// attentionEncW (round 6, the timed path): attentionEncT's layout -- a wave owns 32 x NG query rows and all keys, 512 rows per workgroup share the K / V
+		// tiles through LDS -- rebuilt around what the counters say binds it (profiles/r06_evidence/enc_attn_ablation.txt, enc_attn_pmc_mode2.json): the VALU.
+		// attentionEncT spends ~780 VALU instructions per 128-key tile and wave against 48 MFMAs (1536 matrix-pipe cycles): 3120 issue cycles x 4 waves per SIMD =
+		// twice the matrix time. Of those, 258 are the compare / select pairs that mask keys >= T -- needed in the LAST tile only, executed in every tile once the
+		// compiler turns `if( t == nTiles - 1 )` into selects --, ~64 zero the score accumulators, and the exponential's conversions are one instruction per element.
+		// Here:
+		//   * the last tile is its own instantiation of the tile body (std::true_type / false_type): no masking code in the other eleven;
+		//   * the first MFMA of a score tile takes the inline constant 0 as its C operand;
+		//   * per TWO scores: 2 x v_sub, ONE v_cvt_pk_f16_f32 (the reference's fp16( s - max ), ggml.c:6008), 2 x v_fma_mix_f32 (FP16 source x log2 e),
+		//     2 x v_exp_f32, ONE v_cvt_pk_f16_f32, one v_dot2c for the row sum: 4.5 VALU slots per score (attentionEncT<1>: ~7, the table kernel 4 + an LDS gather);
+		//   * e = fp16( 2^( fp32( fp16( s - max ) ) * log2 e ) ): the FP32 product and v_exp_f32's last bit move e across an FP16 rounding boundary in ~0.3 % of
+		//     the entries against the reference's table (one FP16 ulp each);
+		//   * a ring of W_NBUF K / V tiles with counted waits (the loads of tile t + W_NBUF - 1 go out while tile t is computed).
+		// NG = 1: 16 waves x 32 rows (4 waves per SIMD: the other waves' MFMAs cover a wave's exponentials and LDS latencies). NG = 2: 8 waves x 64 rows -- every
+		// K / V fragment read from LDS feeds two MFMAs (half the LDS traffic per FLOP), but at 2 waves per SIMD the exposed ds_read / MFMA latencies cost what that saves
+		// (measured equal, 1.87 vs 1.85 ms before the VALU diet); kept as an instantiation for the comparison.
+		// ONLINE: ONE sweep -- the running maximum m of a query row is raised only when a sub-tile exceeds it by more than W_LAZY (then O and the row sum are
+		// scaled by exp( m_old - m_new )), so the exponentials' arguments stay <= W_LAZY: e <= e^W_LAZY fits FP16 with the same relative precision, the FP32
+		// sums absorb the range, and the rescale is rare (the first sub-tiles of a row). That removes the max sweep: a third of the MFMAs and K-tile reads. It is NOT
+		// the reference's fp16( s - max ) argument any more (the argument is rounded against the running maximum): an FP16-rounding-sized change per e, held to
+		// account by tests/test_gpu_ops.py::test_flash_attention and the exact-mode bounds of tests/test_gpu_exact.py.
+		constexpr int W_NBUF = 4;
+		constexpr int W_LDS_BYTES = 2 * W_NBUF * F_TILE * 2;
+		constexpr float W_LAZY = 4.0f;
+		template<int NG, bool ONLINE>
+		__global__ void __launch_bounds__( 1024 / NG, NG == 1 ? 4 : 2 ) attentionEncW( const f16* __restrict__ q, const f16* __restrict__ k,
+			const f16* __restrict__ vT, f16* __restrict__ out, int heads, int T, int Tpad, int nQ, int xcdRemap )
+		{
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemW[];
+			f16* const ldsK = (f16*)smemW;				  // [W_NBUF][128][64], chunk-swizzled rows
+			f16* const ldsV = ldsK + W_NBUF * F_TILE;	  // [W_NBUF][8 key blocks][2 dd halves][64 lanes][8]
+			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+			typedef const __attribute__( ( address_space( 1 ) ) ) void* GlobalPtr;
+			typedef _Float16 h2 __attribute__( ( ext_vector_type( 2 ) ) );
+			typedef float f2 __attribute__( ( ext_vector_type( 2 ) ) );
+			constexpr float L2E = 1.44269504088896340736f;
+
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = tid >> 6;
+			const int hi = lane >> 5;
+			const int c = lane & 31;
+			int bh, qb;
+			{
+				const int L = blockIdx.x;
+				if( xcdRemap )
+				{
+					const int kIdx = L >> 3;
+					bh = ( L & 7 ) + 8 * ( kIdx / nQ );
+					qb = kIdx % nQ;
+				}
+				else
+				{
+					bh = L / nQ;
+					qb = L - bh * nQ;
+				}
+			}
+			const f16* const Q = q + (long long)bh * T * HEAD_DIM;
+			const f16* const K = k + (long long)bh * T * HEAD_DIM;
+			const f16* const VT = vT + (long long)bh * HEAD_DIM * Tpad;
+			const int nTiles = ( T + FK - 1 ) / FK;
+			int qRow[ NG ];
+			f16x8 qf[ NG ][ 4 ];
+	#pragma unroll
+			for( int g = 0; g < NG; g++ )
+			{
+				qRow[ g ] = qb * TQ + ( wave * NG + g ) * 32 + c;
+				const int qr = qRow[ g ] < T ? qRow[ g ] : T - 1;
+	#pragma unroll
+				for( int kk = 0; kk < 4; kk++ )
+				{
+					qf[ g ][ kk ] = *(const f16x8*)( Q + (long long)qr * HEAD_DIM + kk * 16 + hi * 8 );
+	#pragma unroll
+					for( int j = 0; j < 8; j++ ) qf[ g ][ kk ][ j ] = qf[ g ][ kk ][ j ] * (f16)0.125f;
+				}
+			}
+			// a tile = 16 pieces of 1 KiB; a wave issues NG of them per operand
+			auto issueK = [ & ]( int t, int buf )
+			{
+	#pragma unroll
+				for( int i = 0; i < NG; i++ )
+				{
+					const int row = ( wave * NG + i ) * 8 + ( lane >> 3 );
+					const int cl = ( lane & 7 ) ^ ( ( row >> 1 ) & 7 );
+					int key = t * FK + row;
+					key = key < T ? key : T - 1;
+					__builtin_amdgcn_global_load_lds( (GlobalPtr)( K + (long long)key * HEAD_DIM + cl * 8 ),
+						(LdsPtr)( ldsK + buf * F_TILE + ( wave * NG + i ) * 512 ), 16, 0, 0 );
+				}
+			};
+			auto issueV = [ & ]( int t, int buf )
+			{
+	#pragma unroll
+				for( int i = 0; i < NG; i++ )
+					__builtin_amdgcn_global_load_lds( (GlobalPtr)( VT + (long long)t * F_TILE + ( wave * NG + i ) * 512 + lane * 8 ),
+						(LdsPtr)( ldsV + buf * F_TILE + ( wave * NG + i ) * 512 ), 16, 0, 0 );
+			};
+			// tile t has landed when at most the loads of the younger tiles (`per` instructions each) are outstanding; vmcnt takes an immediate
+			auto waitTile = [ & ]( int t, auto per )
+			{
+				constexpr int P = decltype( per )::value;	   // load instructions per tile and wave
+				const int younger = min( W_NBUF - 2, nTiles - 1 - t );
+				if( younger >= 2 )
+				{
+					if constexpr( P == 2 ) asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+					else asm volatile( "s_waitcnt vmcnt(8)" ::: "memory" );
+				}
+				else if( younger == 1 )
+				{
+					if constexpr( P == 2 ) asm volatile( "s_waitcnt vmcnt(2)" ::: "memory" );
+					else asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+				}
+				else asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+			};
+			static_assert( W_NBUF == 4 && NG == 2, "waitTile counts two younger tiles of 2 or 4 load instructions" );
+			const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+			// S^T of one 32-key sub-tile for the wave's query groups from ONE set of K fragments
+			auto scores = [ & ]( const f16* kt, int st, int t, auto last, f32x16 ( &S )[ NG ] )
+			{
+				const int row = st * 32 + c;
+				const int sw = ( row >> 1 ) & 7;
+	#pragma unroll
+				for( int kk = 0; kk < 4; kk++ )
+				{
+					const f16x8 kf = *(const f16x8*)( kt + row * HEAD_DIM + ( ( ( kk * 2 + hi ) ^ sw ) << 3 ) );
+	#pragma unroll
+					for( int g = 0; g < NG; g++ ) S[ g ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( kf, qf[ g ][ kk ], kk == 0 ? zero16 : S[ g ], 0, 0, 0 );
+				}
+				if constexpr( decltype( last )::value )
+				{
+					const int limit = T - ( t * FK + st * 32 + 4 * hi );
+	#pragma unroll
+					for( int r = 0; r < 16; r++ )
+					{
+						const bool in = ( r & 3 ) + 8 * ( r >> 2 ) < limit;
+	#pragma unroll
+						for( int g = 0; g < NG; g++ ) S[ g ][ r ] = in ? S[ g ][ r ] : -3.0e38f;	  // fp16( -3e38 - max ) = -inf -> e = 0
+					}
+				}
+			};
+			auto sumP = [ & ]( const f16x8 ( &P )[ 2 ] ) -> float
+			{
+				const h2 ones = { (f16)1.0f, (f16)1.0f };
+				float part = 0.0f;
+	#pragma unroll
+				for( int h = 0; h < 2; h++ )
+	#pragma unroll
+					for( int j = 0; j < 8; j += 2 )
+						part = __builtin_amdgcn_fdot2( h2{ P[ h ][ j ], P[ h ][ j + 1 ] }, ones, part, false );
+				return part;
+			};
+			auto expTile = [ & ]( const f32x16& S, float mref, f16x8 ( &P )[ 2 ] )
+			{
+	#pragma unroll
+				for( int r = 0; r < 16; r += 2 )
+				{
+					const h2 hd = __builtin_convertvector( f2{ S[ r ] - mref, S[ r + 1 ] - mref }, h2 );
+					const f2 e = { __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hd[ 0 ], L2E, 0.0f ) ), __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hd[ 1 ], L2E, 0.0f ) ) };
+					const h2 eh = __builtin_convertvector( e, h2 );
+					P[ r >> 3 ][ r & 7 ] = eh[ 0 ];
+					P[ r >> 3 ][ ( r & 7 ) + 1 ] = eh[ 1 ];
+				}
+			};
+
+			float mx[ NG ];
+	#pragma unroll
+			for( int g = 0; g < NG; g++ ) mx[ g ] = -INFINITY;
+			if constexpr( !ONLINE )
+			{
+				// ---- sweep 1: row maxima ----
+	#pragma unroll
+				for( int i = 0; i < W_NBUF - 1; i++ )
+					if( i < nTiles ) issueK( i, i );
+				for( int t = 0; t < nTiles; t++ )
+				{
+					waitTile( t, std::integral_constant<int, NG>{} );
+					__syncthreads();	   // tile t visible to every wave; every wave is done with tile t - 1, whose buffer the next issue overwrites
+					if( t + W_NBUF - 1 < nTiles ) issueK( t + W_NBUF - 1, ( t + W_NBUF - 1 ) % W_NBUF );
+					const f16* const kt = ldsK + ( t % W_NBUF ) * F_TILE;
+					auto body = [ & ]( auto last )
+					{
+	#pragma unroll
+						for( int st = 0; st < 4; st++ )
+						{
+							f32x16 S[ NG ];
+							scores( kt, st, t, last, S );
+	#pragma unroll
+							for( int g = 0; g < NG; g++ )
+	#pragma unroll
+								for( int r = 0; r < 16; r++ ) mx[ g ] = fmaxf( mx[ g ], S[ g ][ r ] );
+						}
+					};
+					if( t == nTiles - 1 ) body( std::true_type{} ); else body( std::false_type{} );
+				}
+	#pragma unroll
+				for( int g = 0; g < NG; g++ ) mx[ g ] = fmaxf( mx[ g ], __shfl_xor( mx[ g ], 32, 64 ) );
+				__syncthreads();
+			}
+
+			// ---- the e / P.V sweep ----
+			double sum[ NG ];
+			float sumF[ NG ];
+			f32x16 O[ NG ][ 2 ];
+	#pragma unroll
+			for( int g = 0; g < NG; g++ )
+			{
+				sum[ g ] = 0.0;
+				sumF[ g ] = 0.0f;
+	#pragma unroll
+				for( int a = 0; a < 2; a++ )
+	#pragma unroll
+					for( int r = 0; r < 16; r++ ) O[ g ][ a ][ r ] = 0.0f;
+			}
+	#pragma unroll
+			for( int i = 0; i < W_NBUF - 1; i++ )
+				if( i < nTiles ) { issueK( i, i ); issueV( i, i ); }
+			for( int t = 0; t < nTiles; t++ )
+			{
+				waitTile( t, std::integral_constant<int, 2 * NG>{} );
+				__syncthreads();
+				if( t + W_NBUF - 1 < nTiles )
+				{
+					issueK( t + W_NBUF - 1, ( t + W_NBUF - 1 ) % W_NBUF );
+					issueV( t + W_NBUF - 1, ( t + W_NBUF - 1 ) % W_NBUF );
+				}
+				const f16* const kt = ldsK + ( t % W_NBUF ) * F_TILE;
+				const f16* const vt = ldsV + ( t % W_NBUF ) * F_TILE;
+				auto body = [ & ]( auto last )
+				{
+	#pragma unroll
+					for( int st = 0; st < 4; st++ )
+					{
+						f32x16 S[ NG ];
+						scores( kt, st, t, last, S );
+						if constexpr( ONLINE )
+						{
+							float tm[ NG ];
+							bool raise = false;
+	#pragma unroll
+							for( int g = 0; g < NG; g++ )
+							{
+								tm[ g ] = S[ g ][ 0 ];
+	#pragma unroll
+								for( int r = 1; r < 16; r++ ) tm[ g ] = fmaxf( tm[ g ], S[ g ][ r ] );
+								tm[ g ] = fmaxf( tm[ g ], __shfl_xor( tm[ g ], 32, 64 ) );
+								raise = raise || tm[ g ] > mx[ g ] + W_LAZY;
+							}
+							if( __any( raise ) )
+							{
+	#pragma unroll
+								for( int g = 0; g < NG; g++ )
+								{
+									const float mNew = tm[ g ] > mx[ g ] + W_LAZY ? tm[ g ] : mx[ g ];
+									const float f = __builtin_amdgcn_exp2f( ( mx[ g ] - mNew ) * L2E );	   // 1 where the maximum stays; 0 on the first sub-tile (m = -inf)
+									mx[ g ] = mNew;
+									sumF[ g ] *= f;
+	#pragma unroll
+									for( int a = 0; a < 2; a++ )
+	#pragma unroll
+										for( int r = 0; r < 16; r++ ) O[ g ][ a ][ r ] *= f;
+								}
+							}
+						}
+						f16x8 P[ NG ][ 2 ];
+	#pragma unroll
+						for( int g = 0; g < NG; g++ )
+						{
+							expTile( S[ g ], mx[ g ], P[ g ] );
+							if constexpr( ONLINE ) sumF[ g ] += sumP( P[ g ] );
+							else sum[ g ] += (double)sumP( P[ g ] );
+						}
+	#pragma unroll
+						for( int half = 0; half < 2; half++ )
+						{
+							const int kb = st * 2 + half;
+	#pragma unroll
+							for( int ddt = 0; ddt < 2; ddt++ )
+							{
+								const f16x8 vf = *(const f16x8*)( vt + ( ( kb * 2 + ddt ) * 64 + lane ) * 8 );
+	#pragma unroll
+								for( int g = 0; g < NG; g++ ) O[ g ][ ddt ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( vf, P[ g ][ half ], O[ g ][ ddt ], 0, 0, 0 );
+							}
+						}
+					}
+				};
+				if( t == nTiles - 1 ) body( std::true_type{} ); else body( std::false_type{} );
+			}
+	#pragma unroll
+			for( int g = 0; g < NG; g++ )
+			{
+				if constexpr( ONLINE ) sum[ g ] = (double)sumF[ g ];
+				sum[ g ] += __shfl_xor( sum[ g ], 32, 64 );
+				const float invSum = (float)( 1.0 / sum[ g ] );
+				if( qRow[ g ] < T )
+				{
+					const int b = bh / heads, h = bh - b * heads;
+					f16* const o = out + ( (long long)b * T + qRow[ g ] ) * ( heads * HEAD_DIM ) + h * HEAD_DIM;
+	#pragma unroll
+					for( int ddt = 0; ddt < 2; ddt++ )
+	#pragma unroll
+						for( int g4 = 0; g4 < 4; g4++ )
+						{
+							f16x4 pk;
+	#pragma unroll
+							for( int e = 0; e < 4; e++ ) pk[ e ] = (f16)( O[ g ][ ddt ][ 4 * g4 + e ] * invSum );
+							*(f16x4*)( o + ddt * 32 + 8 * g4 + 4 * hi ) = pk;
+						}
+				}
+			}
+		}
+
+		template<int NG, bool ONLINE>
+		int launchEncWideT( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
+		{
+			static PerDeviceOnce once;
+			if( const int onceDev = once.needed(); onceDev >= 0 )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncW<NG, ONLINE>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES ) );
+				once.mark( onceDev );
+			}
+			const int nQ = ( T + TQ - 1 ) / TQ, BH = batch * heads;
+			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
+			hipLaunchKernelGGL( ( attentionEncW<NG, ONLINE> ), dim3( nQ * BH ), dim3( 1024 / NG ), W_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+		// mode (the "enc_exp" option): 2 = two sweeps, 3 = one sweep
+		int launchEncWide( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, int mode, hipStream_t stream )
+		{
+			if( mode == 3 ) return launchEncWideT<2, true>( q, k, vT, out, batch, heads, T, Tpad, stream );
+			return launchEncWideT<2, false>( q, k, vT, out, batch, heads, T, Tpad, stream );
+		}
+
 		int launchEncTable( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, const f16* expTab, hipStream_t stream )
 		{
 			static PerDeviceOnce once;
 			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncT, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncT<0>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncT<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES - T_TABLE_HALFS * 2 ) );
 				once.mark( onceDev );
 			}
 			const int nQ = ( T + TQ - 1 ) / TQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
-			hipLaunchKernelGGL( attentionEncT, dim3( nQ * BH ), dim3( 1024 ), T_LDS_BYTES, stream, q, k, vT, out, expTab, heads, T, Tpad, nQ, xcdRemap );
+			if( g_opt.encExp == 2 || g_opt.encExp == 3 ) return launchEncWide( q, k, vT, out, batch, heads, T, Tpad, g_opt.encExp, stream );
+			if( g_opt.encExp == 1 )
+				hipLaunchKernelGGL( attentionEncT<1>, dim3( nQ * BH ), dim3( 1024 ), T_LDS_BYTES - T_TABLE_HALFS * 2, stream, q, k, vT, out, expTab, heads, T, Tpad, nQ, xcdRemap );
+			else
+			hipLaunchKernelGGL( attentionEncT<0>, dim3( nQ * BH ), dim3( 1024 ), T_LDS_BYTES, stream, q, k, vT, out, expTab, heads, T, Tpad, nQ, xcdRemap );
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}

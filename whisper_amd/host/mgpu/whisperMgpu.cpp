@@ -145,6 +145,10 @@ namespace
 		wh_comm_info( comm, &seenRank, &seenWorld );
 		fprintf( stderr, "[rank %d/%d] device %d of %d, communicator up after %.2f s (RCCL: rank %d of %d)\n", rank, world, device, nDev, since(), seenRank, seenWorld );
 		if( seenRank != rank || seenWorld != world ) return 3;
+		// Every rank holds the communicator, so every rank has read the id: rank 0 removes the file NOW, under an external launcher too (forked mode's
+		// parent removes it again at exit) -- a launch that follows on the same port finds no id of this job, whatever its token looks like.
+		if( 0 != wh_comm_barrier( comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 3; }
+		if( rank == 0 ) unlink( a.idFile.c_str() );
 
 		// ---- model: rank 0 reads, everyone receives (a root that cannot read says so before the broadcast: loadModelShared) ----
 		const std::wstring adapter = std::to_wstring( device ) + L":";
@@ -343,6 +347,17 @@ int main( int argc, char** argv )
 			// what every rank of ONE launch shares and two launches do not: the launcher's run / job id where it exports one, plus the rendezvous port
 			for( const char* name : { "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "SLURM_STEP_ID", "OMPI_MCA_ess_base_jobid", "PMIX_NAMESPACE", "MASTER_ADDR", "MASTER_PORT" } )
 				if( const char* v = getenv( name ) ) { a.job += v; a.job += '/'; }
+			// A launcher that exports no per-launch id (torchrun's TORCHELASTIC_RUN_ID is the literal "none" unless --rdzv-id is given; plain mpirun exports
+			// nothing of the kind) gives two launches on one port the SAME token: a rank of the second launch that starts before its rank 0 would then take the id
+			// a crashed first launch left behind and block in ncclCommInitRank until -timeout. Such a job must name itself.
+			const char* torchId = getenv( "TORCHELASTIC_RUN_ID" );
+			const bool perLaunch = ( torchId && strcmp( torchId, "none" ) != 0 && *torchId ) || getenv( "SLURM_JOB_ID" ) || getenv( "OMPI_MCA_ess_base_jobid" ) || getenv( "PMIX_NAMESPACE" );
+			if( !perLaunch && world > 1 )
+			{
+				fprintf( stderr, "whisper-mgpu: the launcher exports no per-launch id (TORCHELASTIC_RUN_ID is unset or 'none', no SLURM / PMIx job id): give every rank "
+					"the same -job <token> that no other launch uses (e.g. -job \"$(date +%%s)-$$\" set once before the launcher), or torchrun --rdzv-id <token>\n" );
+				return 1;
+			}
 			if( a.job.empty() ) a.job = "external";
 		}
 		return runRank( a, atoi( wr ), world, local );
