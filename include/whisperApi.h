@@ -190,7 +190,7 @@ namespace Whisper
 		int max_tokens;		// max tokens per segment, 0 = no limit
 		struct { int n_past; } greedy;
 		struct { int n_past, beam_width, n_best; } beam_search;
-		int audio_ctx;		// overwrite the audio context size, 0 = default (not supported by this build when non-zero)
+		int audio_ctx;		// overwrite the audio context size, 0 = default: the encoder takes 2 * audio_ctx frames per window, the decoder attends to audio_ctx keys
 		const whisper_token* prompt_tokens;
 		int prompt_n_tokens;
 		pfnNewSegment new_segment_callback;

@@ -28,6 +28,9 @@ int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t nSamples, const
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx /* < 0 keeps the default 16384 */ );
 /* The same with eSamplingStrategy::BeamSearch and beam_search.beam_width = beamWidth (1 .. 8; the reference declares the strategy,
  * Whisper/API/sFullParams.h:10-13, and implements only Greedy): beamWidth hypotheses per window share one pass over its cross-attention K/V. */
+/* whisperc_run_full + sFullParams::audio_ctx (encoder positions / cross-attention keys per window; 0 = the model's) */
+int32_t whisperc_run_full_audio_ctx( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, int audioCtx );
 int32_t whisperc_run_full_beam( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
 	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, int beamWidth );
 /* iMediaFoundation::loadAudioFileData( WAV bytes: 16 kHz, mono/stereo, PCM16/float32 ) + iContext::runStreamed( params,

@@ -150,6 +150,11 @@ WH_API void wh_context_destroy( wh_context* c );
  * wh_buffer_free, which take no context. */
 WH_API int wh_context_bind( wh_context* c );
 WH_API int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads );
+/* sFullParams::audio_ctx (Whisper/API/sFullParams.h; ContextImpl.cpp:24, 55, 488-489 = whisper.cpp's exp_n_audio_ctx): the encoder runs on the first
+ * `audioCtx` positions of a window -- 2 * audioCtx spectrogram frames from its offset, the first audioCtx rows of the positional embedding -- and the
+ * decoder's cross-attention sees that many keys. 0 = the model's n_audio_ctx. Voids the context's encoder output and captured graphs; call it between
+ * windows, not between wh_encode and the decode steps that belong to it. */
+WH_API int wh_context_set_audio_ctx( wh_context* c, int audioCtx );
 /* Blocks until everything queued on the context's stream has finished. When `stream` was NULL at creation the context
  * owns a non-blocking stream (the legacy null stream cannot be captured into a hipGraph), so callers that produce
  * inputs or consume device outputs on another stream must order the two themselves; this is the simple way. */

@@ -40,6 +40,8 @@ def lib():
         L.ref_set_mel_any.argtypes = [C.c_void_p, _f32p, C.c_int, C.c_int]
         L.ref_get_mel.argtypes = [C.c_void_p, _f32p]
         L.ref_encode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_set_audio_ctx.argtypes = [C.c_void_p, C.c_int]
+        L.ref_set_audio_ctx.restype = None
         L.ref_decode.argtypes = [C.c_void_p, _i32p, C.c_int, C.c_int, C.c_int]
         L.ref_logits_size.restype = C.c_size_t
         L.ref_logits_size.argtypes = [C.c_void_p]
@@ -140,6 +142,10 @@ class RefWhisper:
     def encode(self, mel_offset: int = 0):
         rc = self.L.ref_encode(self.ctx, mel_offset, self.n_threads)
         assert rc == 0
+
+    def set_audio_ctx(self, n: int):
+        """whisper_context::exp_n_audio_ctx (what whisper_full sets from params.audio_ctx, whisper.cpp:2800): encoder positions / cross-attention keys; 0 = the model's."""
+        self.L.ref_set_audio_ctx(self.ctx, int(n))
 
     def cross_kv(self, layer: int):
         k = np.zeros((self.n_audio_ctx, self.n_audio_state), np.float32)

@@ -101,6 +101,9 @@ void fake_device_counters( int64_t* out6 )
 const char* wh_last_error( void ) { return "fake device"; }
 void wh_model_destroy( wh_model* m ) { delete m; }
 
+// the double decodes with the reference CPU model at the model's own n_audio_ctx: an override is refused (the device-side override has its own GPU test)
+int wh_context_set_audio_ctx( wh_context* c, int audioCtx ) { return !c ? WH_E_INVALIDARG : ( audioCtx == 0 ? 0 : WH_E_INVALIDARG ); }
+
 int wh_context_create( wh_model* m, int maxBatch, void*, wh_context** out )
 {
 	if( !m || maxBatch <= 0 || !out ) return WH_E_INVALIDARG;

@@ -194,3 +194,56 @@ def test_timed_path_against_the_exact_mode(kind, n_win, n_steps):
         assert t_mean <= 1e-3                      # north_star's tolerance, in the norm in which it can hold
     assert t16_max <= 2.0 * r_max + floor_max and t16_mean <= 2.0 * r_mean
     assert np.array_equal(T.argmax(-1), E0.argmax(-1)) and np.array_equal(T.argmax(-1), E16.argmax(-1))
+
+
+def test_audio_ctx_override(ref_lib_available, tmp_path):
+    """sFullParams::audio_ctx (Whisper/Whisper/ContextImpl.cpp:24, 55, 488-489 == whisper.cpp's exp_n_audio_ctx): the encoder runs on the first audio_ctx
+    positions of a window, the decoder's cross-attention sees that many keys. wh_context_set_audio_ctx against the reference with the same override:
+    the exact mode bit for bit (cross-attention cache of layer 0 -- the reference packs the layers at the overridden stride --, logits, probabilities), the timed
+    path within the bounds of the d = 128 tests; then back to the full context on the same device context: identical to a fresh one (nothing of the short
+    window survives in the padding rows the convolutions and the V operand rely on)."""
+    if not ref_lib_available:
+        pytest.skip("oracle/_ref/libwhisper_ref.so not present")
+    from oracle import ref
+    import bench
+    model = gf.synth_model("test-d128", seed=1234, attn_sharpness=2.0)
+    hp = model.hparams
+    sp = gf.special_tokens(hp)
+    path = str(tmp_path / "m.bin")
+    gf.write_model(path, model)
+    m = binding.HipModel.from_ggml(model)
+    ctx = binding.HipContext(m, 2)
+    pcm_dev = torch.from_numpy(bench.synth_pcm(2, seed=100)).cuda()
+    mels = torch.stack([ctx.mel_spectrogram(pcm_dev[b]) for b in range(2)])
+    toks = np.array([_prompt(sp)] * 2, np.int32)
+    ctx.encode(mels)
+    full_logits, _ = ctx.decode(toks, 0)
+    for n_ctx in (700, 1):
+        w = ref.RefWhisper(path, n_threads=2, log_level=0)
+        w.set_mel_any(mels[1].cpu().numpy())
+        w.set_audio_ctx(n_ctx)
+        w.encode(0)
+        rk, rv = w.cross_kv(0)
+        rl, rp = w.decode([int(t) for t in toks[1]], 0)
+        w.close()
+        ctx.set_audio_ctx(n_ctx)
+        ctx.set_flags(binding.WH_FLAG_PARITY_EXACT, 2)
+        ctx.encode(mels)
+        gk, gv = ctx.debug_read("cross-k", 0), ctx.debug_read("cross-v", 0)
+        gl, gp = ctx.decode(toks, 0)
+        n = n_ctx * hp.n_audio_state             # the device returns [windows][audio_ctx][d] packed at the front of the (full-size) host array
+        assert _bits_equal(gk.reshape(-1)[n:2 * n], rk.reshape(-1)[:n]), "cross-K differs at audio_ctx %d" % n_ctx
+        assert _bits_equal(gv.reshape(-1)[n:2 * n], rv.reshape(-1)[:n])
+        assert _bits_equal(gl[1], rl[-1]) and _bits_equal(gp[1], rp[-1]), "logits differ at audio_ctx %d: max %g" % (n_ctx, np.abs(gl[1] - rl[-1]).max())
+        ctx.set_flags(0, 1)
+        ctx.encode(mels)
+        tl, _ = ctx.decode(toks, 0)
+        d = np.abs(tl[1] - rl[-1])
+        print("audio_ctx %d: exact mode identical; timed path vs the reference (2 threads): max %.2e mean %.2e" % (n_ctx, d.max(), d.mean()))
+        assert d.max() < 0.25 and d.mean() < 4e-2 and int(np.argmax(tl[1])) == int(np.argmax(rl[-1]))
+    ctx.set_audio_ctx(0)
+    ctx.encode(mels)
+    again, _ = ctx.decode(toks, 0)
+    assert np.array_equal(again, full_logits)
+    ctx.close()
+    m.close()

@@ -48,6 +48,7 @@ def lib():
         L.whisperc_is_multilingual.argtypes = [vp]
         L.whisperc_tokenize.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.c_int]
         L.whisperc_run_full.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int]
+        L.whisperc_run_full_audio_ctx.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int, C.c_int]
         L.whisperc_run_full_beam.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, vp, C.c_int, C.c_int, C.c_int]
         L.whisperc_result_counts.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.whisperc_result_segment.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
@@ -148,11 +149,14 @@ class Context:
 
     def run_full(self, pcm: np.ndarray, language: str = "en", flags: int = 0, max_tokens: int = 0,
                  prompt: Optional[Sequence[int]] = None, n_max_text_ctx: int = -1, max_len: int = 0, thold_pt: float = 0.01,
-                 thold_ptsum: float = 0.01, beam_width: int = 0) -> int:
+                 thold_ptsum: float = 0.01, beam_width: int = 0, audio_ctx: int = 0) -> int:
         """runFull on mono float32 16 kHz PCM. Returns the HRESULT (0 = S_OK, 1 = S_FALSE: less than 1 s of audio).
         With TOKEN_TIMESTAMPS in flags the tokens of results() carry t0 / t1 / vlen and max_len > 0 wraps the segments."""
         pcm = np.ascontiguousarray(pcm, np.float32)
         pt = np.ascontiguousarray(prompt if prompt is not None else [], np.int32)
+        if audio_ctx:               # sFullParams::audio_ctx (ContextImpl.cpp:488-489)
+            return _check(lib().whisperc_run_full_audio_ctx(self.h, pcm.ctypes.data_as(C.c_void_p), len(pcm), language.encode(), flags, max_tokens,
+                                                            pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx, audio_ctx), "runFull")
         if beam_width > 0:          # eSamplingStrategy::BeamSearch with this beam_width (extension: the reference only declares it)
             return _check(lib().whisperc_run_full_beam(self.h, pcm.ctypes.data_as(C.c_void_p), len(pcm), language.encode(), flags, max_tokens,
                                                        pt.ctypes.data_as(C.c_void_p) if len(pt) else None, len(pt), n_max_text_ctx, beam_width), "runFull")

@@ -44,7 +44,7 @@ EXPORTS = [
     "wh_model_arena_bytes", "wh_model_create", "wh_model_destroy", "wh_model_set_tensor", "wh_model_set_filters",
     "wh_model_finalize", "wh_model_arena", "wh_model_hparams",
     "wh_comm_runtime_check", "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
-    "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_synchronize", "wh_context_memory",
+    "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_set_audio_ctx", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
     "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
@@ -125,6 +125,7 @@ def lib():
         L.wh_context_destroy.argtypes = [vp]
         L.wh_context_destroy.restype = None
         L.wh_context_set_flags.argtypes = [vp, C.c_uint32, i32]
+        L.wh_context_set_audio_ctx.argtypes = [vp, i32]
         L.wh_context_memory.argtypes = [vp, C.POINTER(i64)]
         L.wh_context_synchronize.argtypes = [vp]
         L.wh_buffer_upload_async.argtypes = [vp, vp, vp, i64]
@@ -486,6 +487,10 @@ class HipContext:
                                               (n + 159) // 160 if n_chunks is None else n_chunks, int(reuse_previous_max), C.c_void_p(out.data_ptr())))
         self.synchronize()
         return out
+
+    def set_audio_ctx(self, audio_ctx: int):
+        """sFullParams::audio_ctx: encoder positions / cross-attention keys per window (0 = the model's n_audio_ctx)."""
+        check(lib().wh_context_set_audio_ctx(self.handle, audio_ctx))
 
     def set_flags(self, flags: int, parity_threads: int = 1):
         check(lib().wh_context_set_flags(self.handle, flags, parity_threads))

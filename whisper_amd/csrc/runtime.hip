@@ -1311,6 +1311,33 @@ int wh_context_bind( wh_context* c )
 	return 0;
 }
 
+int wh_context_set_audio_ctx( wh_context* c, int audioCtx )
+{
+	if( !c ) return WH_E_INVALIDARG;
+	const wh_hparams& hp = c->m->hp;
+	const int T = audioCtx > 0 ? audioCtx : hp.n_audio_ctx;
+	if( T > hp.n_audio_ctx ) { setError( "audio_ctx exceeds the model's n_audio_ctx" ); return WH_E_INVALIDARG; }
+	if( T == c->T ) return 0;
+	WH_BIND( c->m );
+	WH_HIP( hipStreamSynchronize( c->stream ) );
+	// every launch reads the key count from the context (row strides of the caches included), so the override is the context's T; what was captured or
+	// encoded with another T is void
+	if( c->graphExec ) { (void)hipGraphExecDestroy( c->graphExec ); c->graphExec = nullptr; c->graphBatch = 0; }
+	if( c->beamGraphExec ) { (void)hipGraphExecDestroy( c->beamGraphExec ); c->beamGraphExec = nullptr; c->beamGraphBatch = 0; }
+	c->T = T;
+	c->Tpad = roundUp( T, 256 );
+	c->encoded = false;
+	// the convolutions' zero padding sits right behind the last frame: rows 2 T + 1 of the conv input and of conv1's output may hold a longer window's data
+	for( int b = 0; b < c->encChunk; b++ )
+	{
+		WH_HIP( hipMemsetAsync( c->convIn + b * c->convInStride + ( 2ll * T + 1 ) * hp.n_mels, 0, (size_t)hp.n_mels * 2, c->stream ) );
+		WH_HIP( hipMemsetAsync( c->conv1Out + b * c->conv1Stride + ( 2ll * T + 1 ) * hp.n_audio_state, 0, (size_t)hp.n_audio_state * 2, c->stream ) );
+	}
+	// ... and the V operand's key padding [T, Tpad) must be finite and is expected to be zero
+	WH_HIP( hipMemsetAsync( c->vT, 0, (size_t)c->encChunk * hp.n_audio_head * HEAD_DIM * roundUp( hp.n_audio_ctx, 256 ) * 2, c->stream ) );
+	return 0;
+}
+
 int wh_context_set_flags( wh_context* c, uint32_t flags, int parityThreads )
 {
 	if( !c ) return WH_E_INVALIDARG;

@@ -505,6 +505,9 @@ namespace Whisper
 					groups.push_back( std::move( g ) );
 				}
 				if( !shared.loader ) CHECK_WH( wh_context_create( model->gpu, 1, nullptr, &shared.loader ) );
+				// one sFullParams for every stream of the batch: its audio_ctx is the groups' (ContextImpl.cpp:488-489)
+				if( params.audio_ctx < 0 || params.audio_ctx > model->hp.n_audio_ctx ) return E_INVALIDARG;
+				for( Group& g : groups ) CHECK_WH( wh_context_set_audio_ctx( g.gpu, params.audio_ctx ) );
 				Scheduler s( model, owner, params, streams, count, results, perStream, groups, shared, chunk, lookahead );
 				const HRESULT hr = s.run( (int)slots, (int)useGroups );
 				if( FAILED( hr ) ) logError( "runFullBatch: failed, HRESULT 0x%08x", (unsigned)hr );

@@ -123,10 +123,12 @@ namespace Whisper
 				logError( "GPU model doesn't implement the SpeedupAudio flag" );
 				return E_NOTIMPL;
 			}
-			if( params.audio_ctx != 0 && params.audio_ctx != hp.n_audio_ctx )
+			// sFullParams::audio_ctx (ContextImpl.cpp:488-489: exp_n_audio_ctx = params.audio_ctx): the callers hand it to the device context
+			// (wh_context_set_audio_ctx) before the first window; here only the range is checked
+			if( params.audio_ctx < 0 || params.audio_ctx > hp.n_audio_ctx )
 			{
-				logError( "audio_ctx override is not supported by this build" );
-				return E_NOTIMPL;
+				logError( "audio_ctx %d is outside [ 0, %d ]", params.audio_ctx, hp.n_audio_ctx );
+				return E_INVALIDARG;
 			}
 			seekStart = params.offset_ms / 10;
 			seekEndV = seekStart + ( params.duration_ms == 0 ? (int)melLen : params.duration_ms / 10 );

@@ -134,6 +134,7 @@ namespace Whisper
 			HRESULT fillResults( eResultFlags flags, ResultData& res ) const;
 			HRESULT runFullImpl( const sFullParams& params, const sProgressSink& progress );
 			HRESULT encodeWindow( wh_context* ctx, int seek );
+			int audioCtx = 0;	   // sFullParams::audio_ctx of the run in progress (0 = the model's)
 			HRESULT beamContext( int width );
 			HRESULT decodeWindowBeam( const std::vector<int>& prompt, int width, WindowScan& scan, int& steps );
 			HRESULT decodeWindowBeamDevice( const std::vector<int>& prompt, int width, WindowScan& scan, int& steps );
@@ -337,7 +338,7 @@ namespace Whisper
 				return S_OK;
 			}
 			const int64_t i0 = std::min( (int64_t)seek, mel.length );
-			const int64_t i1 = std::min( (int64_t)seek + 2 * hp.n_audio_ctx, mel.length );
+			const int64_t i1 = std::min( (int64_t)seek + 2 * ( audioCtx > 0 ? audioCtx : hp.n_audio_ctx ), mel.length );
 			if( i1 <= i0 ) return E_BOUNDS;
 			const auto t = Clock::now();
 			const bool reuse = mel.lastBufferEnd == i1;
@@ -652,6 +653,9 @@ namespace Whisper
 			}
 			// the ONE device context this run works on: the window x hypotheses context of a beam search, else the stream's own
 			wh_context* const active = beamWidth >= 1 ? gpuBeam : gpu;
+			// overwrite audio_ctx (ContextImpl.cpp:488-489): encoder positions and cross-attention keys of every window of this run
+			audioCtx = params.audio_ctx;
+			CHECK_WH( wh_context_set_audio_ctx( active, audioCtx ) );
 			std::vector<int> prompt;
 			while( true )
 			{
@@ -991,6 +995,26 @@ WHISPER_EXPORT int32_t whisperc_run_full( void* ctx, const float* pcm, uint32_t 
 	p.max_tokens = maxTokens;
 	p.prompt_tokens = promptTokens;
 	p.prompt_n_tokens = nPrompt;
+	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
+	iAudioBuffer* buf = nullptr;
+	CHECK( createAudioBuffer( std::vector<float>( pcm, pcm + nSamples ), {}, &buf ) );
+	const HRESULT hr = c->runFull( p, buf );
+	buf->Release();
+	return hr;
+}
+WHISPER_EXPORT int32_t whisperc_run_full_audio_ctx( void* ctx, const float* pcm, uint32_t nSamples, const char* language, uint32_t flags, int maxTokens,
+	const int32_t* promptTokens, int nPrompt, int nMaxTextCtx, int audioCtx )
+{
+	if( !ctx || ( !pcm && nSamples ) ) return E_POINTER;
+	iContext* c = (iContext*)ctx;
+	sFullParams p;
+	CHECK( c->fullDefaultParams( eSamplingStrategy::Greedy, &p ) );
+	p.flags = (eFullParamsFlags)flags;
+	p.language = makeLanguageKey( language ? language : "en" );
+	p.max_tokens = maxTokens;
+	p.prompt_tokens = promptTokens;
+	p.prompt_n_tokens = nPrompt;
+	p.audio_ctx = audioCtx;
 	if( nMaxTextCtx >= 0 ) p.n_max_text_ctx = nMaxTextCtx;
 	iAudioBuffer* buf = nullptr;
 	CHECK( createAudioBuffer( std::vector<float>( pcm, pcm + nSamples ), {}, &buf ) );
