@@ -735,6 +735,28 @@ def through_boundary(model_kind, steps, C, inflight, B=7):
 # ----------------------------------------------------------------------------------------------------------------------
 # BASELINE configs 3 / 4: N x 30 s synthetic-mel chunks, sharded over the ranks (strong scaling), optional hypotheses
 # ----------------------------------------------------------------------------------------------------------------------
+def pass_floor(hp, windows, hyp, n_prompt, n_steps, measured_ms):
+    """ALGORITHMIC floor of one lock-step pass of `windows` 30 s windows x `hyp` sequences each: the encoder's FLOPs at the dense FP16 MFMA
+    peak plus, per decode step, the bytes a step cannot avoid at the HBM peak -- every decoder weight once, the cross-attention K/V of every window once (the
+    hypotheses of a window share the pass), the self-attention rows written so far, the vocabulary matrix once. Returned as a roofline object of the pass:
+    `frac` = floor / measured (1 = every byte and FLOP at its peak, nothing else)."""
+    d, L, T, V = hp.n_text_state, hp.n_text_layer, hp.n_audio_ctx, hp.n_vocab
+    de, Le = hp.n_audio_state, hp.n_audio_layer
+    enc_flops = windows * (2.0 * 3000 * de * 3 * hp.n_mels + 2.0 * T * de * 3 * de + Le * (2.0 * T * 12 * de * de + 4.0 * T * T * de) + 2.0 * T * 2 * L * d * de)
+    seqs = windows * hyp
+    weights = L * 14.0 * d * d * 2 + V * d * 2.0
+    cross = windows * L * 2.0 * T * d * 2
+    steps = n_steps + 1                         # the prompt step reads what a single-token step reads (its extra rows are FLOPs, not bytes)
+    self_rows = sum(n_prompt + i for i in range(steps))
+    dec_bytes = steps * (weights + cross) + seqs * L * 2.0 * d * 2 * self_rows
+    floor_ms = 1e3 * (enc_flops / 2.5e15 + dec_bytes / 8.0e12)
+    return {"bound": "hbm", "achieved": round(dec_bytes / (measured_ms * 1e-3) * 1e-9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(floor_ms / measured_ms, 4), "traffic": None,
+            "floor_ms_per_pass": round(floor_ms, 3), "measured_ms_per_pass": round(measured_ms, 3), "encoder_flops_per_pass": enc_flops, "decode_bytes_per_pass": dec_bytes,
+            "decode_bytes_per_step": round(dec_bytes / steps), "ms_per_decode_step_if_the_encoder_ran_at_its_peak": round((measured_ms - 1e3 * enc_flops / 2.5e15) / steps, 4),
+            "what": "whole pass: `achieved` = the decode steps' algorithmic bytes / the pass's measured time (the encoder's time is inside: a lower bound on the decode "
+                    "steps' rate); `frac` = (encoder FLOPs / 2.5 PF + decode bytes / 8 TB/s) / measured"}
+
+
 def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_steps, t_bcast):
     import torch
     from whisper_amd import binding, distributed as wd
@@ -876,7 +898,10 @@ def run_chunks(args, hip_model, hp, prompt, rank, world, dist, n_chunks, hyp, n_
                                   len(ctxs), N_PROMPT, n_steps),
                    "model": "ggml-" + args.model, "chunks": n_chunks, "hypotheses": hyp, "windows_per_batch": per,
                    "parallelism": "dp%d (independent windows; RCCL weight broadcast outside the timed region: %s; no collective in the step)" % (world, BCAST_NOTE.get(args.model, "%.3f s" % t_bcast))},
-        "rtf": round(elapsed / (args.steps * n_chunks * 30.0), 6), "roofline": None, "cpu_baseline": None,
+        "rtf": round(elapsed / (args.steps * n_chunks * 30.0), 6),
+        # one lock-step pass = `per` windows on one context; the passes of a step overlap on the contexts in flight, so the chip's time PER PASS is the step's / passes
+        "roofline": pass_floor(hp, min(per, n_chunks), hyp, len(base), n_steps, 1e3 * elapsed / args.steps / max(1, (e - b + per - 1) // per)) if world == 1 else None,
+        "cpu_baseline": None,
         "sequences_per_second": round(n_chunks * hyp * args.steps / elapsed, 2),
         "tokens_checksum": int(np.asarray(toks, np.int64).clip(min=0).sum() % 1000003),
     }
@@ -904,6 +929,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="shard256 / beam5: windows per lock-step batch")
     ap.add_argument("--beam-host", action="store_true", help="beam5: rank every step's candidates on the host (round 4's data path) instead of on the device")
     ap.add_argument("--no-beam", action="store_true", help="skip the beam5 sub-object of the default line (BASELINE configs[2] on the large-v2 model)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the shard256 (large_v2.shard256) and v3stream sub-objects of the default line (BASELINE configs[3] and [4] on one rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-stream", action="store_true")
@@ -1060,7 +1086,7 @@ def main():
         except Exception as e:
             small = {"error": str(e)[:300]}
 
-    single = large = boundary = None
+    single = large = boundary = v3stream = None
     if rank == 0 and world == 1 and args.workload == "clip" and not args.no_boundary and args.model in ("medium", "large-v2"):
         log("the same workload through libWhisper.so (createBatchRunner) ...")
         try:
@@ -1110,10 +1136,20 @@ def main():
                         ba = argparse.Namespace(batch=8, inflight=2, warmup=2, steps=8, model="large-v2", beam_host=False)
                         bl = run_chunks(ba, hm2, hp2, p2, 0, 1, dist, 8, 5, 50, 0.0)
                         large["beam5"] = {"value": bl["value"], "unit": "audio-seconds/sec", "sequences_per_second": bl["sequences_per_second"], "ms_per_step": bl["ms_per_step"],
-                                          "steps": bl["steps"], "tokens_checksum": bl["tokens_checksum"], "workload": bl["config"]["workload"]}
+                                          "steps": bl["steps"], "tokens_checksum": bl["tokens_checksum"], "workload": bl["config"]["workload"], "roofline": bl["roofline"]}
                         log("large-v2 beam5: %s audio-s/s" % bl["value"])
                     except Exception as e:
                         large["beam5"] = {"error": str(e)[:300]}
+                if not args.no_workloads:
+                    # BASELINE configs[3] on ONE rank: large-v2, 256 x 30 s chunks in lock-step batches of 128 windows, two contexts in flight
+                    try:
+                        sa = argparse.Namespace(batch=128, inflight=2, warmup=1, steps=2, model="large-v2", beam_host=False)
+                        sl = run_chunks(sa, hm2, hp2, p2, 0, 1, dist, 256, 1, N_GREEDY, 0.0)
+                        large["shard256"] = {"value": sl["value"], "unit": "audio-seconds/sec", "ms_per_step": sl["ms_per_step"], "steps": sl["steps"], "n_gpus": 1,
+                                             "tokens_checksum": sl["tokens_checksum"], "workload": sl["config"]["workload"], "roofline": sl["roofline"]}
+                        log("large-v2 shard256 on one rank: %s audio-s/s" % sl["value"])
+                    except Exception as e:
+                        large["shard256"] = {"error": str(e)[:300]}
                 if not args.no_cpu_baseline:
                     # BASELINE names both models: the reference's CPU path beside the large-v2 figure too (one window: its encoder alone
                     # is ~15-20 s on 16 threads), and the same parity object as the headline's, at d = 1280 / 20 heads / 32 layers
@@ -1123,6 +1159,31 @@ def main():
                     log("large-v2 cpu baseline done: %s" % cpu2.get("value"))
             except Exception as e:
                 large = {"error": str(e)[:300]}
+        if not args.no_workloads and args.model == "medium":
+            # BASELINE configs[4] on ONE rank: the clip workload on the large-v3 shape (128 mel bins, 51866 tokens), translate task
+            log("large-v3 shape (configs[4]) ...")
+            try:
+                try:
+                    hm2.close()
+                except Exception:
+                    pass
+                hp3, model3, hm3, _, _ = load("large-v3")
+                del model3
+                sp3 = gf.special_tokens(hp3)
+                p3 = [sp3["sot"], sp3["sot"] + 1, sp3["translate"]]
+                C3 = min(C, 16)
+                n3 = 2 * C3
+                m3 = measure_batched(hm3, hp3, p3, n3, 1, B, C3, inflight, 0, 1, dist, want_kernels=False, single_clip=False)
+                ms3 = 1e3 * m3["elapsed"] / len(m3["plan"])
+                v3stream = {"model": "ggml-large-v3", "task": "translate", "value": round(audio_seconds * n3 / m3["elapsed"], 2), "unit": "audio-seconds/sec", "steps": len(m3["plan"]),
+                            "clip_passes": n3, "ms_per_step": round(ms3, 3), "batch_plan": m3["plan"], "n_gpus": 1,
+                            "roofline": pass_floor(hp3, C3 * B, 1, N_PROMPT, N_GREEDY, ms3)}
+                for s_ in m3["slots"]:
+                    s_[0].close()
+                hm3.close()
+                log("large-v3: %s audio-s/s" % v3stream["value"])
+            except Exception as e:
+                v3stream = {"error": str(e)[:300]}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -1131,6 +1192,10 @@ def main():
             "metric": METRIC,
             "value": round(value, 2), "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            # rounds 1-4 called ONE CLIP PASS (7 windows) a step; since round 5 a step is one lock-step batch of `clips_per_step` clips. The figure of the job the driver's
+            # invocation measured then (20 clip passes as two batches of 70 windows) is kept at the top level so that round-over-round readings never mix the two
+            "value_r04_definition": (small or {}).get("value") if isinstance(small, dict) else None,
+            "step_definition": "one lock-step batch of %d clips = %d windows (rounds 1-4: one clip pass = %d windows; that job's figure is value_r04_definition = small_job.value)" % (C, C * B, B),
             # the published number (13.30 audio-s/s, one clip, sequential, GTX 1080Ti) is not this batched workload:
             # the like-for-like ratio is single_stream.vs_baseline
             "vs_baseline": None,
@@ -1155,6 +1220,7 @@ def main():
             "small_job": small,
             "single_stream": single,
             "large_v2": large,
+            "v3stream": v3stream,
             "kernels": kernels,
             "model_build_s": round(t_load, 1),
             "tokens_checksum": int(np.asarray(toks, np.int64)[:B].sum() % 1000003),
