@@ -246,7 +246,10 @@ WH_API int wh_reorder_self_cache( wh_context* c, int batch, const int32_t* paren
  * candidates -> ranking) is ONE captured graph replayed per token. The host enqueues chunks of steps and polls `done`.
  *   wh_beam_window_start    windows x (hypotheses of the context) sequences; promptTokens HOST [windows][nPrompt] (every slot of a window starts from
  *                           it); rules HOST [windows]; the prompt step, the first ranking (sampleTimestamp( true ) rules) and nSteps ranked steps are
- *                           enqueued, nothing blocks. forced != 0 in a window's rules: no stop rules, every hypothesis lives (random-weight workloads).
+ *                           enqueued. The call WAITS for what the stream holds first (the window's rules and initial state are copied synchronously, and the step
+ *                           graph is captured on first use): one host round trip per window, the encoder included; the steps themselves never block. The
+ *                           captured graph is keyed on (sequences, width): kernel options set with wh_debug_set_option / _tuning afterwards do not reach it.
+ *                           forced != 0 in a window's rules: no stop rules, every hypothesis lives (random-weight workloads).
  *   wh_beam_window_continue nSteps more (bounded by n_text_ctx like wh_decode_window_continue). Steps enqueued after a window is done change nothing.
  *   wh_beam_window_status   blocks until everything enqueued has run; the search state of every window: HOST [windows].
  *   wh_beam_window_records  the accepted proposals of ranking steps [firstStep, firstStep + count): HOST [count][windows][width]; a hypothesis' token
@@ -353,7 +356,9 @@ WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, 
  * afterwards (and their captured graphs) use the new setting. */
 WH_API int wh_debug_set_tuning( uint32_t mask );
 /* Integer knobs beyond the 32 switches (whisper_amd/csrc/kernels.h struct Options: "dec_tile", "dec_depth", "dec_wide_rows", "dec_deep_rows", "vocab_decrows",
- * "enc_chunk", "self_fuse_max_rows", "self_nq", "self_wave_min_rows"); also settable as WH_OPT_<NAME> in the environment at load. Unknown names: WH_E_INVALIDARG. */
+ * "enc_chunk", "self_fuse_max_rows", "self_nq", "self_wave_min_rows", "enc_exp", "exact_enc_layers", "exact_alt_order"); also settable as WH_OPT_<NAME> in the environment at load.
+ * Unknown names and values outside [-1, 4096]: WH_E_INVALIDARG (the environment form: ignored with a line on stderr). The options are process-global and read without
+ * synchronisation by every launch: set them BEFORE contexts are created, never while another thread runs one. */
 WH_API int wh_debug_set_option( const char* name, int value );
 WH_API int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter );
 

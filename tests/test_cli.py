@@ -54,6 +54,42 @@ def test_writers_byte_for_byte(exe, tmp_path):
     assert open(prefix + ".vtt", "rb").read() == vtt
 
 
+def test_writers_against_the_references_own(exe, tmp_path):
+    """The .txt / .srt / .vtt writers against the reference's OWN code: Examples/main/textWriter.cpp compiled unmodified (oracle/Makefile ->
+    _ref/libtextwriter_ref.so; ATL / PathCch / wide LPCTSTR through shims) and handed the same segments -- leading blanks and tabs, UTF-8 text, times beyond
+    24 h (the reference prints days * 24 + hours), sub-millisecond ticks (truncated, not rounded), an empty text, a path whose directory has a dot."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libtextwriter_ref.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libtextwriter_ref.so not present")
+    import ctypes as C
+    L = C.CDLL(so)
+    L.tw_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    segs = [(0, 36000000, " And so my fellow Americans,"),
+            (36000000, 3723456 * 10000, "\t ask not what your country can do for you"),
+            (90061001 * 10000, 90061999 * 10000, "ask what you can do for your country."),
+            (12349999, 12350001, "  gr\u00fc\u00dfe, \u4e16\u754c \U0001f600"),
+            (10 ** 7 * 3600 * 24 * 3 + 9999, 10 ** 7 * 3600 * 24 * 3 + 10 ** 7 * 59 + 9990000, ""),
+            (5, 6, "trailing blank ")]
+    d = tmp_path / "dir.with.dot"
+    d.mkdir()
+    texts = (C.c_char_p * len(segs))(*[s[2].encode() for s in segs])
+    b = (C.c_uint64 * len(segs))(*[s[0] for s in segs])
+    e = (C.c_uint64 * len(segs))(*[s[1] for s in segs])
+    ref_prefix = str(d / "reference")
+    for kind, audio in ((0, ref_prefix + ".wav"), (2, ref_prefix + ".wav"), (3, ref_prefix + ".wav"), (1, str(d / "reference_nostamps.flac"))):      # (a path without an extension fails in the reference: its buffer has room for a REPLACED extension only)
+        assert L.tw_write(audio.encode(), kind, len(segs), texts, b, e) == 0
+    seg_file = str(tmp_path / "segments.txt")
+    with open(seg_file, "wb") as f:
+        for s in segs:
+            f.write(("%d %d " % (s[0], s[1])).encode() + s[2].encode() + b"\n")
+    ours = str(d / "ours")
+    assert run(exe, "--format-file", seg_file, ours).returncode == 0
+    for ext, ref_name in ((".txt", ref_prefix + ".txt"), (".srt", ref_prefix + ".srt"), (".vtt", ref_prefix + ".vtt"), (".nostamps.txt", str(d / "reference_nostamps.txt"))):
+        want = open(ref_name, "rb").read()
+        got = open(ours + ext, "rb").read()
+        assert want.startswith(b"\xef\xbb\xbf") and got == want, (ext, got[:200], want[:200])
+
+
 def test_options_and_exit_codes(exe, tmp_path):
     r = run(exe, "--help")
     assert r.returncode == 1 and b"--output-srt" in r.stderr and b"--max-context" in r.stderr

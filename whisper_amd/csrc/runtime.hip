@@ -48,7 +48,14 @@ namespace wh
 			{
 				std::string env = "WH_OPT_";
 				for( const char* p = o.name; *p; p++ ) env.push_back( (char)toupper( (unsigned char)*p ) );
-				if( const char* e = getenv( env.c_str() ) ) g_opt.*( o.field ) = atoi( e );
+				if( const char* e = getenv( env.c_str() ) )
+				{
+					// a number in the options' common range, or the variable is ignored (garbage used to become 0 and re-route kernels silently)
+					char* end = nullptr;
+					const long v = strtol( e, &end, 10 );
+					if( end != e && *end == 0 && v >= -1 && v <= 4096 ) g_opt.*( o.field ) = (int)v;
+					else fprintf( stderr, "[wh] %s='%s' ignored (not an integer in [-1, 4096])\n", env.c_str(), e );
+				}
 			}
 			return true;
 		}();
@@ -1860,7 +1867,10 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	const float kqScale = (float)pow( (double)( (float)d / (float)H ), -0.25 );
 	const int parity = ( c->flags & WH_FLAG_PARITY_PV ) ? c->parityThreads : 0;
 	const int* const nPastDev = devState ? c->seqPos : nullptr;
-	const bool gemv = M <= GEMV_MAX_ROWS && ( d % 128 ) == 0;
+	// the weight-streaming kernels (gemvFused up to 128 rows, gemmDecRows up to 512) are sized and tuned for single-token steps of a lock-step batch; a PROMPT
+	// step of 129 .. 512 rows (one stream with a carried-over prompt of ~224 tokens, small batches with a prompt) keeps the M-tiled MFMA kernel it always had
+	// (raising GEMV_MAX_ROWS to 512 had silently re-routed those, summation order included)
+	const bool gemv = M <= ( nTokens == 1 ? GEMV_MAX_ROWS : GEMV_FUSED_MAX_ROWS ) && ( d % 128 ) == 0;
 	const bool fuseLn = gemv && d <= 1280 && M <= 32 && ( M <= 16 || ( g_tuning & TUNE_GEMV_LN_BLOCK ) || !( g_tuning & TUNE_LN_SEPARATE_BIGM ) );
 	// decode steps: LayerNorm + this head's Q/K/V rows + cache append + self-attention in one launch
 	// (from 9 sequences up: with fewer, one workgroup per (head, sequence) leaves the 6 d^2 bytes of QKV weights to H CUs at
@@ -2972,7 +2982,7 @@ int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F32; g.bias = bias; g.res = residual; g.out32 = out;
 	// the same choice the decoder makes: up to 32 rows go to the gemv when K allows it
-	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
+	if( M <= GEMV_FUSED_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // more rows: the M-tiled kernel (the op has no notion of a decode step)
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -2981,7 +2991,7 @@ int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16, const 
 	if( !bias ) { setError( "mul_mat_gelu: bias is required" ); return WH_E_INVALIDARG; }
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F16_GELU; g.bias = bias; g.out16 = (f16*)outF16;
-	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );
+	if( M <= GEMV_FUSED_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // more rows: the M-tiled kernel (the op has no notion of a decode step)
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -3137,6 +3147,7 @@ int wh_debug_set_option( const char* name, int value )
 	for( const OptionName& o : g_optionNames )
 		if( 0 == strcmp( o.name, name ) )
 		{
+			if( value < -1 || value > 4096 ) { setError( std::string( "option '" ) + name + "': value out of range" ); return WH_E_INVALIDARG; }
 			g_opt.*( o.field ) = value;
 			return 0;
 		}

@@ -323,9 +323,54 @@ namespace
 	}
 }
 
+// hidden: --format-file SEGMENTS PREFIX writes PREFIX.txt / .nostamps.txt / .srt / .vtt from the segments of a file (one per line: begin ticks, end ticks,
+// then the text up to the end of the line, verbatim); tests/test_cli.py holds the bytes against the reference's own writers (oracle/_ref/libtextwriter_ref.so)
+static int formatFile( const char* segFile, const std::string& prefix )
+{
+	FILE* f = fopen( segFile, "rb" );
+	if( !f ) return 20;
+	std::vector<std::string> texts;
+	std::vector<sSegment> segs;
+	char line[ 4096 ];
+	while( fgets( line, sizeof( line ), f ) )
+	{
+		unsigned long long b = 0, e = 0;
+		int used = 0;
+		if( sscanf( line, "%llu %llu %n", &b, &e, &used ) < 2 ) continue;
+		std::string t = line + used;
+		while( !t.empty() && ( t.back() == '\n' || t.back() == '\r' ) ) t.pop_back();
+		// the separator after the second number is ONE blank: what follows (leading blanks included) is the text
+		const char* p = line;
+		int fields = 0;
+		while( *p && fields < 2 ) { while( *p == ' ' ) p++; while( *p && *p != ' ' ) p++; fields++; }
+		if( *p == ' ' ) p++;
+		t = p;
+		while( !t.empty() && ( t.back() == '\n' || t.back() == '\r' ) ) t.pop_back();
+		texts.push_back( t );
+		sSegment s{};
+		s.time.begin.ticks = b;
+		s.time.end.ticks = e;
+		segs.push_back( s );
+	}
+	fclose( f );
+	for( size_t i = 0; i < segs.size(); i++ ) segs[ i ].text = texts[ i ].c_str();
+	const struct { const char* ext; cli::eFormat fm; } outs[] = { { ".txt", cli::eFormat::Text }, { ".nostamps.txt", cli::eFormat::TextNoStamps },
+		{ ".srt", cli::eFormat::SubRip }, { ".vtt", cli::eFormat::WebVTT } };
+	for( const auto& o : outs )
+	{
+		const std::string bytes = cli::renderTranscript( segs.data(), segs.size(), o.fm );
+		FILE* w = fopen( ( prefix + o.ext ).c_str(), "wb" );
+		if( !w ) return 20;
+		fwrite( bytes.data(), 1, bytes.size(), w );
+		fclose( w );
+	}
+	return 0;
+}
+
 int main( int argc, char** argv )
 {
 	if( argc == 3 && !strcmp( argv[ 1 ], "--format-sample" ) ) return formatSample( argv[ 2 ] );
+	if( argc == 4 && !strcmp( argv[ 1 ], "--format-file" ) ) return formatFile( argv[ 2 ], argv[ 3 ] );
 
 	sLoggerSetup log{};
 	log.flags = eLoggerFlags::UseStandardError;
