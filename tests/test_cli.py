@@ -261,6 +261,64 @@ def test_mgpu_harness_one_rank_matches_the_cli(exe, tmp_path):
 
 
 @pytest.mark.gpu
+def test_mgpu_per_recording_keeps_the_sliding_window(exe, tmp_path):
+    """whisper-mgpu -per-recording: whole recordings dealt to the ranks, each ONE stream with the reference's host loop -- windows advance by the
+    timestamp the decoder ended on (seek_delta, ContextImpl.cpp:618-625, 785), text carries over as the next window's prompt -- instead of independent 30 s chunks.
+    Two recordings on one rank (the batch runner decodes them in lock step): each transcript must be what iContext::runFull returns for that recording alone,
+    segment times included; on the multi-window recording that differs from the chunk mode's transcript, which is the trade-off the option makes a choice."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_runfull", os.path.join(ROOT, "tests", "golden", "make_golden_runfull.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from whisper_amd import api
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_runfull_conditioned.json")))
+    cases = [next(c for c in fx["cases"] if c["name"].startswith("long")), next(c for c in fx["cases"] if c["name"].startswith("jfk"))]
+    assert cases[0]["seed"] == cases[1]["seed"]
+    model = str(tmp_path / "cond.bin")
+    gf.write_model(model, mg.model_for(cases[0]["seed"]))
+    wavs, pcms = [], []
+    for i, c in enumerate(cases):
+        pcm = mg.pcm_for(c["pcm"])
+        q = np.clip(np.round(pcm * 32768.0), -32768, 32767).astype("<i2")
+        path = str(tmp_path / ("rec%d.wav" % i))
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1)
+            w.setsampwidth(2)
+            w.setframerate(16000)
+            w.writeframes(q.tobytes())
+        wavs.append(path)
+        pcms.append(q.astype(np.float32) / 32768.0)
+    out = str(tmp_path / "t.txt")
+    r = subprocess.run([build.MGPU_BIN, "-n", "1", "-m", model, "-per-recording", "-f", wavs[0], "-f", wavs[1], "-o", out, "-timeout", "60"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    print(r.stdout.decode(), r.stderr.decode()[-2000:])
+    assert r.returncode == 0
+    text = open(out).read()
+    parts = text.split("== ")[1:]
+    assert len(parts) == 2 and parts[0].startswith(wavs[0]) and parts[1].startswith(wavs[1])
+    m = api.Model(model)
+    for part, pcm in zip(parts, pcms):
+        ctx = m.create_context()
+        assert ctx.run_full(pcm) == 0
+        want = ctx.results()
+        ctx.close()
+        got = part.splitlines()[1:]
+        assert len(got) == len(want) and len(want) >= 1
+        for g, s in zip(got, want):
+            assert g.endswith("] " + s["text"].decode()), (g, s["text"])
+            t0, t1 = float(g[1:10]), float(g[15:24])
+            assert abs(t0 - s["t0"] / 1e7) < 0.006 and abs(t1 - s["t1"] / 1e7) < 0.006
+    m.close()
+    # the chunk mode on the long recording: independent 30 s chunks, another transcript
+    r2 = subprocess.run([build.MGPU_BIN, "-n", "1", "-m", model, "-f", wavs[0], "-o", out + ".chunks", "-timeout", "60"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r2.returncode == 0
+    assert [ln.split("] ", 1)[-1] for ln in open(out + ".chunks").read().splitlines()] != [ln.split("] ", 1)[-1] for ln in parts[0].splitlines()[1:]]
+    # several recordings without the option: refused
+    r3 = subprocess.run([build.MGPU_BIN, "-n", "1", "-m", model, "-f", wavs[0], "-f", wavs[1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r3.returncode == 1 and b"-per-recording" in r3.stderr
+
+
+@pytest.mark.gpu
 def test_mgpu_two_ranks_over_rccl_or_a_loud_failure(exe, tmp_path):
     """whisper-mgpu -n 2 through the C++ path (wh_comm_* over RCCL, loadModelShared, one batch runner per rank). With two devices visible: two ranks on two
     GPUs, the arena broadcast over the fabric, and the concatenated transcript is the one rank's (chunks are independent recordings). With ONE device

@@ -1,6 +1,7 @@
 // One process per GPU over the C ABI, no Python and no torch: the multi-GPU harness of the drop-in library.
 //
 //   whisper-mgpu -n 8 -m ggml-medium.bin -f recording.wav [-l en] [-o out.txt] [-timeout 300] [-job-timeout 0] [-slots 64] [-id file] [-job token]
+//   whisper-mgpu -n 8 -m ggml-medium.bin -per-recording -f a.wav -f b.wav ...   whole recordings, one stream each with the reference's sliding window (no words cut at 30 s)
 //
 // The parent forks N ranks (or, when RANK / WORLD_SIZE / LOCAL_RANK are set by an external launcher, runs as that rank).
 // Rank r binds GPU LOCAL_RANK % devices (sModelSetup.adapter); rank 0 creates the RCCL id and publishes it through a file;
@@ -41,6 +42,8 @@ namespace
 		double timeout = 300.0;		// deadline of the rendezvous and of every collective
 		double jobTimeout = 0.0;	// deadline of the whole job (forked mode: the parent ends the ranks); 0 = none
 		std::string model, wav, lang = "en", out = "transcript.txt", idFile;
+		std::vector<std::string> wavs;	// every -f
+		bool perRecording = false;	// -per-recording: whole recordings dealt round-robin to the ranks, each decoded with the reference's sliding window
 		std::string job;			// token of THIS job: stamped into the id file by rank 0, required by the ranks that read it
 	};
 	std::wstring widen( const std::string& s )
@@ -159,17 +162,47 @@ namespace
 		if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] loadModelShared failed 0x%08x\n", rank, (unsigned)hr ); return 4; }
 		fprintf( stderr, "[rank %d] model ready after %.2f s\n", rank, since() );
 
-		// ---- audio: every rank decodes the file (16 kHz PCM is small next to the model), then takes its chunks ----
+		// ---- audio ----
+		// chunk mode (default): every rank decodes THE file (16 kHz PCM is small next to the model) and takes a contiguous range of its 30 s chunks as independent
+		// streams -- north_star's workload; words across chunk boundaries are cut.
+		// -per-recording: whole recordings are dealt round-robin (recording i -> rank i mod world); each is ONE stream of the batch runner, i.e. the reference's own
+		// host loop on it -- windows advance by the timestamp the decoder ended on (seek_delta, ContextImpl.cpp:618-625, 785) and the text of a window conditions the
+		// next (prompt carry-over) --, so a recording's transcript is what whisper-main prints for it; the recordings of a rank run in lock step.
 		iMediaFoundation* mf = nullptr;
-		iAudioBuffer* audio = nullptr;
 		hr = initMediaFoundation( &mf );
-		if( SUCCEEDED( hr ) ) hr = mf->loadAudioFile( a.wav.c_str(), false, &audio );
-		if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] cannot load %s (0x%08x)\n", rank, a.wav.c_str(), (unsigned)hr ); return 5; }
-		const int64_t nSamples = audio->countSamples();
+		if( FAILED( hr ) ) return 5;
+		std::vector<iAudioBuffer*> audios;
+		std::vector<int> recIndex;
+		std::vector<sBatchStream> streams;
 		const int64_t chunk = 16000 * 30;
-		const int windows = (int)( ( nSamples + chunk - 1 ) / chunk );
-		int wb = 0, we = 0;
-		shardRange( windows, rank, world, wb, we );
+		int windows = 0, wb = 0, we = 0;
+		if( a.perRecording )
+		{
+			for( size_t i = 0; i < a.wavs.size(); i++ )
+			{
+				if( (int)( i % (size_t)world ) != rank ) continue;
+				iAudioBuffer* buf = nullptr;
+				hr = mf->loadAudioFile( a.wavs[ i ].c_str(), false, &buf );
+				if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] cannot load %s (0x%08x)\n", rank, a.wavs[ i ].c_str(), (unsigned)hr ); return 5; }
+				audios.push_back( buf );
+				recIndex.push_back( (int)i );
+				streams.push_back( sBatchStream{ buf, 0, (int64_t)buf->countSamples(), nullptr } );
+				windows += (int)( ( (int64_t)buf->countSamples() + chunk - 1 ) / chunk );
+			}
+			we = windows;
+		}
+		else
+		{
+			iAudioBuffer* audio = nullptr;
+			hr = mf->loadAudioFile( a.wav.c_str(), false, &audio );
+			if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] cannot load %s (0x%08x)\n", rank, a.wav.c_str(), (unsigned)hr ); return 5; }
+			audios.push_back( audio );
+			const int64_t nSamples = audio->countSamples();
+			windows = (int)( ( nSamples + chunk - 1 ) / chunk );
+			shardRange( windows, rank, world, wb, we );
+			for( int w = wb; w < we; w++ )
+				streams.push_back( sBatchStream{ audio, (int64_t)w * chunk, std::min( chunk, nSamples - (int64_t)w * chunk ), nullptr } );
+		}
 
 		sFullParams p;
 		memset( &p, 0, sizeof( p ) );
@@ -179,26 +212,26 @@ namespace
 		p.thold_pt = p.thold_ptsum = 0.01f;
 		p.beam_search.n_past = p.beam_search.beam_width = p.beam_search.n_best = -1;
 		p.language = findLanguageKeyA( a.lang.c_str() );
-		p.setFlag( eFullParamsFlags::NoContext );
-		std::vector<sBatchStream> streams;
-		for( int w = wb; w < we; w++ )
-			streams.push_back( sBatchStream{ audio, (int64_t)w * chunk, std::min( chunk, nSamples - (int64_t)w * chunk ), nullptr } );
+		if( !a.perRecording ) p.setFlag( eFullParamsFlags::NoContext );	   // independent chunks carry nothing over; a whole recording keeps the reference's default
 		iBatchRunner* runner = nullptr;
 		const sBatchSetup bs{ (uint32_t)std::max( 1, std::min( a.slots, 512 ) ), 0, 0, 0 };
 		if( !streams.empty() && FAILED( createBatchRunner( model, &bs, &runner ) ) ) return 6;
 
 		if( 0 != wh_comm_barrier( comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 8; }
 		const double tStart = since();
-		std::string text;
+		std::string textAll;
 		int nSeg = 0;
 		if( !streams.empty() )
 		{
 			std::vector<iTranscribeResult*> results( streams.size(), nullptr );
 			hr = runner->run( p, streams.data(), (uint32_t)streams.size(), results.data(), nullptr );
 			if( FAILED( hr ) ) { fprintf( stderr, "[rank %d] runFullBatch failed 0x%08x\n", rank, (unsigned)hr ); return 7; }
-			for( iTranscribeResult* res : results )
+			for( size_t ri = 0; ri < results.size(); ri++ )
 			{
+				iTranscribeResult* res = results[ ri ];
 				if( !res ) continue;
+				std::string recText;
+				std::string& text = a.perRecording ? recText : textAll;
 				sTranscribeLength len;
 				res->getSize( len );
 				const sSegment* seg = res->getSegments();
@@ -212,13 +245,22 @@ namespace
 				}
 				nSeg += (int)len.countSegments;
 				res->Release();
+				if( a.perRecording )
+				{
+					// one transcript per recording, written by the rank that decoded it
+					FILE* rf = fopen( ( a.out + ".rec" + std::to_string( recIndex[ ri ] ) ).c_str(), "wb" );
+					if( rf ) { fwrite( recText.data(), 1, recText.size(), rf ); fclose( rf ); }
+				}
 			}
 		}
 		const double tRun = since() - tStart;
 		if( 0 != wh_comm_barrier( comm ) ) { fprintf( stderr, "[rank %d] %s\n", rank, wh_last_error() ); return 8; }
 		const double tAll = since() - tStart;
-		FILE* f = fopen( ( a.out + ".rank" + std::to_string( rank ) ).c_str(), "wb" );
-		if( f ) { fwrite( text.data(), 1, text.size(), f ); fclose( f ); }
+		if( !a.perRecording )
+		{
+			FILE* f = fopen( ( a.out + ".rank" + std::to_string( rank ) ).c_str(), "wb" );
+			if( f ) { fwrite( textAll.data(), 1, textAll.size(), f ); fclose( f ); }
+		}
 		fprintf( stderr, "[rank %d] chunks %d..%d of %d: %d segments in %.3f s (%.1f audio-s/s on this rank); all ranks done after %.3f s\n", rank, wb, we, windows,
 			nSeg, tRun, tRun > 0 ? ( we - wb ) * 30.0 / tRun : 0.0, tAll );
 		if( rank == 0 )
@@ -227,7 +269,7 @@ namespace
 			fflush( stdout );	   // the rank leaves through _exit
 		}
 		if( runner ) runner->Release();
-		audio->Release();
+		for( iAudioBuffer* b : audios ) b->Release();
 		mf->Release();
 		model->Release();
 		wh_comm_destroy( comm );
@@ -284,7 +326,8 @@ int main( int argc, char** argv )
 		auto val = [ & ]() -> const char* { return i + 1 < argc ? argv[ ++i ] : ""; };
 		if( !strcmp( argv[ i ], "-n" ) ) a.ranks = atoi( val() );
 		else if( !strcmp( argv[ i ], "-m" ) ) a.model = val();
-		else if( !strcmp( argv[ i ], "-f" ) ) a.wav = val();
+		else if( !strcmp( argv[ i ], "-f" ) ) { a.wav = val(); a.wavs.push_back( a.wav ); }
+		else if( !strcmp( argv[ i ], "-per-recording" ) ) a.perRecording = true;
 		else if( !strcmp( argv[ i ], "-l" ) ) a.lang = val();
 		else if( !strcmp( argv[ i ], "-o" ) ) a.out = val();
 		else if( !strcmp( argv[ i ], "-id" ) ) a.idFile = val();
@@ -321,9 +364,10 @@ int main( int argc, char** argv )
 				if( id[ k ] != (unsigned char)( k * 7 + 1 ) ) return 2;
 			return ok ? 0 : 1;
 		}
-		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-timeout seconds (rendezvous and collectives)] [-job-timeout seconds (whole job; default none)] [-slots n] [-id id-file] [-job token]\n" ); return 1; }
+		else { fprintf( stderr, "usage: whisper-mgpu -n ranks -m model.bin -f audio.wav [-l en] [-o out.txt] [-timeout seconds (rendezvous and collectives)] [-job-timeout seconds (whole job; default none)] [-slots n] [-id id-file] [-job token] [-per-recording -f more.wav ...]\n" ); return 1; }
 	}
 	if( a.model.empty() || a.wav.empty() || a.ranks < 1 ) { fprintf( stderr, "whisper-mgpu: -m and -f are required\n" ); return 1; }
+	if( !a.perRecording && a.wavs.size() > 1 ) { fprintf( stderr, "whisper-mgpu: several -f recordings need -per-recording (the chunk mode shards ONE recording)\n" ); return 1; }
 	if( a.timeout <= 0 ) a.timeout = 300.0;
 
 	// launched by torchrun / mpirun / srun: be the rank the environment names. Every rank is its own process there, so the id file
@@ -380,9 +424,12 @@ int main( int argc, char** argv )
 	if( rc == 0 )
 	{
 		FILE* out = fopen( a.out.c_str(), "wb" );
-		for( int r = 0; out && r < a.ranks; r++ )
+		// chunk mode: the ranks' parts in rank order = the chunks in order. -per-recording: the recordings' transcripts in the order of the -f options
+		const int parts = a.perRecording ? (int)a.wavs.size() : a.ranks;
+		for( int r = 0; out && r < parts; r++ )
 		{
-			const std::string part = a.out + ".rank" + std::to_string( r );
+			const std::string part = a.out + ( a.perRecording ? ".rec" : ".rank" ) + std::to_string( r );
+			if( a.perRecording ) fprintf( out, "== %s\n", a.wavs[ (size_t)r ].c_str() );
 			if( FILE* f = fopen( part.c_str(), "rb" ) )
 			{
 				char buf[ 65536 ];
@@ -395,6 +442,9 @@ int main( int argc, char** argv )
 		if( out ) fclose( out );
 	}
 	else
+	{
 		for( int r = 0; r < a.ranks; r++ ) unlink( ( a.out + ".rank" + std::to_string( r ) ).c_str() );
+		for( size_t r = 0; r < a.wavs.size(); r++ ) unlink( ( a.out + ".rec" + std::to_string( r ) ).c_str() );
+	}
 	return rc;
 }
