@@ -20,7 +20,7 @@ that measurement is still in every line: `small_job`.
 Objects next to the contract fields:
   roofline      algorithmic bytes (or flops) per launch / average launch duration, hipEvent pairs on the launch stream (one batch of the size the timed
                 region ran, one context at a time) minus the calibrated cost of an empty bracket; `traffic` = HBM bytes per launch from the committed PMC
-                pass (profiles/r05_pmc.json; counters cannot be collected inside a timed run). The two classes with the most kernel time are both in
+                pass (profiles/r06_pmc.json, collected at the timed batch size of 448 windows; counters cannot be collected inside a timed run). The two classes with the most kernel time are both in
                 every line -- `mfma_kernel` (the encoder's matrix-core product) and `hbm_kernel` (the decode step's cross-attention) -- and the TOP LEVEL
                 repeats whichever of them sits LOWER against its roofline; `encoder_attention`; `decode_chain` = every launch of a decode step outside the
                 cross-attention as one class; `end_to_end` = (sum flops / 2.5 PF + sum bytes / 8 TB/s) / measured, per batch of the size that ran
@@ -64,7 +64,7 @@ MAX_LOCKSTEP_WINDOWS = 512   # rows of the decode kernels (csrc/kernels.h GEMV_M
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK_TFLOPS = 2500.0    # dense FP16/BF16 MFMA
 MFMA_CLASSES = ("gemmTiled", "attentionEnc")
-PMC_JSON = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc.json" % r) for r in (5, 4, 3)) if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc.json"))
+PMC_JSON = next((p for p in (os.path.join(ROOT, "profiles", "r%02d_pmc.json" % r) for r in (6, 5, 4, 3)) if os.path.exists(p)), os.path.join(ROOT, "profiles", "r04_pmc.json"))
 BCAST_NOTE = {}        # model kind -> what the weight broadcast of this run was (ranks, bytes, seconds, GB/s)
 EMPTY_KERNEL_US = 1.9
 METRIC = "audio-seconds/sec (real-time factor), ggml-medium & large, 30s chunks @1/2/4/8 GPU"

@@ -53,8 +53,8 @@ namespace wh
 					// a number in the options' common range, or the variable is ignored (garbage used to become 0 and re-route kernels silently)
 					char* end = nullptr;
 					const long v = strtol( e, &end, 10 );
-					if( end != e && *end == 0 && v >= -1 && v <= 4096 ) g_opt.*( o.field ) = (int)v;
-					else fprintf( stderr, "[wh] %s='%s' ignored (not an integer in [-1, 4096])\n", env.c_str(), e );
+					if( end != e && *end == 0 && v >= -1 && v <= ( 1 << 24 ) ) g_opt.*( o.field ) = (int)v;
+					else fprintf( stderr, "[wh] %s='%s' ignored (not an integer in [-1, 2^24])\n", env.c_str(), e );
 				}
 			}
 			return true;
@@ -2982,7 +2982,7 @@ int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F32; g.bias = bias; g.res = residual; g.out32 = out;
 	// the same choice the decoder makes: up to 32 rows go to the gemv when K allows it
-	if( M <= GEMV_FUSED_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // more rows: the M-tiled kernel (the op has no notion of a decode step)
+	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // the op-level entry is the decode-step product: up to 512 rows on the weight-streaming kernels
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -2991,7 +2991,7 @@ int wh_op_mul_mat_gelu( void* stream, const void* aF16, const void* wF16, const 
 	if( !bias ) { setError( "mul_mat_gelu: bias is required" ); return WH_E_INVALIDARG; }
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F16_GELU; g.bias = bias; g.out16 = (f16*)outF16;
-	if( M <= GEMV_FUSED_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // more rows: the M-tiled kernel (the op has no notion of a decode step)
+	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // the op-level entry is the decode-step product: up to 512 rows on the weight-streaming kernels
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
 }
 
@@ -3147,7 +3147,7 @@ int wh_debug_set_option( const char* name, int value )
 	for( const OptionName& o : g_optionNames )
 		if( 0 == strcmp( o.name, name ) )
 		{
-			if( value < -1 || value > 4096 ) { setError( std::string( "option '" ) + name + "': value out of range" ); return WH_E_INVALIDARG; }
+			if( value < -1 || value > ( 1 << 24 ) ) { setError( std::string( "option '" ) + name + "': value out of range" ); return WH_E_INVALIDARG; }
 			g_opt.*( o.field ) = value;
 			return 0;
 		}
