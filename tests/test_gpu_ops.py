@@ -175,18 +175,19 @@ def test_flash_attention(batch, heads, T):
                        ("valu-exp", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
                        ("wide", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
                        ("wide-online", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
+                       ("wide-online-fma", binding.TUNE_DEFAULT | binding.TUNE_ATTN_ENC_2SWEEP | binding.TUNE_ATTN_ENC_TABLE | binding.TUNE_ATTN_ENC_TABLE_ANY),
                        ("three-sweep", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_2SWEEP),
                        ("scores-in-registers", binding.TUNE_DEFAULT & ~binding.TUNE_ATTN_ENC_F)):
         L.wh_debug_set_tuning(mask)
         # attentionEncT<0> (the table in LDS) / <1> (v_exp_f32) / attentionEncW<false> (64 query rows per wave) / <true> (one sweep, lazily raised running maximum)
-        binding.set_option("enc_exp", {"valu-exp": 1, "wide": 2, "wide-online": 3}.get(name, 0))
+        binding.set_option("enc_exp", {"valu-exp": 1, "wide": 2, "wide-online": 3, "wide-online-fma": 5}.get(name, 0))
         try:
             out = torch.full((batch, T, heads * D), float("nan"), dtype=torch.float16, device="cuda")
             binding.check(L.wh_op_flash_attention(None, ptr(qd), ptr(kd), ptr(vd), ptr(out), batch, heads, T))
             torch.cuda.synchronize()
         finally:
             L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
-            binding.set_option("enc_exp", 1)
+            binding.set_option("enc_exp", binding.get_option_default("enc_exp"))
         got = out.cpu().numpy().astype(np.float32)
         assert np.isfinite(got).all()
         d = report("flash_attention %s b%d h%d T%d" % (name, batch, heads, T), got, wn.r16(want))
@@ -214,6 +215,12 @@ def test_flash_attention(batch, heads, T):
     print("one-sweep (lazy running maximum) vs two-sweep: max difference %.2e, mean %.2e; against the reference's softmax: max %.2e mean %.2e"
           % (do.max(), do.mean(), np.abs(results["wide-online"] - wn.r16(want)).max(), np.abs(results["wide-online"] - wn.r16(want)).mean()))
     assert do.max() < 4e-3 and do.mean() < 1e-4
+    # ... and the timed default (round 6): the exponential's argument is not rounded to FP16 first (one FMA per score instead of two subtractions, a packed
+    # conversion and two mixed FMAs per pair): each e moves by at most the reference's own argument-rounding error, |x| 2^-11 relative
+    df = np.abs(results["wide-online-fma"] - results["wide-online"])
+    dr = np.abs(results["wide-online-fma"] - wn.r16(want))
+    print("argument not rounded to FP16: vs the rounded form max %.2e mean %.2e; against the reference's softmax max %.2e mean %.2e" % (df.max(), df.mean(), dr.max(), dr.mean()))
+    assert df.max() < 4e-3 and df.mean() < 1.5e-4 and dr.max() < 6e-3 and dr.mean() < 2e-4
 
 
 def test_exp_table_in_the_arena(golden):

@@ -104,17 +104,19 @@ def test_pmc_traffic_covers_the_cited_kernel_classes():
 import pytest  # noqa: E402
 
 
-def _load5():
+def _load5(rnd=5):
     try:
-        line = json.load(open(os.path.join(PROF, "r05_bench.json")))
-        stats = list(csv.DictReader(open(os.path.join(PROF, "r05_kernel_stats.csv"))))
+        line = json.load(open(os.path.join(PROF, "r%02d_bench.json" % rnd)))
+        stats = list(csv.DictReader(open(os.path.join(PROF, "r%02d_kernel_stats.csv" % rnd))))
     except OSError:
-        pytest.skip("profiles/r05_bench.json / r05_kernel_stats.csv not committed yet")
+        pytest.skip("profiles/r%02d_bench.json / r%02d_kernel_stats.csv not committed yet" % (rnd, rnd))
     return line, stats
 
 
-def test_r05_line_structure():
-    line, _ = _load5()
+@pytest.mark.parametrize("rnd", [5, 6])
+def test_r05_line_structure(rnd):
+    """(round 6 keeps the round-5 line's contract and adds to it: see test_r06_line_additions)"""
+    line, _ = _load5(rnd)
     r = line["roofline"]
     m, h = r["mfma_kernel"], r["hbm_kernel"]
     low = m if m["frac"] <= h["frac"] else h
@@ -148,8 +150,9 @@ def test_r05_line_structure():
     assert lv["beam5"]["value"] > 0 and lv["parity"] is not None and lv["cpu_baseline"]["value"] > 0
 
 
-def test_r05_rooflines_recomputed_from_the_rocprof_statistics():
-    line, stats = _load5()
+@pytest.mark.parametrize("rnd", [5, 6])
+def test_r05_rooflines_recomputed_from_the_rocprof_statistics(rnd):
+    line, stats = _load5(rnd)
     r, k = line["roofline"], line["kernels"]
     x = r["hbm_kernel"]
     avg, _ = _avg_us(stats, lambda n: "attentionDecG<" in n and ", true" in n and "<1," in n)
@@ -199,3 +202,21 @@ def test_r05_two_contexts_in_flight_under_the_tracer():
     x = line["roofline"]["hbm_kernel"]
     per_step = x["algorithmic_per_launch"] * x["launches_per_batch_pass"]
     assert per_step / (line["ms_per_step"] * 1e-3) / 1e9 < x["peak"]
+
+
+def test_r06_line_additions():
+    """Round 6: configs[3] and [4] ride in the default line with pass rooflines, beam5 has one, the r04-comparable figure and the step's
+    definition are top-level fields, the counter file is at the timed batch size, and the timed encoder attention is the round's kernel."""
+    line, stats = _load5(6)
+    assert line["value_r04_definition"] == line["small_job"]["value"] and "448 windows" in line["step_definition"]
+    lv = line["large_v2"]
+    for name, obj in (("beam5", lv["beam5"]), ("shard256", lv["shard256"]), ("v3stream", line["v3stream"])):
+        r = obj["roofline"]
+        assert obj["value"] > 0 and r["bound"] == "hbm" and 0 < r["frac"] < 1, name
+        assert abs(r["frac"] - r["floor_ms_per_pass"] / r["measured_ms_per_pass"]) < 2e-3, name
+    assert lv["beam5"]["roofline"]["frac"] < 0.3 < lv["shard256"]["roofline"]["frac"]          # the small batch is the one far from its floor
+    pmc = json.load(open(os.path.join(PROF, "r06_pmc.json")))
+    assert "448 windows" in pmc["note"]
+    m = line["roofline"]["mfma_kernel"]
+    assert abs(m["traffic_over_algorithmic"] - 2.19) < 0.1 and "r06_pmc.json" in m["traffic_source"]
+    assert any("attentionEncW" in x["Name"] for x in stats) and not any("attentionEncT" in x["Name"] for x in stats)

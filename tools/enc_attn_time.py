@@ -28,5 +28,5 @@ for mode, abl in [(m_, 0) for m_ in modes]:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     print("enc_exp %d ablate %d: %.1f us per launch of %d windows = %.0f TFLOP/s = %.3f of 2.5 PF" % (mode, abl, ms * 1e3, batch, flops / ms * 1e-9, flops / ms * 1e-9 / 2500))
-binding.set_option("enc_exp", 1)
+binding.set_option("enc_exp", binding.get_option_default("enc_exp"))
 binding.set_option("enc_ablate", 0)

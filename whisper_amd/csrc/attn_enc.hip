@@ -819,7 +819,7 @@ namespace wh
 		constexpr int W_NBUF = 4;
 		constexpr int W_LDS_BYTES = 2 * W_NBUF * F_TILE * 2;
 		constexpr float W_LAZY = 4.0f;
-		template<int NG, bool ONLINE>
+		template<int NG, bool ONLINE, bool NOARG = false>
 		__global__ void __launch_bounds__( 1024 / NG, NG == 1 ? 4 : 2 ) attentionEncW( const f16* __restrict__ q, const f16* __restrict__ k,
 			const f16* __restrict__ vT, f16* __restrict__ out, int heads, int T, int Tpad, int nQ, int xcdRemap )
 		{
@@ -951,8 +951,18 @@ namespace wh
 	#pragma unroll
 				for( int r = 0; r < 16; r += 2 )
 				{
-					const h2 hd = __builtin_convertvector( f2{ S[ r ] - mref, S[ r + 1 ] - mref }, h2 );
-					const f2 e = { __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hd[ 0 ], L2E, 0.0f ) ), __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hd[ 1 ], L2E, 0.0f ) ) };
+					f2 e;
+					if constexpr( NOARG )
+					{
+						// experiment ("enc_exp" 5): the argument is NOT rounded to FP16 first -- one fused multiply-add per score, s * log2 e - m * log2 e
+						const float mL = mref * L2E;
+						e = f2{ __builtin_amdgcn_exp2f( __builtin_fmaf( S[ r ], L2E, -mL ) ), __builtin_amdgcn_exp2f( __builtin_fmaf( S[ r + 1 ], L2E, -mL ) ) };
+					}
+					else
+					{
+						const h2 hd = __builtin_convertvector( f2{ S[ r ] - mref, S[ r + 1 ] - mref }, h2 );
+						e = f2{ __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hd[ 0 ], L2E, 0.0f ) ), __builtin_amdgcn_exp2f( __builtin_fmaf( (float)hd[ 1 ], L2E, 0.0f ) ) };
+					}
 					const h2 eh = __builtin_convertvector( e, h2 );
 					P[ r >> 3 ][ r & 7 ] = eh[ 0 ];
 					P[ r >> 3 ][ ( r & 7 ) + 1 ] = eh[ 1 ];
@@ -1106,24 +1116,25 @@ namespace wh
 			}
 		}
 
-		template<int NG, bool ONLINE>
+		template<int NG, bool ONLINE, bool NOARG = false>
 		int launchEncWideT( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, hipStream_t stream )
 		{
 			static PerDeviceOnce once;
 			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncW<NG, ONLINE>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionEncW<NG, ONLINE, NOARG>, hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES ) );
 				once.mark( onceDev );
 			}
 			const int nQ = ( T + TQ - 1 ) / TQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
-			hipLaunchKernelGGL( ( attentionEncW<NG, ONLINE> ), dim3( nQ * BH ), dim3( 1024 / NG ), W_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
+			hipLaunchKernelGGL( ( attentionEncW<NG, ONLINE, NOARG> ), dim3( nQ * BH ), dim3( 1024 / NG ), W_LDS_BYTES, stream, q, k, vT, out, heads, T, Tpad, nQ, xcdRemap );
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}
 		// mode (the "enc_exp" option): 2 = two sweeps, 3 = one sweep
 		int launchEncWide( const f16* q, const f16* k, const f16* vT, f16* out, int batch, int heads, int T, int Tpad, int mode, hipStream_t stream )
 		{
+			if( mode == 5 ) return launchEncWideT<2, true, true>( q, k, vT, out, batch, heads, T, Tpad, stream );
 			if( mode == 3 ) return launchEncWideT<2, true>( q, k, vT, out, batch, heads, T, Tpad, stream );
 			return launchEncWideT<2, false>( q, k, vT, out, batch, heads, T, Tpad, stream );
 		}
@@ -1139,7 +1150,7 @@ namespace wh
 			}
 			const int nQ = ( T + TQ - 1 ) / TQ, BH = batch * heads;
 			const int xcdRemap = ( BH % 8 ) == 0 && ( g_tuning & TUNE_ATTN_XCD ) ? 1 : 0;
-			if( g_opt.encExp == 2 || g_opt.encExp == 3 ) return launchEncWide( q, k, vT, out, batch, heads, T, Tpad, g_opt.encExp, stream );
+			if( g_opt.encExp == 2 || g_opt.encExp == 3 || g_opt.encExp == 5 ) return launchEncWide( q, k, vT, out, batch, heads, T, Tpad, g_opt.encExp, stream );
 			if( g_opt.encExp == 1 )
 				hipLaunchKernelGGL( attentionEncT<1>, dim3( nQ * BH ), dim3( 1024 ), T_LDS_BYTES - T_TABLE_HALFS * 2, stream, q, k, vT, out, expTab, heads, T, Tpad, nQ, xcdRemap );
 			else
