@@ -1,5 +1,6 @@
 """What the vendor library reaches on the encoder's product shapes on THIS box (random FP16 operands, FP32 accumulate, plain C = A W^T with no
 epilogue) -- a yardstick for gemmTiled8 (tools/gemm8_probe.py), never part of the product: python tools/hipblaslt_ref.py"""
+import os
 import time
 
 import torch
@@ -9,7 +10,10 @@ SHAPES = [(168000, 1024, 1024), (168000, 3072, 1024), (168000, 4096, 1024), (168
 
 def main():
     torch.manual_seed(0)
-    for (M, N, K) in SHAPES:
+    shapes = SHAPES
+    if os.environ.get("PROBE_SHAPES"):
+        shapes = [tuple(int(x) for x in s.split("x")) for s in os.environ["PROBE_SHAPES"].split(",")]
+    for (M, N, K) in shapes:
         a = (torch.rand((M, K), device="cuda", dtype=torch.float16) - 0.5)
         w = (torch.rand((N, K), device="cuda", dtype=torch.float16) - 0.5)
         for _ in range(2):

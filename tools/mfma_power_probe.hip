@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <type_traits>
 typedef _Float16 f16;
 typedef __attribute__( ( ext_vector_type( 8 ) ) ) _Float16 f16x8;
 typedef __attribute__( ( ext_vector_type( 16 ) ) ) float f32x16;
@@ -71,8 +72,27 @@ __global__ void __launch_bounds__( 256, 2 ) kMix( const f16x8* in, const unsigne
 	unsigned off = ( blockIdx.x * 65536u + wave * 16384u + lane * 16u ) & l2mask;
 	f16x8 fr[ 8 ];
 	for( int i = 0; i < 8; i++ ) fr[ i ] = a[ i & 3 ];
-	for( int it = 0; it < iters; it++ )
+	// MODE & 4: the same 4 KiB per wave and iteration as plain 16-byte loads into registers, written to LDS two iterations later (what a register-staged K loop does)
+	f16x8 st[ 2 ][ 4 ];
+	if constexpr( ( MODE & 4 ) != 0 )
 	{
+		for( int q = 0; q < 2; q++ )
+		{
+			for( int p = 0; p < 4; p++ ) st[ q ][ p ] = *(const f16x8*)( l2buf + ( ( off + p * 1024u ) & l2mask ) );
+			off = ( off + 4096u * 61u ) & l2mask;
+		}
+	}
+	auto iteration = [ & ]( int it, auto parc )
+	{
+		constexpr int PAR = decltype( parc )::value;
+		if constexpr( ( MODE & 4 ) != 0 )
+		{
+#pragma unroll
+			for( int p = 0; p < 4; p++ ) *(f16x8*)( lds + wave * 16384 + ( ( it * 4 + p ) & 15 ) * 1024 + lane * 16 ) = st[ PAR ][ p ];
+#pragma unroll
+			for( int p = 0; p < 4; p++ ) st[ PAR ][ p ] = *(const f16x8*)( l2buf + ( ( off + p * 1024u ) & l2mask ) );
+			off = ( off + 4096u * 61u ) & l2mask;
+		}
 		if constexpr( ( MODE & 1 ) != 0 )
 		{
 #pragma unroll
@@ -95,6 +115,11 @@ __global__ void __launch_bounds__( 256, 2 ) kMix( const f16x8* in, const unsigne
 		for( int i = 0; i < 8; i++ ) c[ i ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( ( MODE & 2 ) ? fr[ i ] : a[ i & 3 ], b[ ( i >> 1 ) & 3 ], c[ i ], 0, 0, 0 );
 #pragma unroll
 		for( int i = 0; i < 8; i++ ) c[ i ] = __builtin_amdgcn_mfma_f32_32x32x16_f16( a[ i & 3 ], ( MODE & 2 ) ? fr[ 7 - i ] : b[ ( i >> 1 ) & 3 ], c[ i ], 0, 0, 0 );
+	};
+	for( int it = 0; it < iters; it += 2 )
+	{
+		iteration( it, std::integral_constant<int, 0>{} );
+		iteration( it + 1, std::integral_constant<int, 1>{} );
 	}
 	asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
 	float s = 0;
@@ -176,6 +201,8 @@ int main()
 	{
 		const double m0 = runMix<0>( dRand, l2buf, out, iters / 4 ), m1 = runMix<1>( dRand, l2buf, out, iters / 4 ), m2 = runMix<2>( dRand, l2buf, out, iters / 4 ), m3 = runMix<3>( dRand, l2buf, out, iters / 4 );
 		printf( "16 MFMAs per iteration, 2048 waves, random: alone %.0f TF | + 4 KiB of LDS-DMA from L2 %.0f | + 8 ds_read_b128 %.0f | + both %.0f\n", m0, m1, m2, m3 );
+		const double m4 = runMix<4>( dRand, l2buf, out, iters / 4 ), m6 = runMix<6>( dRand, l2buf, out, iters / 4 );
+		printf( "   the same 4 KiB as plain loads to registers + ds_write_b128: %.0f TF | + 8 ds_read_b128 %.0f\n", m4, m6 );
 	}
 	return 0;
 }
