@@ -577,12 +577,16 @@ def test_encoder_is_bit_identical_under_the_gemm_variants():
     base = binding.TUNE_DEFAULT & ~(binding.TUNE_GEMM_4WAVE | binding.TUNE_GEMM_FAST_EPI)
     got = []
     try:
-        for mask in (base, base | binding.TUNE_GEMM_FAST_EPI, base | binding.TUNE_GEMM_4WAVE):
+        # (tuning mask, gemm_mf16): the last two are gemmTiled8 with v_mfma_f32_16x16x32_f16 in its K loop (round 6) -- general and lean epilogues.
+        # The matrix cores add a k-block of 8 at a time in both instruction shapes, so even the other MFMA gives the same bits.
+        for mask, mf16 in ((base, 0), (base | binding.TUNE_GEMM_FAST_EPI, 0), (base | binding.TUNE_GEMM_4WAVE, 0), (base, 1), (base | binding.TUNE_GEMM_FAST_EPI, 1)):
             L.wh_debug_set_tuning(mask)
+            binding.set_option("gemm_mf16", mf16)
             ctx.encode(mels)
             got.append([(ctx.debug_read("cross-k", il).copy(), ctx.debug_read("cross-v", il).copy()) for il in (0, hp.n_text_layer // 2, hp.n_text_layer - 1)])
     finally:
         L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+        binding.set_option("gemm_mf16", binding.get_option_default("gemm_mf16"))
     assert np.isfinite(got[0][0][0]).all() and float(np.abs(got[0][0][1]).max()) > 0.1
     for other in got[1:]:
         for (k0, v0), (k1, v1) in zip(got[0], other):

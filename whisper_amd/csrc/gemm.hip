@@ -1094,12 +1094,17 @@ namespace wh
 		}
 
 		// the interior-tile epilogue of both persistent kernels (defined with gemmTiled4 below)
-		template<int EPI, bool HASRES, int FIRST = 0, int LAST = 16, int TJ = 4, bool AGPR = true>
-		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ TJ ], int mW, int nW, int lane, unsigned char* stage );
+		template<int EPI, bool HASRES, int FIRST = 0, int LAST = 16, int TJ = 4, bool AGPR = true, bool L16 = false, typename ACC>
+		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, ACC& acc, int mW, int nW, int lane, unsigned char* stage );
 
-		// MF16 (round 6, experiment): the K loop on v_mfma_f32_16x16x32_f16 (a quadrant = 4 x 2 tiles of 16 x 16, two k-halves of 32; the W fragment stays the
-		// srcB operand of four consecutive instructions) instead of v_mfma_f32_32x32x16_f16; the same LDS image and the same number of fragment reads. The
-		// accumulators are brought into the 32 x 32 register layout through the wave's staging area at the end of a tile, so every epilogue is shared.
+		// MF16 (round 6, the default: option gemm_mf16): the K loop on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 -- a quadrant is 4 x 2 tiles of
+		// 16 x 16 over two k-halves of 32, the W fragment the srcB operand of four consecutive instructions; the same LDS image, the same 24 fragment reads per K
+		// tile, the same 128 accumulator registers. The chip sustains more of this shape under its power limit (tools/mfma_order_probe.hip; the vendor library's
+		// kernel uses it), and the SUMS ARE THE SAME BITS: the matrix cores add a k-block of 8 (one lane's 16 bytes) at a time in both shapes, and both kernels hand
+		// them the k-blocks of a row in the same order (max |diff| = 0 against the 32x32x16 instance on every probed shape; the model-level identity test covers
+		// it). Interior tiles leave through epilogueFast4's L16 form straight from the 16 x 16 tiles; edge tiles and the V third of the encoder's Q/K/V product are
+		// first brought into the 32 x 32 register layout through the wave's staging area (convert16) and take the epilogues written for it.
+		// Measured (profiles/r06_evidence/gemm_vendor_gap.txt): probe +3.4 .. 4.5 % on the encoder's shapes, the class in the model 0.379 -> 0.41 of the MFMA peak.
 		template<int EPI, bool WIDE, bool MF16 = false>
 		__global__ void __launch_bounds__( 512, 2 ) gemmTiled8( const GemmArgs a )
 		{
@@ -1118,7 +1123,7 @@ namespace wh
 			// take consecutive tiles of that range round by round, so the ~32 tiles an XCD has in flight are neighbours in the walk
 			const int tilesM = ( a.M + BM - 1 ) / BM, tilesN = ( a.N + BN - 1 ) / BN;
 			const int nTiles = tilesM * tilesN;
-			const int gm = a.groupM & 255;
+			const int gm = a.groupM;
 			int linFirst, linEnd, linStep;
 			{
 				const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -1127,11 +1132,6 @@ namespace wh
 				linEnd = start + ( xcd < r ? q + 1 : q );
 				linFirst = start + idx;
 				linStep = ( gridDim.x + 7 - xcd ) >> 3;	   // workgroups of this XCD
-				// (experiment, WH_GEMM_STAGGER) the XCD's column groups (the groupM workgroups that share a W tile) and / or the XCDs start a fraction of a tile apart,
-				// so that the chip's epilogues -- matrix pipes idle, stores draining -- do not coincide: bits 8..11 of groupM = s_sleep 127 per column group, 12..15 = per XCD
-				const int perGroup = ( a.groupM >> 8 ) & 15, perXcd = ( a.groupM >> 12 ) & 15;
-				const int naps = perGroup * ( ( idx / max( gm, 1 ) ) & 7 ) + perXcd * xcd;
-				for( int i = 0; i < naps; i++ ) __builtin_amdgcn_s_sleep( 127 );
 			}
 			auto tileCoords = [ & ]( int lin, int& tm, int& tn )
 			{
@@ -1377,33 +1377,37 @@ namespace wh
 					stageFirst();	  // lands under the epilogue below
 				}
 
-				if constexpr( MF16 )
+				auto convert16 = [ & ]()
 				{
-					// 16 x 16 tiles -> the 32 x 32 register layout every epilogue is written for, one 32 x 32 block at a time through the wave's 4 KiB
-					// (a wave's LDS operations execute in order: no wait between the writes, the reads and the next block's writes)
-					float* const st = (float*)( smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
-					const int q = lane >> 4, c16 = lane & 15, hi = lane >> 5, cl = lane & 31;
-	#pragma unroll
-					for( int i = 0; i < 4; i++ )
-	#pragma unroll
-						for( int j = 0; j < 2; j++ )
-						{
-	#pragma unroll
-							for( int ti = 0; ti < 2; ti++ )
-	#pragma unroll
-								for( int tj = 0; tj < 2; tj++ )
-	#pragma unroll
-									for( int r = 0; r < 4; r++ ) st[ ( 16 * ti + 4 * q + r ) * 32 + 16 * tj + c16 ] = acc16[ 2 * i + ti ][ 2 * j + tj ][ r ];
-							__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-							__builtin_amdgcn_wave_barrier();
-							__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-	#pragma unroll
-							for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = st[ ( ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi ) * 32 + cl ];
-							__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-							__builtin_amdgcn_wave_barrier();
-							__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-						}
-				}
+					if constexpr( MF16 )
+					{
+						// 16 x 16 tiles -> the 32 x 32 register layout the general epilogues are written for (edge tiles, V tiles), one 32 x 32 block at a time through
+						// the wave's 4 KiB (a wave's LDS operations execute in order: no wait between the writes, the reads and the next block's writes)
+						float* const st = (float*)( smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE );
+						const int q = lane >> 4, c16 = lane & 15, hi = lane >> 5, cl = lane & 31;
+		#pragma unroll
+						for( int i = 0; i < 4; i++ )
+		#pragma unroll
+							for( int j = 0; j < 2; j++ )
+							{
+		#pragma unroll
+								for( int ti = 0; ti < 2; ti++ )
+		#pragma unroll
+									for( int tj = 0; tj < 2; tj++ )
+		#pragma unroll
+										for( int r = 0; r < 4; r++ ) st[ ( 16 * ti + 4 * q + r ) * 32 + 16 * tj + c16 ] = acc16[ 2 * i + ti ][ 2 * j + tj ][ r ];
+								__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+								__builtin_amdgcn_wave_barrier();
+								__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+		#pragma unroll
+								for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = st[ ( ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi ) * 32 + cl ];
+								__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
+								__builtin_amdgcn_wave_barrier();
+								__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
+							}
+
+					}
+				};
 
 				bool direct = !WIDE;
 				bool fastDone = false;
@@ -1416,7 +1420,19 @@ namespace wh
 					if( a.wideEpi == 2 && !isV && ( tmDone + 1 ) * BM <= a.M && ( tnDone + 1 ) * BN <= a.N )
 					{
 						unsigned char* const stage = smem + C::EPI_OFFSET + wave * C::EPI_PER_WAVE;
-						if constexpr( EPI == EPI_F32 )
+						if constexpr( MF16 )
+						{
+							if constexpr( EPI == EPI_F32 )
+							{
+								if( a.res )
+									epilogueFast4<EPI, true, 0, 16, 2, false, true>( a, acc16, mW, nW, lane, stage );
+								else
+									epilogueFast4<EPI, false, 0, 16, 2, false, true>( a, acc16, mW, nW, lane, stage );
+							}
+							else
+								epilogueFast4<EPI, false, 0, 16, 2, false, true>( a, acc16, mW, nW, lane, stage );
+						}
+						else if constexpr( EPI == EPI_F32 )
 						{
 							if( a.res )
 								epilogueFast4<EPI, true, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
@@ -1427,6 +1443,10 @@ namespace wh
 							epilogueFast4<EPI, false, 0, 16, 2, false>( a, acc, mW, nW, lane, stage );
 						fastDone = true;
 					}
+				}
+				if constexpr( MF16 )
+				{
+					if( !fastDone ) convert16();
 				}
 				if( fastDone )
 				{
@@ -1531,8 +1551,11 @@ namespace wh
 		//     rows cross at most one boundary (segments are at least 128 rows long).
 		// Same arithmetic per element as tileEpilogue / epilogueBlock32x64 (bit-identical outputs).
 		// TJ = MFMA tiles per wave in N: 4 (gemmTiled4: 128 x 128 per wave) or 2 (gemmTiled8: 128 x 64); AGPR = the accumulators are read as assembly (gemmTiled4)
-		template<int EPI, bool HASRES, int FIRST, int LAST, int TJ, bool AGPR>
-		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, f32x16 ( &acc )[ 4 ][ TJ ], int mW, int nW, int lane, unsigned char* stage )
+		// L16 (round 6): acc is f32x4[ 8 ][ 2 TJ ], the tiles of v_mfma_f32_16x16x32_f16 (lane l: column l & 15, rows 4 (l >> 4) .. + 3 of a 16 x 16 tile). Only the
+		// column-wise writes into the staging area differ: a unit is the same 32 rows x 128 bytes, everything behind the LDS round trip is shared. The four row
+		// groups of a tile (l >> 4) would meet in the same banks, so the 16-byte chunk index is XORed with a function of the row on both sides of the round trip.
+		template<int EPI, bool HASRES, int FIRST, int LAST, int TJ, bool AGPR, bool L16, typename ACC>
+		__device__ __forceinline__ void epilogueFast4( const GemmArgs& a, ACC& acc, int mW, int nW, int lane, unsigned char* stage )
 		{
 			static_assert( EPI == EPI_F32 || EPI == EPI_F16_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV, "fast epilogue" );
 			constexpr bool F32OUT = EPI == EPI_F32;
@@ -1542,9 +1565,18 @@ namespace wh
 			// (opaque copy: what follows is a few VALU instructions per tile; hoisted out of the tile loop it would live in scratch)
 			asm volatile( "" : "+v"( lane ) );
 			const int hi = lane >> 5, cl = lane & 31, rl = lane >> 3, ch = lane & 7;
-			float bias[ TJ ];
+			const int q16 = lane >> 4, c16 = lane & 15;
+			float bias[ L16 ? 2 * TJ : TJ ];
+			if constexpr( L16 )
+			{
 	#pragma unroll
-			for( int j = 0; j < TJ; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
+				for( int j = 0; j < 2 * TJ; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 16 * j + c16 ] : 0.0f;
+			}
+			else
+			{
+	#pragma unroll
+				for( int j = 0; j < TJ; j++ ) bias[ j ] = a.bias ? a.bias[ nW + 32 * j + cl ] : 0.0f;
+			}
 
 			// ---- rows (wave-uniform): segment length, position of the tile's first row in its segment, byte offset of that row
 			int seg, segPos;
@@ -1615,7 +1647,53 @@ namespace wh
 			auto writeUnit = [ & ]( auto kc )
 			{
 				constexpr int k = decltype( kc )::value;
-				if constexpr( F32OUT )
+				if constexpr( L16 )
+				{
+					// row R = 16 ti + 4 q + r of the unit; its chunk index is XORed with swz( R ) = ((R >> 2) & 1) << 2 (FP32: eight 4-column chunks per row) or
+					// ((R >> 2) & 3) << 1 (FP16: eight 8-column chunks); (R >> 2) & 3 = q for every ti and r
+					if constexpr( F32OUT )
+					{
+						constexpr int i = k / TJ, j = k % TJ;
+						const int sw = ( q16 & 1 ) << 2;
+	#pragma unroll
+						for( int ti = 0; ti < 2; ti++ )
+	#pragma unroll
+							for( int tj = 0; tj < 2; tj++ )
+	#pragma unroll
+								for( int r = 0; r < 4; r++ )
+								{
+									const int row = 16 * ti + 4 * q16 + r;
+									const int chunk = ( 4 * tj + ( c16 >> 2 ) ) ^ sw;
+									*(float*)( stage + row * 128 + chunk * 16 + ( c16 & 3 ) * 4 ) = acc[ 2 * i + ti ][ 2 * j + tj ][ r ] + bias[ 2 * j + tj ];
+								}
+					}
+					else
+					{
+						constexpr int i = k / JP, jp = k % JP;
+						const int sw = q16 << 1;
+	#pragma unroll
+						for( int ti = 0; ti < 2; ti++ )
+	#pragma unroll
+							for( int tj = 0; tj < 4; tj++ )
+	#pragma unroll
+								for( int r = 0; r < 4; r++ )
+								{
+									const int row = 16 * ti + 4 * q16 + r;
+									const int chunk = ( 2 * tj + ( c16 >> 3 ) ) ^ sw;
+									const float v = acc[ 2 * i + ti ][ 4 * jp + tj ][ r ];
+									const float b = bias[ 4 * jp + tj ];
+									f16 hv;
+									if constexpr( EPI == EPI_F16_GELU )
+										hv = gelu16( v + b );
+									else if constexpr( EPI == EPI_QKV_ENC )
+										hv = (f16)( v + b );
+									else
+										hv = sel ? (f16)( v + b ) : (f16)( v * a.scale );
+									*(f16*)( stage + row * 128 + chunk * 16 + ( c16 & 7 ) * 2 ) = hv;
+								}
+					}
+				}
+				else if constexpr( F32OUT )
 				{
 					constexpr int i = k / TJ, j = k % TJ;
 	#pragma unroll
@@ -1677,7 +1755,16 @@ namespace wh
 			auto readUnit = [ & ]( f32x4( &dv )[ 4 ] )
 			{
 	#pragma unroll
-				for( int it = 0; it < 4; it++ ) dv[ it ] = *(const f32x4*)( stage + ( it * 8 + rl ) * 128 + ch * 16 );
+				for( int it = 0; it < 4; it++ )
+				{
+					int chunk = ch;
+					if constexpr( L16 )
+					{
+						const int row = it * 8 + rl;
+						chunk = F32OUT ? ( ch ^ ( ( ( row >> 2 ) & 1 ) << 2 ) ) : ( ch ^ ( ( ( row >> 2 ) & 3 ) << 1 ) );
+					}
+					dv[ it ] = *(const f32x4*)( stage + ( it * 8 + rl ) * 128 + chunk * 16 );
+				}
 			};
 			auto storeUnit = [ & ]( auto kc, const f32x4( &dv )[ 4 ], const f32x4( &ex )[ 4 ] )
 			{
@@ -1810,12 +1897,7 @@ namespace wh
 		// SCH (probe builds; 0 = the instance that ships; all give correct results): 1 = the DMA pieces of a K tile spread 3 / 3 / 2 over three
 		// substeps (else 4 / 4 over two), 2 = the compiler's own order inside a chunk, 4 = 2 fragment reads per chunk instead of 4 + 4 + 0 + 0,
 		// 16384 = no early W pieces / counted wait after the epilogue
-		// MF16 (round 6): the K loop on v_mfma_f32_16x16x32_f16, a wave's 128 x 128 as 8 x 8 tiles of 16 x 16, one A fragment the srcA operand of EIGHT consecutive
-		// instructions (the order of the vendor library's kernel; tools/mfma_order_probe.hip: 1860 against 1630 TFLOP/s for nothing but MFMAs on random data, one wave per
-		// SIMD). A K tile is two k-halves of 32 = four substeps of 4 chunks x 8 MFMAs; the 16 fragments of the next half are read under the first two chunks of each
-		// substep; the barrier sits in the MIDDLE of a K tile (all of its fragments are in registers once half 0 has been issued) and the 8 DMA pairs of the K tile after
-		// next go out behind the chunks of substeps 2 and 3 -- all of them before the tile's epilogue, so no K tile position needs a schedule of its own.
-		template<int EPI, bool WIDE, int SCH = 0, bool MF16 = false>
+		template<int EPI, bool WIDE, int SCH = 0>
 		__global__ void __launch_bounds__( 256, 1 ) gemmTiled4( const GemmArgs a )
 		{
 			using C = Cfg4;
@@ -1933,12 +2015,6 @@ namespace wh
 			auto dmaAfter = [ & ]( auto sc, auto cc, auto posc )
 			{
 				constexpr int s = decltype( sc )::value, c = decltype( cc )::value, pos = decltype( posc )::value;
-				if constexpr( MF16 )
-				{
-					if constexpr( s == 2 ) dmaA( cc );
-					if constexpr( s == 3 ) dmaW( cc );
-					return;
-				}
 				if constexpr( ( SCH & 1 ) == 0 && ( SCH & 16384 ) == 0 )
 				{
 					if constexpr( pos == 1 && s == 0 ) return;
@@ -1967,36 +2043,14 @@ namespace wh
 				aAddr[ ks ] = (unsigned)( wr * 128 * 128 ) + laneK;
 				wAddr[ ks ] = (unsigned)( C::A_BYTES + wc * 128 * 128 ) + laneK;
 			}
-			// MF16: lane l reads row l & 15 of a 16-row tile, logical chunk 4 h + (l >> 4) of k-half h, stored at chunk ^ ((row >> 1) & 7)
-			unsigned aAddr16[ 2 ], wAddr16[ 2 ];
-	#pragma unroll
-			for( int h = 0; h < 2; h++ )
-			{
-				const unsigned laneK = (unsigned)( ( lane & 15 ) * 128 + ( ( ( ( h << 2 ) + ( lane >> 4 ) ) ^ ( ( lane >> 1 ) & 7 ) ) << 4 ) );
-				aAddr16[ h ] = (unsigned)( wr * 128 * 128 ) + laneK;
-				wAddr16[ h ] = (unsigned)( C::A_BYTES + wc * 128 * 128 ) + laneK;
-			}
 			f32x16 acc[ 4 ][ 4 ];
-			f32x4 acc16[ MF16 ? 8 : 1 ][ MF16 ? 8 : 1 ];
-			if constexpr( !MF16 )
-			{
 	#pragma unroll
-				for( int i = 0; i < 4; i++ )
+			for( int i = 0; i < 4; i++ )
 	#pragma unroll
-					for( int j = 0; j < 4; j++ )
+				for( int j = 0; j < 4; j++ )
 	#pragma unroll
-						for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
-			}
-			else
-			{
-	#pragma unroll
-				for( int i = 0; i < 8; i++ )
-	#pragma unroll
-					for( int j = 0; j < 8; j++ )
-	#pragma unroll
-						for( int r = 0; r < 4; r++ ) acc16[ i ][ j ][ r ] = 0.0f;
-			}
-			f16x8 fa[ 2 ][ MF16 ? 8 : 4 ], fb[ 2 ][ MF16 ? 8 : 4 ];
+					for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = 0.0f;
+			f16x8 fa[ 2 ][ 4 ], fb[ 2 ][ 4 ];
 			// One substep (index s of its K tile) = four chunks of 4 MFMAs (A row tile c x the four W tiles) from register set SET; the
 			// fragments of the NEXT substep (k-substep ksNext of the buffer at bufOff) go to set SET ^ 1: the W fragments with chunk 0,
 			// the A fragments with chunk 1, so that every read has at least 8 MFMAs (256 matrix-pipe cycles) to come back. Nothing
@@ -2069,59 +2123,6 @@ namespace wh
 				chunk( std::integral_constant<int, 2>{} );
 				chunk( std::integral_constant<int, 3>{} );
 			};
-			// MF16: substep s of a K tile = k-half s >> 1, A row tiles 4 (s & 1) .. + 3, one chunk of 8 MFMAs per row tile; fragment set = the k-half. The fragments of
-			// the NEXT half (the other set; from the buffer at bufOff) come in under chunks 0 and 1: the 8 W fragments in an even substep, the 8 A fragments in an odd one
-			auto substep16 = [ & ]( auto sc, auto zeroc, auto posc, unsigned bufOff )
-			{
-				constexpr int s = decltype( sc )::value;
-				constexpr int SET = s >> 1, ODD = s & 1;
-				constexpr bool ZERO = decltype( zeroc )::value;
-				const unsigned char* const pn = smem + bufOff + ( ODD ? aAddr16[ SET ^ 1 ] : wAddr16[ SET ^ 1 ] );
-				auto chunk = [ & ]( auto cc )
-				{
-					constexpr int c = decltype( cc )::value;
-					constexpr int i = 4 * ODD + c;
-					if constexpr( c < 2 )
-					{
-	#pragma unroll
-						for( int k = 0; k < 4; k++ )
-						{
-							if constexpr( ODD )
-								fa[ SET ^ 1 ][ 4 * c + k ] = *(const f16x8*)( pn + ( 4 * c + k ) * 2048 );
-							else
-								fb[ SET ^ 1 ][ 4 * c + k ] = *(const f16x8*)( pn + ( 4 * c + k ) * 2048 );
-						}
-					}
-	#pragma unroll
-					for( int j = 0; j < 8; j++ )
-					{
-						if constexpr( ZERO )
-						{
-							const f32x4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
-							acc16[ i ][ j ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fa[ SET ][ i ], fb[ SET ][ j ], z, 0, 0, 0 );
-						}
-						else
-							acc16[ i ][ j ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fa[ SET ][ i ], fb[ SET ][ j ], acc16[ i ][ j ], 0, 0, 0 );
-					}
-					if constexpr( c < 2 )
-					{
-						// two MFMAs, then a read behind them
-	#pragma unroll
-						for( int k = 0; k < 4; k++ )
-						{
-							__builtin_amdgcn_sched_group_barrier( 0x008, 2, 0 );
-							__builtin_amdgcn_sched_group_barrier( 0x100, 1, 0 );
-						}
-					}
-					__builtin_amdgcn_sched_barrier( 0 );
-					dmaAfter( sc, cc, posc );
-					__builtin_amdgcn_sched_barrier( 0 );
-				};
-				chunk( std::integral_constant<int, 0>{} );
-				chunk( std::integral_constant<int, 1>{} );
-				chunk( std::integral_constant<int, 2>{} );
-				chunk( std::integral_constant<int, 3>{} );
-			};
 			using S0 = std::integral_constant<int, 0>;
 			using S1 = std::integral_constant<int, 1>;
 			using P0 = std::integral_constant<int, 0>;
@@ -2141,24 +2142,6 @@ namespace wh
 			auto kTile = [ & ]( auto zeroc, auto posc )
 			{
 				constexpr int pos = decltype( posc )::value;
-				if constexpr( MF16 )
-				{
-					substep16( P0{}, zeroc, posc, bufOff );
-					substep16( P1{}, zeroc, posc, bufOff );
-					// every fragment of this buffer is in registers (or on its way: lgkmcnt) and this wave's pieces of the next K tile must have landed
-					if( pos == 1 && postEpi >= 63 )
-						asm volatile( "s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory" );
-					else if( pos == 1 && postEpi >= 32 )
-						asm volatile( "s_waitcnt vmcnt(32) lgkmcnt(0)" ::: "memory" );
-					else
-						asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
-					WH_BAR();
-					advanceProducer( bufOff );
-					bufOff ^= (unsigned)C::STAGE_BYTES;
-					substep16( P2{}, ZN{}, posc, bufOff );
-					substep16( P3{}, ZN{}, posc, bufOff );
-					return;
-				}
 				substep( P0{}, S0{}, zeroc, posc, bufOff, 1 );
 				substep( P1{}, S1{}, ZN{}, posc, bufOff, 2 );
 				// substep 2; then every fragment of this buffer is in registers and this wave's pieces of the next K tile must have landed
@@ -2202,12 +2185,12 @@ namespace wh
 						if constexpr( EPI == EPI_F32 )
 						{
 							if( a.res )
-								epilogueFast4<EPI, true, 0, 16, 4, !MF16>( a, acc, mW, nW, lane, stage );
+								epilogueFast4<EPI, true>( a, acc, mW, nW, lane, stage );
 							else
-								epilogueFast4<EPI, false, 0, 16, 4, !MF16>( a, acc, mW, nW, lane, stage );
+								epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
 						}
 						else
-							epilogueFast4<EPI, false, 0, 16, 4, !MF16>( a, acc, mW, nW, lane, stage );
+							epilogueFast4<EPI, false>( a, acc, mW, nW, lane, stage );
 						postEpi = EPI == EPI_F32 ? 64 : 32;
 						return;
 					}
@@ -2273,20 +2256,10 @@ namespace wh
 				dmaW( Q2{} );
 				dmaW( Q3{} );
 			}
-			if constexpr( MF16 )
-			{
 	#pragma unroll
-				for( int i = 0; i < 8; i++ ) fa[ 0 ][ i ] = *(const f16x8*)( smem + aAddr16[ 0 ] + i * 2048 );
+			for( int i = 0; i < 4; i++ ) fa[ 0 ][ i ] = *(const f16x8*)( smem + aAddr[ 0 ] + i * 4096 );
 	#pragma unroll
-				for( int j = 0; j < 8; j++ ) fb[ 0 ][ j ] = *(const f16x8*)( smem + wAddr16[ 0 ] + j * 2048 );
-			}
-			else
-			{
-	#pragma unroll
-				for( int i = 0; i < 4; i++ ) fa[ 0 ][ i ] = *(const f16x8*)( smem + aAddr[ 0 ] + i * 4096 );
-	#pragma unroll
-				for( int j = 0; j < 4; j++ ) fb[ 0 ][ j ] = *(const f16x8*)( smem + wAddr[ 0 ] + j * 4096 );
-			}
+			for( int j = 0; j < 4; j++ ) fb[ 0 ][ j ] = *(const f16x8*)( smem + wAddr[ 0 ] + j * 4096 );
 			__builtin_amdgcn_sched_barrier( 0 );
 
 			using KM = std::integral_constant<int, 0>;
@@ -2301,34 +2274,6 @@ namespace wh
 				int tm, tn;
 				tileCoords( lin, tm, tn );
 				asm volatile( "s_nop 15\n\ts_nop 15" ::: "memory" );	   // the last MFMA's 16 passes are over before the first accumulator is read
-				if constexpr( MF16 )
-				{
-					// (experiment) 16 x 16 tiles -> the 32 x 32 register layout of the epilogues, a 32 x 32 block at a time through the wave's 4 KiB
-					float* const st = (float*)stage;
-					int laneC = lane;
-					asm volatile( "" : "+v"( laneC ) );
-					const int q = laneC >> 4, c16 = laneC & 15, hi = laneC >> 5, cl = laneC & 31;
-	#pragma unroll
-					for( int i = 0; i < 4; i++ )
-	#pragma unroll
-						for( int j = 0; j < 4; j++ )
-						{
-	#pragma unroll
-							for( int ti = 0; ti < 2; ti++ )
-	#pragma unroll
-								for( int tj = 0; tj < 2; tj++ )
-	#pragma unroll
-									for( int r = 0; r < 4; r++ ) st[ ( 16 * ti + 4 * q + r ) * 32 + 16 * tj + c16 ] = acc16[ 2 * i + ti ][ 2 * j + tj ][ r ];
-							__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-							__builtin_amdgcn_wave_barrier();
-							__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-	#pragma unroll
-							for( int r = 0; r < 16; r++ ) acc[ i ][ j ][ r ] = st[ ( ( r & 3 ) + 8 * ( r >> 2 ) + 4 * hi ) * 32 + cl ];
-							__builtin_amdgcn_fence( __ATOMIC_RELEASE, "wavefront" );
-							__builtin_amdgcn_wave_barrier();
-							__builtin_amdgcn_fence( __ATOMIC_ACQUIRE, "wavefront" );
-						}
-				}
 				epilogue( tm, tn, lin + linStep >= linEnd );
 				lin += linStep;
 				if( lin >= linEnd ) break;
@@ -3336,13 +3281,11 @@ namespace wh
 			}
 		}
 		b.wideEpi = wide ? 1 : 0;
-		static const int staggerEnv = []() { const char* e = getenv( "WH_GEMM_STAGGER" ); const int v = e ? atoi( e ) : 0; return v >= 0 && v <= 255 ? v : 0; }();
-		b.groupM = ( b.groupM & 255 ) | ( staggerEnv << 8 );
 		if( wide && ( g_tuning & TUNE_GEMM_FAST_EPI ) && ( EPI != EPI_QKV_ENC || ( a.T % 4 ) == 0 ) && fastEpilogueOk<EPI>( a ) ) b.wideEpi = 2;
 		return wide ? launchTiled8K<EPI, true, MF16>( b, stream ) : launchTiled8K<EPI, false, MF16>( b, stream );
 	}
 
-	template<int EPI, bool WIDE, int SCH = 0, bool MF16 = false>
+	template<int EPI, bool WIDE, int SCH = 0>
 	static int launchTiled4K( const GemmArgs& b, hipStream_t stream )
 	{
 		static PerDeviceOnce once;
@@ -3351,7 +3294,7 @@ namespace wh
 		if( hipGetDevice( &dev ) != hipSuccess ) dev = 0;
 		if( const int onceDev = once.needed(); onceDev >= 0 )
 		{
-			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled4<EPI, WIDE, SCH, MF16>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg4::LDS_BYTES ) );
+			WH_HIP( hipFuncSetAttribute( (const void*)gemmTiled4<EPI, WIDE, SCH>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg4::LDS_BYTES ) );
 			int cus = 0;
 			WH_HIP( hipDeviceGetAttribute( &cus, hipDeviceAttributeMultiprocessorCount, dev ) );
 			cusOfDevice[ onceDev ] = cus;
@@ -3362,13 +3305,13 @@ namespace wh
 		int cus = cusOfDevice[ dev & 63 ] > 0 ? cusOfDevice[ dev & 63 ] : 256;
 		if( b.cuLimit > 0 && b.cuLimit < cus ) cus = b.cuLimit;
 		const int grid = tilesM * tilesN < cus ? tilesM * tilesN : cus;
-		hipLaunchKernelGGL( ( gemmTiled4<EPI, WIDE, SCH, MF16> ), dim3( grid ), dim3( Cfg4::NT ), Cfg4::LDS_BYTES, stream, b );
+		hipLaunchKernelGGL( ( gemmTiled4<EPI, WIDE, SCH> ), dim3( grid ), dim3( Cfg4::NT ), Cfg4::LDS_BYTES, stream, b );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
 
 	// the 4-wave 256x256x64 kernel; preconditions of the LDS-transposed epilogue as launchTiled8, plus T % 4 == 0 for the V columns of the encoder's Q/K/V product
-	template<int EPI, int SCH = 0, bool MF16 = false>
+	template<int EPI, int SCH = 0>
 	static int launchTiled4( const GemmArgs& a, hipStream_t stream )
 	{
 		GemmArgs b = a;
@@ -3390,7 +3333,7 @@ namespace wh
 		}
 		b.wideEpi = wide ? 1 : 0;
 		if( wide && fastEpilogueOk<EPI>( a ) ) b.wideEpi = 2;
-		return wide ? launchTiled4K<EPI, true, SCH, MF16>( b, stream ) : launchTiled4K<EPI, false, SCH, MF16>( b, stream );
+		return wide ? launchTiled4K<EPI, true, SCH>( b, stream ) : launchTiled4K<EPI, false, SCH>( b, stream );
 	}
 
 	// Tile-shape experiments on the plain FP32 epilogue (tools/gemm_probe.py): variant -> configuration
@@ -3399,7 +3342,6 @@ namespace wh
 		switch( variant )
 		{
 		case 40: return launchTiled8<EPI_F32>( a, stream );	   // the 8-wave persistent kernel (round 3)
-		case 53: return launchTiled4<EPI_F32, 0, true>( a, stream );	   // gemmTiled4 with v_mfma_f32_16x16x32_f16, A-stationary runs of 8 (round 6)
 		case 52: return launchTiled8<EPI_F32, true>( a, stream );	   // the same with v_mfma_f32_16x16x32_f16 in the K loop (round 6)
 		case 50: return launchTiled4<EPI_F32>( a, stream );	   // the 4-wave persistent kernel (round 4)
 		case 25: return launchTiledT<EPI_F32, TileCfg<256, 256, 64, 4, 1, true, 2, 2, 2, 1>>( a, stream );	   // the 16-wave kernel of round 2 (products below gemmTiled8's threshold)
@@ -3488,6 +3430,7 @@ namespace wh
 			( a.Mb <= 0 || a.Mb >= a.M || ( a.Mb >= 256 && a.aBatchStride >= (long long)a.Mb * a.lda ) );
 #define WH_TILED( E )                                                    \
 	if( w4 ) return launchTiled4<E>( a, stream );                        \
+	if( w8 && g_opt.gemmMf16 == 1 ) return launchTiled8<E, true>( a, stream ); \
 	if( w8 ) return launchTiled8<E>( a, stream );                        \
 	if( pf && big ) return launchTiledT<E, CfgGlBigPf>( a, stream );     \
 	if( pf ) return launchTiledT<E, CfgGlPf>( a, stream );               \

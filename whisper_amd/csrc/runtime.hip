@@ -40,7 +40,7 @@ namespace wh
 	{
 		struct OptionName { const char* name; int Options::* field; };
 		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
-			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate } };
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
 		{
@@ -3243,7 +3243,8 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 			WH_HIP( hipMemsetAsync( diff, 0, 4, st ) );
 			GemmArgs g2 = plainGemm( (const f16*)A, (const f16*)W, M, N, K );
 			g2.epi = EPI_F32; g2.out32 = (float*)ref;
-			rc = launchGemmVariant( g2, 2, st );	   // the register-staged 128x128x32 kernel: shares no staging or scheduling code with the variants under test
+			static const int refVariant = []() { const char* e = getenv( "WH_PROBE_REF" ); return e ? atoi( e ) : 2; }();
+			rc = launchGemmVariant( g2, refVariant, st );	   // 2 = the register-staged 128x128x32 kernel: shares no staging or scheduling code with the variants under test
 			if( rc == 0 )
 			{
 				hipLaunchKernelGGL( probeMaxDiff, dim3( 2048 ), dim3( 256 ), 0, st, (const float*)out, (const float*)ref, (long long)M * N, diff );
@@ -3252,6 +3253,7 @@ int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, i
 				WH_HIP( hipStreamSynchronize( st ) );
 				float md;
 				memcpy( &md, &bits, 4 );
+				if( getenv( "WH_PROBE_REF" ) ) fprintf( stderr, "[gemm probe] variant %d against variant %d, %d x %d x %d: max |diff| = %g\n", variant, refVariant, M, N, K, (double)md );
 				if( !( md <= 1e-3f ) )
 				{
 					char buf[ 160 ];
