@@ -2911,6 +2911,48 @@ namespace wh
 					*(f16x4*)( a.out16 + (long long)mm * a.ldc + nn ) = hv;
 					continue;
 				}
+				if constexpr( EPI == EPI_QKV_DEC )
+				{
+					// the arithmetic of epilogueOne<EPI_QKV_DEC> on the lane's four consecutive columns (one head, one of Q / K / V: d and HEAD_DIM are multiples of 4),
+					// leaving as ONE 8-byte store: one pair of divisions and one position load per lane instead of four, a quarter of the store instructions
+					if( ( a.N & 3 ) == 0 )
+					{
+						const int d = a.H * HEAD_DIM;
+						const int sel = nn / d;
+						const int c = nn - sel * d;
+						f16x4 hv;
+						f16* dst;
+						if( sel == 0 )
+						{
+							const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+							for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( ( part[ i ][ r ] + bv[ r ] ) * a.scale );
+							dst = a.q + (long long)mm * d + c;
+						}
+						else
+						{
+							const int h = c >> 6, dd = c & 63;
+							const int b = mm / a.nTok;
+							const int pos = ( a.nPastDev ? a.nPastDev[ b ] : a.nPast ) + ( mm - b * a.nTok );
+							const long long o = ( ( (long long)b * a.H + h ) * a.textCtx + pos ) * HEAD_DIM + dd;
+							if( sel == 1 )
+							{
+	#pragma unroll
+								for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( part[ i ][ r ] * a.scale );
+								dst = a.k + o;
+							}
+							else
+							{
+								const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+								for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( part[ i ][ r ] + bv[ r ] );
+								dst = a.v + o;
+							}
+						}
+						*(f16x4*)dst = hv;
+						continue;
+					}
+				}
 	#pragma unroll
 				for( int r = 0; r < 4; r++ )
 					if( nn + r < a.N ) epilogueOne<EPI>( a, mm, nn + r, part[ i ][ r ] );
