@@ -23,8 +23,10 @@ def main():
         res = torch.randn((M, N), device="cuda")
         out = torch.zeros((M, N), device="cuda")
         row = []
-        for label, mask in (("default", binding.TUNE_DEFAULT), ("gemv64", binding.TUNE_DEFAULT & ~(binding.TUNE_GEMV_ALLROWS | binding.TUNE_GEMV_ROWGROUPS))):
+        outs = {}
+        for label, mask in (("dec_lds 0", binding.TUNE_DEFAULT), ("dec_lds 1", binding.TUNE_DEFAULT)):
             L.wh_debug_set_tuning(mask)
+            binding.set_option("dec_lds", int(label[-1]))
             iters = 200 if N < 10000 else 40
             for i in range(8):
                 L.wh_op_mul_mat(None, p(a), p(w[i % pool]), p(bias), p(res), p(out), M, N, K)
@@ -37,7 +39,12 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters
             row.append("%s %.1f us (%.0f GB/s)" % (label, us, N * K * 2 / us / 1e3))
+            L.wh_op_mul_mat(None, p(a), p(w[0]), p(bias), p(res), p(out), M, N, K)
+            torch.cuda.synchronize()
+            outs[label] = out.clone()
         L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
+        binding.set_option("dec_lds", binding.get_option_default("dec_lds"))
+        row.append("same bits: %s (max diff %.2e)" % (bool(torch.equal(outs["dec_lds 0"], outs["dec_lds 1"])), float((outs["dec_lds 0"] - outs["dec_lds 1"]).abs().max())))
         print("M=%d %-9s N=%5d K=%4d  %s" % (M, name, N, K, " | ".join(row)), flush=True)
 
 

@@ -2759,6 +2759,102 @@ namespace wh
 		}
 
 		// -----------------------------------------------------------------------------------------------------------
+		// The epilogue of the decode-rows kernels: group g = wave + NW i of the workgroup's MT x CT tiles of 16 x 16 is in part[ i ] -- D[row][col]: col = lane & 15 =
+		// activation row of the tile, row = (lane >> 4) * 4 + r = weight row slot (four consecutive output columns of one activation row per lane)
+		template<int EPI, int MT, int CT, int NW>
+		__device__ __forceinline__ void decRowsEpilogue( const GemmArgs& a, const f32x4 ( &part )[ ( MT * CT + NW - 1 ) / NW ], int m0, int n0, int wave, int lane )
+		{
+			constexpr int G = MT * CT;
+			constexpr int GPW = ( G + NW - 1 ) / NW;
+			const bool fast32 = EPI == EPI_F32 && ( a.N & 3 ) == 0 && a.Mb >= a.M;
+			const bool fastGelu = EPI == EPI_F16_GELU && ( a.N & 3 ) == 0 && a.Mb >= a.M;
+	#pragma unroll
+			for( int i = 0; i < GPW; i++ )
+			{
+				const int g = wave + NW * i;
+				if( g >= G ) continue;
+				const int t = g / CT, c = g - t * CT;
+				const int mm = m0 + t * 16 + ( lane & 15 );
+				const int nn = n0 + c * 16 + ( lane >> 4 ) * 4;
+				if( mm >= a.M || nn >= a.N ) continue;
+				if( fast32 )
+				{
+					// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
+					f32x4 o = part[ i ];
+					if( a.bias )
+					{
+						const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) o[ r ] += bv[ r ];
+					}
+					const long long off = (long long)mm * a.ldc + nn;
+					if( a.res )
+					{
+						const f32x4 rv = *(const f32x4*)( a.res + off );
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) o[ r ] += rv[ r ];
+					}
+					*(f32x4*)( a.out32 + off ) = o;
+					continue;
+				}
+				if( fastGelu )
+				{
+					// gelu16( acc + bias ), the arithmetic of epilogueOne<EPI_F16_GELU>, four columns as one 8-byte store
+					const f32x4 bv = *(const f32x4*)( a.bias + nn );
+					f16x4 hv;
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) hv[ r ] = gelu16( part[ i ][ r ] + bv[ r ] );
+					*(f16x4*)( a.out16 + (long long)mm * a.ldc + nn ) = hv;
+					continue;
+				}
+				if constexpr( EPI == EPI_QKV_DEC )
+				{
+					// the arithmetic of epilogueOne<EPI_QKV_DEC> on the lane's four consecutive columns (one head, one of Q / K / V: d and HEAD_DIM are multiples of 4),
+					// leaving as ONE 8-byte store: one pair of divisions and one position load per lane instead of four, a quarter of the store instructions
+					if( ( a.N & 3 ) == 0 )
+					{
+						const int d = a.H * HEAD_DIM;
+						const int sel = nn / d;
+						const int c = nn - sel * d;
+						f16x4 hv;
+						f16* dst;
+						if( sel == 0 )
+						{
+							const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+							for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( ( part[ i ][ r ] + bv[ r ] ) * a.scale );
+							dst = a.q + (long long)mm * d + c;
+						}
+						else
+						{
+							const int h = c >> 6, dd = c & 63;
+							const int b = mm / a.nTok;
+							const int pos = ( a.nPastDev ? a.nPastDev[ b ] : a.nPast ) + ( mm - b * a.nTok );
+							const long long o = ( ( (long long)b * a.H + h ) * a.textCtx + pos ) * HEAD_DIM + dd;
+							if( sel == 1 )
+							{
+	#pragma unroll
+								for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( part[ i ][ r ] * a.scale );
+								dst = a.k + o;
+							}
+							else
+							{
+								const f32x4 bv = *(const f32x4*)( a.bias + nn );
+	#pragma unroll
+								for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( part[ i ][ r ] + bv[ r ] );
+								dst = a.v + o;
+							}
+						}
+						*(f16x4*)dst = hv;
+						continue;
+					}
+				}
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+					if( nn + r < a.N ) epilogueOne<EPI>( a, mm, nn + r, part[ i ][ r ] );
+			}
+		}
+
 		// gemmDecRows: the products of a decode step whose lock-step batch is LARGER than 128 sequences (129 .. 512 rows: one
 		// context of 224 .. 448 windows instead of two of 112). At that many rows a product is a small GEMM (448 x 4096 x 1024:
 		// 3.8 GFLOP against 8 MB of weights), and gemvFused's 16-column workgroups would re-read the activation rows once per
@@ -2869,94 +2965,129 @@ namespace wh
 				}
 			}
 
-			// ---- epilogue: D[row][col]: col = lane & 15 = activation row of the tile, row = (lane >> 4) * 4 + r = weight row slot
-			const bool fast32 = EPI == EPI_F32 && ( a.N & 3 ) == 0 && a.Mb >= a.M;
-			const bool fastGelu = EPI == EPI_F16_GELU && ( a.N & 3 ) == 0 && a.Mb >= a.M;
+			decRowsEpilogue<EPI, MT, CT, NW>( a, part, m0, n0, wave, lane );
+		}
+
+		// gemmDecTile (round 6): the same products (129 .. 512 rows) with the operands staged through LDS in FULL 128-byte lines. gemmDecRows' waves read their
+		// fragments straight from L2, 16 rows x 64 bytes per instruction -- every 128-byte line is requested twice, by different instructions, and the kernel is bound by
+		// that request stream (448 x 4096 x 1024: 21 us whatever the prefetch depth, 13 us at half the rows; profiles/r06_evidence/decode_rows_r6p.txt). Here a
+		// workgroup (4 waves, 64 activation rows x 16 CT weight rows) walks K in tiles of 64 = one line per row: LDS-DMA pieces of 8 rows x 128 bytes (source chunk
+		// XOR-swizzled as in the encoder's kernels), a ring of DT_NBUF tiles with counted waits and one barrier per tile, fragments by ds_read_b128. Wave w owns the
+		// 16-column tile w % CT of MT / (4 / CT) row tiles -- the groups g = w + 4 i of decRowsEpilogue -- so its W fragment is the srcA operand of consecutive MFMAs.
+		// THE SUMS ARE gemvFused's / gemmDecRows': those kernels give every wave a quarter of K and add the four partial tiles in wave order; here every wave walks all of
+		// K, but closes an accumulator at each quarter of K and adds the four in the same order: ((P0 + P1) + P2) + P3, each Pi the same chain of k-steps of 32.
+		constexpr int DT_NBUF = 4;
+		__device__ __forceinline__ void ldsDmaOne( const void* base, unsigned off0, unsigned dst )
+		{
+			unsigned keep;
+			asm volatile( "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %2, %1\n\ts_mov_b32 m0, %0"
+						  : "=&s"( keep )
+						  : "s"( base ), "v"( off0 ), "s"( dst )
+						  : "memory" );
+		}
+		template<int EPI, int CT>
+		__global__ void __launch_bounds__( 256 ) gemmDecTile( const GemmArgs a )
+		{
+			static_assert( CT == 4 || CT == 2, "wave w owns column tile w % CT" );
+			constexpr int MT = 4, NW = 4, GPW = MT * CT / NW;
+			constexpr int A_BYTES = MT * 16 * 128, W_BYTES = CT * 16 * 128, STAGE = A_BYTES + W_BYTES;
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemD[];
+			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+			const int n0 = blockIdx.x * 16 * CT;
+			const int m0 = blockIdx.y * 16 * MT;
+			const int nk = a.K / 64, perQ = nk / 4;
+
+			// ---- producer: A = 8 pieces of 8 rows (wave w: pieces 2 w, 2 w + 1), W = 2 CT pieces (CT = 4: 2 w, 2 w + 1; CT = 2: piece w)
+			const int rIn = lane >> 3, cPhys = lane & 7;
+			unsigned offA[ 2 ], offW[ 2 ];
 	#pragma unroll
-			for( int i = 0; i < GPW; i++ )
+			for( int i = 0; i < 2; i++ )
 			{
-				const int g = wave + NW * i;
-				if( g >= G ) continue;
-				const int t = g / CT, c = g - t * CT;
-				const int mm = m0 + t * 16 + ( lane & 15 );
-				const int nn = n0 + c * 16 + ( lane >> 4 ) * 4;
-				if( mm >= a.M || nn >= a.N ) continue;
-				if( fast32 )
-				{
-					// out = (acc + bias) + res, the same order as epilogueOne<EPI_F32>
-					f32x4 o = part[ i ];
-					if( a.bias )
-					{
-						const f32x4 bv = *(const f32x4*)( a.bias + nn );
-	#pragma unroll
-						for( int r = 0; r < 4; r++ ) o[ r ] += bv[ r ];
-					}
-					const long long off = (long long)mm * a.ldc + nn;
-					if( a.res )
-					{
-						const f32x4 rv = *(const f32x4*)( a.res + off );
-	#pragma unroll
-						for( int r = 0; r < 4; r++ ) o[ r ] += rv[ r ];
-					}
-					*(f32x4*)( a.out32 + off ) = o;
-					continue;
-				}
-				if( fastGelu )
-				{
-					// gelu16( acc + bias ), the arithmetic of epilogueOne<EPI_F16_GELU>, four columns as one 8-byte store
-					const f32x4 bv = *(const f32x4*)( a.bias + nn );
-					f16x4 hv;
-	#pragma unroll
-					for( int r = 0; r < 4; r++ ) hv[ r ] = gelu16( part[ i ][ r ] + bv[ r ] );
-					*(f16x4*)( a.out16 + (long long)mm * a.ldc + nn ) = hv;
-					continue;
-				}
-				if constexpr( EPI == EPI_QKV_DEC )
-				{
-					// the arithmetic of epilogueOne<EPI_QKV_DEC> on the lane's four consecutive columns (one head, one of Q / K / V: d and HEAD_DIM are multiples of 4),
-					// leaving as ONE 8-byte store: one pair of divisions and one position load per lane instead of four, a quarter of the store instructions
-					if( ( a.N & 3 ) == 0 )
-					{
-						const int d = a.H * HEAD_DIM;
-						const int sel = nn / d;
-						const int c = nn - sel * d;
-						f16x4 hv;
-						f16* dst;
-						if( sel == 0 )
-						{
-							const f32x4 bv = *(const f32x4*)( a.bias + nn );
-	#pragma unroll
-							for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( ( part[ i ][ r ] + bv[ r ] ) * a.scale );
-							dst = a.q + (long long)mm * d + c;
-						}
-						else
-						{
-							const int h = c >> 6, dd = c & 63;
-							const int b = mm / a.nTok;
-							const int pos = ( a.nPastDev ? a.nPastDev[ b ] : a.nPast ) + ( mm - b * a.nTok );
-							const long long o = ( ( (long long)b * a.H + h ) * a.textCtx + pos ) * HEAD_DIM + dd;
-							if( sel == 1 )
-							{
-	#pragma unroll
-								for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( part[ i ][ r ] * a.scale );
-								dst = a.k + o;
-							}
-							else
-							{
-								const f32x4 bv = *(const f32x4*)( a.bias + nn );
-	#pragma unroll
-								for( int r = 0; r < 4; r++ ) hv[ r ] = (f16)( part[ i ][ r ] + bv[ r ] );
-								dst = a.v + o;
-							}
-						}
-						*(f16x4*)dst = hv;
-						continue;
-					}
-				}
-	#pragma unroll
-				for( int r = 0; r < 4; r++ )
-					if( nn + r < a.N ) epilogueOne<EPI>( a, mm, nn + r, part[ i ][ r ] );
+				const int row = ( wave * 2 + i ) * 8 + rIn;
+				const int cl = cPhys ^ ( ( row >> 1 ) & 7 );
+				int m = m0 + row;
+				m = m < a.M ? m : a.M - 1;
+				offA[ i ] = (unsigned)( ( rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + cl * 8 ) * 2 );
+				const int rowW = CT == 4 ? row : wave * 8 + rIn;
+				const int clW = cPhys ^ ( ( rowW >> 1 ) & 7 );
+				int n = n0 + rowW;
+				n = n < a.N ? n : a.N - 1;
+				offW[ i ] = (unsigned)( ( (long long)n * a.K + clW * 8 ) * 2 );
 			}
+			const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)smemD );
+			auto issue = [ & ]( int kt )
+			{
+				const unsigned buf = ldsBase + (unsigned)( kt % DT_NBUF ) * STAGE;
+				ldsDmaPair( a.A + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * 2048u );
+				if constexpr( CT == 4 )
+					ldsDmaPair( a.W + kt * 64, offW[ 0 ], offW[ 1 ], buf + A_BYTES + (unsigned)wave * 2048u );
+				else
+					ldsDmaOne( a.W + kt * 64, offW[ 0 ], buf + A_BYTES + (unsigned)wave * 1024u );
+			};
+
+			// ---- consumer: lane l reads row l & 15 of a 16-row tile, logical chunk 4 h + (l >> 4), stored at chunk ^ ((row >> 1) & 7)
+			const int cTile = wave % CT, tFirst = wave / CT;	 // group g = wave + 4 i: column tile g % CT = cTile, row tile g / CT = tFirst + ( 4 / CT ) i
+			unsigned fragOff[ 2 ];
+	#pragma unroll
+			for( int h = 0; h < 2; h++ ) fragOff[ h ] = (unsigned)( ( lane & 15 ) * 128 + ( ( ( ( h << 2 ) + ( lane >> 4 ) ) ^ ( ( lane >> 1 ) & 7 ) ) << 4 ) );
+
+			f32x4 acc[ GPW ], tot[ GPW ];
+	#pragma unroll
+			for( int i = 0; i < GPW; i++ ) acc[ i ] = tot[ i ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+
+	#pragma unroll
+			for( int d = 0; d < DT_NBUF - 1; d++ )
+				if( d < nk ) issue( d );
+			int inQ = 0, quarter = 0;
+			for( int kt = 0; kt < nk; kt++ )
+			{
+				// tile kt has landed when no more than the pieces of the (up to DT_NBUF - 2) younger tiles are outstanding
+				const int younger = min( DT_NBUF - 2, nk - 1 - kt );
+				if( younger >= 2 )
+				{
+					if constexpr( CT == 4 ) asm volatile( "s_waitcnt vmcnt(8)" ::: "memory" );
+					else asm volatile( "s_waitcnt vmcnt(6)" ::: "memory" );
+				}
+				else if( younger == 1 )
+				{
+					if constexpr( CT == 4 ) asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
+					else asm volatile( "s_waitcnt vmcnt(3)" ::: "memory" );
+				}
+				else
+					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
+				asm volatile( "s_barrier" ::: "memory" );	 // tile kt complete for every wave; every wave has issued the MFMAs of tile kt - 1, whose buffer the next issue overwrites
+				if( kt + DT_NBUF - 1 < nk ) issue( kt + DT_NBUF - 1 );
+				const unsigned char* const buf = smemD + ( kt % DT_NBUF ) * STAGE;
+				f16x8 fw[ 2 ], fx[ GPW ][ 2 ];
+	#pragma unroll
+				for( int h = 0; h < 2; h++ )
+				{
+					fw[ h ] = *(const f16x8*)( buf + A_BYTES + cTile * 2048 + fragOff[ h ] );
+	#pragma unroll
+					for( int i = 0; i < GPW; i++ ) fx[ i ][ h ] = *(const f16x8*)( buf + ( tFirst + ( 4 / CT ) * i ) * 2048 + fragOff[ h ] );
+				}
+	#pragma unroll
+				for( int h = 0; h < 2; h++ )
+	#pragma unroll
+					for( int i = 0; i < GPW; i++ ) acc[ i ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ h ], fx[ i ][ h ], acc[ i ], 0, 0, 0 );
+				if( ++inQ == perQ )
+				{
+					// a quarter of K is complete: the partial tile of gemvFused's wave `quarter`
+	#pragma unroll
+					for( int i = 0; i < GPW; i++ )
+					{
+	#pragma unroll
+						for( int r = 0; r < 4; r++ ) tot[ i ][ r ] = quarter == 0 ? acc[ i ][ r ] : tot[ i ][ r ] + acc[ i ][ r ];
+						acc[ i ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+					}
+					inQ = 0;
+					quarter++;
+				}
+			}
+			decRowsEpilogue<EPI, MT, CT, NW>( a, tot, m0, n0, wave, lane );
 		}
 	}	// namespace
 
@@ -3020,6 +3151,30 @@ namespace wh
 		return launchDecRowsD<EPI, MT, CT, 2>( a, stream );
 	}
 
+	// gemmDecTile: K must divide into four quarters of whole 64-element tiles (the K split the sums follow); operands addressed as a 64-bit base + 32-bit offsets
+	template<int EPI, int CT>
+	static int launchDecTileK( const GemmArgs& a, hipStream_t stream )
+	{
+		constexpr int lds = DT_NBUF * ( 4 * 16 * 128 + CT * 16 * 128 );
+		if( lds > 48 * 1024 )
+		{
+			static PerDeviceOnce once;
+			if( const int onceDev = once.needed(); onceDev >= 0 )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecTile<EPI, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				once.mark( onceDev );
+			}
+		}
+		hipLaunchKernelGGL( ( gemmDecTile<EPI, CT> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 63 ) / 64 ), dim3( 256 ), lds, stream, a );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+	static bool decTileOk( const GemmArgs& a )
+	{
+		const long long aBytes = 2ll * ( a.Mb > 0 && a.Mb < a.M ? ( (long long)( a.M / a.Mb ) + 1 ) * a.aBatchStride + (long long)a.Mb * a.lda : (long long)a.M * a.lda ) + 2ll * a.K;
+		return ( a.K % 256 ) == 0 && ( a.lda % 8 ) == 0 && ( a.aBatchStride % 8 ) == 0 && aBytes < ( 1ll << 31 ) && 2ll * a.N * a.K < ( 1ll << 31 );
+	}
+
 	// Tile of a big-batch decode product: 64 x 64 (rows x columns) while that leaves enough workgroups for the chip, else 64 x 32, else 32 x 32.
 	// Option dec_tile = <MT><CT> (44, 42, 24, 22) pins one for A/B runs and tests.
 	template<int EPI>
@@ -3027,6 +3182,14 @@ namespace wh
 	{
 		const int pinned = g_opt.decTile;
 		auto wgs = [ & ]( int mt, int ct ) { return ( ( a.N + 16 * ct - 1 ) / ( 16 * ct ) ) * ( ( a.M + 16 * mt - 1 ) / ( 16 * mt ) ); };
+		// option dec_lds: the LDS-staged kernel (64 x 64, or 64 x 32 while the wider tile leaves fewer than 192 workgroups)
+		// (measured, tools/gemv_time.py: 448 x 4096 x 1024 14.4 against 22.1 us, 448 x 1024 x 4096 21.2 / 26.7, 448 x 1024 x 1024 7.7 / 9.2, 224 x 4096 x 1024 10.8 / 14.1;
+		// at 224 rows the N = 1024 products would get 128 workgroups of 64 x 32 and lose to gemmDecRows' 32 x 32 tiles: 7.6 / 6.6 and 20.5 / 18.1 us -- those keep it)
+		if( g_opt.decLds == 1 && pinned == 0 && decTileOk( a ) )
+		{
+			if( wgs( 4, 4 ) >= 192 ) return launchDecTileK<EPI, 4>( a, stream );
+			if( wgs( 4, 2 ) >= 192 ) return launchDecTileK<EPI, 2>( a, stream );
+		}
 		int tile = pinned;
 		if( tile != 44 && tile != 42 && tile != 24 && tile != 22 )
 			tile = wgs( 4, 4 ) >= 192 ? 44 : ( wgs( 4, 2 ) >= 192 ? 42 : 22 );

@@ -71,6 +71,8 @@ namespace wh
 		int encExp = 5;				 // "enc_exp": encoder attention on the timed path: 5 = attentionEncW<2, true, true> (one sweep, lazily raised running maximum, e = fp16( 2^( s log2 e - m log2 e ) ) with NO FP16 rounding of the argument: 1.46-1.49 ms per 112 windows isolated), 3 = the same with the reference's fp16( s - m ) argument (1.59-1.65), 2 = its two-sweep form (1.85), 1 = attentionEncT<1> (two sweeps, v_exp_f32; 1.83), 0 = attentionEncT<0> (the reference's table in LDS, bit-exact e; 1.91-2.14: round 5's kernel)
 		int encAblate = 0;			 // "enc_ablate": attentionEncW, measurement only (results wrong): 1 = no exponentials, 2 = no P.V MFMAs, 4 = a quarter of the Q.K MFMAs
 		int exactAltOrder = 0;		 // "exact_alt_order": WH_FLAG_PARITY_EXACT, measurement only: the weight products add their 32 chains left to right instead of in ggml's tree
+		int decLds = 1;				 // "dec_lds": decode products of 129 .. 512 rows: 1 = gemmDecTile where its 64 x 64 / 64 x 32 tiles fill the chip (operands staged through LDS in
+									 // full 128-byte lines, the same sums: 448 x 4096 x 1024 14.4 against 22.1 us), 0 = gemmDecRows everywhere (round 5)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
