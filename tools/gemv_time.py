@@ -24,9 +24,10 @@ def main():
         out = torch.zeros((M, N), device="cuda")
         row = []
         outs = {}
-        for label, mask in (("dec_lds 0", binding.TUNE_DEFAULT), ("dec_lds 1", binding.TUNE_DEFAULT)):
+        for label, mask in (("dec_lds 0", binding.TUNE_DEFAULT), ("dec_lds 1", binding.TUNE_DEFAULT), ("ks 2", binding.TUNE_DEFAULT)):
             L.wh_debug_set_tuning(mask)
-            binding.set_option("dec_lds", int(label[-1]))
+            binding.set_option("dec_lds", 0 if label == "dec_lds 0" else 1)
+            binding.set_option("dec_lds_ks", 2 if label == "ks 2" else 1)
             iters = 200 if N < 10000 else 40
             for i in range(8):
                 L.wh_op_mul_mat(None, p(a), p(w[i % pool]), p(bias), p(res), p(out), M, N, K)
@@ -44,7 +45,8 @@ def main():
             outs[label] = out.clone()
         L.wh_debug_set_tuning(binding.TUNE_DEFAULT)
         binding.set_option("dec_lds", binding.get_option_default("dec_lds"))
-        row.append("same bits: %s (max diff %.2e)" % (bool(torch.equal(outs["dec_lds 0"], outs["dec_lds 1"])), float((outs["dec_lds 0"] - outs["dec_lds 1"]).abs().max())))
+        binding.set_option("dec_lds_ks", binding.get_option_default("dec_lds_ks"))
+        row.append("same bits: %s %s" % (bool(torch.equal(outs["dec_lds 0"], outs["dec_lds 1"])), bool(torch.equal(outs["dec_lds 0"], outs["ks 2"]))))
         print("M=%d %-9s N=%5d K=%4d  %s" % (M, name, N, K, " | ".join(row)), flush=True)
 
 

@@ -2985,12 +2985,14 @@ namespace wh
 						  : "s"( base ), "v"( off0 ), "s"( dst )
 						  : "memory" );
 		}
-		template<int EPI, int CT>
+		template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF>
 		__global__ void __launch_bounds__( 256 ) gemmDecTile( const GemmArgs a )
 		{
+			// KS = K tiles of 64 per ring slot and barrier (2 for the deep products: K = 4096 is 64 tiles, and a tile is only 4 .. 8 MFMAs per wave)
 			static_assert( CT == 4 || CT == 2, "wave w owns column tile w % CT" );
 			constexpr int MT = 4, NW = 4, GPW = MT * CT / NW;
-			constexpr int A_BYTES = MT * 16 * 128, W_BYTES = CT * 16 * 128, STAGE = A_BYTES + W_BYTES;
+			constexpr int A_BYTES = MT * 16 * 128, W_BYTES = CT * 16 * 128, TILE = A_BYTES + W_BYTES, STAGE = KS * TILE;
+			constexpr int P = KS * ( CT == 4 ? 4 : 3 );	  // load instructions per slot and wave
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemD[];
 			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
 			const int tid = threadIdx.x;
@@ -2998,7 +3000,7 @@ namespace wh
 			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
 			const int n0 = blockIdx.x * 16 * CT;
 			const int m0 = blockIdx.y * 16 * MT;
-			const int nk = a.K / 64, perQ = nk / 4;
+			const int nk = a.K / 64, perQ = nk / 4, nSlots = nk / KS;
 
 			// ---- producer: A = 8 pieces of 8 rows (wave w: pieces 2 w, 2 w + 1), W = 2 CT pieces (CT = 4: 2 w, 2 w + 1; CT = 2: piece w)
 			const int rIn = lane >> 3, cPhys = lane & 7;
@@ -3018,14 +3020,19 @@ namespace wh
 				offW[ i ] = (unsigned)( ( (long long)n * a.K + clW * 8 ) * 2 );
 			}
 			const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)smemD );
-			auto issue = [ & ]( int kt )
+			auto issue = [ & ]( int slot )
 			{
-				const unsigned buf = ldsBase + (unsigned)( kt % DT_NBUF ) * STAGE;
-				ldsDmaPair( a.A + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * 2048u );
-				if constexpr( CT == 4 )
-					ldsDmaPair( a.W + kt * 64, offW[ 0 ], offW[ 1 ], buf + A_BYTES + (unsigned)wave * 2048u );
-				else
-					ldsDmaOne( a.W + kt * 64, offW[ 0 ], buf + A_BYTES + (unsigned)wave * 1024u );
+	#pragma unroll
+				for( int u = 0; u < KS; u++ )
+				{
+					const int kt = slot * KS + u;
+					const unsigned buf = ldsBase + (unsigned)( slot % NBUF ) * STAGE + u * TILE;
+					ldsDmaPair( a.A + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * 2048u );
+					if constexpr( CT == 4 )
+						ldsDmaPair( a.W + kt * 64, offW[ 0 ], offW[ 1 ], buf + A_BYTES + (unsigned)wave * 2048u );
+					else
+						ldsDmaOne( a.W + kt * 64, offW[ 0 ], buf + A_BYTES + (unsigned)wave * 1024u );
+				}
 			};
 
 			// ---- consumer: lane l reads row l & 15 of a 16-row tile, logical chunk 4 h + (l >> 4), stored at chunk ^ ((row >> 1) & 7)
@@ -3039,52 +3046,51 @@ namespace wh
 			for( int i = 0; i < GPW; i++ ) acc[ i ] = tot[ i ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
 
 	#pragma unroll
-			for( int d = 0; d < DT_NBUF - 1; d++ )
-				if( d < nk ) issue( d );
+			for( int d = 0; d < NBUF - 1; d++ )
+				if( d < nSlots ) issue( d );
 			int inQ = 0, quarter = 0;
-			for( int kt = 0; kt < nk; kt++ )
+			for( int slot = 0; slot < nSlots; slot++ )
 			{
-				// tile kt has landed when no more than the pieces of the (up to DT_NBUF - 2) younger tiles are outstanding
-				const int younger = min( DT_NBUF - 2, nk - 1 - kt );
+				// slot `slot` has landed when no more than the pieces of the (up to NBUF - 2) younger slots are outstanding
+				const int younger = min( NBUF - 2, nSlots - 1 - slot );
+				static_assert( NBUF == 3 || NBUF == 4, "one or two younger slots" );
 				if( younger >= 2 )
-				{
-					if constexpr( CT == 4 ) asm volatile( "s_waitcnt vmcnt(8)" ::: "memory" );
-					else asm volatile( "s_waitcnt vmcnt(6)" ::: "memory" );
-				}
+					asm volatile( "s_waitcnt vmcnt(%0)" ::"n"( 2 * P ) : "memory" );
 				else if( younger == 1 )
-				{
-					if constexpr( CT == 4 ) asm volatile( "s_waitcnt vmcnt(4)" ::: "memory" );
-					else asm volatile( "s_waitcnt vmcnt(3)" ::: "memory" );
-				}
+					asm volatile( "s_waitcnt vmcnt(%0)" ::"n"( P ) : "memory" );
 				else
 					asm volatile( "s_waitcnt vmcnt(0)" ::: "memory" );
-				asm volatile( "s_barrier" ::: "memory" );	 // tile kt complete for every wave; every wave has issued the MFMAs of tile kt - 1, whose buffer the next issue overwrites
-				if( kt + DT_NBUF - 1 < nk ) issue( kt + DT_NBUF - 1 );
-				const unsigned char* const buf = smemD + ( kt % DT_NBUF ) * STAGE;
-				f16x8 fw[ 2 ], fx[ GPW ][ 2 ];
+				asm volatile( "s_barrier" ::: "memory" );	 // the slot is complete for every wave; every wave has issued the MFMAs of the slot before, whose buffer the next issue overwrites
+				if( slot + NBUF - 1 < nSlots ) issue( slot + NBUF - 1 );
 	#pragma unroll
-				for( int h = 0; h < 2; h++ )
+				for( int u = 0; u < KS; u++ )
 				{
-					fw[ h ] = *(const f16x8*)( buf + A_BYTES + cTile * 2048 + fragOff[ h ] );
+					const unsigned char* const buf = smemD + ( slot % NBUF ) * STAGE + u * TILE;
+					f16x8 fw[ 2 ], fx[ GPW ][ 2 ];
 	#pragma unroll
-					for( int i = 0; i < GPW; i++ ) fx[ i ][ h ] = *(const f16x8*)( buf + ( tFirst + ( 4 / CT ) * i ) * 2048 + fragOff[ h ] );
-				}
-	#pragma unroll
-				for( int h = 0; h < 2; h++ )
-	#pragma unroll
-					for( int i = 0; i < GPW; i++ ) acc[ i ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ h ], fx[ i ][ h ], acc[ i ], 0, 0, 0 );
-				if( ++inQ == perQ )
-				{
-					// a quarter of K is complete: the partial tile of gemvFused's wave `quarter`
-	#pragma unroll
-					for( int i = 0; i < GPW; i++ )
+					for( int h = 0; h < 2; h++ )
 					{
+						fw[ h ] = *(const f16x8*)( buf + A_BYTES + cTile * 2048 + fragOff[ h ] );
 	#pragma unroll
-						for( int r = 0; r < 4; r++ ) tot[ i ][ r ] = quarter == 0 ? acc[ i ][ r ] : tot[ i ][ r ] + acc[ i ][ r ];
-						acc[ i ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						for( int i = 0; i < GPW; i++ ) fx[ i ][ h ] = *(const f16x8*)( buf + ( tFirst + ( 4 / CT ) * i ) * 2048 + fragOff[ h ] );
 					}
-					inQ = 0;
-					quarter++;
+	#pragma unroll
+					for( int h = 0; h < 2; h++ )
+	#pragma unroll
+						for( int i = 0; i < GPW; i++ ) acc[ i ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( fw[ h ], fx[ i ][ h ], acc[ i ], 0, 0, 0 );
+					if( ++inQ == perQ )
+					{
+						// a quarter of K is complete: the partial tile of gemvFused's wave `quarter`
+	#pragma unroll
+						for( int i = 0; i < GPW; i++ )
+						{
+	#pragma unroll
+							for( int r = 0; r < 4; r++ ) tot[ i ][ r ] = quarter == 0 ? acc[ i ][ r ] : tot[ i ][ r ] + acc[ i ][ r ];
+							acc[ i ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+						}
+						inQ = 0;
+						quarter++;
+					}
 				}
 			}
 			decRowsEpilogue<EPI, MT, CT, NW>( a, tot, m0, n0, wave, lane );
@@ -3152,20 +3158,20 @@ namespace wh
 	}
 
 	// gemmDecTile: K must divide into four quarters of whole 64-element tiles (the K split the sums follow); operands addressed as a 64-bit base + 32-bit offsets
-	template<int EPI, int CT>
+	template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF>
 	static int launchDecTileK( const GemmArgs& a, hipStream_t stream )
 	{
-		constexpr int lds = DT_NBUF * ( 4 * 16 * 128 + CT * 16 * 128 );
+		constexpr int lds = NBUF * KS * ( 4 * 16 * 128 + CT * 16 * 128 );
 		if( lds > 48 * 1024 )
 		{
 			static PerDeviceOnce once;
 			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecTile<EPI, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecTile<EPI, CT, KS, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
 				once.mark( onceDev );
 			}
 		}
-		hipLaunchKernelGGL( ( gemmDecTile<EPI, CT> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 63 ) / 64 ), dim3( 256 ), lds, stream, a );
+		hipLaunchKernelGGL( ( gemmDecTile<EPI, CT, KS, NBUF> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 63 ) / 64 ), dim3( 256 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -3188,7 +3194,13 @@ namespace wh
 		if( g_opt.decLds == 1 && pinned == 0 && decTileOk( a ) )
 		{
 			if( wgs( 4, 4 ) >= 192 ) return launchDecTileK<EPI, 4>( a, stream );
-			if( wgs( 4, 2 ) >= 192 ) return launchDecTileK<EPI, 2>( a, stream );
+			// (64 x 32 tiles from 160 workgroups: 320 x 1024 x 4096 17.5 against 30.9 us, 320 x 1024 x 1024 7.6 / 10.1; at 128 workgroups -- 224 / 256 rows -- 7.6 against 6.5 us)
+			if( wgs( 4, 2 ) >= 160 )
+			{
+				// deep products (the MLP down-projection): two K tiles per ring slot and barrier when a quarter of K is an even number of tiles (448 x 1024 x 4096: 18.1 against 21.7 us)
+				if( g_opt.decLdsKs == 2 && a.K >= 2048 && ( a.K % 512 ) == 0 ) return launchDecTileK<EPI, 2, 2, 3>( a, stream );
+				return launchDecTileK<EPI, 2>( a, stream );
+			}
 		}
 		int tile = pinned;
 		if( tile != 44 && tile != 42 && tile != 24 && tile != 22 )

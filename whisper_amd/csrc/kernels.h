@@ -73,6 +73,7 @@ namespace wh
 		int exactAltOrder = 0;		 // "exact_alt_order": WH_FLAG_PARITY_EXACT, measurement only: the weight products add their 32 chains left to right instead of in ggml's tree
 		int decLds = 1;				 // "dec_lds": decode products of 129 .. 512 rows: 1 = gemmDecTile where its 64 x 64 / 64 x 32 tiles fill the chip (operands staged through LDS in
 									 // full 128-byte lines, the same sums: 448 x 4096 x 1024 14.4 against 22.1 us), 0 = gemmDecRows everywhere (round 5)
+		int decLdsKs = 2;			 // "dec_lds_ks": gemmDecTile on 64 x 32 tiles with K >= 2048: 2 = two K tiles per ring slot and barrier (18.1 against 21.7 us at 448 rows), 1 = one
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
