@@ -137,7 +137,7 @@ def test_r05_line_structure(rnd):
     assert line["small_job"]["clip_passes"] == 20 and line["small_job"]["batch_plan"] == [10, 10] and 0.6 * line["value"] < line["small_job"]["value"] < line["value"]
     assert abs(r["end_to_end"]["frac"] - r["end_to_end"]["floor_ms_per_batch"] / r["end_to_end"]["measured_ms_per_batch"]) < 1e-3
     ch = r["decode_chain"]
-    assert ch["bound"] == "hbm" and ch["frac"] < 0.2 and ch["share_of_kernel_time"] < 0.35 and ch["us_per_window_step_layer"] > 0
+    assert ch["bound"] == "hbm" and ch["frac"] < 0.3 and ch["share_of_kernel_time"] < 0.35 and ch["us_per_window_step_layer"] > 0
     # the ids of the timed region against the same windows one at a time
     t = line["parity"]["timed_ids"]
     assert t["consistent"] is True and t["samples_compared"] == 7 * 52
@@ -175,8 +175,8 @@ def test_r05_rooflines_recomputed_from_the_rocprof_statistics(rnd):
         print("%s: bench %.2f us, rocprof %.2f us" % (cls, k[cls]["avg_us"], avg))
         assert abs(avg - k[cls]["avg_us"]) / k[cls]["avg_us"] < 0.06
     # the decode chain's own kernels (round 5): the products of > 128 rows and the wave-per-pair self-attention
-    avg, calls = _avg_us(stats, lambda n: "gemmDecRows" in n)
-    print("gemmDecRows: rocprof %.2f us over %d launches; bench class gemvFused %.2f us" % (avg, calls, k["gemvFused"]["avg_us"]))
+    avg, calls = _avg_us(stats, lambda n: "gemmDecRows" in n or "gemmDecTile" in n)       # (round 6: gemmDecTile where its tiles fill the chip)
+    print("gemmDecRows / gemmDecTile: rocprof %.2f us over %d launches; bench class gemvFused %.2f us" % (avg, calls, k["gemvFused"]["avg_us"]))
     assert calls > 0 and 0.55 * avg < k["gemvFused"]["avg_us"] < 1.6 * avg      # (the tracer adds 3-5 us to a 10 us launch, and a few outliers of milliseconds)
     avg, calls = _avg_us(stats, lambda n: "selfAttnDecWave" in n)
     print("selfAttnDecWave: rocprof %.2f us over %d launches; bench class attentionDec %.2f us" % (avg, calls, k["attentionDec"]["avg_us"]))
