@@ -179,6 +179,11 @@ WH_API int wh_buffer_upload_async( wh_context* c, void* dev, const void* host, i
  * The normalisation maximum is over the whole buffer, as in runFull. */
 WH_API int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, float* melDev, int64_t* nLenOut );
 
+/* The same for `batch` independent buffers of nSamples each (buffer b at pcmDev + b * pcmStride -> melDev + b * melStride, each normalised by its OWN
+ * maximum: what `batch` calls of wh_mel_spectrogram give, bit for bit) in three launches instead of 3 x batch -- the independent 30 s chunks of the
+ * batch path (a chunk alone is 188 workgroups: less than the chip). Strides in elements; melStride >= n_mel * (nSamples / 160). */
+WH_API int wh_mel_spectrogram_batch( wh_context* c, const float* pcmDev, int64_t nSamples, int64_t pcmStride, int batch, float* melDev, int64_t melStride );
+
 /* One window of a STREAMED spectrogram. Replaces MelStreamer::makeBuffer + makeTransposedBuffer
  * (Whisper/Whisper/MelStreamer.cpp:189-245, :125-187), what iContext::runStreamed feeds the encoder with: frames
  * [frame0, frame0 + nFrames) of the stream (frame f = 400 samples from f*160, zero past nSamples; frames >= nChunks, the

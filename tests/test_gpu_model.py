@@ -123,6 +123,27 @@ def test_encoder(hip_tiny, golden, np_tiny):
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_batched_spectrogram_equals_one_call_per_buffer(hip_tiny):
+    """wh_mel_spectrogram_batch (three launches for `batch` independent buffers, a maximum each) against one wh_mel_spectrogram call per buffer: the same kernels
+    with a buffer index in the grid, so the same bits -- including a silent buffer (its own maximum, not its neighbour's) and a row stride beyond the samples."""
+    rng = np.random.default_rng(11)
+    n = 176000
+    pcm = (0.1 * rng.standard_normal((5, n + 320))).astype(np.float32)
+    pcm[2] *= 1e-4          # a quiet buffer: normalised by ITS maximum
+    pcm[3] = 0.0            # silence
+    dev_pcm = torch.from_numpy(pcm).cuda()
+    ctx = binding.HipContext(hip_tiny, 1)
+    view = dev_pcm[:, :n]   # rows n + 320 apart
+    got = ctx.mel_spectrogram_batch(view).cpu().numpy()
+    for b in range(5):
+        one = ctx.mel_spectrogram(dev_pcm[b, :n].contiguous()).cpu().numpy()
+        assert np.array_equal(one, got[b]), b
+    assert not np.array_equal(got[0], got[2])
+    ctx.close()
+
+
+
 def test_encoder_batch_and_offsets(hip_tiny, golden):
     """Windows in one batch are independent: same window at different batch slots / offsets gives identical caches."""
     ctx = binding.HipContext(hip_tiny, 3)

@@ -46,7 +46,7 @@ EXPORTS = [
     "wh_comm_runtime_check", "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_set_audio_ctx", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
+    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_mel_spectrogram_batch", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -145,6 +145,7 @@ def lib():
         L.wh_decode_window_continue.argtypes = [vp, i32]
         L.wh_decode_window_fetch.argtypes = [vp, i32, i32, C.POINTER(TokenDataC)]
         L.wh_mel_spectrogram_window.argtypes = [vp, vp, i64, i64, i64, i64, i32, vp]
+        L.wh_mel_spectrogram_batch.argtypes = [vp, vp, i64, i64, i32, vp, i64]
         L.wh_debug_probe.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
         L.wh_profile_enable.argtypes = [vp, i32]
         L.wh_profile_read.argtypes = [vp, C.POINTER(ProfileEntryC), i32, C.POINTER(i32)]
@@ -306,6 +307,23 @@ class HipContext:
             out_dev = torch.empty((self.hp.n_mels, n_len), dtype=torch.float32, device=pcm_dev.device)
         got = C.c_int64()
         check(lib().wh_mel_spectrogram(self.handle, C.c_void_p(pcm_dev.data_ptr()), n, C.c_void_p(out_dev.data_ptr()), C.byref(got)))
+        if sync:
+            self.synchronize()
+        return out_dev
+
+    def mel_spectrogram_batch(self, pcm_dev, out_dev=None, sync: bool = True):
+        """pcm_dev: torch float32 CUDA tensor [batch][n] (contiguous rows): `batch` independent buffers, each normalised by its own maximum, in three
+        launches. Returns torch float32 [batch][n_mel][n//160]."""
+        import torch
+        if sync:
+            self._wait_for_torch()
+        assert pcm_dev.dim() == 2 and pcm_dev.stride(1) == 1
+        batch, n = pcm_dev.shape
+        n_len = n // 160
+        if out_dev is None:
+            out_dev = torch.empty((batch, self.hp.n_mels, n_len), dtype=torch.float32, device=pcm_dev.device)
+        assert out_dev.is_contiguous()
+        check(lib().wh_mel_spectrogram_batch(self.handle, C.c_void_p(pcm_dev.data_ptr()), n, pcm_dev.stride(0), batch, C.c_void_p(out_dev.data_ptr()), self.hp.n_mels * n_len))
         if sync:
             self.synchronize()
         return out_dev

@@ -398,6 +398,8 @@ namespace wh
 	int launchMel( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
 		int nMel, float* maxScratch, hipStream_t stream );
 	// one window of a streamed spectrogram, normalised by its own maximum (MelStreamer semantics); maxScratch holds 2 ints
+	int launchMelBatch( const float* pcm, long long nSamples, long long pcmStride, int batch, const float* filters, const double* dftTable, float* mel, long long melStride,
+		long long nLen, int nMel, float* maxScratch, hipStream_t stream );	 // 1 = shape not covered (loop over launchMel)
 	int launchMelWindow( const float* pcm, long long nSamples, const float* filters, const double* dftTable, float* mel, long long nLen,
 		long long nValidFrames, int nMel, int reusePreviousMax, float* maxScratch, hipStream_t stream );
 }

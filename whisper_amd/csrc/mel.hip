@@ -115,10 +115,14 @@ namespace wh
 		constexpr int MF_SAMPLES_SKEWED = MF_SAMPLES + MF_SAMPLES / HOP + 1;
 		typedef double f64x4 __attribute__( ( ext_vector_type( 4 ) ) );
 
+		// blockIdx.y = buffer of a batch of equally long, independent buffers (pcmStride / melStride elements apart, one maximum each): wh_mel_spectrogram_batch
 		__global__ void __launch_bounds__( 512 ) melKernelMf( const float* __restrict__ pcm, long long nSamples,
 			const float* __restrict__ filters, const double* __restrict__ dft, float* __restrict__ mel, long long nLen, int nMel,
-			int* __restrict__ maxOrdered, long long nValidFrames )
+			int* __restrict__ maxOrdered, long long nValidFrames, long long pcmStride = 0, long long melStride = 0 )
 		{
+			pcm += blockIdx.y * pcmStride;
+			mel += blockIdx.y * melStride;
+			maxOrdered += blockIdx.y;
 			__shared__ double tw[ 2 ][ N_FFT ];
 			__shared__ float hannS[ N_FFT ];
 			__shared__ float pcmS[ MF_SAMPLES_SKEWED ];
@@ -208,9 +212,10 @@ namespace wh
 			if( tid == 0 && shMax != (int)0x80000000 ) atomicMax( maxOrdered, shMax );
 		}
 
-		__global__ void __launch_bounds__( 256 ) melNormalize( float* __restrict__ mel, long long count, const int* __restrict__ maxOrdered )
+		__global__ void __launch_bounds__( 256 ) melNormalize( float* __restrict__ mel, long long count, const int* __restrict__ maxOrdered, long long melStride = 0 )
 		{
-			const double mmax = (double)fromOrderedInt( *maxOrdered ) - 8.0;
+			mel += blockIdx.y * melStride;
+			const double mmax = (double)fromOrderedInt( maxOrdered[ blockIdx.y ] ) - 8.0;
 			for( long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256 )
 			{
 				double v = (double)mel[ i ];
@@ -220,6 +225,11 @@ namespace wh
 		}
 
 		__global__ void melInitMax( int* maxOrdered ) { *maxOrdered = (int)0x80000000; }
+		__global__ void melInitMaxN( int* maxOrdered, int n )
+		{
+			const int i = blockIdx.x * blockDim.x + threadIdx.x;
+			if( i < n ) maxOrdered[ i ] = (int)0x80000000;
+		}
 		__global__ void melInitMaxFloor( int* maxOrdered, float floorValue ) { *maxOrdered = orderedInt( floorValue ); }
 
 		// MelStreamer::makeTransposedBuffer's second pass (Whisper/Whisper/MelStreamer.cpp:148-187), all in FP32 like its SSE
@@ -262,6 +272,24 @@ namespace wh
 		const long long count = nLen * nMel;
 		const int nb = (int)( ( count + 255 ) / 256 < 2048 ? ( count + 255 ) / 256 : 2048 );
 		hipLaunchKernelGGL( melNormalize, dim3( nb ), dim3( 256 ), 0, stream, mel, count, mx );
+		WH_HIP( hipGetLastError() );
+		return 0;
+	}
+
+	// `batch` independent buffers of nSamples each in THREE launches instead of 3 x batch: a 30 s window is 188 workgroups -- less than the chip -- and its three
+	// launches cost ~65 us in sequence (448 windows: 29 ms of a 1.2 s batch pass). Same kernels, same arithmetic, a maximum per buffer. maxScratch: `batch` ints.
+	int launchMelBatch( const float* pcm, long long nSamples, long long pcmStride, int batch, const float* filters, const double* dftTable, float* mel, long long melStride,
+		long long nLen, int nMel, float* maxScratch, hipStream_t stream )
+	{
+		if( nLen <= 0 || batch <= 0 ) return 0;
+		if( !( ( g_tuning & TUNE_MEL_MFMA ) && ( nMel % 16 ) == 0 && nMel <= 128 ) || batch > 65535 ) return 1;	   // the caller loops over launchMel
+		int* const mx = (int*)maxScratch;
+		hipLaunchKernelGGL( melInitMaxN, dim3( ( batch + 255 ) / 256 ), dim3( 256 ), 0, stream, mx, batch );
+		const int blocks = (int)( ( nLen + MF_FR - 1 ) / MF_FR );
+		hipLaunchKernelGGL( melKernelMf, dim3( blocks, batch ), dim3( 512 ), 0, stream, pcm, nSamples, filters, dftTable, mel, nLen, nMel, mx, nLen, pcmStride, melStride );
+		const long long count = nLen * nMel;
+		const int nb = (int)( ( count + 255 ) / 256 < 256 ? ( count + 255 ) / 256 : 256 );
+		hipLaunchKernelGGL( melNormalize, dim3( nb, batch ), dim3( 256 ), 0, stream, mel, count, mx, melStride );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

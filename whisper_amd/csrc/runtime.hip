@@ -80,6 +80,7 @@ namespace
 	// conv1 as an implicit GEMM: K = 3 taps * n_mels channels, zero-padded to a multiple of 64 (80 mels: 240 -> 256;
 	// the 128 mels of the large-v3 shape: 384 exactly)
 	constexpr int CONV1_KPAD_MAX = 512;
+	constexpr int MEL_BATCH_MAX = 1024;	   // buffers per launch of wh_mel_spectrogram_batch (a maximum each in the context's scratch)
 	inline int conv1Kpad( const wh_hparams& hp ) { return roundUp( 3 * hp.n_mels, 64 ); }
 
 	// Special token ids follow from the vocabulary size (Whisper/Whisper/Vocabulary.h:27-41 hard-codes 51864 / 51865):
@@ -1236,7 +1237,7 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	rc = rc ? rc : c->alloc( c->melOffsetsDev, B, wh_context::DONT_CARE, "melOffsetsDev" );
 	rc = rc ? rc : c->alloc( c->melWindowsDev, B, wh_context::MUST_BE_ZERO, "melWindowsDev" );
 	rc = rc ? rc : c->alloc( c->tokDataDev, S, wh_context::DONT_CARE, "tokDataDev" );
-	rc = rc ? rc : c->alloc( c->melScratch, 64, wh_context::DONT_CARE, "melScratch" );
+	rc = rc ? rc : c->alloc( c->melScratch, 64 + 4 * MEL_BATCH_MAX, wh_context::DONT_CARE, "melScratch" );	  // [0..15]: the single / streamed entry points, then one maximum per buffer of a batch
 	rc = rc ? rc : c->alloc( c->state, 1, wh_context::MUST_BE_ZERO, "state" );
 	rc = rc ? rc : c->alloc( c->seqPos, S, wh_context::MUST_BE_ZERO, "seqPos" );
 	if( rc == 0 )
@@ -1471,6 +1472,36 @@ int wh_mel_spectrogram( wh_context* c, const float* pcmDev, int64_t nSamples, fl
 	const wh_model* m = c->m;
 	return profiled( c, KC_MEL, 2.0 * 2.0 * 400.0 * 201.0 * nLen, 4.0 * nSamples + 4.0 * 2.0 * nLen * m->hp.n_mels,
 		[ & ]() { return launchMel( pcmDev, nSamples, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), melDev, nLen, m->hp.n_mels, c->melScratch, c->stream ); } );
+}
+
+int wh_mel_spectrogram_batch( wh_context* c, const float* pcmDev, int64_t nSamples, int64_t pcmStride, int batch, float* melDev, int64_t melStride )
+{
+	if( !c || nSamples < 0 || batch < 0 || pcmStride < 0 || melStride < 0 ) { setError( "mel_batch: bad argument" ); return WH_E_INVALIDARG; }
+	WH_BIND( c->m );
+	const int64_t nLen = nSamples / 160;
+	if( nLen == 0 || batch == 0 ) return 0;
+	if( !pcmDev || !melDev ) { setError( "mel_batch: null buffer" ); return WH_E_INVALIDARG; }
+	const wh_model* m = c->m;
+	if( melStride < nLen * m->hp.n_mels || pcmStride < nSamples ) { setError( "mel_batch: buffers overlap" ); return WH_E_INVALIDARG; }
+	for( int b0 = 0; b0 < batch; b0 += MEL_BATCH_MAX )
+	{
+		const int nb = batch - b0 < MEL_BATCH_MAX ? batch - b0 : MEL_BATCH_MAX;
+		const float* const pcm = pcmDev + (int64_t)b0 * pcmStride;
+		float* const mel = melDev + (int64_t)b0 * melStride;
+		int covered = 0;
+		const int rc = profiled( c, KC_MEL, 2.0 * 2.0 * 400.0 * 201.0 * nLen * nb, ( 4.0 * nSamples + 4.0 * 2.0 * nLen * m->hp.n_mels ) * nb,
+			[ & ]() {
+				covered = launchMelBatch( pcm, nSamples, pcmStride, nb, m->at<float>( m->L.filters ), m->at<double>( m->L.dft ), mel, melStride, nLen, m->hp.n_mels, c->melScratch + 16, c->stream );
+				return covered == 1 ? 0 : covered; } );
+		if( rc ) return rc;
+		if( covered == 1 )
+			for( int b = 0; b < nb; b++ )
+			{
+				const int r1 = wh_mel_spectrogram( c, pcm + (int64_t)b * pcmStride, nSamples, mel + (int64_t)b * melStride, nullptr );
+				if( r1 ) return r1;
+			}
+	}
+	return 0;
 }
 
 int wh_mel_spectrogram_window( wh_context* c, const float* pcmDev, int64_t nSamples, int64_t frame0, int64_t nFrames, int64_t nChunks,
