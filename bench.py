@@ -1090,7 +1090,7 @@ def main():
     if rank == 0 and world == 1 and args.workload == "clip" and not args.no_boundary and args.model in ("medium", "large-v2"):
         log("the same workload through libWhisper.so (createBatchRunner) ...")
         try:
-            Cb = min(C, 32)         # the batch runner's groups at 224 slots each (what tests/test_batch_api.py and the sessions cover)
+            Cb = C                  # the batch runner's groups at the headline's batch size (64 clips = 448 slots each; round 6: 10311 against 9801 at 224 slots on one box)
             boundary = through_boundary(args.model, min(passes, 2 * Cb), Cb, inflight, B)
             log("through the boundary: %s audio-s/s" % boundary["value"])
         except Exception as e:
