@@ -57,9 +57,12 @@ TILES = (0, 44, 42, 24, 22)
 
 
 @pytest.mark.parametrize("M,N,K", [(129, 1024, 1024), (224, 1024, 4096), (448, 4096, 1024), (512, 1024, 1024), (300, 1280, 5120), (336, 3840, 1280),
-                                   (200, 1000, 384), (448, 52, 2048), (150, 128, 128)])
+                                   (200, 1000, 384), (448, 52, 2048), (150, 128, 128),
+                                   # round 6, gemmDecTile's edges: ragged last row / column tiles, an odd N (element-wise epilogue), a quarter of K of ONE tile,
+                                   # two K tiles per ring slot with the fewest slots (K = 2048 on 64 x 32 tiles)
+                                   (450, 4100, 256), (449, 1031, 768), (320, 1024, 2048), (330, 2052, 1024)])
 def test_mul_mat_big_batch_decode_rows(M, N, K):
-    """129 .. 512 activation rows through gemmDecRows: against float64, repeated launches and every tile shape bit-identical (the tile only
+    """129 .. 512 activation rows through gemmDecTile (the default where its tiles fill the chip, round 6) and gemmDecRows (every pinned tile shape): against float64, repeated launches and every tile shape bit-identical (the tile only
     decides which workgroup computes an element, never the order of its sum), and rows [0, 112) bit-identical with what gemvFused gives for a
     112-row batch when both split K over 4 waves (K < 2048: at K >= 2048 the 112-row kernel splits K over 8)."""
     rng = np.random.default_rng(M * 3 + N)
