@@ -69,7 +69,9 @@ __global__ void __launch_bounds__( 256, 2 ) kMix( const f16x8* in, const unsigne
 	for( int i = 0; i < 8; i++ )
 		for( int r = 0; r < 16; r++ ) c[ i ][ r ] = 0.0f;
 	const unsigned ldsBase = __builtin_amdgcn_readfirstlane( (unsigned)(size_t)(LdsPtr)lds ) + wave * 16384;
-	unsigned off = ( blockIdx.x * 65536u + wave * 16384u + lane * 16u ) & l2mask;
+	// MODE & 8: the 16-byte chunks of every 128-byte row fetched in a permuted order (chunk ^ row, the encoder kernels' swizzled source) instead of lane order
+	const unsigned laneSrc = ( MODE & 8 ) ? ( ( lane & ~7u ) | ( ( lane & 7u ) ^ ( ( lane >> 3 ) & 7u ) ) ) : (unsigned)lane;
+	unsigned off = ( blockIdx.x * 65536u + wave * 16384u + laneSrc * 16u ) & l2mask;
 	f16x8 fr[ 8 ];
 	for( int i = 0; i < 8; i++ ) fr[ i ] = a[ i & 3 ];
 	// MODE & 4: the same 4 KiB per wave and iteration as plain 16-byte loads into registers, written to LDS two iterations later (what a register-staged K loop does)
@@ -201,6 +203,8 @@ int main()
 	{
 		const double m0 = runMix<0>( dRand, l2buf, out, iters / 4 ), m1 = runMix<1>( dRand, l2buf, out, iters / 4 ), m2 = runMix<2>( dRand, l2buf, out, iters / 4 ), m3 = runMix<3>( dRand, l2buf, out, iters / 4 );
 		printf( "16 MFMAs per iteration, 2048 waves, random: alone %.0f TF | + 4 KiB of LDS-DMA from L2 %.0f | + 8 ds_read_b128 %.0f | + both %.0f\n", m0, m1, m2, m3 );
+		const double m9 = runMix<9>( dRand, l2buf, out, iters / 4 ), m11 = runMix<11>( dRand, l2buf, out, iters / 4 );
+		printf( "   LDS-DMA with the chunks of a row in permuted order: %.0f TF | + 8 ds_read_b128 %.0f\n", m9, m11 );
 		const double m4 = runMix<4>( dRand, l2buf, out, iters / 4 ), m6 = runMix<6>( dRand, l2buf, out, iters / 4 );
 		printf( "   the same 4 KiB as plain loads to registers + ds_write_b128: %.0f TF | + 8 ds_read_b128 %.0f\n", m4, m6 );
 	}
