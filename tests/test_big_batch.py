@@ -392,8 +392,18 @@ def test_wide_decode_products_in_one_row_tile(M, N, K, golden):
             binding.check(L.wh_op_mul_mat(None, ptr(a), ptr(w), ptr(bias), None, ptr(o32), M, N, K))
             torch.cuda.synchronize()
             outs[mode], acc[mode] = out, o32
+        # round 6: the one-tile path is gemmDecTile (LDS-staged, 4 / 6 / 8 row tiles) by default; dec_lds 0 = gemmDecRows' one-tile instances -- the same bits
+        binding.set_option("dec_lds", 0)
+        binding.set_option("dec_wide_rows", 2)
+        alt16 = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+        binding.check(L.wh_op_mul_mat_gelu(None, ptr(a), ptr(w), ptr(bias), ptr(alt16), M, N, K))
+        alt32 = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+        binding.check(L.wh_op_mul_mat(None, ptr(a), ptr(w), ptr(bias), None, ptr(alt32), M, N, K))
+        torch.cuda.synchronize()
     finally:
         binding.set_option("dec_wide_rows", default)
+        binding.set_option("dec_lds", binding.get_option_default("dec_lds"))
+    assert torch.equal(acc[2], alt32) and torch.equal(outs[2], alt16), "gemmDecTile's one-tile instances differ from gemmDecRows'"
     assert torch.equal(acc[0], acc[2]), "FP32 accumulators of the one-tile instances differ from gemvFused's"
     table = torch.from_numpy(golden["table_gelu"].astype(np.int32)).cuda()
     want = table[(acc[0].half().view(torch.int16).to(torch.int32) & 0xFFFF).long()].to(torch.int16).view(torch.float16).float()

@@ -2985,14 +2985,16 @@ namespace wh
 						  : "s"( base ), "v"( off0 ), "s"( dst )
 						  : "memory" );
 		}
-		template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF>
+		template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF, int MT = 4>
 		__global__ void __launch_bounds__( 256 ) gemmDecTile( const GemmArgs a )
 		{
 			// KS = K tiles of 64 per ring slot and barrier (2 for the deep products: K = 4096 is 64 tiles, and a tile is only 4 .. 8 MFMAs per wave)
+			// MT = row tiles of 16 per workgroup: 4, or 6 / 8 with CT = 2 for the wide products of 65 .. 128 rows (all rows in one workgroup per 32 columns)
 			static_assert( CT == 4 || CT == 2, "wave w owns column tile w % CT" );
-			constexpr int MT = 4, NW = 4, GPW = MT * CT / NW;
+			static_assert( MT == 4 || ( CT == 2 && ( MT == 6 || MT == 8 ) ), "an even number of row tiles per column pair" );
+			constexpr int NW = 4, GPW = MT * CT / NW, AP = MT / 2;	  // AP = A pieces (8 rows x 128 bytes) per wave
 			constexpr int A_BYTES = MT * 16 * 128, W_BYTES = CT * 16 * 128, TILE = A_BYTES + W_BYTES, STAGE = KS * TILE;
-			constexpr int P = KS * ( CT == 4 ? 4 : 3 );	  // load instructions per slot and wave
+			constexpr int P = KS * ( AP + ( CT == 4 ? 2 : 1 ) );	  // load instructions per slot and wave
 			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemD[];
 			typedef __attribute__( ( address_space( 3 ) ) ) void* LdsPtr;
 			const int tid = threadIdx.x;
@@ -3002,18 +3004,22 @@ namespace wh
 			const int m0 = blockIdx.y * 16 * MT;
 			const int nk = a.K / 64, perQ = nk / 4, nSlots = nk / KS;
 
-			// ---- producer: A = 8 pieces of 8 rows (wave w: pieces 2 w, 2 w + 1), W = 2 CT pieces (CT = 4: 2 w, 2 w + 1; CT = 2: piece w)
+			// ---- producer: A = 2 MT pieces of 8 rows (wave w: pieces AP w .. AP w + AP - 1), W = 2 CT pieces (CT = 4: 2 w, 2 w + 1; CT = 2: piece w)
 			const int rIn = lane >> 3, cPhys = lane & 7;
-			unsigned offA[ 2 ], offW[ 2 ];
+			unsigned offA[ AP ], offW[ 2 ];
 	#pragma unroll
-			for( int i = 0; i < 2; i++ )
+			for( int i = 0; i < AP; i++ )
 			{
-				const int row = ( wave * 2 + i ) * 8 + rIn;
+				const int row = ( wave * AP + i ) * 8 + rIn;
 				const int cl = cPhys ^ ( ( row >> 1 ) & 7 );
 				int m = m0 + row;
 				m = m < a.M ? m : a.M - 1;
 				offA[ i ] = (unsigned)( ( rowOffset( m, a.Mb, a.lda, a.aBatchStride ) + cl * 8 ) * 2 );
-				const int rowW = CT == 4 ? row : wave * 8 + rIn;
+			}
+	#pragma unroll
+			for( int i = 0; i < 2; i++ )
+			{
+				const int rowW = CT == 4 ? ( wave * 2 + i ) * 8 + rIn : wave * 8 + rIn;
 				const int clW = cPhys ^ ( ( rowW >> 1 ) & 7 );
 				int n = n0 + rowW;
 				n = n < a.N ? n : a.N - 1;
@@ -3027,7 +3033,9 @@ namespace wh
 				{
 					const int kt = slot * KS + u;
 					const unsigned buf = ldsBase + (unsigned)( slot % NBUF ) * STAGE + u * TILE;
-					ldsDmaPair( a.A + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * 2048u );
+					ldsDmaPair( a.A + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * ( AP * 1024u ) );
+					if constexpr( AP == 3 ) ldsDmaOne( a.A + kt * 64, offA[ 2 ], buf + (unsigned)wave * ( AP * 1024u ) + 2048u );
+					if constexpr( AP == 4 ) ldsDmaPair( a.A + kt * 64, offA[ 2 ], offA[ 3 ], buf + (unsigned)wave * ( AP * 1024u ) + 2048u );
 					if constexpr( CT == 4 )
 						ldsDmaPair( a.W + kt * 64, offW[ 0 ], offW[ 1 ], buf + A_BYTES + (unsigned)wave * 2048u );
 					else
@@ -3036,7 +3044,7 @@ namespace wh
 			};
 
 			// ---- consumer: lane l reads row l & 15 of a 16-row tile, logical chunk 4 h + (l >> 4), stored at chunk ^ ((row >> 1) & 7)
-			const int cTile = wave % CT, tFirst = wave / CT;	 // group g = wave + 4 i: column tile g % CT = cTile, row tile g / CT = tFirst + ( 4 / CT ) i
+			const int cTile = wave % CT, tFirst = wave / CT;	 // group g = wave + 4 i: column tile g % CT = cTile, row tile g / CT = tFirst + ( 4 / CT ) i (G = MT CT is a multiple of 4)
 			unsigned fragOff[ 2 ];
 	#pragma unroll
 			for( int h = 0; h < 2; h++ ) fragOff[ h ] = (unsigned)( ( lane & 15 ) * 128 + ( ( ( ( h << 2 ) + ( lane >> 4 ) ) ^ ( ( lane >> 1 ) & 7 ) ) << 4 ) );
@@ -3158,20 +3166,20 @@ namespace wh
 	}
 
 	// gemmDecTile: K must divide into four quarters of whole 64-element tiles (the K split the sums follow); operands addressed as a 64-bit base + 32-bit offsets
-	template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF>
+	template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF, int MT = 4>
 	static int launchDecTileK( const GemmArgs& a, hipStream_t stream )
 	{
-		constexpr int lds = NBUF * KS * ( 4 * 16 * 128 + CT * 16 * 128 );
+		constexpr int lds = NBUF * KS * ( MT * 16 * 128 + CT * 16 * 128 );
 		if( lds > 48 * 1024 )
 		{
 			static PerDeviceOnce once;
 			if( const int onceDev = once.needed(); onceDev >= 0 )
 			{
-				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecTile<EPI, CT, KS, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				WH_HIP( hipFuncSetAttribute( (const void*)gemmDecTile<EPI, CT, KS, NBUF, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
 				once.mark( onceDev );
 			}
 		}
-		hipLaunchKernelGGL( ( gemmDecTile<EPI, CT, KS, NBUF> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 63 ) / 64 ), dim3( 256 ), lds, stream, a );
+		hipLaunchKernelGGL( ( gemmDecTile<EPI, CT, KS, NBUF, MT> ), dim3( ( a.N + 16 * CT - 1 ) / ( 16 * CT ), ( a.M + 16 * MT - 1 ) / ( 16 * MT ) ), dim3( 256 ), lds, stream, a );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}
@@ -3220,6 +3228,14 @@ namespace wh
 	template<int EPI>
 	static int launchDecRowsOneTile( const GemmArgs& a, hipStream_t stream )
 	{
+		// option dec_lds (round 6): the LDS-staged kernel with all rows in one workgroup per 32 columns (4 / 6 / 8 row tiles), the same sums
+		if( g_opt.decLds == 1 && g_opt.decTile == 0 && decTileOk( a ) )
+		{
+			const int mt = ( a.M + 15 ) / 16;
+			if( mt <= 4 ) return launchDecTileK<EPI, 2, 1, DT_NBUF, 4>( a, stream );
+			if( mt <= 6 ) return launchDecTileK<EPI, 2, 1, DT_NBUF, 6>( a, stream );
+			return launchDecTileK<EPI, 2, 1, DT_NBUF, 8>( a, stream );
+		}
 		switch( ( a.M + 15 ) / 16 )
 		{
 		case 3: return launchDecRowsK<EPI, 3, 2>( a, stream );
