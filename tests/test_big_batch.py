@@ -433,6 +433,7 @@ def test_deep_decode_products_all_rows_per_workgroup(M, N, K):
     outs = {}
     default = binding.get_option_default("dec_deep_rows")
     try:
+        binding.set_option("dec_split", 0)         # (round 6's default route for this shape; its own test follows)
         for on in (0, 1):
             binding.set_option("dec_deep_rows", on)
             out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
@@ -441,9 +442,46 @@ def test_deep_decode_products_all_rows_per_workgroup(M, N, K):
             outs[on] = out
     finally:
         binding.set_option("dec_deep_rows", default)
+        binding.set_option("dec_split", binding.get_option_default("dec_split"))
     d = report("deep decode product %dx%dx%d" % (M, N, K), outs[1].cpu().numpy(), want)
     assert d.max() < 2e-5 * max(1.0, np.sqrt(K / 128))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 1280, 5120), (33, 1024, 4096), (64, 1024, 4096), (70, 1280, 5120), (96, 1024, 4096), (100, 1280, 5120), (128, 1280, 5120), (128, 1024, 2048),
+                                   (47, 2048, 4096), (70, 1000, 4096), (40, 1024, 2304)])
+def test_deep_decode_products_k_split_over_workgroups(M, N, K):
+    """Option dec_split (round 6, default): the MLP down-projection of 33 .. 128 rows as gemmDecTile<SPLIT = 8> -- the eight K shares of gemvFused's eight waves on
+    eight workgroups per 32 columns, partial tiles in the context's scratch -- plus decSplitCombine adding them in wave order: FP32 + bias + residual, the SAME BITS as
+    gemvFused (dec_split 0), also with the residual updated in place as the decoder does, and without bias / residual. N = 1000 and K = 2304 are not covered by the split
+    kernel (N % 32, K % 512): both settings run gemvFused."""
+    rng = np.random.default_rng(M * 5 + N)
+    a = rng.standard_normal((M, K)).astype(np.float16)
+    w = (0.05 * rng.standard_normal((N, K))).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    want = (a.astype(np.float64) @ w.astype(np.float64).T + bias + res).astype(np.float32)
+    ad, wd, bd, rd = dev(a), dev(w), dev(bias), dev(res)
+    L = binding.lib()
+    outs, inplace, bare = {}, {}, {}
+    try:
+        for on in (0, 1):
+            binding.set_option("dec_split", on)
+            out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+            binding.check(L.wh_op_mul_mat(None, ptr(ad), ptr(wd), ptr(bd), ptr(rd), ptr(out), M, N, K))
+            x = rd.clone()
+            binding.check(L.wh_op_mul_mat(None, ptr(ad), ptr(wd), ptr(bd), ptr(x), ptr(x), M, N, K))
+            y = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+            binding.check(L.wh_op_mul_mat(None, ptr(ad), ptr(wd), None, None, ptr(y), M, N, K))
+            torch.cuda.synchronize()
+            outs[on], inplace[on], bare[on] = out, x, y
+    finally:
+        binding.set_option("dec_split", binding.get_option_default("dec_split"))
+    d = report("K-split decode product %dx%dx%d" % (M, N, K), outs[1].cpu().numpy(), want)
+    assert d.max() < 2e-5 * max(1.0, np.sqrt(K / 128))
+    assert torch.equal(outs[0], outs[1]), "the K-split product differs from gemvFused's eight-wave sums"
+    assert torch.equal(inplace[0], inplace[1]) and torch.equal(inplace[1], outs[1])
+    assert torch.equal(bare[0], bare[1])
 
 
 def test_wide_qkv_product_appends_the_same_cache_rows(hip_medium):

@@ -2985,7 +2985,11 @@ namespace wh
 						  : "s"( base ), "v"( off0 ), "s"( dst )
 						  : "memory" );
 		}
-		template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF, int MT = 4>
+		// SPLIT = 8 (round 6, the MLP down-projection of 33 .. 128 rows: N = d gives only N / 32 = 32 .. 40 column tiles): blockIdx.y selects an EIGHTH of K instead of
+		// a row tile -- gemvFused's eight-wave K split (TUNE_GEMV_K8) dealt to eight workgroups. The FP32 partial tile P_e goes to a.splitScratch[e][M][N]; the launch
+		// that follows (decSplitCombine) adds the eight in gemvFused's order, ((P0 + P1) + ... ) + P7, then bias and residual: the same bits. Two launches, no atomics
+		// (a last-arrival combine needs agent-scope fences: an L2 write-back per workgroup on gfx950, 5-30 us -- see gemmAllRows).
+		template<int EPI, int CT, int KS = 1, int NBUF = DT_NBUF, int MT = 4, int SPLIT = 0>
 		__global__ void __launch_bounds__( 256 ) gemmDecTile( const GemmArgs a )
 		{
 			// KS = K tiles of 64 per ring slot and barrier (2 for the deep products: K = 4096 is 64 tiles, and a tile is only 4 .. 8 MFMAs per wave)
@@ -3001,8 +3005,11 @@ namespace wh
 			const int lane = tid & 63;
 			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
 			const int n0 = blockIdx.x * 16 * CT;
-			const int m0 = blockIdx.y * 16 * MT;
-			const int nk = a.K / 64, perQ = nk / 4, nSlots = nk / KS;
+			const int m0 = SPLIT ? 0 : blockIdx.y * 16 * MT;
+			const int kOff = SPLIT ? blockIdx.y * ( a.K / ( SPLIT ? SPLIT : 1 ) ) : 0;	 // first K element of this workgroup's share
+			const int nk = SPLIT ? a.K / ( SPLIT ? SPLIT : 1 ) / 64 : a.K / 64, perQ = SPLIT ? nk : nk / 4, nSlots = nk / KS;
+			const f16* const Ak = a.A + kOff;
+			const f16* const Wk = a.W + kOff;
 
 			// ---- producer: A = 2 MT pieces of 8 rows (wave w: pieces AP w .. AP w + AP - 1), W = 2 CT pieces (CT = 4: 2 w, 2 w + 1; CT = 2: piece w)
 			const int rIn = lane >> 3, cPhys = lane & 7;
@@ -3033,13 +3040,13 @@ namespace wh
 				{
 					const int kt = slot * KS + u;
 					const unsigned buf = ldsBase + (unsigned)( slot % NBUF ) * STAGE + u * TILE;
-					ldsDmaPair( a.A + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * ( AP * 1024u ) );
-					if constexpr( AP == 3 ) ldsDmaOne( a.A + kt * 64, offA[ 2 ], buf + (unsigned)wave * ( AP * 1024u ) + 2048u );
-					if constexpr( AP == 4 ) ldsDmaPair( a.A + kt * 64, offA[ 2 ], offA[ 3 ], buf + (unsigned)wave * ( AP * 1024u ) + 2048u );
+					ldsDmaPair( Ak + kt * 64, offA[ 0 ], offA[ 1 ], buf + (unsigned)wave * ( AP * 1024u ) );
+					if constexpr( AP == 3 ) ldsDmaOne( Ak + kt * 64, offA[ 2 ], buf + (unsigned)wave * ( AP * 1024u ) + 2048u );
+					if constexpr( AP == 4 ) ldsDmaPair( Ak + kt * 64, offA[ 2 ], offA[ 3 ], buf + (unsigned)wave * ( AP * 1024u ) + 2048u );
 					if constexpr( CT == 4 )
-						ldsDmaPair( a.W + kt * 64, offW[ 0 ], offW[ 1 ], buf + A_BYTES + (unsigned)wave * 2048u );
+						ldsDmaPair( Wk + kt * 64, offW[ 0 ], offW[ 1 ], buf + A_BYTES + (unsigned)wave * 2048u );
 					else
-						ldsDmaOne( a.W + kt * 64, offW[ 0 ], buf + A_BYTES + (unsigned)wave * 1024u );
+						ldsDmaOne( Wk + kt * 64, offW[ 0 ], buf + A_BYTES + (unsigned)wave * 1024u );
 				}
 			};
 
@@ -3101,7 +3108,50 @@ namespace wh
 					}
 				}
 			}
-			decRowsEpilogue<EPI, MT, CT, NW>( a, tot, m0, n0, wave, lane );
+			if constexpr( SPLIT != 0 )
+			{
+				// the partial tile of this eighth of K: group g = wave + 4 i, lane = (activation row, four consecutive columns) as in decRowsEpilogue
+				float* const part = a.splitScratch + (long long)blockIdx.y * a.M * a.N;
+	#pragma unroll
+				for( int i = 0; i < GPW; i++ )
+				{
+					const int g = wave + NW * i;
+					const int t = g / CT, c = g - t * CT;
+					const int mm = t * 16 + ( lane & 15 );
+					const int nn = n0 + c * 16 + ( lane >> 4 ) * 4;
+					if( mm < a.M && nn < a.N ) *(f32x4*)( part + (long long)mm * a.N + nn ) = tot[ i ];
+				}
+			}
+			else
+				decRowsEpilogue<EPI, MT, CT, NW>( a, tot, m0, n0, wave, lane );
+		}
+
+		// out[m][n] = ( ( ( P0 + P1 ) + ... + P7 ) + bias ) + res: the eight partial tiles of gemmDecTile<.., SPLIT = 8> in gemvFused's wave order, then epilogueOne<EPI_F32>'s order
+		template<int SPLIT>
+		__global__ void __launch_bounds__( 256 ) decSplitCombine( const GemmArgs a )
+		{
+			const int n4 = a.N >> 2;
+			const int idx = blockIdx.x * 256 + threadIdx.x;
+			if( idx >= a.M * n4 ) return;
+			const int mm = idx / n4, nn = ( idx - mm * n4 ) * 4;
+			const long long stride = (long long)a.M * a.N;
+			const float* const p = a.splitScratch + (long long)mm * a.N + nn;
+			f32x4 v[ SPLIT ];
+	#pragma unroll
+			for( int e = 0; e < SPLIT; e++ ) v[ e ] = *(const f32x4*)( p + e * stride );
+			const long long off = (long long)mm * a.ldc + nn;
+			f32x4 bv = { 0.0f, 0.0f, 0.0f, 0.0f }, rv = { 0.0f, 0.0f, 0.0f, 0.0f };
+			if( a.bias ) bv = *(const f32x4*)( a.bias + nn );
+			if( a.res ) rv = *(const f32x4*)( a.res + off );
+			f32x4 o = v[ 0 ];
+	#pragma unroll
+			for( int e = 1; e < SPLIT; e++ )
+	#pragma unroll
+				for( int r = 0; r < 4; r++ ) o[ r ] += v[ e ][ r ];
+			// (gemvFused adds its zero-initialised bias / residual registers when the pointers are null: so does this)
+	#pragma unroll
+			for( int r = 0; r < 4; r++ ) o[ r ] = ( o[ r ] + bv[ r ] ) + rv[ r ];
+			*(f32x4*)( a.out32 + off ) = o;
 		}
 	}	// namespace
 
@@ -3261,6 +3311,38 @@ namespace wh
 		default: return launchDecRowsD<EPI_F32, 8, 1, 3, 8>( a, stream );
 		}
 	}
+	// 33 .. 128 rows against a NARROW, DEEP weight matrix, option dec_split (round 6): the eight K shares of gemvFused's eight waves dealt to eight workgroups of the
+	// LDS-staged kernel per 32 columns (N / 32 x 8 = 256 .. 320 workgroups instead of gemvFused's N / 16 x 2 re-reading the rows per 16 columns), the eight partial tiles
+	// added by a second launch in wave order: the same bits. Needs the context's scratch (8 x M x N floats). Returns 1 when the shape is not covered.
+	static int launchDecRowsSplit( const GemmArgs& a, hipStream_t stream )
+	{
+		if( a.lnX || a.epi != EPI_F32 || !a.splitScratch || a.M <= 32 || a.M > GEMV_FUSED_MAX_ROWS || a.N > 2048 || ( a.N % 32 ) != 0 || a.K < 2048 || ( a.K % 512 ) != 0 || a.Mb < a.M ||
+			!( g_tuning & TUNE_GEMV_K8 ) || !decTileOk( a ) )
+			return 1;
+		auto go = [ & ]( auto mtTag ) -> int
+		{
+			constexpr int MT = decltype( mtTag )::value;
+			constexpr int lds = DT_NBUF * ( MT * 16 * 128 + 2 * 16 * 128 );
+			if( lds > 48 * 1024 )
+			{
+				static PerDeviceOnce once;
+				if( const int onceDev = once.needed(); onceDev >= 0 )
+				{
+					WH_HIP( hipFuncSetAttribute( (const void*)gemmDecTile<EPI_F32, 2, 1, DT_NBUF, MT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+					once.mark( onceDev );
+				}
+			}
+			hipLaunchKernelGGL( ( gemmDecTile<EPI_F32, 2, 1, DT_NBUF, MT, 8> ), dim3( a.N / 32, 8 ), dim3( 256 ), lds, stream, a );
+			WH_HIP( hipGetLastError() );
+			hipLaunchKernelGGL( ( decSplitCombine<8> ), dim3( ( a.M * ( a.N / 4 ) + 255 ) / 256 ), dim3( 256 ), 0, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		};
+		const int mt = ( a.M + 15 ) / 16;
+		if( mt <= 4 ) return go( std::integral_constant<int, 4>{} );
+		if( mt <= 6 ) return go( std::integral_constant<int, 6>{} );
+		return go( std::integral_constant<int, 8>{} );
+	}
 	// returns 1 when the shape is not one of these
 	static int launchDecRowsWide( const GemmArgs& a, hipStream_t stream )
 	{
@@ -3357,6 +3439,12 @@ namespace wh
 		if( a.M > 32 && !ln && g_opt.decWideRows )
 		{
 			const int rc = launchDecRowsWide( a, stream );
+			if( rc <= 0 ) return rc;
+		}
+		// option dec_split: the same product with the eight K shares on eight workgroups of gemmDecTile and a combine launch
+		if( a.M > 32 && !ln && g_opt.decSplit )
+		{
+			const int rc = launchDecRowsSplit( a, stream );
 			if( rc <= 0 ) return rc;
 		}
 		// option dec_deep_rows: 33 .. 128 rows against N <= 2048, K >= 2048 (MLP down-projection) with all rows per 16-column workgroup and 8 waves over K

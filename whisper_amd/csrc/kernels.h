@@ -74,6 +74,8 @@ namespace wh
 		int decLds = 1;				 // "dec_lds": decode products of 129 .. 512 rows: 1 = gemmDecTile where its 64 x 64 / 64 x 32 tiles fill the chip (operands staged through LDS in
 									 // full 128-byte lines, the same sums: 448 x 4096 x 1024 14.4 against 22.1 us), 0 = gemmDecRows everywhere (round 5)
 		int decLdsKs = 2;			 // "dec_lds_ks": gemmDecTile on 64 x 32 tiles with K >= 2048: 2 = two K tiles per ring slot and barrier (18.1 against 21.7 us at 448 rows), 1 = one
+		int decSplit = 1;			 // "dec_split": the MLP down-projection (N <= 2048, K >= 2048) of 33 .. 128 rows: 1 = the eight K shares of gemvFused's eight waves on eight workgroups of
+									 // gemmDecTile per 32 columns + decSplitCombine (the same bits, two launches), 0 = gemvFused<.., 8 waves> (rounds 4-5)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
@@ -128,6 +130,7 @@ namespace wh
 		const float* lnB;
 		int wideEpi;		  // tiled kernel, set by the launcher: the LDS-transposed epilogue with 16-byte stores applies
 		int groupM;			  // tiled kernel: M tiles per band of the block walk (0 = default for the tile shape, 1 = rows of tiles)
+		float* splitScratch;  // decode-step products, option dec_split: [8][M][N] partial tiles of the K-split launch (the context's; null = the split path is not taken)
 		int cuLimit;		  // persistent tiled kernel: CUs the launch stream may use (0 = all of the device)
 	};
 

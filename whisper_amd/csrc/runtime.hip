@@ -40,7 +40,7 @@ namespace wh
 	{
 		struct OptionName { const char* name; int Options::* field; };
 		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
-			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 }, { "dec_lds", &Options::decLds }, { "dec_lds_ks", &Options::decLdsKs } };
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 }, { "dec_lds", &Options::decLds }, { "dec_lds_ks", &Options::decLdsKs }, { "dec_split", &Options::decSplit } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
 		{
@@ -283,6 +283,7 @@ struct wh_context
 	// decoder activations
 	float *dx = nullptr, *logits = nullptr, *probs = nullptr;
 	f16 *dxn = nullptr, *dq = nullptr, *dattn = nullptr, *dh = nullptr;
+	float* splitK = nullptr;	 // [8][min( maxRows, 128 )][d]: partial tiles of the K-split MLP down-projection (option dec_split)
 	// single-stream decode steps (decode1.hip): cross-attention scores, per-split maxima and partial results of up to 4 sequences
 	float *crossScores = nullptr, *crossSplitMax = nullptr, *crossPart = nullptr;
 	int* tokensDev = nullptr;
@@ -1225,6 +1226,7 @@ int wh_context_create_hyp( wh_model* m, int maxBatch, int hypotheses, void* stre
 	rc = rc ? rc : c->alloc( c->dq, rowsD * d, wh_context::DONT_CARE, "dq" );
 	rc = rc ? rc : c->alloc( c->dattn, rowsD * d, wh_context::DONT_CARE, "dattn" );
 	rc = rc ? rc : c->alloc( c->dh, rowsD * 4 * d, wh_context::DONT_CARE, "dh" );
+	rc = rc ? rc : c->alloc( c->splitK, 8ll * ( rowsD < GEMV_FUSED_MAX_ROWS ? rowsD : GEMV_FUSED_MAX_ROWS ) * d, wh_context::DONT_CARE, "splitK" );	   // partial tiles of the K-split MLP down-projection (33 .. 128 rows)
 	{
 		const int64_t sm = S < SMALL_MAX_ROWS ? S : SMALL_MAX_ROWS;
 		rc = rc ? rc : c->alloc( c->crossScores, sm * hp.n_text_head * T, wh_context::DONT_CARE, "crossScores" );
@@ -1915,6 +1917,7 @@ static int decodeGraph( wh_context* c, int batch, int nTokens, int nPast, bool d
 	{
 		g.nPastDev = nPastDev;
 		if( !gemv ) return gemmP( c, g, true, true );
+		if( g.N <= d ) g.splitScratch = c->splitK;
 		if( lnW && fuseLn )
 		{
 			g.lnX = c->dx; g.lnW = lnW; g.lnB = lnB;
@@ -3012,6 +3015,18 @@ int wh_op_mul_mat( void* stream, const void* aF16, const void* wF16, const float
 {
 	GemmArgs g = plainGemm( (const f16*)aF16, (const f16*)wF16, M, N, K );
 	g.epi = EPI_F32; g.bias = bias; g.res = residual; g.out32 = out;
+	if( M > 32 && M <= GEMV_FUSED_MAX_ROWS && N <= 2048 && K >= 2048 )
+	{
+		// option dec_split needs room for its eight partial tiles: no context here, so the op-level entry keeps one buffer per device (calls on different streams
+		// would share it: this entry point is the tests' and tools', the decoder passes its context's buffer)
+		static std::mutex mx;
+		static float* bufs[ 64 ] = {};
+		int dev = 0;
+		WH_HIP( hipGetDevice( &dev ) );
+		std::lock_guard<std::mutex> lk( mx );
+		if( !bufs[ dev & 63 ] ) WH_HIP( hipMalloc( (void**)&bufs[ dev & 63 ], 8ull * GEMV_FUSED_MAX_ROWS * 2048 * sizeof( float ) ) );
+		g.splitScratch = bufs[ dev & 63 ];
+	}
 	// the same choice the decoder makes: up to 32 rows go to the gemv when K allows it
 	if( M <= GEMV_MAX_ROWS && ( K % 128 ) == 0 ) return launchGemv( g, (hipStream_t)stream );	   // the op-level entry is the decode-step product: up to 512 rows on the weight-streaming kernels
 	return M <= 32 ? launchGemmSkinny( g, (hipStream_t)stream ) : launchGemm( g, (hipStream_t)stream );
