@@ -540,3 +540,45 @@ def test_decoder_cross_attention_fused_query(seqs, heads, group):
     dd = report("fused cross attention seqs=%d heads=%d group=%d" % (seqs, heads, group), got, wn.r16(want))
     # one more rounding point than the plain attention test: an FP16 flip of a LayerNorm output or of q moves a score by ~1e-3
     assert dd.max() < 4e-3 and dd.mean() < 3e-4
+
+
+@pytest.mark.parametrize("blocks,heads,group,n_keys,stride", [(8, 20, 5, 1500, 1500), (3, 16, 5, 1500, 1500), (2, 2, 2, 1500, 1500), (2, 6, 3, 1500, 1536), (2, 8, 4, 700, 1500),
+                                                              (1, 16, 8, 1500, 1500), (2, 20, 5, 37, 1500), (2, 16, 5, 1, 1500), (1, 2, 5, 129, 1500), (1, 16, 5, 1489, 1500)])
+def test_decoder_cross_attention_of_hypothesis_groups_on_the_matrix_cores(blocks, heads, group, n_keys, stride):
+    """attentionDecM (option cross_mfma, round 6's default for hypothesis groups: LayerNorm by a wave per row, query projection, K.Q^T and V^T.P^T as 16x16x32 MFMAs,
+    V transposed through per-wave LDS) against the numpy restatement of WhisperContext.cpp:489-519 and against attentionDecG<NQ, true> (cross_mfma 0): groups of
+    2 / 3 / 4 / 5 / 8 rows, key counts that end inside a tile, inside the first tile, on one key (audio_ctx overrides), d = 128 .. 1280."""
+    rng = np.random.default_rng(blocks * 7 + heads + group + n_keys)
+    seqs = blocks * group
+    d = heads * 64
+    x = (rng.standard_normal((seqs, d)) * 2 + 0.3).astype(np.float32)
+    lnw = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    lnb = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    wq = (rng.standard_normal((d, d)) * (1.0 / np.sqrt(d))).astype(np.float16)
+    bq = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    scale = np.float32(64.0 ** -0.25)
+    K = (rng.standard_normal((blocks, heads, stride, 64)) * 0.8).astype(np.float16)
+    V = rng.standard_normal((blocks, heads, stride, 64)).astype(np.float16)
+    V[:, :, n_keys:, :] = np.float16(np.nan)          # rows beyond the key count must never reach a sum
+    K[:, :, n_keys:, :] = np.float16(np.nan)
+    xn = wn.layer_norm(x, lnw, lnb)
+    q = wn.r16(((wn.mul_mat_w(wq, xn) + bq).astype(np.float32) * scale).astype(np.float32))
+    want = _np_decoder_attention(q.astype(np.float16), K[:, :, :n_keys], V[:, :, :n_keys], 1, n_keys, 0, 0, group, 0)
+    xd, lw, lb, wd, bd, kd, vd = dev(x), dev(lnw), dev(lnb), dev(wq), dev(bq), dev(K), dev(V)
+    got = {}
+    try:
+        for mode in (0, 1):
+            binding.set_option("cross_mfma", mode)
+            out = torch.full((seqs, d), float("nan"), dtype=torch.float16, device="cuda")
+            binding.check(binding.lib().wh_op_decoder_cross_attention(None, ptr(xd), ptr(lw), ptr(lb), ptr(wd), ptr(bd), C.c_float(float(scale)), ptr(kd), ptr(vd),
+                                                                      ptr(out), seqs, heads, n_keys, stride, group))
+            torch.cuda.synchronize()
+            got[mode] = out.cpu().numpy().astype(np.float32)
+    finally:
+        binding.set_option("cross_mfma", binding.get_option_default("cross_mfma"))
+    assert np.isfinite(got[1]).all()
+    dd = report("cross attention on the matrix cores blocks=%d heads=%d group=%d keys=%d" % (blocks, heads, group, n_keys), got[1], wn.r16(want))
+    d0 = np.abs(got[0] - wn.r16(want))
+    print("  attentionDecG against the same restatement: max %.2e mean %.2e; the two kernels: max %.2e" % (d0.max(), d0.mean(), np.abs(got[0] - got[1]).max()))
+    assert dd.max() < 4e-3 and dd.mean() < 3e-4
+    assert np.abs(got[0] - got[1]).max() < 4e-3

@@ -1144,6 +1144,258 @@ namespace wh
 			return 0;
 		}
 
+		// ---------------------------------------------------------------------------------------------------------------
+		// attentionDecM (round 6): the cross-attention of a decode step for HYPOTHESIS GROUPS -- NQ = 2 .. 8 rows (the hypotheses of a window in beam search) share
+		// one pass over the window's keys -- on the matrix cores. attentionDecG<5, true> spends 48 us per launch at 8 windows x 20 heads (1.3 TB/s): ~4500 VALU
+		// instructions per lane (8-lane partial dot products, three shuffles each, for 5 queries per key row), a fused query projection of 8 lanes per weight row, and
+		// a chain of ten dependent memory round trips. Here, per (head, window) workgroup of 8 waves:
+		//   * every load of the kernel's first half is in flight before anything is computed: the head's 64 query-weight rows (MFMA operand fragments, k-steps
+		//     dealt to the waves) and ALL K tiles of the wave (tiles wave, wave + 8, ...: 16 keys x 64 dims each, two 16-byte fragments per lane);
+		//   * LayerNorm of row q by wave q (layerNormRows: the bits of the standalone kernel), query projection as 4 row tiles x d / 32 k-steps of
+		//     v_mfma_f32_16x16x32_f16 with the NQ rows in NQ of the 16 operand columns, the 8 partial tiles added in wave order;
+		//   * S^T = K . Q^T: two MFMAs per tile of 16 keys; a lane ends up with 4 consecutive keys of ONE query (column lane & 15) per tile -- the scores stay
+		//     in registers (12 tiles x 4), maxima meet through LDS, e = exp16( s - max ), double sums (ggml.c:5030-5090);
+		//   * O^T = V^T . P^T: P's MFMA operand IS the lane's own e registers (k index = 8 (lane >> 4) + e <-> tile t0 / t1, key 4 (lane >> 4) + (e & 3)); V is
+		//     stored [key][64] (attentionDecG's layout), so its operand needs 8 keys of one dim per lane: each wave stages the two V tiles of a 32-key block
+		//     in its own 4 KiB of LDS (coalesced 128-byte rows in, chunks XOR-swizzled by row / 4, conflict-free 2-byte reads out);
+		//   * e is an FP16 value, so P enters the product exactly; the 1 / sum factor is applied to the FP32 result (the reference rounds e / sum to FP16 first,
+		//     ggml.c:5912-6097; attentionDecG multiplies in FP32): results differ from attentionDecG<NQ> by summation order and that one rounding.
+		// Grid (head, window); nTok == 1, not causal, fused query only.
+		constexpr int M_TPW = MAX_KEYS / 16 / NW;	  // 12 key tiles per wave
+		constexpr int M_QSTEPS = G_MAXD / 32 / NW;	  // 5 k-steps of the query projection per wave
+
+		template<int NQ>
+		struct DecMLds
+		{
+			float part[ NW ][ 4 ][ 4 ][ 64 ];		   // the waves' partial tiles [wave][tile][register][lane]: query projection, later O^T
+			unsigned char vst[ NW ][ 2 ][ 2048 ];	   // per wave: the two V tiles of a 32-key block
+			f16 xn[ NQ ][ G_MAXD ];
+			f16 qh[ NQ ][ HEAD_DIM ];
+			float wmax[ NW ][ 16 ];
+			double wsum[ NW ][ 16 ];
+		};
+
+		template<int NQ>
+		__global__ void __launch_bounds__( NT, 1 ) attentionDecM( const DecAttnArgs a )
+		{
+			static_assert( NQ >= 1 && NQ <= NW, "wave q normalises row q" );
+			extern __shared__ __attribute__( ( aligned( 16 ) ) ) unsigned char smemM[];
+			DecMLds<NQ>& L = *(DecMLds<NQ>*)smemM;
+			const int tid = threadIdx.x;
+			const int lane = tid & 63;
+			const int wave = __builtin_amdgcn_readfirstlane( tid >> 6 );
+			const int lr = lane & 15, lg = lane >> 4;
+			const int h = blockIdx.x, bw = blockIdx.y;
+			const int d = a.H * HEAD_DIM;
+			const f16* const K = a.kc + ( (long long)bw * a.H + h ) * a.keyStride * HEAD_DIM;
+			const f16* const V = a.vc + ( (long long)bw * a.H + h ) * a.keyStride * HEAD_DIM;
+			const int nk = a.nKeys;
+			const int nTiles = ( nk + 15 ) >> 4;
+			const int steps = d >> 5;
+
+			// ---- everything the first half needs goes out now: query weights (row tile rt, k-step wave + 8 s), then the wave's K tiles ----
+			f16x8 wq[ M_QSTEPS ][ 4 ];
+	#pragma unroll
+			for( int s = 0; s < M_QSTEPS; s++ )
+			{
+				const int ks = wave + NW * s;
+				if( ks < steps )
+	#pragma unroll
+					for( int rt = 0; rt < 4; rt++ ) wq[ s ][ rt ] = *(const f16x8*)( a.qW + ( (long long)h * HEAD_DIM + rt * 16 + lr ) * d + ks * 32 + lg * 8 );
+			}
+			f16x8 kf[ M_TPW ][ 2 ];
+	#pragma unroll
+			for( int j = 0; j < M_TPW; j++ )
+			{
+				const int t = wave + NW * j;
+				if( t < nTiles )
+				{
+					int key = t * 16 + lr;
+					key = key < nk ? key : nk - 1;
+					const f16* const p = K + (long long)key * HEAD_DIM + lg * 8;
+					kf[ j ][ 0 ] = __builtin_nontemporal_load( (const f16x8*)p );
+					kf[ j ][ 1 ] = __builtin_nontemporal_load( (const f16x8*)( p + 32 ) );
+				}
+			}
+
+			// ---- LayerNorm of the group's residual rows: wave q takes row q ----
+			if( wave < NQ )
+				layerNormRows<G_MAXD / 256, 1>( a.lnX + ( (long long)bw * NQ + wave ) * d, 0, 1, a.lnW, a.lnB, d, lane, [ & ]( int, int c, f16x4 v ) { *(f16x4*)( &L.xn[ wave ][ c ] ) = v; } );
+			__syncthreads();
+
+			// ---- query projection: D[row = weight row of the tile][col = q] ----
+			const int qrow = lr < NQ ? lr : NQ - 1;	   // operand columns beyond the group repeat its last row (their results are never read)
+			{
+				f32x4 qa[ 4 ];
+	#pragma unroll
+				for( int rt = 0; rt < 4; rt++ ) qa[ rt ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+	#pragma unroll
+				for( int s = 0; s < M_QSTEPS; s++ )
+				{
+					const int ks = wave + NW * s;
+					if( ks < steps )
+					{
+						const f16x8 xb = *(const f16x8*)( &L.xn[ qrow ][ ks * 32 + lg * 8 ] );
+	#pragma unroll
+						for( int rt = 0; rt < 4; rt++ ) qa[ rt ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( wq[ s ][ rt ], xb, qa[ rt ], 0, 0, 0 );
+					}
+				}
+	#pragma unroll
+				for( int rt = 0; rt < 4; rt++ )
+	#pragma unroll
+					for( int r = 0; r < 4; r++ ) L.part[ wave ][ rt ][ r ][ lane ] = qa[ rt ][ r ];
+			}
+			__syncthreads();
+			if( tid < NQ * HEAD_DIM )
+			{
+				const int q = tid >> 6, j = tid & 63;
+				const int rt = j >> 4, ln = ( ( j & 15 ) >> 2 ) * 16 + q, r = j & 3;
+				float t = L.part[ 0 ][ rt ][ r ][ ln ];
+	#pragma unroll
+				for( int w = 1; w < NW; w++ ) t += L.part[ w ][ rt ][ r ][ ln ];
+				L.qh[ q ][ j ] = (f16)( ( t + a.qB[ h * HEAD_DIM + j ] ) * a.qScale );
+			}
+			__syncthreads();
+
+			// ---- the first half of the wave's V tiles goes out before the scores wait for K (lane = row lane >> 3 (+ 8), chunk lane & 7: whole 128-byte rows) ----
+			f16x8 vf[ M_TPW ][ 2 ];
+			auto loadV = [ & ]( int j )
+			{
+				const int t = wave + NW * j;
+	#pragma unroll
+				for( int i = 0; i < 2; i++ )
+				{
+					int key = t * 16 + ( lane >> 3 ) + 8 * i;
+					key = key < nk ? key : nk - 1;
+					vf[ j ][ i ] = __builtin_nontemporal_load( (const f16x8*)( V + (long long)key * HEAD_DIM + ( lane & 7 ) * 8 ) );
+				}
+			};
+	#pragma unroll
+			for( int j = 0; j < M_TPW / 2; j++ )
+				if( wave + NW * ( j & ~1 ) < nTiles ) loadV( j );
+
+			// ---- scores: S^T[key][q], lane = (q = lane & 15, keys 4 (lane >> 4) + r of the tile) ----
+			const f16x8 qb0 = *(const f16x8*)( &L.qh[ qrow ][ lg * 8 ] ), qb1 = *(const f16x8*)( &L.qh[ qrow ][ 32 + lg * 8 ] );
+			f32x4 sc[ M_TPW ];
+			float mx = -INFINITY;
+	#pragma unroll
+			for( int j = 0; j < M_TPW; j++ )
+			{
+				const int t = wave + NW * j;
+				sc[ j ] = f32x4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+				if( t < nTiles )
+				{
+					f32x4 s4 = { 0.0f, 0.0f, 0.0f, 0.0f };
+					s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16( kf[ j ][ 0 ], qb0, s4, 0, 0, 0 );
+					s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16( kf[ j ][ 1 ], qb1, s4, 0, 0, 0 );
+	#pragma unroll
+					for( int r = 0; r < 4; r++ )
+						if( t * 16 + lg * 4 + r < nk )
+						{
+							sc[ j ][ r ] = s4[ r ];
+							mx = fmaxf( mx, s4[ r ] );
+						}
+				}
+			}
+	#pragma unroll
+			for( int j = M_TPW / 2; j < M_TPW; j++ )
+				if( wave + NW * ( j & ~1 ) < nTiles ) loadV( j );
+			mx = fmaxf( mx, __shfl_xor( mx, 16, 64 ) );
+			mx = fmaxf( mx, __shfl_xor( mx, 32, 64 ) );
+			if( lg == 0 ) L.wmax[ wave ][ lr ] = mx;
+			__syncthreads();
+			mx = L.wmax[ 0 ][ lr ];
+	#pragma unroll
+			for( int w = 1; w < NW; w++ ) mx = fmaxf( mx, L.wmax[ w ][ lr ] );
+
+			// ---- e = exp16( s - max ) (an FP16 value), double sum ----
+			f16x4 pe[ M_TPW ];
+			double sum = 0.0;
+	#pragma unroll
+			for( int j = 0; j < M_TPW; j++ )
+	#pragma unroll
+				for( int r = 0; r < 4; r++ )
+				{
+					const float e = sc[ j ][ r ] == -INFINITY ? 0.0f : exp16( sc[ j ][ r ] - mx );
+					pe[ j ][ r ] = (f16)e;
+					sum += (double)e;
+				}
+			sum += __shfl_xor( sum, 16, 64 );
+			sum += __shfl_xor( sum, 32, 64 );
+			if( lg == 0 ) L.wsum[ wave ][ lr ] = sum;
+
+			// ---- O^T[dim][q] += V^T . P^T per block of 32 keys (two of the wave's tiles) ----
+			f32x4 oa[ 4 ];
+	#pragma unroll
+			for( int dt = 0; dt < 4; dt++ ) oa[ dt ] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+			unsigned char* const vs = &L.vst[ wave ][ 0 ][ 0 ];
+	#pragma unroll
+			for( int jb = 0; jb < M_TPW / 2; jb++ )
+			{
+				if( wave + NW * ( 2 * jb ) >= nTiles ) continue;
+	#pragma unroll
+				for( int tt = 0; tt < 2; tt++ )
+	#pragma unroll
+					for( int i = 0; i < 2; i++ )
+					{
+						const int row = ( lane >> 3 ) + 8 * i;
+						*(f16x8*)( vs + tt * 2048 + row * 128 + ( ( ( lane & 7 ) ^ ( ( ( row >> 2 ) & 3 ) << 1 ) ) << 4 ) ) = vf[ 2 * jb + tt ][ i ];
+					}
+				f16x8 pb;
+	#pragma unroll
+				for( int e = 0; e < 4; e++ )
+				{
+					pb[ e ] = pe[ 2 * jb ][ e ];
+					pb[ 4 + e ] = pe[ 2 * jb + 1 ][ e ];
+				}
+	#pragma unroll
+				for( int dt = 0; dt < 4; dt++ )
+				{
+					const int dim = dt * 16 + lr;
+					f16x8 va;
+	#pragma unroll
+					for( int e = 0; e < 8; e++ )
+						va[ e ] = *(const f16*)( vs + ( e >> 2 ) * 2048 + ( lg * 4 + ( e & 3 ) ) * 128 + ( ( ( dim >> 3 ) ^ ( lg << 1 ) ) << 4 ) + ( dim & 7 ) * 2 );
+					oa[ dt ] = __builtin_amdgcn_mfma_f32_16x16x32_f16( va, pb, oa[ dt ], 0, 0, 0 );
+				}
+			}
+	#pragma unroll
+			for( int dt = 0; dt < 4; dt++ )
+	#pragma unroll
+				for( int r = 0; r < 4; r++ ) L.part[ wave ][ dt ][ r ][ lane ] = oa[ dt ][ r ];
+			__syncthreads();
+			if( tid < NQ * HEAD_DIM )
+			{
+				const int q = tid >> 6, j = tid & 63;
+				const int dt = j >> 4, ln = ( ( j & 15 ) >> 2 ) * 16 + q, r = j & 3;
+				float t = L.part[ 0 ][ dt ][ r ][ ln ];
+				double tot = L.wsum[ 0 ][ q ];
+	#pragma unroll
+				for( int w = 1; w < NW; w++ )
+				{
+					t += L.part[ w ][ dt ][ r ][ ln ];
+					tot += L.wsum[ w ][ q ];
+				}
+				a.out[ ( (long long)bw * NQ + q ) * d + h * HEAD_DIM + j ] = (f16)( t * (float)( 1.0 / tot ) );
+			}
+		}
+
+		template<int NQ>
+		int launchDecM( const DecAttnArgs& a, hipStream_t stream )
+		{
+			constexpr int lds = (int)sizeof( DecMLds<NQ> );
+			static_assert( lds <= 160 * 1024, "attentionDecM LDS" );
+			static PerDeviceOnce once;
+			if( const int onceDev = once.needed(); onceDev >= 0 )
+			{
+				WH_HIP( hipFuncSetAttribute( (const void*)attentionDecM<NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
+				once.mark( onceDev );
+			}
+			hipLaunchKernelGGL( ( attentionDecM<NQ> ), dim3( a.H, a.batch / NQ ), dim3( NT ), lds, stream, a );
+			WH_HIP( hipGetLastError() );
+			return 0;
+		}
+
 		template<int NQ, bool FUSEQ, bool NT_LOADS = false>
 		int launchDecG( const DecAttnArgs& a, hipStream_t stream )
 		{
@@ -1199,6 +1451,18 @@ namespace wh
 		}
 		// the decode step's cross-attention (a query per window, fused query projection, all of a window's keys): streamed rows
 		if( group == 1 && fuse && !a.causal && ( g_tuning & TUNE_ATTN_DEC_NT ) ) return launchDecG<1, true, true>( a, stream );
+		// hypothesis groups (the cross-attention of a beam step): the matrix-core kernel (option cross_mfma)
+		if( group > 1 && fuse && !a.causal && a.nTok == 1 && a.parityThreads <= 0 && g_opt.crossMfma )
+		{
+			switch( group )
+			{
+			case 2: return launchDecM<2>( a, stream );
+			case 3: return launchDecM<3>( a, stream );
+			case 4: return launchDecM<4>( a, stream );
+			case 5: return launchDecM<5>( a, stream );
+			case 8: return launchDecM<8>( a, stream );
+			}
+		}
 	#define WH_DECG( N ) case N: return fuse ? launchDecG<N, true>( a, stream ) : launchDecG<N, false>( a, stream );
 		switch( group )
 		{

@@ -76,6 +76,8 @@ namespace wh
 		int decLdsKs = 2;			 // "dec_lds_ks": gemmDecTile on 64 x 32 tiles with K >= 2048: 2 = two K tiles per ring slot and barrier (18.1 against 21.7 us at 448 rows), 1 = one
 		int decSplit = 1;			 // "dec_split": the MLP down-projection (N <= 2048, K >= 2048) of 33 .. 128 rows: 1 = the eight K shares of gemvFused's eight waves on eight workgroups of
 									 // gemmDecTile per 32 columns + decSplitCombine (the same bits, two launches), 0 = gemvFused<.., 8 waves> (rounds 4-5)
+		int crossMfma = 1;			 // "cross_mfma": the cross-attention of a decode step for hypothesis groups (beam search): 1 = attentionDecM (scores and P.V on the matrix cores, every
+									 // load of the first half in flight at once), 0 = attentionDecG<NQ, true> (rounds 2-5)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
