@@ -373,10 +373,15 @@ namespace wh
 		__global__ void __launch_bounds__( 64 ) beamRankKernel( const TokenData* __restrict__ cand, int slots, int width, const BeamRules* __restrict__ rules,
 			BeamWindow* __restrict__ state, BeamRecord* __restrict__ records, int maxSteps, int windows, int* __restrict__ parents, int* __restrict__ nextTokens )
 		{
-			if( threadIdx.x != 0 ) return;
 			const int w = blockIdx.x;
-			BeamWindow& S = state[ w ];
 			const int base = w * slots;
+			// the log-probabilities of the step's slots x width proposals, one lane each (a double-precision log is ~1 us on a single lane: 25 of them were half
+			// of this kernel's 54 us per step); the ranking and the state machines below stay on lane 0
+			__shared__ double logP[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
+			if( (int)threadIdx.x < slots * width ) logP[ threadIdx.x ] = log( fmax( (double)cand[ (long long)base * width + threadIdx.x ].p, 1e-30 ) );
+			__syncthreads();
+			if( threadIdx.x != 0 ) return;
+			BeamWindow& S = state[ w ];
 			if( S.done || S.step >= maxSteps )
 			{
 				// nothing moves any more: every slot continues itself (the reorder skips it) and feeds its last token again
@@ -395,7 +400,7 @@ namespace wh
 			for( int i = 0; i < nParents; i++ )
 				for( int k = 0; k < width; k++ )
 				{
-					const double lp = log( fmax( (double)cand[ (long long)( base + i ) * width + k ].p, 1e-30 ) );
+					const double lp = logP[ i * width + k ];
 					pool[ nPool++ ] = Prop{ i, k, ( first ? 0.0 : S.live[ i ].sum ) + lp };
 				}
 			for( int a = 1; a < nPool; a++ )	   // stable insertion sort, descending score

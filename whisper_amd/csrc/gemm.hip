@@ -3314,11 +3314,16 @@ namespace wh
 	// 33 .. 128 rows against a NARROW, DEEP weight matrix, option dec_split (round 6): the eight K shares of gemvFused's eight waves dealt to eight workgroups of the
 	// LDS-staged kernel per 32 columns (N / 32 x 8 = 256 .. 320 workgroups instead of gemvFused's N / 16 x 2 re-reading the rows per 16 columns), the eight partial tiles
 	// added by a second launch in wave order: the same bits. Needs the context's scratch (8 x M x N floats). Returns 1 when the shape is not covered.
+	static bool decSplitShape( const GemmArgs& a )
+	{
+		// (measured and not kept: LayerNorm of the finished rows for the next product inside the combine launch, a wave per row -- 10 workgroups at 40 rows take 6.2 us
+		// against 2.5 + 5.3 for the two launches it replaces, the beam job did not move: 1271 against 1270 audio-s/s)
+		return !( a.lnX || a.epi != EPI_F32 || !a.splitScratch || a.M <= 32 || a.M > GEMV_FUSED_MAX_ROWS || a.N > 2048 || ( a.N % 32 ) != 0 || a.K < 2048 || ( a.K % 512 ) != 0 || a.Mb < a.M ||
+			!( g_tuning & TUNE_GEMV_K8 ) || !decTileOk( a ) );
+	}
 	static int launchDecRowsSplit( const GemmArgs& a, hipStream_t stream )
 	{
-		if( a.lnX || a.epi != EPI_F32 || !a.splitScratch || a.M <= 32 || a.M > GEMV_FUSED_MAX_ROWS || a.N > 2048 || ( a.N % 32 ) != 0 || a.K < 2048 || ( a.K % 512 ) != 0 || a.Mb < a.M ||
-			!( g_tuning & TUNE_GEMV_K8 ) || !decTileOk( a ) )
-			return 1;
+		if( !decSplitShape( a ) ) return 1;
 		auto go = [ & ]( auto mtTag ) -> int
 		{
 			constexpr int MT = decltype( mtTag )::value;
@@ -3453,6 +3458,10 @@ namespace wh
 			const int rc = launchDecRowsDeep( a, stream );
 			if( rc <= 0 ) return rc;
 		}
+		// option vocab_lds (round 6): the vocabulary product (N / 32 >= 512) of 33 .. 64 rows as 64 x 64 tiles of the LDS-staged kernel: the rows are re-read once per
+		// 64 columns instead of gemmAllRows' once per 32; the same K quarters added in the same order
+		if( a.M > 32 && a.M <= 64 && !ln && a.epi == EPI_F32 && ( a.N + 31 ) / 32 >= 512 && a.Mb >= a.M && g_opt.vocabLds == 1 && ( g_tuning & TUNE_GEMV_ALLROWS ) && decTileOk( a ) )
+			return launchDecTileK<EPI_F32, 4>( a, stream );
 		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_ALLROWS ) )
 		{
 			const int rc = launchAllRows( a, stream );
