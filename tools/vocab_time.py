@@ -1,4 +1,4 @@
-"""The vocabulary product of a decode step at 33 .. 64 rows (FP32 out, no bias): us per launch for vocab_lds 0 (gemmAllRows) and 1 (gemmDecTile, 64 x 64 tiles).  python tools/vocab_time.py"""
+"""The vocabulary product of a decode step at 33 .. 128 rows (FP32 out, no bias): us per launch for vocab_lds 0 (gemmAllRows) and 1 (gemmDecTile, 64 x 64 tiles).  python tools/vocab_time.py"""
 import ctypes as C
 import os
 import sys
@@ -11,9 +11,9 @@ def main():
     from whisper_amd import binding
     L = binding.lib()
     p = lambda t: C.c_void_p(t.data_ptr())
-    for (N, K) in ((51865, 1280), (51865, 1024), (51866, 1280)):
+    for (N, K) in ((51865, 1280), (51865, 1024)):
         w = (0.05 * torch.randn((4, N, K), device="cuda")).half()
-        for M in (40, 33, 64, 56):
+        for M in (40, 64, 70, 100, 128):
             a = torch.randn((M, K), device="cuda").half()
             out = torch.zeros((M, N), device="cuda")
             row, outs = [], {}

@@ -3458,9 +3458,10 @@ namespace wh
 			const int rc = launchDecRowsDeep( a, stream );
 			if( rc <= 0 ) return rc;
 		}
-		// option vocab_lds (round 6): the vocabulary product (N / 32 >= 512) of 33 .. 64 rows as 64 x 64 tiles of the LDS-staged kernel: the rows are re-read once per
-		// 64 columns instead of gemmAllRows' once per 32; the same K quarters added in the same order
-		if( a.M > 32 && a.M <= 64 && !ln && a.epi == EPI_F32 && ( a.N + 31 ) / 32 >= 512 && a.Mb >= a.M && g_opt.vocabLds == 1 && ( g_tuning & TUNE_GEMV_ALLROWS ) && decTileOk( a ) )
+		// option vocab_lds (round 6): the vocabulary product (N / 32 >= 512) of 33 .. 128 rows as 64 x 64 tiles of the LDS-staged kernel (one or two row tiles): the rows
+		// are re-read once per 64 columns instead of gemmAllRows' once per 32, the second row tile finds the weights in the Infinity Cache; the same K quarters added in
+		// the same order (40 x 51865 x 1280: 37.7 against 67.1 us, 128 rows: 67.7 against 132.8)
+		if( a.M > 32 && a.M <= GEMV_FUSED_MAX_ROWS && !ln && a.epi == EPI_F32 && ( a.N + 31 ) / 32 >= 512 && a.Mb >= a.M && g_opt.vocabLds == 1 && ( g_tuning & TUNE_GEMV_ALLROWS ) && decTileOk( a ) )
 			return launchDecTileK<EPI_F32, 4>( a, stream );
 		if( a.M > 32 && !ln && ( g_tuning & TUNE_GEMV_ALLROWS ) )
 		{
