@@ -1,4 +1,4 @@
-"""attentionDecM<5> at 8 windows x 20 heads with parts removed (option cross_ablate; results wrong, times only).  python tools/cross_ablate.py"""
+"""attentionDecM<5> at 8 windows x 20 heads with parts removed (option cross_ablate; results wrong, times only). The ablation instances left the source after session r6v: check out commit 1576939 to run this.  python tools/cross_ablate.py"""
 import ctypes as C
 import os
 import sys

@@ -1175,8 +1175,9 @@ namespace wh
 			double wsum[ NW ][ 16 ];
 		};
 
-		// ABL (option cross_ablate, measurement only, results wrong): 1 = no exponentials, 2 = no V transposes through LDS, 4 = no V loads, 16 = no K loads
-		template<int NQ, int ABL = 0>
+		// (the ablation instances behind `cross_ablate` -- no exponentials / no V transposes / no V loads / no K loads -- were measured and removed again: the numbers are in
+		// profiles/r06_evidence/small_batch_products.txt, the code in the history at commit 1576939, the records of session r6v)
+		template<int NQ>
 		__global__ void __launch_bounds__( NT, 1 ) attentionDecM( const DecAttnArgs a )
 		{
 			static_assert( NQ >= 1 && NQ <= NW, "wave q normalises row q" );
@@ -1215,16 +1216,8 @@ namespace wh
 					int key = t * 16 + lr;
 					key = key < nk ? key : nk - 1;
 					const f16* const p = K + (long long)key * HEAD_DIM + lg * 8;
-					if constexpr( ABL & 16 )
-					{
-						kf[ j ][ 0 ] = wq[ 0 ][ 0 ];
-						kf[ j ][ 1 ] = wq[ 0 ][ 1 ];
-					}
-					else
-					{
-						kf[ j ][ 0 ] = __builtin_nontemporal_load( (const f16x8*)p );
-						kf[ j ][ 1 ] = __builtin_nontemporal_load( (const f16x8*)( p + 32 ) );
-					}
+					kf[ j ][ 0 ] = __builtin_nontemporal_load( (const f16x8*)p );
+					kf[ j ][ 1 ] = __builtin_nontemporal_load( (const f16x8*)( p + 32 ) );
 				}
 			}
 
@@ -1277,10 +1270,7 @@ namespace wh
 				{
 					int key = t * 16 + ( lane >> 3 ) + 8 * i;
 					key = key < nk ? key : nk - 1;
-					if constexpr( ABL & 4 )
-						vf[ j ][ i ] = kf[ j ][ i ];
-					else
-						vf[ j ][ i ] = __builtin_nontemporal_load( (const f16x8*)( V + (long long)key * HEAD_DIM + ( lane & 7 ) * 8 ) );
+					vf[ j ][ i ] = __builtin_nontemporal_load( (const f16x8*)( V + (long long)key * HEAD_DIM + ( lane & 7 ) * 8 ) );
 				}
 			};
 	#pragma unroll
@@ -1329,7 +1319,7 @@ namespace wh
 	#pragma unroll
 				for( int r = 0; r < 4; r++ )
 				{
-					const float e = sc[ j ][ r ] == -INFINITY ? 0.0f : ( ( ABL & 1 ) ? sc[ j ][ r ] - mx : exp16( sc[ j ][ r ] - mx ) );
+					const float e = sc[ j ][ r ] == -INFINITY ? 0.0f : exp16( sc[ j ][ r ] - mx );
 					pe[ j ][ r ] = (f16)e;
 					sum += (double)e;
 				}
@@ -1351,7 +1341,6 @@ namespace wh
 	#pragma unroll
 					for( int i = 0; i < 2; i++ )
 					{
-						if constexpr( ABL & 2 ) continue;
 						const int row = ( lane >> 3 ) + 8 * i;
 						*(f16x8*)( vs + tt * 2048 + row * 128 + ( ( ( lane & 7 ) ^ ( ( ( row >> 2 ) & 3 ) << 1 ) ) << 4 ) ) = vf[ 2 * jb + tt ][ i ];
 					}
@@ -1366,8 +1355,7 @@ namespace wh
 				for( int dt = 0; dt < 4; dt++ )
 				{
 					const int dim = dt * 16 + lr;
-					f16x8 va = vf[ 2 * jb + ( dt >> 1 ) ][ dt & 1 ];
-					if constexpr( !( ABL & 2 ) )
+					f16x8 va;
 	#pragma unroll
 					for( int e = 0; e < 8; e++ )
 						va[ e ] = *(const f16*)( vs + ( e >> 2 ) * 2048 + ( lg * 4 + ( e & 3 ) ) * 128 + ( ( ( dim >> 3 ) ^ ( lg << 1 ) ) << 4 ) + ( dim & 7 ) * 2 );
@@ -1407,20 +1395,6 @@ namespace wh
 				once.mark( onceDev );
 			}
 			hipLaunchKernelGGL( ( attentionDecM<NQ> ), dim3( a.H, a.batch / NQ ), dim3( NT ), lds, stream, a );
-			WH_HIP( hipGetLastError() );
-			return 0;
-		}
-		template<int ABL>
-		int launchDecMAblated( const DecAttnArgs& a, hipStream_t stream )
-		{
-			constexpr int lds = (int)sizeof( DecMLds<5> );
-			static PerDeviceOnce once;
-			if( const int onceDev = once.needed(); onceDev >= 0 )
-			{
-				WH_HIP( hipFuncSetAttribute( (const void*)attentionDecM<5, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds ) );
-				once.mark( onceDev );
-			}
-			hipLaunchKernelGGL( ( attentionDecM<5, ABL> ), dim3( a.H, a.batch / 5 ), dim3( NT ), lds, stream, a );
 			WH_HIP( hipGetLastError() );
 			return 0;
 		}
@@ -1483,17 +1457,6 @@ namespace wh
 		// hypothesis groups (the cross-attention of a beam step): the matrix-core kernel (option cross_mfma)
 		if( group > 1 && fuse && !a.causal && a.nTok == 1 && a.parityThreads <= 0 && g_opt.crossMfma )
 		{
-			if( group == 5 && g_opt.crossAblate )
-				switch( g_opt.crossAblate )
-				{
-				case 1: return launchDecMAblated<1>( a, stream );
-				case 2: return launchDecMAblated<2>( a, stream );
-				case 4: return launchDecMAblated<4>( a, stream );
-				case 6: return launchDecMAblated<6>( a, stream );
-				case 7: return launchDecMAblated<7>( a, stream );
-				case 16: return launchDecMAblated<16>( a, stream );
-				case 23: return launchDecMAblated<23>( a, stream );
-				}
 			switch( group )
 			{
 			case 2: return launchDecM<2>( a, stream );

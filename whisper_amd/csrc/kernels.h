@@ -78,7 +78,6 @@ namespace wh
 									 // gemmDecTile per 32 columns + decSplitCombine (the same bits, two launches), 0 = gemvFused<.., 8 waves> (rounds 4-5)
 		int crossMfma = 1;			 // "cross_mfma": the cross-attention of a decode step for hypothesis groups (beam search): 1 = attentionDecM (scores and P.V on the matrix cores, every
 									 // load of the first half in flight at once), 0 = attentionDecG<NQ, true> (rounds 2-5)
-		int crossAblate = 0;		 // "cross_ablate": attentionDecM<5>, measurement only (results wrong): 1 = no exponentials, 2 = no V transposes, 4 = no V loads, 16 = no K loads (sums: 6, 7, 23)
 		int vocabLds = 1;			 // "vocab_lds": the vocabulary product of 33 .. 128 rows: 1 = gemmDecTile's 64 x 64 tiles (one or two row tiles), 0 = gemmAllRows (32 columns x all rows per workgroup, rounds 3-5)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
