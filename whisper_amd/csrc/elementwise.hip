@@ -369,19 +369,20 @@ namespace wh
 		}
 		__device__ __forceinline__ double beamPerToken( const BeamHyp& h ) { return h.sum / (double)max( 1, h.nTok ); }
 
-		// One workgroup (one working lane: 64 proposals, a handful of state machines) per window.
-		__global__ void __launch_bounds__( 64 ) beamRankKernel( const TokenData* __restrict__ cand, int slots, int width, const BeamRules* __restrict__ rules,
-			BeamWindow* __restrict__ state, BeamRecord* __restrict__ records, int maxSteps, int windows, int* __restrict__ parents, int* __restrict__ nextTokens )
+		// The ranking of one window by ONE lane: S, cand (the window's slots x width proposals) and logP live in LDS (the kernel below stages them: a lane walking its
+		// state in global memory paid a dependent round trip per field, 48 us per step)
+		struct BeamProp { int parent, k; double score; };
+		// lane 0's working arrays: in LDS as well (private arrays indexed at run time are scratch memory -- a memory round trip per element of the insertion sort)
+		struct BeamRankWork
 		{
-			const int w = blockIdx.x;
+			BeamProp pool[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
+			BeamHyp newLive[ BEAM_MAX_WIDTH ];
+			int parentSlot[ BEAM_MAX_WIDTH ], lastTok[ BEAM_MAX_WIDTH ];
+		};
+		__device__ __forceinline__ void beamRankWindow( BeamWindow& S, BeamRankWork& W, const TokenData* cand, const double* logP, int w, int slots, int width, const BeamRules* __restrict__ rules,
+			BeamRecord* __restrict__ records, int maxSteps, int windows, int* __restrict__ parents, int* __restrict__ nextTokens )
+		{
 			const int base = w * slots;
-			// the log-probabilities of the step's slots x width proposals, one lane each (a double-precision log is ~1 us on a single lane: 25 of them were half
-			// of this kernel's 54 us per step); the ranking and the state machines below stay on lane 0
-			__shared__ double logP[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
-			if( (int)threadIdx.x < slots * width ) logP[ threadIdx.x ] = log( fmax( (double)cand[ (long long)base * width + threadIdx.x ].p, 1e-30 ) );
-			__syncthreads();
-			if( threadIdx.x != 0 ) return;
-			BeamWindow& S = state[ w ];
 			if( S.done || S.step >= maxSteps )
 			{
 				// nothing moves any more: every slot continues itself (the reorder skips it) and feeds its last token again
@@ -393,8 +394,8 @@ namespace wh
 			const int step = S.step;
 			const bool first = step == 0;
 			// ---- the pool: (parent, candidate) with parent score + log p, ranked; ties keep the parent's order, then the candidate's ----
-			struct Prop { int parent, k; double score; };
-			Prop pool[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
+			typedef BeamProp Prop;
+			Prop* const pool = W.pool;
 			int nPool = 0;
 			const int nParents = first ? 1 : S.nLive;	   // the first sample: every slot holds the same prompt, slot 0 speaks for all
 			for( int i = 0; i < nParents; i++ )
@@ -411,14 +412,15 @@ namespace wh
 				pool[ b + 1 ] = x;
 			}
 			// ---- the best `width` proposals continue their parents: live or, when the stop rules end the window, finished ----
-			BeamHyp newLive[ BEAM_MAX_WIDTH ];
-			int parentSlot[ BEAM_MAX_WIDTH ], lastTok[ BEAM_MAX_WIDTH ];
+			BeamHyp* const newLive = W.newLive;
+			int* const parentSlot = W.parentSlot;
+			int* const lastTok = W.lastTok;
 			int nNew = 0, accepted = 0;
 			BeamRecord* const rec = records + ( (long long)step * windows + w ) * width;
 			for( int q = 0; q < nPool && accepted < width; q++ )
 			{
 				const Prop pr = pool[ q ];
-				const TokenData t = cand[ (long long)( base + pr.parent ) * width + pr.k ];
+				const TokenData t = cand[ pr.parent * width + pr.k ];
 				BeamHyp h;
 				if( first )
 				{
@@ -491,6 +493,33 @@ namespace wh
 				parents[ base + b ] = base + parentSlot[ j ];
 				nextTokens[ base + b ] = lastTok[ j ];
 			}
+		}
+
+		// One workgroup per window: 64 lanes stage the window's state, proposals and their log-probabilities (a double-precision log is ~1 us on a single lane) in LDS,
+		// lane 0 ranks and runs the state machines, 64 lanes write the state back.
+		__global__ void __launch_bounds__( 64 ) beamRankKernel( const TokenData* __restrict__ cand, int slots, int width, const BeamRules* __restrict__ rules,
+			BeamWindow* __restrict__ state, BeamRecord* __restrict__ records, int maxSteps, int windows, int* __restrict__ parents, int* __restrict__ nextTokens )
+		{
+			const int w = blockIdx.x;
+			__shared__ BeamWindow S;
+			__shared__ TokenData candS[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
+			__shared__ double logP[ BEAM_MAX_WIDTH * BEAM_MAX_WIDTH ];
+			__shared__ BeamRankWork work;
+			static_assert( sizeof( BeamWindow ) % 4 == 0, "staged as 32-bit words" );
+			constexpr int nWords = (int)( sizeof( BeamWindow ) / 4 );
+			int* const sw = (int*)&S;
+			int* const gw = (int*)&state[ w ];
+			for( int i = threadIdx.x; i < nWords; i += 64 ) sw[ i ] = gw[ i ];
+			if( (int)threadIdx.x < slots * width )
+			{
+				const TokenData t = cand[ (long long)w * slots * width + threadIdx.x ];
+				candS[ threadIdx.x ] = t;
+				logP[ threadIdx.x ] = log( fmax( (double)t.p, 1e-30 ) );
+			}
+			__syncthreads();
+			if( threadIdx.x == 0 ) beamRankWindow( S, work, candS, logP, w, slots, width, rules, records, maxSteps, windows, parents, nextTokens );
+			__syncthreads();
+			for( int i = threadIdx.x; i < nWords; i += 64 ) gw[ i ] = sw[ i ];
 		}
 
 		// ---- logits row -> table softmax -> sampleBest in ONE kernel, the row held in registers -----------------------

@@ -72,7 +72,8 @@ namespace wh
 		int encAblate = 0;			 // "enc_ablate": attentionEncW, measurement only (results wrong): 1 = no exponentials, 2 = no P.V MFMAs, 4 = a quarter of the Q.K MFMAs
 		int exactAltOrder = 0;		 // "exact_alt_order": WH_FLAG_PARITY_EXACT, measurement only: the weight products add their 32 chains left to right instead of in ggml's tree
 		int decLds = 1;				 // "dec_lds": decode products of 129 .. 512 rows: 1 = gemmDecTile where its 64 x 64 / 64 x 32 tiles fill the chip (operands staged through LDS in
-									 // full 128-byte lines, the same sums: 448 x 4096 x 1024 14.4 against 22.1 us), 0 = gemmDecRows everywhere (round 5)
+									 // full 128-byte lines, the same sums: 448 x 4096 x 1024 14.4 against 22.1 us) and, with 4 / 6 / 8 row tiles per workgroup, for the wide
+									 // products of 33 .. 128 rows (128 x 4096 x 1024: 10.2 against 15.7 us); 0 = gemmDecRows everywhere (round 5)
 		int decLdsKs = 2;			 // "dec_lds_ks": gemmDecTile on 64 x 32 tiles with K >= 2048: 2 = two K tiles per ring slot and barrier (18.1 against 21.7 us at 448 rows), 1 = one
 		int decSplit = 1;			 // "dec_split": the MLP down-projection (N <= 2048, K >= 2048) of 33 .. 128 rows: 1 = the eight K shares of gemvFused's eight waves on eight workgroups of
 									 // gemmDecTile per 32 columns + decSplitCombine (the same bits, two launches), 0 = gemvFused<.., 8 waves> (rounds 4-5)
