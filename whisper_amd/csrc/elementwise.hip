@@ -298,6 +298,46 @@ namespace wh
 				}
 		}
 
+		// softMaxRows with the ROW IN REGISTERS (round 6, option beam_regs): one read and one write of the row instead of three reads and two writes (a workgroup per row:
+		// 40 CUs at 40 rows) -- 37.8 -> 18.3 us at 40 x 51865. The same arithmetic in the same order (e = exp16( x - max ), the double sum thread by thread in column
+		// order, p = e * float( 1 / sum )): the same bits. cols <= SC_PER * 1024. Built, measured and NOT kept: the candidate search the same way (51 selects per round and
+		// thread where beamCandidatesKernel re-reads the row: 57.6 against 26 us, VALU-bound, a third of the row spilled), and both in one launch (124 us: 288 spill
+		// instructions under the 128-register cap of a 1024-thread workgroup).
+		constexpr int SC_PER = 51;
+		__global__ void __launch_bounds__( 1024 ) softMaxRowsReg( const float* __restrict__ in, float* __restrict__ out, int cols )
+		{
+			__shared__ float shf[ 16 ];
+			__shared__ double shd[ 16 ];
+			const float* const x = in + (long long)blockIdx.x * cols;
+			float* const y = out + (long long)blockIdx.x * cols;
+			float v[ SC_PER ];
+			float m = -INFINITY;
+	#pragma unroll
+			for( int i = 0; i < SC_PER; i++ )
+			{
+				const int c = threadIdx.x + 1024 * i;
+				const float t = x[ c < cols ? c : cols - 1 ];	  // (clamped address + select: a branch per element would serialise the loads)
+				v[ i ] = c < cols ? t : -INFINITY;
+				m = fmaxf( m, v[ i ] );
+			}
+			m = blockMax<16>( m, shf );
+			double s = 0.0;
+	#pragma unroll
+			for( int i = 0; i < SC_PER; i++ )
+			{
+				const float e = ( v[ i ] == -INFINITY ) ? 0.0f : exp16( v[ i ] - m );
+				v[ i ] = e;
+				s += (double)e;
+			}
+			s = blockSumD<16>( s, shd );
+			const float inv = (float)( 1.0 / s );
+	#pragma unroll
+			for( int i = 0; i < SC_PER; i++ )
+			{
+				const int c = threadIdx.x + 1024 * i;
+				if( c < cols ) y[ c ] = v[ i ] * inv;
+			}
+		}
 		// ---- self-attention cache rows of sequence parents[j] -> sequence j (beam search: hypotheses change lineage) ----
 		// Two launches through a scratch copy, so that a permutation (j <- p while p <- q) reads only rows nobody has overwritten:
 		// phase 0: scratch[ j ] = cache[ parents[ j ] ], phase 1: cache[ j ] = scratch[ j ]; sequences with parents[ j ] == j are skipped.
@@ -890,7 +930,11 @@ namespace wh
 
 	int launchVocabSoftMax( const float* logits, float* probs, int rows, int nVocab, hipStream_t stream )
 	{
-		hipLaunchKernelGGL( softMaxRows, dim3( rows ), dim3( 1024 ), 0, stream, logits, probs, nVocab );
+		// option beam_regs: the row in registers (one read and one write instead of three reads and two writes), the same probabilities
+		if( g_opt.beamRegs && nVocab <= SC_PER * 1024 )
+			hipLaunchKernelGGL( softMaxRowsReg, dim3( rows ), dim3( 1024 ), 0, stream, logits, probs, nVocab );
+		else
+			hipLaunchKernelGGL( softMaxRows, dim3( rows ), dim3( 1024 ), 0, stream, logits, probs, nVocab );
 		WH_HIP( hipGetLastError() );
 		return 0;
 	}

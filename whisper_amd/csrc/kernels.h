@@ -80,6 +80,8 @@ namespace wh
 		int crossMfma = 1;			 // "cross_mfma": the cross-attention of a decode step for hypothesis groups (beam search): 1 = attentionDecM (scores and P.V on the matrix cores, every
 									 // load of the first half in flight at once), 0 = attentionDecG<NQ, true> (rounds 2-5)
 		int vocabLds = 1;			 // "vocab_lds": the vocabulary product of 33 .. 128 rows: 1 = gemmDecTile's 64 x 64 tiles (one or two row tiles), 0 = gemmAllRows (32 columns x all rows per workgroup, rounds 3-5)
+		int beamRegs = 1;			 // "beam_regs": the vocabulary softmax over rows (beam steps, wh_op_soft_max, wh_decode's probabilities): 1 = the row in registers (softMaxRowsReg: one
+									 // read and one write, the same bits: 37.8 -> 18.3 us at 40 rows), 0 = softMaxRows (three reads, two writes)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
