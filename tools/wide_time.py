@@ -1,4 +1,5 @@
-"""The wide decode products (FP16 GELU epilogue) at 33 .. 128 rows: us per launch for dec_lds 0 (gemmDecRows, one row tile) and 1 (gemmDecTile).  python tools/wide_time.py"""
+"""The wide decode products (FP16 GELU epilogue) at 33 .. 128 rows: us per launch for dec_lds 0 (gemmDecRows, one row tile), 1 (gemmDecTile) and gemmDecTile with one K tile per ring
+slot (dec_lds_ks 1).  python tools/wide_time.py"""
 import ctypes as C
 import os
 import sys
@@ -19,8 +20,9 @@ def main():
             bias = torch.randn(N, device="cuda")
             out = torch.zeros((M, N), device="cuda", dtype=torch.float16)
             row, outs = [], {}
-            for lds in (0, 1):
-                binding.set_option("dec_lds", lds)
+            for lds in (0, 1, 2):
+                binding.set_option("dec_lds", min(lds, 1))
+                binding.set_option("dec_lds_ks", 1 if lds == 2 else binding.get_option_default("dec_lds_ks"))
                 for i in range(8):
                     L.wh_op_mul_mat_gelu(None, p(a), p(w[i % pool]), p(bias), p(out), M, N, K)
                 torch.cuda.synchronize()
@@ -30,12 +32,13 @@ def main():
                     L.wh_op_mul_mat_gelu(None, p(a), p(w[i % pool]), p(bias), p(out), M, N, K)
                 e1.record()
                 torch.cuda.synchronize()
-                row.append("dec_lds %d %.1f us" % (lds, e0.elapsed_time(e1) * 1e3 / 200))
+                row.append("%s %.1f us" % (("dec_lds 0", "dec_lds 1", "dec_lds 1 / dec_lds_ks 1")[lds], e0.elapsed_time(e1) * 1e3 / 200))
                 L.wh_op_mul_mat_gelu(None, p(a), p(w[0]), p(bias), p(out), M, N, K)
                 torch.cuda.synchronize()
                 outs[lds] = out.clone()
             binding.set_option("dec_lds", binding.get_option_default("dec_lds"))
-            print("M=%3d N=%4d K=%4d  %s | same bits %s" % (M, N, K, " | ".join(row), bool(torch.equal(outs[0], outs[1]))), flush=True)
+            binding.set_option("dec_lds_ks", binding.get_option_default("dec_lds_ks"))
+            print("M=%3d N=%4d K=%4d  %s | same bits %s" % (M, N, K, " | ".join(row), bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]))), flush=True)
 
 
 if __name__ == "__main__":

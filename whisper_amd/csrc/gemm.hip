@@ -3282,6 +3282,11 @@ namespace wh
 		if( g_opt.decLds == 1 && g_opt.decTile == 0 && decTileOk( a ) )
 		{
 			const int mt = ( a.M + 15 ) / 16;
+			// two K tiles per ring slot and barrier (dec_lds_ks 2, the default) for 4 and 6 row tiles: 40 x 5120 x 1280 8.9 -> 7.8 us, 70 rows 10.9 -> 10.0; level at 8
+			// row tiles (123 KiB of LDS), and SLOWER for the K-split instances (K = 5120 at 70 rows: 11.9 -> 13.9) and the vocabulary product (38 -> 48 us: one
+			// workgroup per CU instead of three) -- those keep one tile per slot (profiles/r06_evidence/small_batch_products.txt)
+			if( g_opt.decLdsKs == 2 && ( a.K % 128 ) == 0 && mt <= 6 )
+				return mt <= 4 ? launchDecTileK<EPI, 2, 2, 3, 4>( a, stream ) : launchDecTileK<EPI, 2, 2, 3, 6>( a, stream );
 			if( mt <= 4 ) return launchDecTileK<EPI, 2, 1, DT_NBUF, 4>( a, stream );
 			if( mt <= 6 ) return launchDecTileK<EPI, 2, 1, DT_NBUF, 6>( a, stream );
 			return launchDecTileK<EPI, 2, 1, DT_NBUF, 8>( a, stream );

@@ -74,7 +74,8 @@ namespace wh
 		int decLds = 1;				 // "dec_lds": decode products of 129 .. 512 rows: 1 = gemmDecTile where its 64 x 64 / 64 x 32 tiles fill the chip (operands staged through LDS in
 									 // full 128-byte lines, the same sums: 448 x 4096 x 1024 14.4 against 22.1 us) and, with 4 / 6 / 8 row tiles per workgroup, for the wide
 									 // products of 33 .. 128 rows (128 x 4096 x 1024: 10.2 against 15.7 us); 0 = gemmDecRows everywhere (round 5)
-		int decLdsKs = 2;			 // "dec_lds_ks": gemmDecTile on 64 x 32 tiles with K >= 2048: 2 = two K tiles per ring slot and barrier (18.1 against 21.7 us at 448 rows), 1 = one
+		int decLdsKs = 2;			 // "dec_lds_ks": 2 = two K tiles per ring slot and barrier where that pays -- gemmDecTile on 64 x 32 tiles with K >= 2048 (18.1 against 21.7 us at 448 rows)
+									 // and the wide products of 33 .. 96 rows (40 x 5120 x 1280: 7.8 against 8.9 us) --, 1 = one tile per slot everywhere
 		int decSplit = 1;			 // "dec_split": the MLP down-projection (N <= 2048, K >= 2048) of 33 .. 128 rows: 1 = the eight K shares of gemvFused's eight waves on eight workgroups of
 									 // gemmDecTile per 32 columns + decSplitCombine (the same bits, two launches), 0 = gemvFused<.., 8 waves> (rounds 4-5)
 		int crossMfma = 1;			 // "cross_mfma": the cross-attention of a decode step for hypothesis groups (beam search): 1 = attentionDecM (scores and P.V on the matrix cores, every
