@@ -359,6 +359,42 @@ namespace wh
 			for( int i = threadIdx.x; i < rows * 8; i += 256 ) *(f16x8*)( dst + i * 8 ) = *(const f16x8*)( src + i * 8 );
 		}
 
+		// The same move for the hypotheses of ONE WINDOW in ONE launch and without the scratch copy (round 6, option reorder_group): the ranking keeps a hypothesis'
+		// parent inside its window's group of `group` consecutive sequences, and row r of sequence j depends on row r of its parent only -- so the thread that owns
+		// an element position reads that position from every moved sequence's parent into registers and only then writes the moved sequences: no position is written
+		// before its last reader has it. Half the bytes of the two-phase copy (no scratch round trip), one launch instead of two. grid (heads, windows, layers x 2).
+		template<int GROUP>
+		__global__ void __launch_bounds__( 256 ) reorderCacheGroup( f16* __restrict__ cacheK, f16* __restrict__ cacheV, const int* __restrict__ parents, int heads,
+			int seqStrideSeqs, int keyStride, const int* __restrict__ rowsDev )
+		{
+			const int h = blockIdx.x, w = blockIdx.y, l = blockIdx.z >> 1, kv = blockIdx.z & 1;
+			const int base = w * GROUP;
+			int par[ GROUP ];
+			bool any = false;
+	#pragma unroll
+			for( int j = 0; j < GROUP; j++ )
+			{
+				int p = parents[ base + j ] - base;
+				p = ( p < 0 || p >= GROUP ) ? j : p;	  // (a parent outside the group cannot come from the ranking kernel; such a slot stays as it is)
+				par[ j ] = p;
+				any = any || p != j;
+			}
+			if( !any ) return;
+			const int rows = min( max( rowsDev[ base ], 0 ), keyStride );	  // the sequences of a window stand at one position
+			f16* const cache = ( kv ? cacheV : cacheK ) + (long long)l * seqStrideSeqs * heads * keyStride * HEAD_DIM;
+			auto rowsOf = [ & ]( int j ) -> f16* { return cache + ( (long long)( base + j ) * heads + h ) * keyStride * HEAD_DIM; };
+			for( int i = threadIdx.x; i < rows * 8; i += 256 )
+			{
+				f16x8 val[ GROUP ];
+	#pragma unroll
+				for( int j = 0; j < GROUP; j++ )
+					if( par[ j ] != j ) val[ j ] = *(const f16x8*)( rowsOf( par[ j ] ) + i * 8 );
+	#pragma unroll
+				for( int j = 0; j < GROUP; j++ )
+					if( par[ j ] != j ) *(f16x8*)( rowsOf( j ) + i * 8 ) = val[ j ];
+			}
+		}
+
 		// ---- beam search: the ranking of a step on the device (see kernels.h; the host version it restates: ContextImpl::decodeWindowBeam) ----
 		constexpr int BEAM_CHUNK_FRAMES = 3000;	   // CHUNK_FRAMES of host/hostLoop.h
 		// WindowScan::feed (host/hostLoop.h = ContextImpl.cpp:597-673) on the state of one hypothesis; true = its window is over
@@ -971,8 +1007,19 @@ namespace wh
 	}
 
 	int launchReorderCacheDev( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, const int* rowsDev, int layers, int sequences, int maxSeq,
-		int heads, int keyStride, hipStream_t stream )
+		int heads, int keyStride, int group, hipStream_t stream )
 	{
+		// option reorder_group: the hypotheses of a window move inside their group, in one launch through registers
+		if( g_opt.reorderGroup && rowsDev && group > 1 && ( sequences % group ) == 0 )
+		{
+			const dim3 grid( heads, sequences / group, layers * 2 );
+			switch( group )
+			{
+	#define WH_RG( G ) case G: hipLaunchKernelGGL( reorderCacheGroup<G>, grid, dim3( 256 ), 0, stream, cacheK, cacheV, parents, heads, maxSeq, keyStride, rowsDev ); WH_HIP( hipGetLastError() ); return 0;
+				WH_RG( 2 ) WH_RG( 3 ) WH_RG( 4 ) WH_RG( 5 ) WH_RG( 6 ) WH_RG( 7 ) WH_RG( 8 )
+	#undef WH_RG
+			}
+		}
 		for( int phase = 0; phase < 2; phase++ )
 		{
 			hipLaunchKernelGGL( reorderCacheKernel, dim3( heads, sequences, layers * 2 ), dim3( 256 ), 0, stream, cacheK, cacheV, scratchK, scratchV, parents,

@@ -83,6 +83,8 @@ namespace wh
 		int vocabLds = 1;			 // "vocab_lds": the vocabulary product of 33 .. 128 rows: 1 = gemmDecTile's 64 x 64 tiles (one or two row tiles), 0 = gemmAllRows (32 columns x all rows per workgroup, rounds 3-5)
 		int beamRegs = 1;			 // "beam_regs": the vocabulary softmax over rows (beam steps, wh_op_soft_max, wh_decode's probabilities): 1 = the row in registers (softMaxRowsReg: one
 									 // read and one write, the same bits: 37.8 -> 18.3 us at 40 rows), 0 = softMaxRows (three reads, two writes)
+		int reorderGroup = 1;		 // "reorder_group": the ranked beam step's cache reorder: 1 = reorderCacheGroup (a window's hypotheses in one launch through registers), 0 = the two-phase
+									 // copy through the scratch cache (round 4)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences
@@ -364,8 +366,9 @@ namespace wh
 	int launchBeamRank( const TokenData* cand, int windows, int slots, int width, const BeamRules* rules, BeamWindow* state, BeamRecord* records, int maxSteps,
 		int* parents, int* nextTokens, hipStream_t stream );
 	// launchReorderCache with the number of rows taken from device memory: rowsDev[ j ] rows of sequence j (its decoder position)
+	// group > 1 (beam search on the device: parents stay inside their window's group of `group` consecutive sequences): one launch through registers, no scratch copy
 	int launchReorderCacheDev( f16* cacheK, f16* cacheV, f16* scratchK, f16* scratchV, const int* parents, const int* rowsDev, int layers, int sequences, int maxSeq,
-		int heads, int keyStride, hipStream_t stream );
+		int heads, int keyStride, int group, hipStream_t stream );
 
 	// Device-resident state of the greedy loop: lets one captured hipGraph be replayed for every token. The POSITIONS live next to
 	// it as one int per sequence (wh_context::seqPos): the sequences of a lock-step batch may stand at different positions (streams

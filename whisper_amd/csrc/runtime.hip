@@ -40,7 +40,7 @@ namespace wh
 	{
 		struct OptionName { const char* name; int Options::* field; };
 		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
-			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 }, { "dec_lds", &Options::decLds }, { "dec_lds_ks", &Options::decLdsKs }, { "dec_split", &Options::decSplit }, { "vocab_lds", &Options::vocabLds }, { "beam_regs", &Options::beamRegs }, { "cross_mfma", &Options::crossMfma } };
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 }, { "dec_lds", &Options::decLds }, { "dec_lds_ks", &Options::decLdsKs }, { "dec_split", &Options::decSplit }, { "vocab_lds", &Options::vocabLds }, { "beam_regs", &Options::beamRegs }, { "reorder_group", &Options::reorderGroup }, { "cross_mfma", &Options::crossMfma } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
 		{
@@ -2680,7 +2680,7 @@ static int beamStep( wh_context* c, int batch, int width )
 	hipStream_t st = c->stream;
 	WH_CHECK( profiled( c, KC_EMBED, 0.0, 4.0 * 2.0 * 2.0 * c->profKeysHint * hp.n_text_state * hp.n_text_layer * batch,
 		[ & ]() { return launchReorderCacheDev( c->selfK, c->selfV, c->selfKScratch, c->selfVScratch, c->beamParents, c->seqPos, hp.n_text_layer, batch, c->maxSeq,
-			hp.n_text_head, hp.n_text_ctx, st ); } ) );
+			hp.n_text_head, hp.n_text_ctx, c->hyp, st ); } ) );
 	WH_CHECK( decodeGraph( c, batch, 1, 0, true ) );
 	WH_CHECK( profiled( c, KC_SOFTMAX, 10.0 * batch * hp.n_vocab, 12.0 * batch * hp.n_vocab, [ & ]() { return launchVocabSoftMax( c->logits, c->probs, batch, hp.n_vocab, st ); } ) );
 	WH_CHECK( profiled( c, KC_SAMPLE, 0.0, ( 4.0 + width ) * 4.0 * batch * hp.n_vocab,
