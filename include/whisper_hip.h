@@ -361,7 +361,7 @@ WH_API int wh_debug_read( wh_context* c, const char* what, int layer, int rows, 
  * afterwards (and their captured graphs) use the new setting. */
 WH_API int wh_debug_set_tuning( uint32_t mask );
 /* Integer knobs beyond the 32 switches (whisper_amd/csrc/kernels.h struct Options: "dec_tile", "dec_depth", "dec_wide_rows", "dec_deep_rows", "vocab_decrows",
- * "enc_chunk", "self_fuse_max_rows", "self_nq", "self_wave_min_rows", "enc_exp", "exact_enc_layers", "exact_alt_order", "gemm_mf16", "dec_lds", "dec_lds_ks", "dec_split", "cross_mfma", "vocab_lds", "beam_regs", "reorder_group"); also settable as WH_OPT_<NAME> in the environment at load.
+ * "enc_chunk", "self_fuse_max_rows", "self_nq", "self_wave_min_rows", "enc_exp", "exact_enc_layers", "exact_alt_order", "gemm_mf16", "dec_lds", "dec_lds_ks", "dec_split", "cross_mfma", "vocab_lds", "beam_regs", "reorder_group", "gemm_big_min_rows"); also settable as WH_OPT_<NAME> in the environment at load.
  * Unknown names and values outside [-1, 2^24]: WH_E_INVALIDARG (the environment form: ignored with a line on stderr). The options are process-global and read without
  * synchronisation by every launch: set them BEFORE contexts are created, never while another thread runs one. */
 WH_API int wh_debug_set_option( const char* name, int value );

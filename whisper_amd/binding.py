@@ -171,7 +171,7 @@ def set_option(name: str, value: int):
 
 
 # the defaults of csrc/kernels.h struct Options (what a test restores an option to)
-OPTION_DEFAULTS = {"dec_tile": 0, "dec_depth": 0, "dec_wide_rows": 1, "dec_deep_rows": 0, "vocab_decrows": 0, "enc_chunk": 128, "self_fuse_max_rows": 32, "self_nq": 0, "self_wave_min_rows": 32, "enc_exp": 5, "exact_enc_layers": -1, "exact_alt_order": 0, "gemm_mf16": 1, "dec_lds": 1, "dec_lds_ks": 2, "dec_split": 1, "cross_mfma": 1, "vocab_lds": 1, "beam_regs": 1, "reorder_group": 1}
+OPTION_DEFAULTS = {"dec_tile": 0, "dec_depth": 0, "dec_wide_rows": 1, "dec_deep_rows": 0, "vocab_decrows": 0, "enc_chunk": 128, "self_fuse_max_rows": 32, "self_nq": 0, "self_wave_min_rows": 32, "enc_exp": 5, "exact_enc_layers": -1, "exact_alt_order": 0, "gemm_mf16": 1, "dec_lds": 1, "dec_lds_ks": 2, "dec_split": 1, "cross_mfma": 1, "vocab_lds": 1, "beam_regs": 1, "reorder_group": 1, "gemm_big_min_rows": 8192}
 
 
 def get_option_default(name: str) -> int:

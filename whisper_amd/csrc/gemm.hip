@@ -3752,7 +3752,7 @@ namespace wh
 	{
 		WH_CHECK( checkArgs( a ) );
 		// big tiles only when they still give every CU a workgroup and M is several clips deep
-		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= 16384 && ( g_tuning & TUNE_GEMM_BIG );
+		const bool big = (long long)( ( a.M + 255 ) / 256 ) * ( ( a.N + 255 ) / 256 ) >= 300 && a.M >= g_opt.gemmBigMinRows && ( g_tuning & TUNE_GEMM_BIG );
 		const bool gl = ( g_tuning & TUNE_GEMM_GL ) != 0;
 		const bool pf = gl && ( g_tuning & TUNE_GEMM_FRAGPF ) != 0;
 		// gemmTiled8 addresses its operands as a 64-bit base + 32-bit byte offsets

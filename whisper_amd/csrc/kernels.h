@@ -85,6 +85,8 @@ namespace wh
 									 // read and one write, the same bits: 37.8 -> 18.3 us at 40 rows), 0 = softMaxRows (three reads, two writes)
 		int reorderGroup = 1;		 // "reorder_group": the ranked beam step's cache reorder: 1 = reorderCacheGroup (a window's hypotheses in one launch through registers), 0 = the two-phase
 									 // copy through the scratch cache (round 4)
+		int gemmBigMinRows = 8192;	 // "gemm_big_min_rows": products of at least this many rows (and 300 tiles of 256 x 256) take the persistent 256 x 256 kernel (rounds 3-5: 16384;
+									 // 8 windows = 12000 rows: beam5 1341 -> 1370 audio-s/s with 8192, the same ids)
 		int gemmMf16 = 1;			 // "gemm_mf16": 1 = gemmTiled8's K loop on v_mfma_f32_16x16x32_f16 (same bits as the 32x32x16 form, +9 % on the class in the model:
 									 // profiles/r06_evidence/gemm_vendor_gap.txt); 0 = v_mfma_f32_32x32x16_f16 (rounds 3-5)
 		int selfWaveMinRows = 32;	 // "self_wave_min_rows": single-token causal self-attention as its own launch: a wave per (sequence, head) beyond this many sequences

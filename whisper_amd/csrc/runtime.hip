@@ -40,7 +40,7 @@ namespace wh
 	{
 		struct OptionName { const char* name; int Options::* field; };
 		const OptionName g_optionNames[] = { { "dec_tile", &Options::decTile }, { "dec_depth", &Options::decDepth }, { "dec_wide_rows", &Options::decWideRows }, { "dec_deep_rows", &Options::decDeepRows }, { "vocab_decrows", &Options::vocabDecRows }, { "enc_chunk", &Options::encChunk },
-			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 }, { "dec_lds", &Options::decLds }, { "dec_lds_ks", &Options::decLdsKs }, { "dec_split", &Options::decSplit }, { "vocab_lds", &Options::vocabLds }, { "beam_regs", &Options::beamRegs }, { "reorder_group", &Options::reorderGroup }, { "cross_mfma", &Options::crossMfma } };
+			{ "self_fuse_max_rows", &Options::selfFuseMaxRows }, { "self_nq", &Options::selfNq }, { "self_wave_min_rows", &Options::selfWaveMinRows }, { "exact_enc_layers", &Options::exactEncLayers }, { "exact_alt_order", &Options::exactAltOrder }, { "enc_exp", &Options::encExp }, { "enc_ablate", &Options::encAblate }, { "gemm_mf16", &Options::gemmMf16 }, { "dec_lds", &Options::decLds }, { "dec_lds_ks", &Options::decLdsKs }, { "dec_split", &Options::decSplit }, { "vocab_lds", &Options::vocabLds }, { "beam_regs", &Options::beamRegs }, { "reorder_group", &Options::reorderGroup }, { "gemm_big_min_rows", &Options::gemmBigMinRows }, { "cross_mfma", &Options::crossMfma } };
 		// WH_OPT_DEC_TILE=44 ... at load
 		const bool g_optionsFromEnv = []()
 		{
