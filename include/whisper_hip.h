@@ -365,6 +365,8 @@ WH_API int wh_debug_set_tuning( uint32_t mask );
  * Unknown names and values outside [-1, 2^24]: WH_E_INVALIDARG (the environment form: ignored with a line on stderr). The options are process-global and read without
  * synchronisation by every launch: set them BEFORE contexts are created, never while another thread runs one. */
 WH_API int wh_debug_set_option( const char* name, int value );
+/* The current value of an option (its compiled-in default until wh_debug_set_option or WH_OPT_<NAME> changes it). Host only: works without a device. */
+WH_API int wh_debug_get_option( const char* name, int* value );
 WH_API int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter );
 
 /* ---- op-level entry points (replace the MlContext methods, Whisper/ML/MlContext.h:13-113). Device pointers. ---- */

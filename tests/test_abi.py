@@ -98,3 +98,27 @@ def test_tuning_bits_of_the_binding_match_the_library_header():
     for name, v in values.items():
         assert hasattr(binding, name), name + " is missing in binding.py"
         assert getattr(binding, name) == v, (name, getattr(binding, name), v)
+
+
+def test_option_defaults_of_the_binding_match_the_library():
+    """binding.OPTION_DEFAULTS mirrors the initialisers of csrc/kernels.h `struct Options` by hand, and tests restore an option from it after an A/B: a value that differs
+    from the library's compiled-in default would silently change what the rest of a session runs. Read back from the library itself (wh_debug_get_option is host code) in
+    a child process without WH_OPT_* variables, so that neither this session's environment nor an earlier test's set_option is in the way."""
+    import subprocess
+    import sys
+    code = ("import json; from whisper_amd import binding; "
+            "print(json.dumps({k: binding.get_option(k) for k in binding.OPTION_DEFAULTS}))")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("WH_OPT_")}
+    env["PYTHONPATH"] = ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got == binding.OPTION_DEFAULTS, {k: (got[k], v) for k, v in binding.OPTION_DEFAULTS.items() if got[k] != v}
+    # every option the library knows is mirrored (the names are listed in the header's comment of wh_debug_set_option)
+    text = open(os.path.join(ROOT, "include", "whisper_hip.h")).read()
+    at = text.index("WH_API int wh_debug_set_option")
+    listed = set(re.findall(r'"([a-z0-9_]+)"', text[at - 2000:at]))
+    assert set(binding.OPTION_DEFAULTS) <= listed | {"enc_ablate"}, sorted(set(binding.OPTION_DEFAULTS) - listed)
+    with pytest.raises(RuntimeError):
+        binding.get_option("no_such_option")

@@ -46,7 +46,7 @@ EXPORTS = [
     "wh_comm_runtime_check", "wh_comm_unique_id", "wh_comm_create", "wh_comm_destroy", "wh_comm_info", "wh_comm_barrier", "wh_comm_create_timeout", "wh_comm_set_timeout", "wh_comm_broadcast_i32", "wh_model_broadcast",
     "wh_context_create", "wh_context_create_hyp", "wh_context_destroy", "wh_context_bind", "wh_context_set_flags", "wh_context_set_audio_ctx", "wh_context_synchronize", "wh_context_memory",
     "wh_buffer_alloc", "wh_buffer_free", "wh_buffer_upload", "wh_buffer_upload_async", "wh_buffer_download",
-    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_mel_spectrogram_batch", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option",
+    "wh_mel_spectrogram", "wh_encode", "wh_encode_windows", "wh_decode", "wh_sample_best", "wh_beam_candidates", "wh_reorder_self_cache", "wh_beam_window_start", "wh_beam_window_continue", "wh_beam_window_status", "wh_beam_window_records", "wh_decode_greedy", "wh_decode_window_start", "wh_decode_window_finish", "wh_decode_window_continue", "wh_decode_window_fetch", "wh_decode_window_start_ragged", "wh_decode_window_ready", "wh_mel_spectrogram_window", "wh_mel_spectrogram_batch", "wh_profile_enable", "wh_profile_read", "wh_debug_read", "wh_debug_probe", "wh_debug_set_tuning", "wh_debug_set_option", "wh_debug_get_option",
     "wh_op_mul_mat", "wh_op_mul_mat_gelu", "wh_op_layer_norm", "wh_op_flash_attention", "wh_op_soft_max", "wh_op_decoder_attention", "wh_op_decoder_cross_attention",
 ]
 
@@ -102,6 +102,7 @@ def lib():
         L.wh_last_error.restype = C.c_char_p
         L.wh_debug_set_tuning.argtypes = [C.c_uint32]
         L.wh_debug_set_option.argtypes = [C.c_char_p, C.c_int]
+        L.wh_debug_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
         L.wh_beam_window_start.argtypes = [vp, i32, vp, i32, i32, C.POINTER(BeamRulesC), i32]
         L.wh_beam_window_continue.argtypes = [vp, i32]
         L.wh_beam_window_status.argtypes = [vp, C.POINTER(BeamWindowC)]
@@ -172,6 +173,13 @@ def set_option(name: str, value: int):
 
 # the defaults of csrc/kernels.h struct Options (what a test restores an option to)
 OPTION_DEFAULTS = {"dec_tile": 0, "dec_depth": 0, "dec_wide_rows": 1, "dec_deep_rows": 0, "vocab_decrows": 0, "enc_chunk": 128, "self_fuse_max_rows": 32, "self_nq": 0, "self_wave_min_rows": 32, "enc_exp": 5, "exact_enc_layers": -1, "exact_alt_order": 0, "gemm_mf16": 1, "dec_lds": 1, "dec_lds_ks": 2, "dec_split": 1, "cross_mfma": 1, "vocab_lds": 1, "beam_regs": 1, "reorder_group": 1, "gemm_big_min_rows": 8192}
+
+
+def get_option(name: str) -> int:
+    """The library's current value of an option (host only)."""
+    v = C.c_int(0)
+    check(lib().wh_debug_get_option(name.encode(), C.byref(v)))
+    return v.value
 
 
 def get_option_default(name: str) -> int:

@@ -3201,6 +3201,19 @@ int wh_debug_set_option( const char* name, int value )
 	return WH_E_INVALIDARG;
 }
 
+int wh_debug_get_option( const char* name, int* value )
+{
+	if( !name || !value ) { setError( "debug_get_option: null argument" ); return WH_E_INVALIDARG; }
+	for( const OptionName& o : g_optionNames )
+		if( 0 == strcmp( o.name, name ) )
+		{
+			*value = g_opt.*( o.field );
+			return 0;
+		}
+	setError( "debug_get_option: unknown option" );
+	return WH_E_INVALIDARG;
+}
+
 int wh_debug_probe( wh_context* c, int kind, int variant, int M, int N, int K, int iters, float* msPerIter )
 {
 	if( !c || !msPerIter || iters <= 0 ) return WH_E_INVALIDARG;
